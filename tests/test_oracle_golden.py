@@ -1,0 +1,124 @@
+"""Pins the CPU oracle (oracle/letkf_oracle.py) against vectors produced by the
+reference itself (tools/gen_golden.py imports pytassim's core/localization/kernels/
+wrapper modules) and against the closed-form answers of the reference's unit tests."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import letkf_oracle as O
+from conftest import rel_fro
+
+TOL = 1e-12
+
+
+def test_g1_known_answer(golden):
+    g = golden("g1_known_answer.npz")
+    w_mean, w_perts, pa = O.etkf_weights_parts(torch.tensor(g["yb"]), torch.tensor(g["d"]), 1.0)
+    # closed forms quoted in tests/unit_tests/core/test_etkf.py:142-156,181-187
+    np.testing.assert_allclose(pa.numpy(), [[0.75, 0.25], [0.25, 0.75]], atol=1e-12)
+    np.testing.assert_allclose(w_mean.numpy().ravel(), [0.1, -0.1], atol=1e-12)
+    np.testing.assert_allclose((w_perts @ w_perts.T).numpy(), pa.numpy(), atol=1e-12)
+    np.testing.assert_allclose(w_mean.numpy(), g["w_mean"], atol=TOL)
+    np.testing.assert_allclose(w_perts.numpy(), g["w_perts"], atol=TOL)
+    np.testing.assert_allclose(pa.numpy(), g["pa"], atol=TOL)
+    w = O.etkf_weights(g["yb"], g["d"], 1.0).numpy()
+    np.testing.assert_allclose(w, g["weights"], atol=TOL)
+    # mean_j(weights - I) = w_mean  (test_etkf.py:219-225)
+    np.testing.assert_allclose((w - np.eye(2)).mean(axis=1), w_mean.numpy().ravel(), atol=1e-12)
+
+
+def test_g2_prior_and_errors(golden):
+    g = golden("g2_prior.npz")
+    w = O.etkf_weights(np.ones((10, 0)), np.ones((1, 0)), 1.1).numpy()
+    np.testing.assert_allclose(w, g["weights"], atol=TOL)
+    np.testing.assert_allclose(w, np.sqrt(1.1) * np.eye(10), atol=1e-15)
+    with pytest.raises(ValueError):
+        O.etkf_weights(np.ones((10, 4)), np.ones((1, 3)))
+
+
+def test_g3_g4_blocks(golden):
+    g = golden("g3_g4_core_blocks.npz")
+    for ci, (k, p) in enumerate(g["cases"]):
+        yb, d = g[f"yb_{ci}"], g[f"d_{ci}"]
+        for inf in (1.0, 1.1):
+            tag = f"{ci}_{str(inf).replace('.', 'p')}"
+            assert rel_fro(O.etkf_weights(yb, d, inf).numpy(), g[f"etkf_{tag}"]) < TOL
+            for name, kern in (("rbf0p5", lambda x, y: O.rbf_kernel(x, y, 0.5)),
+                               ("rbf10", lambda x, y: O.rbf_kernel(x, y, 10.0)),
+                               ("gauss2", lambda x, y: O.rbf_kernel(x, y, 0.5 / 2.0 ** 2)),
+                               ("linear", O.linear_kernel)):
+                got = O.ketkf_weights(yb, d, kern, inf).numpy()
+                assert rel_fro(got, g[f"ketkf_{name}_{tag}"]) < 1e-10, (name, tag)
+            # linear-kernel KETKF == ETKF (tests/unit_tests/interface/test_lketkf.py:109-117)
+            assert rel_fro(g[f"ketkf_linear_{tag}"], g[f"etkf_{tag}"]) < 1e-9
+    x, y = torch.tensor(g["kern_x"]), torch.tensor(g["kern_y"])
+    np.testing.assert_allclose(O.rbf_kernel(x, y, 0.5).numpy(), g["kern_rbf0p5"], atol=1e-14)
+    np.testing.assert_allclose(O.rbf_kernel(x, y, 10.0).numpy(), g["kern_rbf10"], atol=1e-14)
+    np.testing.assert_allclose(O.rbf_kernel(x, y, 0.125).numpy(), g["kern_gauss2"], atol=1e-14)
+    np.testing.assert_allclose(O.linear_kernel(x, y).numpy(), g["kern_linear"], atol=1e-14)
+
+
+def test_g5_gaspari_cohn(golden):
+    g = golden("g5_gaspari_cohn.npz")
+    r = g["r"]
+    np.testing.assert_array_equal(O.gc_f1(r), g["f1"])
+    with np.errstate(all="ignore"):
+        np.testing.assert_array_equal(O.gc_f2(r[r > 0]), g["f2"])
+    for c in (1.0, 10.0, 16.5):
+        use, w = O.localize_obs(r * c, c)
+        np.testing.assert_array_equal(use, g[f"use_c{c}"])
+        np.testing.assert_array_equal(w, g[f"w_c{c}"])
+    use, w = O.localize_obs(np.stack([g["dh"], g["dv"]]), (10.0, 1.5))
+    np.testing.assert_array_equal(use, g["use_2r"])
+    np.testing.assert_array_equal(w, g["w_2r"])
+    use, w = O.localize_obs(r * 10.0, 10.0, epsilon=1e-3)
+    np.testing.assert_array_equal(use, g["use_eps1e3"])
+    # sanity values observed with the reference class
+    _, w1 = O.localize_obs(np.array([0, .5, 1, 1.5, 1.8, 1.9, 2.0]), 1.0)
+    np.testing.assert_allclose(w1, [1, 0.684896, 0.208333, 0.016493, 4.696e-4, 3.03e-5, 0.0], atol=2e-6)
+    assert w1[-1] == 0.0
+
+
+def test_g6_reference_fixture_letkf(golden):
+    g = golden("g6_reference_fixture_letkf.npz")
+    state, ti = g["state"], int(g["time_index"])
+    yb, d = O.obs_space_corr(state[0, ti], g["obs"][ti], g["cov"])
+    np.testing.assert_allclose(yb, g["yb"], atol=1e-13)
+    np.testing.assert_allclose(d, g["d"], atol=1e-13)
+    for inf in (1.0, 1.1):
+        tag = str(inf).replace(".", "p")
+        ana, w = O.letkf_analysis(state[:, [ti]], g["grid"], g["obs_grid"], yb, d, 10.0, inf)
+        assert rel_fro(w, g[f"weights_{tag}"]) < TOL
+        assert rel_fro(ana, g[f"analysis_{tag}"]) < TOL
+        ana_g, w_g = O.etkf_analysis(state[:, [ti]], yb, d, inf)
+        assert rel_fro(w_g, g[f"weights_global_{tag}"]) < TOL
+        assert rel_fro(ana_g, g[f"analysis_global_{tag}"]) < TOL
+
+
+@pytest.mark.parametrize("name,k,s,c,gamma", [("c2", 40, 2, 10.0, None), ("c4", 80, 1, 16.5, None),
+                                              ("c5", 40, 2, 10.0, 0.5), ("c2m3", 40, 2, 10.0, None)])
+def test_g7_synthetic(golden, name, k, s, c, gamma):
+    g = golden("g7_synthetic_configs.npz")
+    st = g[f"{name}_state"]
+    G = st.shape[-1]
+    case = O.synthetic_case(G, k, s, seed=42, m=st.shape[0])
+    np.testing.assert_array_equal(case["state"], st)
+    np.testing.assert_allclose(case["yb"], g[f"{name}_yb"], atol=1e-15)
+    np.testing.assert_allclose(case["d"], g[f"{name}_d"], atol=1e-15)
+    core = O.etkf_weights if gamma is None else (
+        lambda a, b, inf: O.ketkf_weights(a, b, lambda x, y: O.rbf_kernel(x, y, gamma), inf))
+    for inf in (1.0, 1.1):
+        tag = f"{name}_{str(inf).replace('.', 'p')}"
+        ana, w = O.letkf_analysis(st, case["grid_x"], case["obs_x"], case["yb"], case["d"], c, inf, core=core)
+        assert rel_fro(w[g[f"{name}_widx"]], g[f"{tag}_weights"]) < 1e-11
+        assert rel_fro(ana, g[f"{tag}_analysis"]) < 1e-11
+
+
+def test_g7_c1_global(golden):
+    g = golden("g7_synthetic_configs.npz")
+    st = g["c1_state"]
+    for inf in (1.0, 1.1):
+        tag = f"c1_{str(inf).replace('.', 'p')}"
+        ana, w = O.etkf_analysis(st, g["c1_yb"], g["c1_d"], inf)
+        assert rel_fro(w, g[f"{tag}_weights"][0]) < 1e-10
+        assert rel_fro(ana, g[f"{tag}_analysis"]) < 1e-10
