@@ -1,0 +1,163 @@
+/* mia_letkf.h -- C ABI of the MI355X-native LETKF local-analysis engine.
+ *
+ * The reference (tobifinn/torch-assimilate, "pytassim" v0.2.1) is pure Python and has no
+ * native/FFI boundary; its seam for this path is the per-grid-point closure
+ *   wrapper_localization(wrapper_bridge(ETKFModule))      pytassim/interface/wrapper.py:29-99
+ * driven by LETKF.estimate_weights                         pytassim/interface/letkf.py:104-148
+ * and followed by BaseAssimilation._apply_weights          pytassim/interface/base.py:257-278.
+ * Each entry point below replaces one stage of that seam; the comment on every function
+ * cites the reference code it stands in for.  INTEGRATION.md shows the ctypes stub a
+ * pytassim maintainer would add.
+ *
+ * Conventions
+ *  - all array pointers are DEVICE pointers (gfx950 HBM); the library never allocates,
+ *    frees or retains caller memory; scratch comes from the `ws` argument whose size is
+ *    obtained from the matching *_workspace_bytes query;
+ *  - `stream` is a hipStream_t passed as void*; everything is enqueued on it, nothing
+ *    synchronises the host;
+ *  - functions never throw; return value 0 = ok, <0 = invalid argument (MIA_ERR_*),
+ *    >0 = hipError_t of the failing runtime call;
+ *  - dense layouts are row-major with the LAST index fastest;
+ *  - ensemble-space results use the reference's orientation:
+ *    weights[i][j] = w_mean[i] + W[i][j],  i = 'ensemble', j = 'ensemble_new'
+ *    (pytassim/core/etkf.py:102, interface/letkf.py:145-146).
+ */
+#ifndef MIA_LETKF_H
+#define MIA_LETKF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIA_VERSION 100 /* 0.1.0 */
+
+#define MIA_OK 0
+#define MIA_ERR_NULL (-1)        /* required pointer is NULL */
+#define MIA_ERR_SIZE (-2)        /* negative / zero / inconsistent size */
+#define MIA_ERR_UNSUPPORTED (-3) /* shape outside what the kernels are built for (e.g. LDS) */
+#define MIA_ERR_WORKSPACE (-4)   /* workspace too small */
+#define MIA_ERR_ALIGN (-5)       /* pointer not aligned as documented */
+
+/* per-grid-point flag bits written to `flags_opt` */
+#define MIA_FLAG_OVERFLOW 1 /* more local observations than p_max: point NOT analysed */
+#define MIA_FLAG_NOCONV 2   /* Jacobi eigensolver hit its sweep cap (result still returned) */
+#define MIA_FLAG_NONFINITE 4 /* non-finite value met in the local block */
+
+#define MIA_MAX_COORD 3
+#define MIA_MAX_RADII 3
+
+int mia_version(void);
+const char* mia_status_string(int status);
+
+/* ------------------------------------------------------------------------------------
+ * Gaspari-Cohn taper of normalised distances r = dist / c (unit-testable stage).
+ * Replaces GaspariCohn._f1/_f2 and the piecewise assembly in
+ * pytassim/localization/gaspari_cohn.py:78-95,127-133 (strict `<` at r = 1 and r = 2).
+ * ---------------------------------------------------------------------------------- */
+int mia_gaspari_cohn_f64(const double* r, int64_t n, double* w, void* stream);
+int mia_gaspari_cohn_f32(const float* r, int64_t n, float* w, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Localisation: for every grid point g in [g0, g1) the list of observations with
+ * Gaspari-Cohn weight > gc_eps and sqrt(weight) for each.
+ * Replaces GaspariCohn.localize_obs (gaspari_cohn.py:97-136) evaluated once per grid
+ * point inside wrapper_localization (interface/wrapper.py:88-91), for the built-in
+ * metric family: coordinate c belongs to radius group coord_group[c]; the distance of
+ * group i is the Euclidean norm over its coordinates; weight = prod_i GC(dist_i/gc_c[i]).
+ * (n_coord = 1, one group: |x_g - x_o|, the metric of examples/benchmark_letkf.py:85-87.)
+ * Evaluated in float64 like the reference, so the use/skip decision is the reference's.
+ * Instead of the reference's O(G*P) all-pairs pass the observations are binned into a
+ * uniform cell grid (cell edge >= 2*c per coordinate) built in `ws`.
+ *
+ *  grid_xyz [G_total][n_coord] f64     obs_xyz [P][n_coord] f64
+ *  nbr_cnt  [g1-g0]           i32  true number of local obs (may exceed p_cap)
+ *  nbr_idx  [g1-g0][p_cap]    i32  obs indices, ascending cell order, -1 padded
+ *  nbr_w    [g1-g0][p_cap]    f64  sqrt(GC weight)           (wrapper.py:91)
+ *  stats    [2]               i32  [0] = max count over the shard, [1] = #points with
+ *                                  count > p_cap (lists truncated; caller must retry)
+ * ---------------------------------------------------------------------------------- */
+int mia_letkf_localize_workspace_bytes(int64_t P, int n_coord, size_t* bytes);
+int mia_letkf_localize_f64(const double* grid_xyz, int64_t g0, int64_t g1,
+                           const double* obs_xyz, int64_t P, int n_coord,
+                           const int32_t* coord_group /* host, [n_coord] */,
+                           const double* gc_c /* host, [n_r] */, int n_r, double gc_eps,
+                           int p_cap, int32_t* nbr_cnt, int32_t* nbr_idx, double* nbr_w,
+                           int32_t* stats, void* ws, size_t ws_bytes, void* stream);
+
+/* Same lists from caller-evaluated distances (an arbitrary Python dist_func evaluated on
+ * the host in batch): dist [n_r][g1-g0][p_cap] f64, cand_idx [g1-g0][p_cap] (-1 = pad).
+ * Compacts in place the candidates whose weight product exceeds gc_eps. */
+int mia_letkf_localize_from_dist_f64(const double* dist, const int32_t* cand_idx, int64_t n_pts,
+                                     int p_cap, const double* gc_c /* host */, int n_r,
+                                     double gc_eps, int32_t* nbr_cnt, int32_t* nbr_idx,
+                                     double* nbr_w, int32_t* stats, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Local analysis for grid points [g0, g1): mask & sqrt(rho)-scale (wrapper.py:91-97),
+ * ETKF weights (core/etkf.py:57-103: Gram matrix, symmetric eigensolve with clamp>=0 and
+ * (k-1)/inf shift, Pa, w_mean, symmetric square root W; empty list -> sqrt(inf)*I,
+ * etkf.py:91-95) and the ensemble transform xa = mean + X' (w_mean 1^T + W)
+ * (interface/base.py:257-278), fused.
+ *
+ *  X   [m][k][ldx]   prior ensemble, grid fastest (pytassim dims var_name*time, ensemble,
+ *                    grid); point g is column g of every (m, k) row
+ *  Yb  [k][P]        R^-1/2-normalised obs-space perturbations (base.py:359-379)
+ *  d   [P]           normalised innovations
+ *  nbr_*             lists for this shard as produced above, row stride p_cap
+ *  p_max             upper bound on nbr_cnt over the shard (stats[0]); sizes the LDS block
+ *  Xa  [m][k][ldo]   analysis; point g is written to column (g - g0 + o0)
+ *  W_opt             NULL or [g1-g0][k][k] weights (what estimate_weights returns)
+ *  flags_opt         NULL or [g1-g0] MIA_FLAG_* bits
+ * ---------------------------------------------------------------------------------- */
+int mia_letkf_analysis_workspace_bytes(int k, int64_t P, int elem_bytes, size_t* bytes);
+int mia_letkf_analysis_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                           const float* Yb, const float* d, int64_t P,
+                           const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w,
+                           int p_cap, int p_max, float inf_factor,
+                           float* Xa, int64_t ldo, int64_t o0, float* W_opt, int32_t* flags_opt,
+                           void* ws, size_t ws_bytes, void* stream);
+int mia_letkf_analysis_f64(const double* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                           const double* Yb, const double* d, int64_t P,
+                           const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w,
+                           int p_cap, int p_max, double inf_factor,
+                           double* Xa, int64_t ldo, int64_t o0, double* W_opt, int32_t* flags_opt,
+                           void* ws, size_t ws_bytes, void* stream);
+
+/* Kernelised variant: KETKFModule with RBFKernel(gamma) (core/ketkf.py:65-94,
+ * kernels/rbf.py:75-81,110-111), same localisation and transform (LKETKF,
+ * interface/lketkf.py:77). */
+int mia_lketkf_rbf_analysis_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                const float* Yb, const float* d, int64_t P,
+                                const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w,
+                                int p_cap, int p_max, float inf_factor, float gamma,
+                                float* Xa, int64_t ldo, int64_t o0, float* W_opt, int32_t* flags_opt,
+                                void* ws, size_t ws_bytes, void* stream);
+int mia_lketkf_rbf_analysis_f64(const double* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                const double* Yb, const double* d, int64_t P,
+                                const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w,
+                                int p_cap, int p_max, double inf_factor, double gamma,
+                                double* Xa, int64_t ldo, int64_t o0, double* W_opt, int32_t* flags_opt,
+                                void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Global (unlocalised) ETKF: one (k, P) solve, ETKF.estimate_weights
+ * (interface/etkf.py:99-120) -> weights [k][k]; and the global ensemble transform
+ * _apply_weights with 2-D weights (base.py:257-278).
+ * ---------------------------------------------------------------------------------- */
+int mia_etkf_workspace_bytes(int k, int64_t P, int elem_bytes, size_t* bytes);
+int mia_etkf_weights_f32(const float* Yb, const float* d, int k, int64_t P, float inf_factor,
+                         float* W, int32_t* flags_opt, void* ws, size_t ws_bytes, void* stream);
+int mia_etkf_weights_f64(const double* Yb, const double* d, int k, int64_t P, double inf_factor,
+                         double* W, int32_t* flags_opt, void* ws, size_t ws_bytes, void* stream);
+int mia_apply_weights_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                          const float* W, float* Xa, int64_t ldo, int64_t o0, void* stream);
+int mia_apply_weights_f64(const double* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                          const double* W, double* Xa, int64_t ldo, int64_t o0, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIA_LETKF_H */

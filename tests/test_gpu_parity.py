@@ -1,0 +1,225 @@
+"""GPU parity: the HIP path (through the C ABI) against the committed golden vectors that
+were produced by the reference itself, and against the CPU oracle on seeded inputs.
+
+Tolerances: float32 kernels <= 1e-5 relative Frobenius error on the analysis ensemble
+(BASELINE.json north_star); float64 kernels <= 1e-10; localisation masks bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_fro
+from oracle import letkf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 1e-5
+TOL64 = 1e-10
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch_assimilate_amd as mia
+    mia.build()
+    return mia.LetkfEngine("cuda:0")
+
+
+def dev(a, dtype):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(device="cuda:0", dtype=dtype)
+
+
+def all_obs_lists(eng, n_pts, p):
+    """every grid point sees every observation with weight 1 (distance 0)"""
+    cap = max(p, 1)
+    cand = np.tile(np.arange(cap, dtype=np.int32), (n_pts, 1))
+    if p == 0:
+        cand[:] = -1
+    return eng.localize_from_dist(np.zeros((1, n_pts, cap)), cand, [1.0])
+
+
+def test_gaspari_cohn_kernel(eng, golden):
+    g = golden("g5_gaspari_cohn.npz")
+    r = g["r"]
+    w64 = eng.gaspari_cohn(dev(r, torch.float64)).cpu().numpy()
+    np.testing.assert_allclose(w64, g["w_c1.0"], rtol=0, atol=4e-15)
+    assert w64[r >= 2.0].max() == 0.0
+    w32 = eng.gaspari_cohn(dev(r, torch.float32)).cpu().numpy()
+    np.testing.assert_allclose(w32, g["w_c1.0"], rtol=0, atol=3e-6)
+
+
+@pytest.mark.parametrize("name,c", [("c2", 10.0), ("c4", 16.5)])
+def test_localize_1d_matches_reference_mask(eng, golden, name, c):
+    g = golden("g7_synthetic_configs.npz")
+    gx, ox = g[f"{name}_grid_x"], g[f"{name}_obs_x"]
+    nb = eng.localize(gx, ox, [c])
+    cnt, idx, w = nb.cnt.cpu().numpy(), nb.idx.cpu().numpy(), nb.w.cpu().numpy()
+    for gi in range(len(gx)):
+        use, wt = O.localize_obs(O.abs_distance_1d(gx[gi], ox), c)
+        ref = np.nonzero(use)[0]
+        assert cnt[gi] == len(ref)
+        got = idx[gi, :cnt[gi]]
+        order = np.argsort(got)
+        np.testing.assert_array_equal(got[order], ref)
+        np.testing.assert_allclose(w[gi, :cnt[gi]][order] ** 2, wt[ref], rtol=1e-12, atol=1e-18)
+        assert (idx[gi, cnt[gi]:] == -1).all()
+    assert nb.p_max == cnt.max()
+
+
+@pytest.mark.parametrize("nc,groups,radii", [(2, [0, 0], [0.08]), (3, [0, 0, 1], [0.15, 0.3]), (3, [0, 1, 2], [0.2, 0.1, 0.4])])
+def test_localize_nd_matches_oracle(eng, nc, groups, radii):
+    rs = np.random.RandomState(7)
+    G, P = 300, 2000
+    grid = rs.uniform(-0.1, 1.1, size=(G, nc))
+    obs = rs.uniform(0, 1, size=(P, nc))
+    nb = eng.localize(grid, obs, radii, coord_group=groups, p_cap=16)   # forces the retry path
+    cnt, idx, w = nb.cnt.cpu().numpy(), nb.idx.cpu().numpy(), nb.w.cpu().numpy()
+    for gi in range(G):
+        dist = O.grouped_euclid_distance(grid[gi], obs, groups, len(radii))
+        use, wt = O.localize_obs(dist, radii)
+        ref = np.nonzero(use)[0]
+        assert cnt[gi] == len(ref), gi
+        got = idx[gi, :cnt[gi]]
+        order = np.argsort(got)
+        np.testing.assert_array_equal(got[order], ref)
+        np.testing.assert_allclose(w[gi, :cnt[gi]][order] ** 2, wt[ref], rtol=1e-11, atol=1e-18)
+    assert cnt.max() > 16
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, TOL64), (torch.float32, TOL32)])
+def test_core_blocks_vs_reference(eng, golden, dtype, tol):
+    """ETKFModule outputs of the reference for random (k, p) blocks, both eigen routes
+    (p <= k dual, p > k primal), incl. the (40,20)/(40,19)/(80,64) shapes of the configs."""
+    g = golden("g3_g4_core_blocks.npz")
+    for ci, (k, p) in enumerate(g["cases"]):
+        yb, d = g[f"yb_{ci}"], g[f"d_{ci}"]
+        X = np.random.RandomState(ci).normal(size=(2, k, 1))
+        nb = all_obs_lists(eng, 1, p)
+        for inf in (1.0, 1.1):
+            tag = f"{ci}_{str(inf).replace('.', 'p')}"
+            xa, W, fl = eng.analysis(dev(X, dtype), dev(yb, dtype), dev(d, dtype), nb, inf,
+                                     return_weights=True, return_flags=True)
+            assert int(fl.cpu()[0]) == 0
+            ref_w = g[f"etkf_{tag}"]
+            assert rel_fro(W.cpu().numpy()[0], ref_w) < tol, (k, p, inf)
+            assert rel_fro(xa.cpu().numpy(), O.apply_weights(X, ref_w[None])) < tol, (k, p, inf)
+
+
+def test_known_answer_and_prior(eng, golden):
+    g = golden("g1_known_answer.npz")
+    X = np.array([[[0.5], [-0.5]]])
+    nb = all_obs_lists(eng, 1, 1)
+    _, W = eng.analysis(dev(X, torch.float64), dev(g["yb"], torch.float64), dev(g["d"].ravel(), torch.float64),
+                        nb, 1.0, return_weights=True)
+    np.testing.assert_allclose(W.cpu().numpy()[0], g["weights"], atol=1e-12)
+    # empty observation set -> sqrt(inf) * I  (tests/unit_tests/core/test_etkf.py:227-233)
+    g2 = golden("g2_prior.npz")
+    X = np.random.RandomState(0).normal(size=(1, 10, 5))
+    nb = eng.localize(np.arange(5.0), np.zeros((0, 1)), [10.0])
+    assert nb.p_max == 0
+    for dtype in (torch.float32, torch.float64):
+        xa, W = eng.analysis(dev(X, dtype), torch.zeros((10, 0)), torch.zeros(0), nb, 1.1, return_weights=True)
+        np.testing.assert_allclose(W.cpu().numpy()[3], g2["weights"], atol=1e-6 if dtype == torch.float32 else 1e-14)
+        assert rel_fro(xa.cpu().numpy(), O.apply_weights(X, g2["weights"])) < 1e-6
+    with pytest.raises(ValueError):
+        eng.analysis(dev(X, torch.float32), torch.ones((10, 4)), torch.ones(3), nb, 1.0)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, TOL64), (torch.float32, TOL32)])
+def test_reference_fixture_letkf(eng, golden, dtype, tol):
+    """End-to-end on the reference's own test data (tests/data/test_state.nc / test_single_obs.nc),
+    the case of tests/unit_tests/interface/test_letkf.py:106-157."""
+    g = golden("g6_reference_fixture_letkf.npz")
+    ti = int(g["time_index"])
+    X = g["state"][:, ti]                               # (2, 10, 40): m = n_var
+    nb = eng.localize(g["grid"], g["obs_grid"], [10.0])
+    for inf in (1.0, 1.1):
+        tag = str(inf).replace(".", "p")
+        xa, W = eng.analysis(dev(X, dtype), dev(g["yb"], dtype), dev(g["d"], dtype), nb, inf, return_weights=True)
+        assert rel_fro(W.cpu().numpy(), g[f"weights_{tag}"]) < tol
+        assert rel_fro(xa.cpu().numpy(), g[f"analysis_{tag}"][:, 0]) < tol
+        Wg = eng.etkf_weights(dev(g["yb"], dtype), dev(g["d"], dtype), inf)
+        assert rel_fro(Wg.cpu().numpy(), g[f"weights_global_{tag}"]) < tol
+        xg = eng.apply_weights(dev(X, dtype), Wg)
+        assert rel_fro(xg.cpu().numpy(), g[f"analysis_global_{tag}"][:, 0]) < tol
+
+
+@pytest.mark.parametrize("name,c,gamma", [("c2", 10.0, None), ("c4", 16.5, None), ("c2m3", 10.0, None), ("c5", 10.0, 0.5)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, TOL64), (torch.float32, TOL32)])
+def test_scaled_configs_vs_reference(eng, golden, name, c, gamma, dtype, tol):
+    g = golden("g7_synthetic_configs.npz")
+    X = g[f"{name}_state"]
+    nb = eng.localize(g[f"{name}_grid_x"], g[f"{name}_obs_x"], [c])
+    for inf in (1.0, 1.1):
+        tag = f"{name}_{str(inf).replace('.', 'p')}"
+        xa, W, fl = eng.analysis(dev(X, dtype), dev(g[f"{name}_yb"], dtype), dev(g[f"{name}_d"], dtype), nb, inf,
+                                 return_weights=True, rbf_gamma=gamma, return_flags=True)
+        assert int(fl.max().cpu()) == 0
+        ref = g[f"{tag}_analysis"]
+        err = rel_fro(xa.cpu().numpy(), ref)
+        mean = ref.mean(axis=1, keepdims=True)
+        err_inc = rel_fro(xa.cpu().numpy() - X.mean(axis=1, keepdims=True), ref - X.mean(axis=1, keepdims=True))
+        werr = rel_fro(W.cpu().numpy()[g[f"{name}_widx"]], g[f"{tag}_weights"])
+        print(f"{tag} {dtype}: analysis {err:.2e} increments {err_inc:.2e} weights {werr:.2e}")
+        assert err < tol and werr < tol and err_inc < 10 * tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, TOL64), (torch.float32, TOL32)])
+def test_c1_global_etkf(eng, golden, dtype, tol):
+    g = golden("g7_synthetic_configs.npz")
+    X = g["c1_state"]
+    for inf in (1.0, 1.1):
+        tag = f"c1_{str(inf).replace('.', 'p')}"
+        W = eng.etkf_weights(dev(g["c1_yb"], dtype), dev(g["c1_d"], dtype), inf)
+        assert rel_fro(W.cpu().numpy(), g[f"{tag}_weights"][0]) < tol
+        xa = eng.apply_weights(dev(X, dtype), W)
+        assert rel_fro(xa.cpu().numpy(), g[f"{tag}_analysis"]) < tol
+
+
+def test_ketkf_blocks_vs_reference(eng, golden):
+    g = golden("g3_g4_core_blocks.npz")
+    for ci, (k, p) in enumerate(g["cases"]):
+        yb, d = g[f"yb_{ci}"], g[f"d_{ci}"]
+        X = np.random.RandomState(ci).normal(size=(1, k, 1))
+        nb = all_obs_lists(eng, 1, p)
+        for gname, gamma in (("rbf0p5", 0.5), ("rbf10", 10.0), ("gauss2", 0.125)):
+            for dtype, tol in ((torch.float64, 1e-9), (torch.float32, TOL32)):
+                _, W = eng.analysis(dev(X, dtype), dev(yb, dtype), dev(d, dtype), nb, 1.1,
+                                    return_weights=True, rbf_gamma=gamma)
+                assert rel_fro(W.cpu().numpy()[0], g[f"ketkf_{gname}_{ci}_1p1"]) < tol, (k, p, gname, dtype)
+
+
+def test_overflow_is_flagged_not_truncated(eng, golden):
+    g = golden("g7_synthetic_configs.npz")
+    X = g["c2_state"]
+    nb = eng.localize(g["c2_grid_x"], g["c2_obs_x"], [10.0])
+    nb.p_max = 10                                   # lie about the bound
+    xa, fl = eng.analysis(dev(X, torch.float32), dev(g["c2_yb"], torch.float32), dev(g["c2_d"], torch.float32),
+                          nb, 1.0, return_flags=True)
+    fl = fl.cpu().numpy()
+    assert (fl[20:-20] & 1).all()
+    assert np.isnan(xa.cpu().numpy()[0, :, 100]).all()
+
+
+def test_large_grid_properties(eng):
+    """BASELINE config-2 size: properties that need no oracle at scale -- analysis mean/perturbation
+    structure (weights rows sum: W 1 = 1 when perturbations are centred), determinism, shard invariance."""
+    case = O.synthetic_case(100000, 40, 2)
+    X = dev(case["state"], torch.float32)
+    yb, d = dev(case["yb"], torch.float32), dev(case["d"], torch.float32)
+    nb = eng.localize(case["grid_x"], case["obs_x"], [10.0])
+    assert nb.p_max == 20
+    xa = eng.analysis(X, yb, d, nb, 1.1)
+    xa2 = eng.analysis(X, yb, d, nb, 1.1)
+    assert torch.equal(xa, xa2)
+    assert torch.isfinite(xa).all()
+    # shard [30000, 30100) equals the same columns of the full run, bit for bit
+    nb_s = eng.localize(case["grid_x"], case["obs_x"], [10.0], g0=30000, g1=30100)
+    xs = eng.analysis(X, yb, d, nb_s, 1.1)
+    assert torch.equal(xs, xa[:, :, 30000:30100])
+    # oracle on a random subset of points
+    sel = np.random.RandomState(1).choice(100000, 64, replace=False)
+    for gi in sel:
+        dist = O.abs_distance_1d(case["grid_x"][gi], case["obs_x"])
+        w = O.localized_weights(dist, case["yb"], case["d"], [10.0], 1.1)
+        ref = O.apply_weights(case["state"][:, :, [gi]], w[None])
+        assert rel_fro(xa[:, :, gi].cpu().numpy(), ref[:, :, 0]) < TOL32

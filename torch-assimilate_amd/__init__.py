@@ -1,0 +1,25 @@
+"""MI355X-native LETKF local-analysis engine (drop-in for pytassim's ensemble-transform path).
+
+Import name: ``torch_assimilate_amd`` (the directory name carries a hyphen; the repo-root
+module ``torch_assimilate_amd.py`` maps the import name onto this directory).
+"""
+from ._build import build, LIB_PATH            # noqa: F401
+from ._cabi import MiaError, EXPORTED_SYMBOLS  # noqa: F401
+
+__version__ = "0.1.0"
+
+_LAZY = {
+    "LetkfEngine": "engine", "NeighbourLists": "engine",
+    "GaspariCohn": "localization",
+    "LETKF": "interface", "ETKF": "interface", "LKETKF": "interface", "KETKF": "interface",
+    "RBFKernel": "kernels", "GaussKernel": "kernels", "LinearKernel": "kernels",
+    "ShardedLetkf": "sharded",
+}
+
+
+def __getattr__(name):
+    if name in _LAZY:
+        import importlib
+        mod = importlib.import_module("." + _LAZY[name], __name__)
+        return getattr(mod, name)
+    raise AttributeError(name)

@@ -1,0 +1,61 @@
+"""Builds the gfx950 shared library (C ABI in include/mia_letkf.h) in-tree with hipcc.
+
+hipcc cross-compiles for gfx950 without a GPU; the resulting .so is git-ignored but
+travels with the working tree to the GPU box.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libmia_letkf.so")
+STAMP = os.path.join(LIB_DIR, "libmia_letkf.stamp")
+SOURCES = ["localize.hip", "letkf_generic.hip", "etkf_global.hip", "letkf_wave.hip", "api.cc"]
+HEADERS = ["mia_common.h", os.path.join(ROOT, "include", "mia_letkf.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
+def _sources():
+    return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _digest():
+    h = hashlib.sha256()
+    for f in _sources() + [f if os.path.isabs(f) else os.path.join(CSRC, f) for f in HEADERS]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def hipcc_path():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into lib/libmia_letkf.so (skipped if up to date)."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    dig = _digest()
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(STAMP):
+        with open(STAMP) as fh:
+            if fh.read().strip() == dig:
+                return LIB_PATH
+    cmd = [hipcc_path()] + FLAGS + _sources() + ["-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    with open(STAMP, "w") as fh:
+        fh.write(dig)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,63 @@
+"""ctypes binding of the C ABI declared in include/mia_letkf.h.
+
+There is no CPU fallback: if the gfx950 library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+
+from ._build import LIB_PATH
+
+_lib = None
+
+i32, i64, f32, f64, vp, sz = C.c_int, C.c_int64, C.c_float, C.c_double, C.c_void_p, C.c_size_t
+_PROTOS = {
+    "mia_version": ([], i32),
+    "mia_status_string": ([i32], C.c_char_p),
+    "mia_gaspari_cohn_f64": ([vp, i64, vp, vp], i32),
+    "mia_gaspari_cohn_f32": ([vp, i64, vp, vp], i32),
+    "mia_letkf_localize_workspace_bytes": ([i64, i32, C.POINTER(sz)], i32),
+    "mia_letkf_localize_f64": ([vp, i64, i64, vp, i64, i32, C.POINTER(C.c_int32), C.POINTER(f64), i32, f64,
+                                i32, vp, vp, vp, vp, vp, sz, vp], i32),
+    "mia_letkf_localize_from_dist_f64": ([vp, vp, i64, i32, C.POINTER(f64), i32, f64, vp, vp, vp, vp, vp], i32),
+    "mia_letkf_analysis_workspace_bytes": ([i32, i64, i32, C.POINTER(sz)], i32),
+    "mia_letkf_analysis_f32": ([vp, i64, i32, i32, i64, i64, vp, vp, i64, vp, vp, vp, i32, i32, f32,
+                                vp, i64, i64, vp, vp, vp, sz, vp], i32),
+    "mia_letkf_analysis_f64": ([vp, i64, i32, i32, i64, i64, vp, vp, i64, vp, vp, vp, i32, i32, f64,
+                                vp, i64, i64, vp, vp, vp, sz, vp], i32),
+    "mia_lketkf_rbf_analysis_f32": ([vp, i64, i32, i32, i64, i64, vp, vp, i64, vp, vp, vp, i32, i32, f32, f32,
+                                     vp, i64, i64, vp, vp, vp, sz, vp], i32),
+    "mia_lketkf_rbf_analysis_f64": ([vp, i64, i32, i32, i64, i64, vp, vp, i64, vp, vp, vp, i32, i32, f64, f64,
+                                     vp, i64, i64, vp, vp, vp, sz, vp], i32),
+    "mia_etkf_workspace_bytes": ([i32, i64, i32, C.POINTER(sz)], i32),
+    "mia_etkf_weights_f32": ([vp, vp, i32, i64, f32, vp, vp, vp, sz, vp], i32),
+    "mia_etkf_weights_f64": ([vp, vp, i32, i64, f64, vp, vp, vp, sz, vp], i32),
+    "mia_apply_weights_f32": ([vp, i64, i32, i32, i64, i64, vp, vp, i64, i64, vp], i32),
+    "mia_apply_weights_f64": ([vp, i64, i32, i32, i64, i64, vp, vp, i64, i64, vp], i32),
+}
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+
+class MiaError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) the in-tree gfx950 library; fail loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MiaError(
+                "HIP extension %s not found: run `python -c \"import __graft_entry__ as g; g.build()\"` "
+                "(there is no CPU fallback for the LETKF hot path)" % LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        for name, (args, res) in _PROTOS.items():
+            fn = getattr(h, name)      # AttributeError if the library does not export it
+            fn.argtypes, fn.restype = args, res
+        _lib = h
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().mia_status_string(status).decode()
+        raise MiaError("%s failed with status %d: %s" % (what, status, msg))

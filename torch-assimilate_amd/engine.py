@@ -1,0 +1,219 @@
+"""Array-level host engine: torch-ROCm tensors in, torch-ROCm tensors out, every
+floating-point operation of the hot path done by the gfx950 kernels behind the C ABI.
+
+torch is plumbing here (device memory, streams); nothing in this file computes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+
+from . import _cabi
+
+__all__ = ["LetkfEngine", "NeighbourLists"]
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+@dataclass
+class NeighbourLists:
+    """Per-grid-point local observation lists of one shard [g0, g1)."""
+    cnt: torch.Tensor      # (n,) int32
+    idx: torch.Tensor      # (n, p_cap) int32, -1 padded
+    w: torch.Tensor        # (n, p_cap) float64, sqrt(Gaspari-Cohn weight)
+    p_cap: int
+    p_max: int
+    g0: int
+    g1: int
+
+
+class LetkfEngine:
+    """One engine per process / GPU.  All work is enqueued on the current torch stream of
+    ``device``; results are ordinary device tensors."""
+
+    def __init__(self, device: Optional[torch.device] = None):
+        self.lib = _cabi.lib()
+        if not torch.cuda.is_available():
+            raise _cabi.MiaError("no MI355X visible: the LETKF hot path has no CPU fallback")
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self._ws = {}
+        self._p_cap_hint = 32
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, tag: str, nbytes: int) -> torch.Tensor:
+        cur = self._ws.get(tag)
+        if cur is None or cur.numel() < nbytes:
+            cur = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+            assert cur.data_ptr() % 256 == 0
+            self._ws[tag] = cur
+        return cur
+
+    def _dev(self, a, dtype):
+        t = torch.as_tensor(a)
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    # ------------------------------------------------------------ localisation
+    def gaspari_cohn(self, r: torch.Tensor) -> torch.Tensor:
+        r = r.to(self.device).contiguous()
+        out = torch.empty_like(r)
+        fn = {torch.float64: self.lib.mia_gaspari_cohn_f64, torch.float32: self.lib.mia_gaspari_cohn_f32}[r.dtype]
+        _cabi.check(fn(_ptr(r), r.numel(), _ptr(out), self._stream()), "mia_gaspari_cohn")
+        return out
+
+    def localize(self, grid_xyz, obs_xyz, radii: Sequence[float], coord_group: Optional[Sequence[int]] = None,
+                 eps: float = 1e-5, g0: int = 0, g1: Optional[int] = None,
+                 p_cap: Optional[int] = None) -> NeighbourLists:
+        grid = self._dev(grid_xyz, torch.float64)
+        obs = self._dev(obs_xyz, torch.float64)
+        if grid.dim() == 1:
+            grid = grid[:, None].contiguous()
+        if obs.dim() == 1:
+            obs = obs[:, None].contiguous()
+        G, nc = grid.shape
+        P = obs.shape[0]
+        if P and obs.shape[1] != nc:
+            raise ValueError("grid and observation coordinates differ in dimensionality")
+        g1 = G if g1 is None else g1
+        n = g1 - g0
+        radii = [float(r) for r in (radii if hasattr(radii, "__len__") else [radii])]
+        n_r = len(radii)
+        coord_group = [0] * nc if coord_group is None else [int(c) for c in coord_group]
+        if len(coord_group) != nc:
+            raise ValueError("coord_group needs one entry per coordinate")
+        cg = (C.c_int32 * nc)(*coord_group)
+        rc = (C.c_double * n_r)(*radii)
+        nbytes = C.c_size_t(0)
+        _cabi.check(self.lib.mia_letkf_localize_workspace_bytes(P, nc, C.byref(nbytes)), "localize_workspace_bytes")
+        ws = self._workspace("loc", nbytes.value)
+        stats = torch.empty(2, dtype=torch.int32, device=self.device)
+        cap = int(p_cap) if p_cap is not None else self._p_cap_hint
+        while True:
+            cnt = torch.empty(n, dtype=torch.int32, device=self.device)
+            idx = torch.empty((n, cap), dtype=torch.int32, device=self.device)
+            w = torch.empty((n, cap), dtype=torch.float64, device=self.device)
+            _cabi.check(self.lib.mia_letkf_localize_f64(
+                _ptr(grid), g0, g1, _ptr(obs), P, nc, cg, rc, n_r, float(eps), cap,
+                _ptr(cnt), _ptr(idx), _ptr(w), _ptr(stats), _ptr(ws), ws.numel(), self._stream()),
+                "mia_letkf_localize_f64")
+            p_max, n_over = (int(v) for v in stats.tolist())   # host sync: sizes the analysis launch
+            if n_over == 0:
+                break
+            cap = (p_max + 7) // 8 * 8          # lists were truncated: retry with room for all
+        self._p_cap_hint = max(8, (p_max + 7) // 8 * 8)
+        return NeighbourLists(cnt, idx, w, cap, p_max, g0, g1)
+
+    def localize_from_dist(self, dist, cand_idx, radii: Sequence[float], eps: float = 1e-5,
+                           g0: int = 0) -> NeighbourLists:
+        """dist (n_r, n, p_cap) float64 caller-evaluated distances, cand_idx (n, p_cap) int32 (-1 pad)."""
+        dist = self._dev(dist, torch.float64)
+        if dist.dim() == 2:
+            dist = dist[None]
+        cand = self._dev(cand_idx, torch.int32)
+        n_r, n, cap = dist.shape
+        radii = [float(r) for r in (radii if hasattr(radii, "__len__") else [radii])]
+        if len(radii) != n_r:
+            raise ValueError("one radius per distance component")
+        rc = (C.c_double * n_r)(*radii)
+        cnt = torch.empty(n, dtype=torch.int32, device=self.device)
+        idx = torch.empty((n, cap), dtype=torch.int32, device=self.device)
+        w = torch.empty((n, cap), dtype=torch.float64, device=self.device)
+        stats = torch.empty(2, dtype=torch.int32, device=self.device)
+        _cabi.check(self.lib.mia_letkf_localize_from_dist_f64(
+            _ptr(dist), _ptr(cand), n, cap, rc, n_r, float(eps), _ptr(cnt), _ptr(idx), _ptr(w), _ptr(stats),
+            self._stream()), "mia_letkf_localize_from_dist_f64")
+        p_max = int(stats[0].item())
+        return NeighbourLists(cnt, idx, w, cap, p_max, g0, g0 + n)
+
+    # ---------------------------------------------------------------- analysis
+    def analysis(self, X: torch.Tensor, Yb: torch.Tensor, d: torch.Tensor, nbrs: NeighbourLists,
+                 inf_factor: float = 1.0, return_weights: bool = False, rbf_gamma: Optional[float] = None,
+                 out: Optional[torch.Tensor] = None, out_offset: int = 0, return_flags: bool = False):
+        """X (m, k, G) prior ensemble (grid fastest), Yb (k, P), d (P,): analysis of the shard
+        described by ``nbrs``.  Returns Xa (m, k, n) [, W (n, k, k)] [, flags (n,)]."""
+        if X.dim() == 2:
+            X = X[None]
+        X = X.to(self.device).contiguous()
+        dtype = X.dtype
+        if dtype not in (torch.float32, torch.float64):
+            raise TypeError("state must be float32 or float64")
+        m, k, G = X.shape
+        Yb = Yb.to(device=self.device, dtype=dtype).contiguous()
+        d = d.to(device=self.device, dtype=dtype).contiguous().reshape(-1)
+        if Yb.dim() != 2 or Yb.shape[0] != k:
+            raise ValueError("Yb must be (k, P) with the state's ensemble size")
+        P = Yb.shape[1]
+        if d.shape[0] != P:
+            raise ValueError(
+                "Observational size between ensemble ({0:d}) and observations ({1:d}) do not match!".format(
+                    P, d.shape[0]))
+        n = nbrs.g1 - nbrs.g0
+        if out is None:
+            out = torch.empty((m, k, n), dtype=dtype, device=self.device)
+            out_offset = 0
+        ldo = out.shape[-1]
+        W = torch.empty((n, k, k), dtype=dtype, device=self.device) if return_weights else None
+        flags = torch.empty(n, dtype=torch.int32, device=self.device)
+        eb = 4 if dtype == torch.float32 else 8
+        nbytes = C.c_size_t(0)
+        _cabi.check(self.lib.mia_letkf_analysis_workspace_bytes(k, P, eb, C.byref(nbytes)), "analysis_workspace_bytes")
+        ws = self._workspace("ana", nbytes.value)
+        sfx = "f32" if dtype == torch.float32 else "f64"
+        common = (_ptr(X), G, m, k, nbrs.g0, nbrs.g1, _ptr(Yb), _ptr(d), P, _ptr(nbrs.cnt), _ptr(nbrs.idx),
+                  _ptr(nbrs.w), nbrs.p_cap, nbrs.p_max)
+        tail = (_ptr(out), ldo, out_offset, _ptr(W), _ptr(flags), _ptr(ws), ws.numel(), self._stream())
+        if rbf_gamma is None:
+            fn = getattr(self.lib, "mia_letkf_analysis_" + sfx)
+            _cabi.check(fn(*common, float(inf_factor), *tail), "mia_letkf_analysis_" + sfx)
+        else:
+            fn = getattr(self.lib, "mia_lketkf_rbf_analysis_" + sfx)
+            _cabi.check(fn(*common, float(inf_factor), float(rbf_gamma), *tail), "mia_lketkf_rbf_analysis_" + sfx)
+        res = [out]
+        if return_weights:
+            res.append(W)
+        if return_flags:
+            res.append(flags)
+        return res[0] if len(res) == 1 else tuple(res)
+
+    # ------------------------------------------------------------- global ETKF
+    def etkf_weights(self, Yb: torch.Tensor, d: torch.Tensor, inf_factor: float = 1.0) -> torch.Tensor:
+        Yb = Yb.to(self.device).contiguous()
+        dtype = Yb.dtype
+        d = d.to(device=self.device, dtype=dtype).contiguous().reshape(-1)
+        k, P = Yb.shape
+        if d.shape[0] != P:
+            raise ValueError(
+                "Observational size between ensemble ({0:d}) and observations ({1:d}) do not match!".format(
+                    P, d.shape[0]))
+        eb = 4 if dtype == torch.float32 else 8
+        nbytes = C.c_size_t(0)
+        _cabi.check(self.lib.mia_etkf_workspace_bytes(k, P, eb, C.byref(nbytes)), "etkf_workspace_bytes")
+        ws = self._workspace("etkf", nbytes.value)
+        W = torch.empty((k, k), dtype=dtype, device=self.device)
+        flags = torch.zeros(1, dtype=torch.int32, device=self.device)
+        sfx = "f32" if dtype == torch.float32 else "f64"
+        fn = getattr(self.lib, "mia_etkf_weights_" + sfx)
+        _cabi.check(fn(_ptr(Yb), _ptr(d), k, P, float(inf_factor), _ptr(W), _ptr(flags), _ptr(ws), ws.numel(),
+                       self._stream()), "mia_etkf_weights_" + sfx)
+        return W
+
+    def apply_weights(self, X: torch.Tensor, W: torch.Tensor, g0: int = 0, g1: Optional[int] = None) -> torch.Tensor:
+        if X.dim() == 2:
+            X = X[None]
+        X = X.to(self.device).contiguous()
+        m, k, G = X.shape
+        g1 = G if g1 is None else g1
+        W = W.to(device=self.device, dtype=X.dtype).contiguous()
+        out = torch.empty((m, k, g1 - g0), dtype=X.dtype, device=self.device)
+        sfx = "f32" if X.dtype == torch.float32 else "f64"
+        fn = getattr(self.lib, "mia_apply_weights_" + sfx)
+        _cabi.check(fn(_ptr(X), G, m, k, g0, g1, _ptr(W), _ptr(out), g1 - g0, 0, self._stream()),
+                    "mia_apply_weights_" + sfx)
+        return out
