@@ -126,6 +126,26 @@ int mia_letkf_analysis_f64(const double* X, int64_t ldx, int m, int k, int64_t g
                            double* Xa, int64_t ldo, int64_t o0, double* W_opt, int32_t* flags_opt,
                            void* ws, size_t ws_bytes, void* stream);
 
+/* The same in two steps, so that the packed observation records can be reused across shards /
+ * calls and the analysis kernel can be timed on its own: pack [k][P] (+ d[P]) into obs-major
+ * records rec [P][kp], kp = round_up(k + 1, 4) (what the per-point mask-gather
+ * `arg[..., luse]`, wrapper.py:94-97, reads), then analyse from the records.
+ * gamma <= 0 selects the plain ETKF core, gamma > 0 the RBF-kernelised one. */
+int mia_letkf_pack_obs_f32(const float* Yb, const float* d, int k, int64_t P, float* rec, void* stream);
+int mia_letkf_pack_obs_f64(const double* Yb, const double* d, int k, int64_t P, double* rec, void* stream);
+int mia_letkf_analysis_packed_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                  const float* rec, int64_t P,
+                                  const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w,
+                                  int p_cap, int p_max, float inf_factor, float gamma,
+                                  float* Xa, int64_t ldo, int64_t o0, float* W_opt, int32_t* flags_opt,
+                                  void* stream);
+int mia_letkf_analysis_packed_f64(const double* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                  const double* rec, int64_t P,
+                                  const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w,
+                                  int p_cap, int p_max, double inf_factor, double gamma,
+                                  double* Xa, int64_t ldo, int64_t o0, double* W_opt, int32_t* flags_opt,
+                                  void* stream);
+
 /* Kernelised variant: KETKFModule with RBFKernel(gamma) (core/ketkf.py:65-94,
  * kernels/rbf.py:75-81,110-111), same localisation and transform (LKETKF,
  * interface/lketkf.py:77). */

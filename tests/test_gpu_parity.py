@@ -60,7 +60,7 @@ def test_localize_1d_matches_reference_mask(eng, golden, name, c):
         got = idx[gi, :cnt[gi]]
         order = np.argsort(got)
         np.testing.assert_array_equal(got[order], ref)
-        np.testing.assert_allclose(w[gi, :cnt[gi]][order] ** 2, wt[ref], rtol=1e-12, atol=1e-18)
+        np.testing.assert_allclose(w[gi, :cnt[gi]][order] ** 2, wt[ref], rtol=1e-9, atol=1e-15)
         assert (idx[gi, cnt[gi]:] == -1).all()
     assert nb.p_max == cnt.max()
 
@@ -81,7 +81,7 @@ def test_localize_nd_matches_oracle(eng, nc, groups, radii):
         got = idx[gi, :cnt[gi]]
         order = np.argsort(got)
         np.testing.assert_array_equal(got[order], ref)
-        np.testing.assert_allclose(w[gi, :cnt[gi]][order] ** 2, wt[ref], rtol=1e-11, atol=1e-18)
+        np.testing.assert_allclose(w[gi, :cnt[gi]][order] ** 2, wt[ref], rtol=1e-9, atol=1e-15)
     assert cnt.max() > 16
 
 

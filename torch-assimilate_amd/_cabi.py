@@ -24,6 +24,12 @@ _PROTOS = {
                                 vp, i64, i64, vp, vp, vp, sz, vp], i32),
     "mia_letkf_analysis_f64": ([vp, i64, i32, i32, i64, i64, vp, vp, i64, vp, vp, vp, i32, i32, f64,
                                 vp, i64, i64, vp, vp, vp, sz, vp], i32),
+    "mia_letkf_pack_obs_f32": ([vp, vp, i32, i64, vp, vp], i32),
+    "mia_letkf_pack_obs_f64": ([vp, vp, i32, i64, vp, vp], i32),
+    "mia_letkf_analysis_packed_f32": ([vp, i64, i32, i32, i64, i64, vp, i64, vp, vp, vp, i32, i32, f32, f32,
+                                       vp, i64, i64, vp, vp, vp], i32),
+    "mia_letkf_analysis_packed_f64": ([vp, i64, i32, i32, i64, i64, vp, i64, vp, vp, vp, i32, i32, f64, f64,
+                                       vp, i64, i64, vp, vp, vp], i32),
     "mia_lketkf_rbf_analysis_f32": ([vp, i64, i32, i32, i64, i64, vp, vp, i64, vp, vp, vp, i32, i32, f32, f32,
                                      vp, i64, i64, vp, vp, vp, sz, vp], i32),
     "mia_lketkf_rbf_analysis_f64": ([vp, i64, i32, i32, i64, i64, vp, vp, i64, vp, vp, vp, i32, i32, f64, f64,
@@ -49,6 +55,10 @@ def lib():
             raise MiaError(
                 "HIP extension %s not found: run `python -c \"import __graft_entry__ as g; g.build()\"` "
                 "(there is no CPU fallback for the LETKF hot path)" % LIB_PATH)
+        # torch bundles its own libamdhip64 (SONAME libamdhip64.so.7) but links it as
+        # "libamdhip64.so"; loading ours first would pull /opt/rocm's copy and leave the process
+        # with two HIP runtimes.  Import torch first so both bind to the same runtime.
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, (args, res) in _PROTOS.items():
             fn = getattr(h, name)      # AttributeError if the library does not export it

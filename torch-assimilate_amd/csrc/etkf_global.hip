@@ -203,17 +203,21 @@ extern "C" int mia_etkf_workspace_bytes(int k, int64_t P, int elem_bytes, size_t
 
 extern "C" int mia_etkf_weights_f32(const float* Yb, const float* d, int k, int64_t P, float inf_factor, float* W,
                                     int32_t* flags_opt, void* ws, size_t ws_bytes, void* stream) {
+  (void)hipGetLastError();  // drop stale per-thread error state left by other users of the runtime
   return etkf_weights_impl<float>(Yb, d, k, P, inf_factor, W, flags_opt, ws, ws_bytes, (hipStream_t)stream);
 }
 extern "C" int mia_etkf_weights_f64(const double* Yb, const double* d, int k, int64_t P, double inf_factor,
                                     double* W, int32_t* flags_opt, void* ws, size_t ws_bytes, void* stream) {
+  (void)hipGetLastError();  // drop stale per-thread error state left by other users of the runtime
   return etkf_weights_impl<double>(Yb, d, k, P, inf_factor, W, flags_opt, ws, ws_bytes, (hipStream_t)stream);
 }
 extern "C" int mia_apply_weights_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
                                      const float* W, float* Xa, int64_t ldo, int64_t o0, void* stream) {
+  (void)hipGetLastError();  // drop stale per-thread error state left by other users of the runtime
   return apply_weights_impl<float>(X, ldx, m, k, g0, g1, W, Xa, ldo, o0, (hipStream_t)stream);
 }
 extern "C" int mia_apply_weights_f64(const double* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
                                      const double* W, double* Xa, int64_t ldo, int64_t o0, void* stream) {
+  (void)hipGetLastError();  // drop stale per-thread error state left by other users of the runtime
   return apply_weights_impl<double>(X, ldx, m, k, g0, g1, W, Xa, ldo, o0, (hipStream_t)stream);
 }

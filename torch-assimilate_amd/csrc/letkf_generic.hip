@@ -62,8 +62,8 @@ __global__ __launch_bounds__(NT) void letkf_generic_kernel(AnaParams<T> P) {
   T* sb = qb + nmax;                 // [nmax]
   T* red = sb + nmax;                // [4]
   int* iflag = reinterpret_cast<int*>(red + 4);  // [4]
-  T* Mq = reinterpret_cast<T*>(iflag + 4);       // [k][lda] only when W is requested
-  int* lidx = reinterpret_cast<int*>(Mq + (P.W ? (size_t)k * lda : 0));  // [pm + 1]
+  T* Mq = reinterpret_cast<T*>(iflag + 4);       // [k][lda] only for W output on the dual route (primal: M = V)
+  int* lidx = reinterpret_cast<int*>(Mq + ((P.W && P.dual) ? (size_t)k * lda : 0));  // [pm + 1]
   T* lw = reinterpret_cast<T*>(lidx + ((pm + 2) & ~1));                  // [pm + 1]
 
   const T km1 = T(k - 1);
@@ -273,19 +273,22 @@ __global__ __launch_bounds__(NT) void letkf_generic_kernel(AnaParams<T> P) {
     }
     // ---- optional weights output: w_mean_i + f0*delta_ij + sum_r gW_r M_ir M_jr,  M = B V
     if (P.W) {
-      for (int it = tid; it < k * n; it += NT) {
-        const int i = it / n, r = it - i * n;
-        T acc;
-        if (P.dual) { acc = T(0); for (int b = 0; b < cnt; ++b) acc += Yl[i * ldy + b] * V[b * lda + r]; }
-        else acc = V[i * lda + r];
-        Mq[i * lda + r] = acc;
+      const T* Mm = V;
+      if (P.dual) {
+        for (int it = tid; it < k * n; it += NT) {
+          const int i = it / n, r = it - i * n;
+          T acc = T(0);
+          for (int b = 0; b < cnt; ++b) acc += Yl[i * ldy + b] * V[b * lda + r];
+          Mq[i * lda + r] = acc;
+        }
+        Mm = Mq;
+        __syncthreads();
       }
-      __syncthreads();
       T* wout = P.W + pt * (int64_t)k * k;
       for (int it = tid; it < k * k; it += NT) {
         const int i = it / k, j = it - i * k;
         T acc = wbar[i] + (i == j ? f0 : T(0));
-        for (int r = 0; r < n; ++r) acc += gW[r] * Mq[i * lda + r] * Mq[j * lda + r];
+        for (int r = 0; r < n; ++r) acc += gW[r] * Mm[i * lda + r] * Mm[j * lda + r];
         wout[it] = acc;
       }
     }
@@ -324,21 +327,33 @@ __global__ __launch_bounds__(256) void pack_obs_kernel(const T* Yb, const T* d, 
 }
 
 template <typename T>
-static size_t generic_lds_bytes(int k, int p_max, int nmax, int lda, int ldy, bool want_w) {
+static size_t generic_lds_bytes(int k, int p_max, int nmax, int lda, int ldy, bool want_mq) {
   size_t e = (size_t)k * ldy + (p_max + 2) + 2 * (size_t)nmax * lda + 5 * (size_t)nmax + 2 * (size_t)k +
              3 * (size_t)nmax + 4;
   size_t b = e * sizeof(T) + 4 * sizeof(int);
-  if (want_w) b += (size_t)k * lda * sizeof(T);
+  if (want_mq) b += (size_t)k * lda * sizeof(T);
   b += (size_t)((p_max + 2) & ~1) * sizeof(int) + (size_t)(p_max + 2) * sizeof(T);
   return align_up(b, 16);
 }
 
 template <typename T>
-static int analysis_impl(const T* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1, const T* Yb,
-                         const T* d, int64_t P, const int32_t* nbr_cnt, const int32_t* nbr_idx,
-                         const double* nbr_w, int p_cap, int p_max, T inf_factor, int kernel_mode, T gamma,
-                         T* Xa, int64_t ldo, int64_t o0, T* W_opt, int32_t* flags_opt, void* ws,
-                         size_t ws_bytes, hipStream_t stream) {
+static int pack_impl(const T* Yb, const T* d, int k, int64_t P, T* rec, hipStream_t stream) {
+  if (k < 2 || P < 0) return MIA_ERR_SIZE;
+  if (P == 0) return MIA_OK;
+  if (!Yb || !d || !rec) return MIA_ERR_NULL;
+  if (((uintptr_t)rec) & 15) return MIA_ERR_ALIGN;
+  const int kp = (k + 1 + 3) & ~3;
+  if ((P + 31) / 32 > 2147483647LL) return MIA_ERR_UNSUPPORTED;
+  pack_obs_kernel<T><<<dim3((unsigned)((P + 31) / 32)), dim3(256), 0, stream>>>(Yb, d, k, P, kp, rec);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+template <typename T>
+static int analysis_packed_impl(const T* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1, const T* rec,
+                                int64_t P, const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w,
+                                int p_cap, int p_max, T inf_factor, int kernel_mode, T gamma, T* Xa, int64_t ldo,
+                                int64_t o0, T* W_opt, int32_t* flags_opt, hipStream_t stream) {
   if (g1 < g0 || g0 < 0 || m < 1 || k < 2 || P < 0 || p_cap < 1 || p_max < 0) return MIA_ERR_SIZE;
   if (!(inf_factor > T(0))) return MIA_ERR_SIZE;
   const int64_t ng = g1 - g0;
@@ -346,18 +361,8 @@ static int analysis_impl(const T* X, int64_t ldx, int m, int k, int64_t g0, int6
   if (!X || !Xa || !nbr_cnt || !nbr_idx || !nbr_w) return MIA_ERR_NULL;
   if (ldx < g1 || ldo < o0 + ng) return MIA_ERR_SIZE;
   if (p_max > p_cap) p_max = p_cap;
-  if (P > 0 && (!Yb || !d || !ws)) return MIA_ERR_NULL;
-  size_t need = 0;
-  int rc = mia_letkf_analysis_workspace_bytes(k, P, (int)sizeof(T), &need);
-  if (rc != MIA_OK) return rc;
-  if (ws_bytes < need) return MIA_ERR_WORKSPACE;
-  if (P > 0 && (((uintptr_t)ws) & 255)) return MIA_ERR_ALIGN;
+  if (P > 0 && !rec) return MIA_ERR_NULL;
   const int kp = (k + 1 + 3) & ~3;
-  T* rec = (T*)ws;
-  if (P > 0) {
-    pack_obs_kernel<T><<<dim3((unsigned)((P + 31) / 32)), dim3(256), 0, stream>>>(Yb, d, k, P, kp, rec);
-    MIA_LAUNCH_CHECK();
-  }
   AnaParams<T> ap;
   ap.X = X; ap.ldx = ldx; ap.m = m; ap.k = k; ap.g0 = g0; ap.ng = ng; ap.rec = rec; ap.kp = kp;
   ap.cnt = nbr_cnt; ap.idx = nbr_idx; ap.w = nbr_w; ap.p_cap = p_cap; ap.p_max = p_max;
@@ -372,7 +377,7 @@ static int analysis_impl(const T* X, int64_t ldx, int m, int k, int64_t g0, int6
   ap.ldy = (p_max + 1) | 1;
   ap.max_sweeps = sizeof(T) == 4 ? 16 : 24;
   ap.tol = sizeof(T) == 4 ? T(2.4e-7) : T(9e-16);
-  const size_t lds = generic_lds_bytes<T>(k, p_max, ap.nmax, ap.lda, ap.ldy, W_opt != nullptr);
+  const size_t lds = generic_lds_bytes<T>(k, p_max, ap.nmax, ap.lda, ap.ldy, W_opt != nullptr && ap.dual);
   if (lds > 160 * 1024) return MIA_ERR_UNSUPPORTED;
   const bool big = ap.nmax > 32;
   // enough workgroups to fill 256 CUs several times over, but contiguous runs per workgroup
@@ -395,6 +400,25 @@ static int analysis_impl(const T* X, int64_t ldx, int m, int k, int64_t g0, int6
   return MIA_OK;
 }
 
+template <typename T>
+static int analysis_impl(const T* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1, const T* Yb,
+                         const T* d, int64_t P, const int32_t* nbr_cnt, const int32_t* nbr_idx,
+                         const double* nbr_w, int p_cap, int p_max, T inf_factor, int kernel_mode, T gamma,
+                         T* Xa, int64_t ldo, int64_t o0, T* W_opt, int32_t* flags_opt, void* ws,
+                         size_t ws_bytes, hipStream_t stream) {
+  if (k < 2 || P < 0) return MIA_ERR_SIZE;
+  if (P > 0 && (!Yb || !d || !ws)) return MIA_ERR_NULL;
+  size_t need = 0;
+  int rc = mia_letkf_analysis_workspace_bytes(k, P, (int)sizeof(T), &need);
+  if (rc != MIA_OK) return rc;
+  if (ws_bytes < need) return MIA_ERR_WORKSPACE;
+  if (P > 0 && (((uintptr_t)ws) & 255)) return MIA_ERR_ALIGN;
+  rc = pack_impl<T>(Yb, d, k, P, (T*)ws, stream);
+  if (rc != MIA_OK) return rc;
+  return analysis_packed_impl<T>(X, ldx, m, k, g0, g1, (const T*)ws, P, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max,
+                                 inf_factor, kernel_mode, gamma, Xa, ldo, o0, W_opt, flags_opt, stream);
+}
+
 }  // namespace mia
 
 using namespace mia;
@@ -412,6 +436,7 @@ extern "C" int mia_letkf_analysis_f32(const float* X, int64_t ldx, int m, int k,
                                       const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
                                       float inf_factor, float* Xa, int64_t ldo, int64_t o0, float* W_opt,
                                       int32_t* flags_opt, void* ws, size_t ws_bytes, void* stream) {
+  (void)hipGetLastError();  // drop stale per-thread error state left by other users of the runtime
   return analysis_impl<float>(X, ldx, m, k, g0, g1, Yb, d, P, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max,
                               inf_factor, 0, 0.0f, Xa, ldo, o0, W_opt, flags_opt, ws, ws_bytes,
                               (hipStream_t)stream);
@@ -422,6 +447,7 @@ extern "C" int mia_letkf_analysis_f64(const double* X, int64_t ldx, int m, int k
                                       const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
                                       double inf_factor, double* Xa, int64_t ldo, int64_t o0, double* W_opt,
                                       int32_t* flags_opt, void* ws, size_t ws_bytes, void* stream) {
+  (void)hipGetLastError();  // drop stale per-thread error state left by other users of the runtime
   return analysis_impl<double>(X, ldx, m, k, g0, g1, Yb, d, P, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max,
                                inf_factor, 0, 0.0, Xa, ldo, o0, W_opt, flags_opt, ws, ws_bytes,
                                (hipStream_t)stream);
@@ -433,6 +459,7 @@ extern "C" int mia_lketkf_rbf_analysis_f32(const float* X, int64_t ldx, int m, i
                                            float inf_factor, float gamma, float* Xa, int64_t ldo, int64_t o0,
                                            float* W_opt, int32_t* flags_opt, void* ws, size_t ws_bytes,
                                            void* stream) {
+  (void)hipGetLastError();  // drop stale per-thread error state left by other users of the runtime
   if (!(gamma > 0.0f)) return MIA_ERR_SIZE;
   return analysis_impl<float>(X, ldx, m, k, g0, g1, Yb, d, P, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max,
                               inf_factor, 1, gamma, Xa, ldo, o0, W_opt, flags_opt, ws, ws_bytes,
@@ -445,8 +472,36 @@ extern "C" int mia_lketkf_rbf_analysis_f64(const double* X, int64_t ldx, int m, 
                                            double inf_factor, double gamma, double* Xa, int64_t ldo, int64_t o0,
                                            double* W_opt, int32_t* flags_opt, void* ws, size_t ws_bytes,
                                            void* stream) {
+  (void)hipGetLastError();  // drop stale per-thread error state left by other users of the runtime
   if (!(gamma > 0.0)) return MIA_ERR_SIZE;
   return analysis_impl<double>(X, ldx, m, k, g0, g1, Yb, d, P, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max,
                                inf_factor, 1, gamma, Xa, ldo, o0, W_opt, flags_opt, ws, ws_bytes,
                                (hipStream_t)stream);
+}
+
+extern "C" int mia_letkf_pack_obs_f32(const float* Yb, const float* d, int k, int64_t P, float* rec, void* stream) {
+  (void)hipGetLastError();
+  return pack_impl<float>(Yb, d, k, P, rec, (hipStream_t)stream);
+}
+extern "C" int mia_letkf_pack_obs_f64(const double* Yb, const double* d, int k, int64_t P, double* rec, void* stream) {
+  (void)hipGetLastError();
+  return pack_impl<double>(Yb, d, k, P, rec, (hipStream_t)stream);
+}
+extern "C" int mia_letkf_analysis_packed_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                             const float* rec, int64_t P, const int32_t* nbr_cnt,
+                                             const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
+                                             float inf_factor, float gamma, float* Xa, int64_t ldo, int64_t o0,
+                                             float* W_opt, int32_t* flags_opt, void* stream) {
+  (void)hipGetLastError();
+  return analysis_packed_impl<float>(X, ldx, m, k, g0, g1, rec, P, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
+                                     gamma > 0.0f ? 1 : 0, gamma, Xa, ldo, o0, W_opt, flags_opt, (hipStream_t)stream);
+}
+extern "C" int mia_letkf_analysis_packed_f64(const double* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                             const double* rec, int64_t P, const int32_t* nbr_cnt,
+                                             const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
+                                             double inf_factor, double gamma, double* Xa, int64_t ldo, int64_t o0,
+                                             double* W_opt, int32_t* flags_opt, void* stream) {
+  (void)hipGetLastError();
+  return analysis_packed_impl<double>(X, ldx, m, k, g0, g1, rec, P, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
+                                      gamma > 0.0 ? 1 : 0, gamma, Xa, ldo, o0, W_opt, flags_opt, (hipStream_t)stream);
 }

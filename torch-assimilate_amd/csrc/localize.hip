@@ -298,6 +298,7 @@ static int cell_cap_for(int64_t P) {
 using namespace mia;
 
 extern "C" int mia_gaspari_cohn_f64(const double* r, int64_t n, double* w, void* stream) {
+  (void)hipGetLastError();  // drop stale per-thread error state left by other users of the runtime
   if (n < 0) return MIA_ERR_SIZE;
   if (n == 0) return MIA_OK;
   if (!r || !w) return MIA_ERR_NULL;
@@ -309,6 +310,7 @@ extern "C" int mia_gaspari_cohn_f64(const double* r, int64_t n, double* w, void*
 }
 
 extern "C" int mia_gaspari_cohn_f32(const float* r, int64_t n, float* w, void* stream) {
+  (void)hipGetLastError();  // drop stale per-thread error state left by other users of the runtime
   if (n < 0) return MIA_ERR_SIZE;
   if (n == 0) return MIA_OK;
   if (!r || !w) return MIA_ERR_NULL;
@@ -339,6 +341,7 @@ extern "C" int mia_letkf_localize_f64(const double* grid_xyz, int64_t g0, int64_
                                       double gc_eps, int p_cap, int32_t* nbr_cnt, int32_t* nbr_idx,
                                       double* nbr_w, int32_t* stats, void* ws, size_t ws_bytes,
                                       void* stream_) {
+  (void)hipGetLastError();  // drop stale per-thread error state left by other users of the runtime
   hipStream_t stream = (hipStream_t)stream_;
   if (g1 < g0 || g0 < 0 || P < 0) return MIA_ERR_SIZE;
   if (n_coord < 1 || n_coord > MIA_MAX_COORD || n_r < 1 || n_r > MIA_MAX_RADII || p_cap < 1) return MIA_ERR_SIZE;
@@ -403,6 +406,7 @@ extern "C" int mia_letkf_localize_from_dist_f64(const double* dist, const int32_
                                                 int64_t n_pts, int p_cap, const double* gc_c, int n_r,
                                                 double gc_eps, int32_t* nbr_cnt, int32_t* nbr_idx,
                                                 double* nbr_w, int32_t* stats, void* stream_) {
+  (void)hipGetLastError();  // drop stale per-thread error state left by other users of the runtime
   hipStream_t stream = (hipStream_t)stream_;
   if (n_pts < 0 || p_cap < 1 || n_r < 1 || n_r > MIA_MAX_RADII) return MIA_ERR_SIZE;
   if (!gc_c || !stats) return MIA_ERR_NULL;

@@ -133,11 +133,32 @@ class LetkfEngine:
         return NeighbourLists(cnt, idx, w, cap, p_max, g0, g0 + n)
 
     # ---------------------------------------------------------------- analysis
-    def analysis(self, X: torch.Tensor, Yb: torch.Tensor, d: torch.Tensor, nbrs: NeighbourLists,
-                 inf_factor: float = 1.0, return_weights: bool = False, rbf_gamma: Optional[float] = None,
-                 out: Optional[torch.Tensor] = None, out_offset: int = 0, return_flags: bool = False):
-        """X (m, k, G) prior ensemble (grid fastest), Yb (k, P), d (P,): analysis of the shard
-        described by ``nbrs``.  Returns Xa (m, k, n) [, W (n, k, k)] [, flags (n,)]."""
+    def pack_obs(self, Yb: torch.Tensor, d: torch.Tensor, dtype=None) -> torch.Tensor:
+        """(k, P) perturbations + (P,) innovations -> obs-major records (P, kp) on the device."""
+        dtype = dtype or (Yb.dtype if Yb.dtype in (torch.float32, torch.float64) else torch.float32)
+        Yb = Yb.to(device=self.device, dtype=dtype).contiguous()
+        d = d.to(device=self.device, dtype=dtype).contiguous().reshape(-1)
+        if Yb.dim() != 2:
+            raise ValueError("Yb must be (k, P)")
+        k, P = Yb.shape
+        if d.shape[0] != P:
+            raise ValueError(
+                "Observational size between ensemble ({0:d}) and observations ({1:d}) do not match!".format(
+                    P, d.shape[0]))
+        kp = (k + 1 + 3) // 4 * 4
+        rec = torch.empty((max(P, 1), kp), dtype=dtype, device=self.device)
+        sfx = "f32" if dtype == torch.float32 else "f64"
+        fn = getattr(self.lib, "mia_letkf_pack_obs_" + sfx)
+        _cabi.check(fn(_ptr(Yb), _ptr(d), k, P, _ptr(rec), self._stream()), "mia_letkf_pack_obs_" + sfx)
+        return rec[:P]
+
+    def analysis(self, X: torch.Tensor, Yb: Optional[torch.Tensor], d: Optional[torch.Tensor],
+                 nbrs: NeighbourLists, inf_factor: float = 1.0, return_weights: bool = False,
+                 rbf_gamma: Optional[float] = None, out: Optional[torch.Tensor] = None, out_offset: int = 0,
+                 return_flags: bool = False, rec: Optional[torch.Tensor] = None):
+        """X (m, k, G) prior ensemble (grid fastest), Yb (k, P), d (P,) [or their packed records
+        ``rec`` from :meth:`pack_obs`]: analysis of the shard described by ``nbrs``.
+        Returns Xa (m, k, n) [, W (n, k, k)] [, flags (n,)]."""
         if X.dim() == 2:
             X = X[None]
         X = X.to(self.device).contiguous()
@@ -145,15 +166,13 @@ class LetkfEngine:
         if dtype not in (torch.float32, torch.float64):
             raise TypeError("state must be float32 or float64")
         m, k, G = X.shape
-        Yb = Yb.to(device=self.device, dtype=dtype).contiguous()
-        d = d.to(device=self.device, dtype=dtype).contiguous().reshape(-1)
-        if Yb.dim() != 2 or Yb.shape[0] != k:
-            raise ValueError("Yb must be (k, P) with the state's ensemble size")
-        P = Yb.shape[1]
-        if d.shape[0] != P:
-            raise ValueError(
-                "Observational size between ensemble ({0:d}) and observations ({1:d}) do not match!".format(
-                    P, d.shape[0]))
+        if rec is None:
+            if Yb.dim() != 2 or Yb.shape[0] != k:
+                raise ValueError("Yb must be (k, P) with the state's ensemble size")
+            rec = self.pack_obs(Yb, d, dtype)
+        if rec.dtype != dtype or rec.shape[1] != (k + 1 + 3) // 4 * 4:
+            raise ValueError("packed records do not match the state's dtype / ensemble size")
+        P = rec.shape[0]
         n = nbrs.g1 - nbrs.g0
         if out is None:
             out = torch.empty((m, k, n), dtype=dtype, device=self.device)
@@ -161,20 +180,13 @@ class LetkfEngine:
         ldo = out.shape[-1]
         W = torch.empty((n, k, k), dtype=dtype, device=self.device) if return_weights else None
         flags = torch.empty(n, dtype=torch.int32, device=self.device)
-        eb = 4 if dtype == torch.float32 else 8
-        nbytes = C.c_size_t(0)
-        _cabi.check(self.lib.mia_letkf_analysis_workspace_bytes(k, P, eb, C.byref(nbytes)), "analysis_workspace_bytes")
-        ws = self._workspace("ana", nbytes.value)
         sfx = "f32" if dtype == torch.float32 else "f64"
-        common = (_ptr(X), G, m, k, nbrs.g0, nbrs.g1, _ptr(Yb), _ptr(d), P, _ptr(nbrs.cnt), _ptr(nbrs.idx),
-                  _ptr(nbrs.w), nbrs.p_cap, nbrs.p_max)
-        tail = (_ptr(out), ldo, out_offset, _ptr(W), _ptr(flags), _ptr(ws), ws.numel(), self._stream())
-        if rbf_gamma is None:
-            fn = getattr(self.lib, "mia_letkf_analysis_" + sfx)
-            _cabi.check(fn(*common, float(inf_factor), *tail), "mia_letkf_analysis_" + sfx)
-        else:
-            fn = getattr(self.lib, "mia_lketkf_rbf_analysis_" + sfx)
-            _cabi.check(fn(*common, float(inf_factor), float(rbf_gamma), *tail), "mia_lketkf_rbf_analysis_" + sfx)
+        fn = getattr(self.lib, "mia_letkf_analysis_packed_" + sfx)
+        _cabi.check(fn(_ptr(X), G, m, k, nbrs.g0, nbrs.g1, _ptr(rec), P, _ptr(nbrs.cnt), _ptr(nbrs.idx),
+                       _ptr(nbrs.w), nbrs.p_cap, nbrs.p_max, float(inf_factor),
+                       float(rbf_gamma) if rbf_gamma is not None else 0.0,
+                       _ptr(out), ldo, out_offset, _ptr(W), _ptr(flags), self._stream()),
+                    "mia_letkf_analysis_packed_" + sfx)
         res = [out]
         if return_weights:
             res.append(W)
