@@ -23,7 +23,15 @@
 #include "mia_common.h"
 #include "mia_jacobi.h"
 
+#include <cstdlib>
+
 namespace mia {
+
+template <typename T>
+int wave_analysis_launch(const T* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const T* rec,
+                         const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap,
+                         int p_max, T inf_factor, int kernel_mode, T gamma, T* Xa, int64_t ldo, int64_t o0,
+                         T* W_opt, int32_t* flags_opt, hipStream_t stream);
 
 template <typename T>
 struct AnaParams {
@@ -363,6 +371,9 @@ static int analysis_packed_impl(const T* X, int64_t ldx, int m, int k, int64_t g
   if (p_max > p_cap) p_max = p_cap;
   if (P > 0 && !rec) return MIA_ERR_NULL;
   const int kp = (k + 1 + 3) & ~3;
+  if (!getenv("MIA_USE_GENERIC_KERNEL"))   // default: second-generation kernel (letkf_wave.hip)
+    return wave_analysis_launch<T>(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
+                                   kernel_mode, gamma, Xa, ldo, o0, W_opt, flags_opt, stream);
   AnaParams<T> ap;
   ap.X = X; ap.ldx = ldx; ap.m = m; ap.k = k; ap.g0 = g0; ap.ng = ng; ap.rec = rec; ap.kp = kp;
   ap.cnt = nbr_cnt; ap.idx = nbr_idx; ap.w = nbr_w; ap.p_cap = p_cap; ap.p_max = p_max;

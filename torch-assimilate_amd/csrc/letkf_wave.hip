@@ -1,0 +1,438 @@
+// Fused per-grid-point LETKF analysis for gfx950, second generation ("wave" kernel).
+//
+// Same mathematics and reference citations as letkf_generic.hip (mask/scale wrapper.py:91-97,
+// Gram utils.py:172, eigensolve + clamp + shift utils.py:57-60 / etkf.py:67, w_mean and W
+// etkf.py:70-76, transform base.py:257-278; RBF route ketkf.py:65-94), restructured around the
+// measured bottleneck of the first kernel (instruction issue: ~1.1e5 wave-instructions per
+// analysis, most of them integer modulo arithmetic and a poorly mapped eigenvector update):
+//
+//  * one 64-lane wavefront owns one grid point (NT = 64; NT = 256 for orders > 44), the local
+//    block lives in LDS in the obs-major layout of the packed records, so the gather is a
+//    scaled float4 copy;
+//  * the symmetric matrix is kept ONCE (canonical upper-triangle addressing), so a Jacobi round
+//    updates n/2 diagonal 2x2 blocks (done by the lanes that also derive the rotations) and
+//    (n/2)(n/2-1)/2 off-diagonal blocks - half the work of a full-storage update;
+//  * tournament indices come from add/compare/select (no division, no tables), the block ->
+//    (pair, pair) decode is a table built once per workgroup;
+//  * rounds in which no pair exceeds the threshold skip the block/eigenvector update
+//    (one barrier + reduction decides, wave-uniformly);
+//  * eigenvector rows are mapped (pair = lane % pairs, row = lane / pairs) so each lane keeps
+//    one rotation for all its rows.
+#include <type_traits>
+#include "mia_common.h"
+#include "mia_jacobi.h"
+
+namespace mia {
+
+template <typename T>
+struct WaveParams {
+  const T* X; int64_t ldx; int m; int k;
+  int64_t g0, ng;
+  const T* rec; int kp;
+  const int32_t* cnt; const int32_t* idx; const double* w; int p_cap; int p_max;
+  T reg; T* Xa; int64_t ldo, o0; T* W; int32_t* flags;
+  int dual; int nmax; int lda; int rows; int pts_per_block; int max_sweeps; T tol2;
+  int kernel_mode; T gamma;
+};
+
+template <typename T> struct Vec4 { T x, y, z, w; };
+
+__device__ inline int wrap_up(int v, int n1) { return v >= n1 ? v - n1 : v; }
+__device__ inline int wrap_dn(int v, int n1) { return v < 0 ? v + n1 : v; }
+
+// pair i of round r in the round-robin tournament on n players (n even): player n-1 stays,
+// the others rotate; every unordered pair meets exactly once in n-1 rounds.
+__device__ inline void pair_of(int r, int i, int n1, int& p, int& q) {
+  p = wrap_up(r + i, n1);
+  q = (i == 0) ? n1 : wrap_dn(r - i, n1);
+}
+
+template <typename T>
+__device__ inline T& sym(T* S, int lda, int x, int y) {   // canonical (upper) element of a symmetric matrix
+  const int lo = x < y ? x : y, hi = x < y ? y : x;
+  return S[lo * lda + hi];
+}
+
+// Threshold parallel-order Jacobi, symmetric matrix in canonical upper storage.
+// V (nv rows x n) accumulates rotations.  Returns true when a full sweep needed no rotation.
+template <typename T, int NT>
+__device__ bool jacobi_sym(T* S, T* V, T* cs, const unsigned short* dec, int n, int nv, int lda, T shift,
+                           T tol2, int max_sweeps) {
+  if (n < 2) return true;
+  const int tid = threadIdx.x;
+  const int nb = n >> 1, n1 = n - 1;
+  const int noff = nb * (nb - 1) / 2;
+  // eigenvector mapping: lane -> (pair vj, first row vr0), rows advance by vstep per pass
+  const int vstep = NT / nb;
+  const int vj = tid % nb, vr0 = tid / nb;
+  const bool vact = vr0 < vstep;
+  bool converged = false;
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+    int rotated = 0;
+    for (int r = 0; r < n1; ++r) {
+      // ---- step 1: rotation of every pair + its diagonal block
+      int rot = 0;
+      for (int i = tid; i < nb; i += NT) {
+        int p, q;
+        pair_of(r, i, n1, p, q);
+        const T app = S[p * lda + p], aqq = S[q * lda + q];
+        T& rpq = sym(S, lda, p, q);
+        const T apq = rpq;
+        T c = T(1), s = T(0);
+        if (apq * apq > tol2 * (t_abs(app) + shift) * (t_abs(aqq) + shift)) {
+          const T tau = (aqq - app) / (T(2) * apq);
+          const T t = (tau >= T(0) ? T(1) : T(-1)) / (t_abs(tau) + t_sqrt(T(1) + tau * tau));
+          c = T(1) / t_sqrt(T(1) + t * t);
+          s = t * c;
+          S[p * lda + p] = app - t * apq;
+          S[q * lda + q] = aqq + t * apq;
+          rpq = T(0);
+          rot = 1;
+        }
+        cs[2 * i] = c; cs[2 * i + 1] = s;
+      }
+      if (!__syncthreads_or(rot)) continue;   // nothing to rotate in this round (uniform)
+      rotated = 1;
+      // ---- step 2a: off-diagonal 2x2 blocks  B <- R1^T B R2
+      for (int it = tid; it < noff; it += NT) {
+        const int d = dec[it];
+        const int bi = d & 0xff, bj = d >> 8;
+        const T c1 = cs[2 * bi], s1 = cs[2 * bi + 1], c2 = cs[2 * bj], s2 = cs[2 * bj + 1];
+        if (s1 == T(0) && s2 == T(0)) continue;
+        int p1, q1, p2, q2;
+        pair_of(r, bi, n1, p1, q1);
+        pair_of(r, bj, n1, p2, q2);
+        T& e00 = sym(S, lda, p1, p2); T& e01 = sym(S, lda, p1, q2);
+        T& e10 = sym(S, lda, q1, p2); T& e11 = sym(S, lda, q1, q2);
+        const T a00 = e00, a01 = e01, a10 = e10, a11 = e11;
+        const T b00 = c1 * a00 - s1 * a10, b01 = c1 * a01 - s1 * a11;
+        const T b10 = s1 * a00 + c1 * a10, b11 = s1 * a01 + c1 * a11;
+        e00 = c2 * b00 - s2 * b01; e01 = s2 * b00 + c2 * b01;
+        e10 = c2 * b10 - s2 * b11; e11 = s2 * b10 + c2 * b11;
+      }
+      // ---- step 2b: eigenvectors  V <- V J
+      if (vact) {
+        const T c2 = cs[2 * vj], s2 = cs[2 * vj + 1];
+        if (s2 != T(0)) {
+          int p2, q2;
+          pair_of(r, vj, n1, p2, q2);
+          for (int row = vr0; row < nv; row += vstep) {
+            const T v0 = V[row * lda + p2], v1 = V[row * lda + q2];
+            V[row * lda + p2] = c2 * v0 - s2 * v1;
+            V[row * lda + q2] = s2 * v0 + c2 * v1;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (!rotated) { converged = true; break; }
+  }
+  return converged;
+}
+
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void letkf_wave_kernel(WaveParams<T> P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const int k = P.k, kp = P.kp, pm = P.p_max, nmax = P.nmax, lda = P.lda, rows = P.rows;
+  T* Yt = reinterpret_cast<T*>(smem_raw);   // [rows][kp]  obs-major local block: yb[0..k), d, pad
+  T* S = Yt + (size_t)rows * kp;            // [nmax][lda]  canonical upper storage
+  T* V = S + (size_t)nmax * lda;            // [nmax][lda]
+  T* cs = V + (size_t)nmax * lda;           // [nmax]
+  T* gW = cs + nmax;                        // [nmax]
+  T* gM = gW + nmax;                        // [nmax]
+  T* av = gM + nmax;                        // [nmax]
+  T* uv = av + nmax;                        // [nmax]
+  T* zb = uv + nmax;                        // [nmax]
+  T* qb = zb + nmax;                        // [nmax]
+  T* sb = qb + nmax;                        // [nmax]
+  T* xp = sb + nmax;                        // [k]
+  T* wbar = xp + k;                         // [k]
+  T* red = wbar + k;                        // [8]
+  T* lw = red + 8;                          // [pm + 2]
+  int* lidx = reinterpret_cast<int*>(lw + ((pm + 2 + 1) & ~1));   // [pm + 2]
+  int* iflag = lidx + ((pm + 2 + 1) & ~1);                        // [4]
+  unsigned short* dec = reinterpret_cast<unsigned short*>(iflag + 4);  // [nbmax*(nbmax-1)/2]
+  const int nbmax = nmax >> 1;
+  const int ndec = nbmax * (nbmax - 1) / 2;
+  T* Mq = reinterpret_cast<T*>(dec + ((ndec + 7) & ~7));          // [k][lda] (W on the dual route)
+
+  // block (bi < bj) enumeration bj-major: valid for every order n <= nmax
+  for (int it = tid; it < ndec; it += NT) {
+    int bj = 1;
+    while ((bj + 1) * bj / 2 <= it) ++bj;
+    const int bi = it - bj * (bj - 1) / 2;
+    dec[it] = (unsigned short)(bi | (bj << 8));
+  }
+
+  const T km1 = T(k - 1);
+  const T reg = P.reg;
+  const T f0 = P.dual ? t_sqrt(km1 / reg) : T(0);
+
+  const int64_t pt_begin = (int64_t)blockIdx.x * P.pts_per_block;
+  int64_t pt_end = pt_begin + P.pts_per_block;
+  if (pt_end > P.ng) pt_end = P.ng;
+
+  for (int64_t pt = pt_begin; pt < pt_end; ++pt) {
+    const int64_t g = P.g0 + pt;
+    const int cnt = P.cnt[pt];
+    int flag = 0;
+    __syncthreads();
+    if (cnt > pm || cnt > P.p_cap) {   // loud failure: never analyse with a truncated list
+      if (P.flags && tid == 0) P.flags[pt] = MIA_FLAG_OVERFLOW;
+      const T nanv = T(__builtin_nanf(""));
+      for (int it = tid; it < P.m * k; it += NT) P.Xa[(int64_t)it * P.ldo + P.o0 + pt] = nanv;
+      if (P.W) for (int it = tid; it < k * k; it += NT) P.W[pt * (int64_t)k * k + it] = nanv;
+      continue;
+    }
+    for (int j = tid; j < cnt; j += NT) {
+      lidx[j] = P.idx[pt * P.p_cap + j];
+      lw[j] = T(P.w[pt * P.p_cap + j]);
+    }
+    __syncthreads();
+    // ---- gather + sqrt(rho) scale: records are 16-byte aligned rows of kp elements
+    {
+      constexpr int VW = 16 / sizeof(T);
+      const int kpv = kp / VW;
+      using VT = typename std::conditional<sizeof(T) == 4, float4, double2>::type;
+      for (int it = tid; it < cnt * kpv; it += NT) {
+        const int j = it / kpv, c = it - j * kpv;
+        VT v = reinterpret_cast<const VT*>(P.rec + (int64_t)lidx[j] * kp)[c];
+        const T wj = lw[j];
+        if constexpr (sizeof(T) == 4) { v.x *= wj; v.y *= wj; v.z *= wj; v.w *= wj; }
+        else { v.x *= wj; v.y *= wj; }
+        reinterpret_cast<VT*>(Yt + (size_t)j * kp)[c] = v;
+      }
+    }
+    const int ntrue = P.dual ? cnt : k;
+    const int n = (ntrue + 1) & ~1;
+    if (P.dual && n > cnt) for (int i = tid; i < kp; i += NT) Yt[(size_t)cnt * kp + i] = T(0);
+    __syncthreads();
+    // ---- Gram matrix (canonical upper triangle) + identity
+    for (int it = tid; it < n * n; it += NT) {
+      const int a = it / n, b = it - a * n;
+      V[a * lda + b] = (a == b) ? T(1) : T(0);
+      if (a > b) continue;
+      T acc = T(0);
+      if (P.dual) {
+        const T* ya = Yt + (size_t)a * kp; const T* yb = Yt + (size_t)b * kp;
+        for (int i = 0; i < k; ++i) acc += ya[i] * yb[i];
+      } else if (b < k) {
+        if (P.kernel_mode == 0) {
+          for (int j = 0; j < cnt; ++j) acc += Yt[(size_t)j * kp + a] * Yt[(size_t)j * kp + b];
+        } else {   // RBF Gram exp(-gamma |y_a - y_b|^2)  (kernels/rbf.py:75-81,110-111)
+          for (int j = 0; j < cnt; ++j) { const T df = Yt[(size_t)j * kp + a] - Yt[(size_t)j * kp + b]; acc += df * df; }
+          acc = t_exp(-P.gamma * acc);
+        }
+      }
+      S[a * lda + b] = acc;
+    }
+    __syncthreads();
+    // ---- right-hand side of the mean weights (primal only; dual uses d directly)
+    if (!P.dual) {
+      if (P.kernel_mode == 0) {
+        for (int i = tid; i < n; i += NT) {
+          T acc = T(0);
+          if (i < k) for (int j = 0; j < cnt; ++j) acc += Yt[(size_t)j * kp + i] * Yt[(size_t)j * kp + k];
+          zb[i] = acc;
+        }
+        __syncthreads();
+      } else {
+        // double centring of K and centring of k(Yb, d)   (core/ketkf.py:77-89)
+        for (int i = tid; i < k; i += NT) {
+          T acc = T(0);
+          for (int j = 0; j < k; ++j) acc += sym(S, lda, i, j);
+          uv[i] = acc / T(k);
+          T ko = T(0);
+          for (int j = 0; j < cnt; ++j) { const T df = Yt[(size_t)j * kp + i] - Yt[(size_t)j * kp + k]; ko += df * df; }
+          zb[i] = t_exp(-P.gamma * ko);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          T gm = T(0), om = T(0);
+          for (int i = 0; i < k; ++i) { gm += uv[i]; om += zb[i]; }
+          red[0] = gm / T(k); red[1] = om / T(k);
+        }
+        __syncthreads();
+        for (int it = tid; it < k * k; it += NT) {
+          const int a = it / k, b = it - a * k;
+          if (a <= b) S[a * lda + b] = S[a * lda + b] - uv[b] - (uv[a] - red[0]);
+        }
+        for (int i = tid; i < n; i += NT) zb[i] = i < k ? zb[i] - red[1] - (uv[i] - red[0]) : T(0);
+        __syncthreads();
+      }
+    }
+    // ---- symmetric eigensolve
+    const bool conv = jacobi_sym<T, NT>(S, V, cs, dec, n, n, lda, reg, P.tol2, P.max_sweeps);
+    if (!conv) flag |= MIA_FLAG_NOCONV;
+    __syncthreads();
+    // ---- per-mode factors (clamp >= 0 then + reg: core/utils.py:58-59)
+    for (int r = tid; r < n; r += NT) {
+      T lam = S[r * lda + r];
+      lam = lam > T(0) ? lam : T(0);
+      const T le = lam + reg;
+      T acc = T(0);
+      if (P.dual) {
+        const T sl = t_sqrt(le), sr = t_sqrt(reg);
+        gW[r] = (r < ntrue) ? -t_sqrt(km1) / (sl * sr * (sr + sl)) : T(0);
+        for (int b = 0; b < cnt; ++b) acc += V[b * lda + r] * Yt[(size_t)b * kp + k];
+      } else {
+        gW[r] = (r < ntrue) ? t_sqrt(km1 / le) : T(0);
+        for (int b = 0; b < k; ++b) acc += V[b * lda + r] * zb[b];
+      }
+      gM[r] = (r < ntrue) ? T(1) / le : T(0);
+      av[r] = acc * gM[r];
+    }
+    __syncthreads();
+    for (int b = tid; b < n; b += NT) {   // u = V (gM o V^T rhs)
+      T acc = T(0);
+      for (int r = 0; r < n; ++r) acc += V[b * lda + r] * av[r];
+      uv[b] = acc;
+    }
+    __syncthreads();
+    if (P.W) {   // w_mean explicitly only for the weights output
+      for (int i = tid; i < k; i += NT) {
+        T acc;
+        if (P.dual) { acc = T(0); for (int b = 0; b < cnt; ++b) acc += Yt[(size_t)b * kp + i] * uv[b]; }
+        else acc = uv[i];
+        wbar[i] = acc;
+      }
+    }
+    // ---- ensemble transform, one state row at a time
+    for (int mi = 0; mi < P.m; ++mi) {
+      const T* xrow = P.X + (int64_t)mi * k * P.ldx + g;
+      for (int i = tid; i < k; i += NT) xp[i] = xrow[(int64_t)i * P.ldx];
+      __syncthreads();
+      // every lane sums the k members itself (LDS broadcast reads): no serial section, no barrier
+      T xm = T(0);
+      for (int i = 0; i < k; ++i) xm += xp[i];
+      xm /= T(k);
+      // z = X' B  (dual: B = Yl -> z_b = sum_i x'_i Yl[i][b]; primal: B = I)
+      for (int b = tid; b < n; b += NT) {
+        T acc = T(0);
+        if (P.dual) {
+          if (b < cnt) { const T* yb = Yt + (size_t)b * kp; for (int i = 0; i < k; ++i) acc += (xp[i] - xm) * yb[i]; }
+        } else acc = b < k ? xp[b] - xm : T(0);
+        zb[b] = acc;
+      }
+      __syncthreads();
+      for (int r = tid; r < n; r += NT) {
+        T acc = T(0);
+        for (int b = 0; b < n; ++b) acc += zb[b] * V[b * lda + r];
+        qb[r] = acc * gW[r];
+      }
+      __syncthreads();
+      T zu = T(0);   // X' w_mean = z . u  (every lane, broadcast reads)
+      for (int b = 0; b < n; ++b) zu += zb[b] * uv[b];
+      for (int b = tid; b < n; b += NT) {
+        T acc = T(0);
+        for (int r = 0; r < n; ++r) acc += qb[r] * V[b * lda + r];
+        sb[b] = acc;
+      }
+      __syncthreads();
+      const T mterm = xm + zu;
+      T* orow = P.Xa + (int64_t)mi * k * P.ldo + P.o0 + pt;
+      for (int j = tid; j < k; j += NT) {
+        T acc;
+        if (P.dual) { acc = f0 * (xp[j] - xm); for (int b = 0; b < cnt; ++b) acc += sb[b] * Yt[(size_t)b * kp + j]; }
+        else acc = sb[j];
+        const T out = mterm + acc;
+        if (!(t_abs(out) <= T(1e30))) flag |= MIA_FLAG_NONFINITE;
+        orow[(int64_t)j * P.ldo] = out;
+      }
+      __syncthreads();
+    }
+    // ---- optional weights output: w_mean_i + f0*delta_ij + sum_r gW_r M_ir M_jr,  M = B V
+    if (P.W) {
+      const T* Mm = V;
+      if (P.dual) {
+        for (int it = tid; it < k * n; it += NT) {
+          const int i = it / n, r = it - i * n;
+          T acc = T(0);
+          for (int b = 0; b < cnt; ++b) acc += Yt[(size_t)b * kp + i] * V[b * lda + r];
+          Mq[i * lda + r] = acc;
+        }
+        Mm = Mq;
+        __syncthreads();
+      }
+      T* wout = P.W + pt * (int64_t)k * k;
+      for (int it = tid; it < k * k; it += NT) {
+        const int i = it / k, j = it - i * k;
+        T acc = wbar[i] + (i == j ? f0 : T(0));
+        for (int r = 0; r < n; ++r) acc += gW[r] * Mm[i * lda + r] * Mm[j * lda + r];
+        wout[it] = acc;
+      }
+    }
+    if (P.flags) {
+      if (tid == 0) iflag[2] = 0;
+      __syncthreads();
+      if (flag) atomicOr(&iflag[2], flag);
+      __syncthreads();
+      if (tid == 0) P.flags[pt] = iflag[2];
+    }
+  }
+}
+
+template <typename T>
+static size_t wave_lds_bytes(int k, int kp, int p_max, int nmax, int lda, int rows, bool want_mq) {
+  size_t e = (size_t)rows * kp + 2 * (size_t)nmax * lda + 8 * (size_t)nmax + 2 * (size_t)k + 8 + ((p_max + 3) & ~1);
+  size_t b = e * sizeof(T);
+  b += (size_t)((p_max + 3) & ~1) * sizeof(int) + 4 * sizeof(int);
+  const int nb = nmax / 2;
+  b += (size_t)((nb * (nb - 1) / 2 + 7) & ~7) * sizeof(unsigned short);
+  if (want_mq) b += (size_t)k * lda * sizeof(T);
+  return align_up(b, 16);
+}
+
+template <typename T>
+int wave_analysis_launch(const T* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const T* rec,
+                         const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap,
+                         int p_max, T inf_factor, int kernel_mode, T gamma, T* Xa, int64_t ldo, int64_t o0,
+                         T* W_opt, int32_t* flags_opt, hipStream_t stream) {
+  WaveParams<T> ap;
+  ap.X = X; ap.ldx = ldx; ap.m = m; ap.k = k; ap.g0 = g0; ap.ng = ng; ap.rec = rec;
+  ap.kp = (k + 1 + 3) & ~3;
+  ap.cnt = nbr_cnt; ap.idx = nbr_idx; ap.w = nbr_w; ap.p_cap = p_cap; ap.p_max = p_max;
+  ap.reg = T(k - 1) / inf_factor;
+  ap.Xa = Xa; ap.ldo = ldo; ap.o0 = o0; ap.W = W_opt; ap.flags = flags_opt;
+  ap.kernel_mode = kernel_mode; ap.gamma = gamma;
+  ap.dual = (kernel_mode == 0 && p_max <= k) ? 1 : 0;
+  const int ntrue = ap.dual ? p_max : k;
+  ap.nmax = (ntrue + 1) & ~1;
+  if (ap.nmax < 2) ap.nmax = 2;
+  if (ap.nmax > 510) return MIA_ERR_UNSUPPORTED;   // 8-bit pair ids in the block table
+  ap.lda = ap.nmax + 1;
+  ap.rows = ap.dual ? ap.nmax : (p_max > 0 ? p_max : 1);
+  ap.max_sweeps = sizeof(T) == 4 ? 16 : 24;
+  const T tol = sizeof(T) == 4 ? T(2.4e-7) : T(9e-16);
+  ap.tol2 = tol * tol;
+  const size_t lds = wave_lds_bytes<T>(k, ap.kp, p_max, ap.nmax, ap.lda, ap.rows, W_opt != nullptr && ap.dual);
+  if (lds > 160 * 1024) return MIA_ERR_UNSUPPORTED;
+  const bool big = ap.nmax > 44;
+  int ppb = (int)((ng + 16383) / 16384);
+  if (ppb < 4) ppb = 4;
+  if (ppb > 32) ppb = 32;
+  ap.pts_per_block = ppb;
+  const int64_t nblk = (ng + ppb - 1) / ppb;
+  if (nblk > 2147483647LL) return MIA_ERR_UNSUPPORTED;
+  if (big) {
+    auto kern = letkf_wave_kernel<T, 256>;
+    if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kern<<<dim3((unsigned)nblk), dim3(256), lds, stream>>>(ap);
+  } else {
+    auto kern = letkf_wave_kernel<T, 64>;
+    if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kern<<<dim3((unsigned)nblk), dim3(64), lds, stream>>>(ap);
+  }
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+template int wave_analysis_launch<float>(const float*, int64_t, int, int, int64_t, int64_t, const float*,
+                                         const int32_t*, const int32_t*, const double*, int, int, float, int, float,
+                                         float*, int64_t, int64_t, float*, int32_t*, hipStream_t);
+template int wave_analysis_launch<double>(const double*, int64_t, int, int, int64_t, int64_t, const double*,
+                                          const int32_t*, const int32_t*, const double*, int, int, double, int, double,
+                                          double*, int64_t, int64_t, double*, int32_t*, hipStream_t);
+
+}  // namespace mia

@@ -234,7 +234,9 @@ __global__ __launch_bounds__(256) void localize_kernel(LocalizeParams p) {
   for (int s = count + lane; s < p.p_cap; s += 64) { my_idx[s] = -1; my_w[s] = 0.0; }
   if (lane == 0) {
     p.cnt[pt] = count;
-    atomicMax(&p.stats[0], count);
+    // same-address atomics serialise at ~11 ns each (1e5 points -> 1 ms): the running maximum only
+    // grows, so a relaxed look first lets almost every wavefront skip the atomic
+    if (count > __hip_atomic_load(&p.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&p.stats[0], count);
     if (count > p.p_cap) atomicAdd(&p.stats[1], 1);
   }
 }
@@ -276,7 +278,10 @@ __global__ __launch_bounds__(256) void localize_from_dist_kernel(FromDistParams 
     count += __popcll(mask);
   }
   for (int s = count + lane; s < p.p_cap; s += 64) { my_idx[s] = -1; my_w[s] = 0.0; }
-  if (lane == 0) { p.cnt[pt] = count; atomicMax(&p.stats[0], count); }
+  if (lane == 0) {
+    p.cnt[pt] = count;
+    if (count > __hip_atomic_load(&p.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&p.stats[0], count);
+  }
 }
 
 template <typename T>
