@@ -45,6 +45,8 @@ extern "C" {
 #define MIA_FLAG_OVERFLOW 1 /* more local observations than p_max: point NOT analysed */
 #define MIA_FLAG_NOCONV 2   /* Jacobi eigensolver hit its sweep cap (result still returned) */
 #define MIA_FLAG_NONFINITE 4 /* non-finite value met in the local block */
+/* bits 8-15: Jacobi sweeps started, bits 16-31: tournament rounds that rotated (diagnostics) */
+#define MIA_FLAG_MASK 0xff
 
 #define MIA_MAX_COORD 3
 #define MIA_MAX_RADII 3

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+import torch_assimilate_amd as mia
+dev = torch.device("cuda:0")
+eng = mia.LetkfEngine(dev)
+cfgs = {"c2": (40, 2, 10.0, None), "c4": (80, 1, 16.5, None), "c5": (40, 2, 10.0, 0.5)}
+for name in sys.argv[1:] or ["c2"]:
+    k, stride, c, gamma = cfgs[name]
+    X, gx, ox, Yb, d = bench.make_case(100000, k, stride, dev)
+    nb = eng.localize(gx, ox, [c])
+    rec = eng.pack_obs(Yb, d, torch.float32)
+    for tol in ("2.4e-4", "1e-3"):
+        for ppb in ("1", "2", "3", "4", "5", "7", "10"):
+            os.environ["MIA_JACOBI_STOP_TOL"] = tol
+            os.environ["MIA_PTS_PER_BLOCK"] = ppb
+            for _ in range(3):
+                eng.analysis(X, None, None, nb, 1.1, rec=rec, rbf_gamma=gamma)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                eng.analysis(X, None, None, nb, 1.1, rec=rec, rbf_gamma=gamma)
+            torch.cuda.synchronize()
+            print(f"{name} tol={tol} pts/block={ppb:3s}: {(time.perf_counter()-t0)*100:.3f} ms")

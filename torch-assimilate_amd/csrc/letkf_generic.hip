@@ -33,6 +33,11 @@ int wave_analysis_launch(const T* X, int64_t ldx, int m, int k, int64_t g0, int6
                          int p_max, T inf_factor, int kernel_mode, T gamma, T* Xa, int64_t ldo, int64_t o0,
                          T* W_opt, int32_t* flags_opt, hipStream_t stream);
 
+int sys_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
+                        const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
+                        float inf_factor, int kernel_mode, float gamma, float* Xa, int64_t ldo, int64_t o0,
+                        float* W_opt, int32_t* flags_opt, hipStream_t stream);
+
 template <typename T>
 struct AnaParams {
   const T* X; int64_t ldx; int m; int k;
@@ -371,7 +376,15 @@ static int analysis_packed_impl(const T* X, int64_t ldx, int m, int k, int64_t g
   if (p_max > p_cap) p_max = p_cap;
   if (P > 0 && !rec) return MIA_ERR_NULL;
   const int kp = (k + 1 + 3) & ~3;
-  if (!getenv("MIA_USE_GENERIC_KERNEL"))   // default: second-generation kernel (letkf_wave.hip)
+  const char* which = getenv("MIA_KERNEL");   // experiments: "generic" | "wave" | default (systolic, then wave)
+  if constexpr (sizeof(T) == 4) {
+    if (!which || which[0] == 's') {
+      const int rc = sys_analysis_launch(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
+                                         kernel_mode, gamma, Xa, ldo, o0, W_opt, flags_opt, stream);
+      if (rc != MIA_ERR_UNSUPPORTED) return rc;
+    }
+  }
+  if (!which || which[0] != 'g')   // runtime-order kernel (letkf_wave.hip): float64 and orders > 64
     return wave_analysis_launch<T>(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
                                    kernel_mode, gamma, Xa, ldo, o0, W_opt, flags_opt, stream);
   AnaParams<T> ap;

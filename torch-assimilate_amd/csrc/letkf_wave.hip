@@ -18,6 +18,7 @@
 //    (one barrier + reduction decides, wave-uniformly);
 //  * eigenvector rows are mapped (pair = lane % pairs, row = lane / pairs) so each lane keeps
 //    one rotation for all its rows.
+#include <cstdlib>
 #include <type_traits>
 #include "mia_common.h"
 #include "mia_jacobi.h"
@@ -31,7 +32,7 @@ struct WaveParams {
   const T* rec; int kp;
   const int32_t* cnt; const int32_t* idx; const double* w; int p_cap; int p_max;
   T reg; T* Xa; int64_t ldo, o0; T* W; int32_t* flags;
-  int dual; int nmax; int lda; int rows; int pts_per_block; int max_sweeps; T tol2;
+  int dual; int nmax; int lda; int rows; int pts_per_block; int max_sweeps; T rot_tol2, stop_tol2;
   int kernel_mode; T gamma;
 };
 
@@ -53,11 +54,37 @@ __device__ inline T& sym(T* S, int lda, int x, int y) {   // canonical (upper) e
   return S[lo * lda + hi];
 }
 
+// rotation (c, s) annihilating a_pq; returns t = tan(theta).  float: hardware rcp/rsq/sqrt
+// (1 ulp) followed by one normalisation step so that c^2 + s^2 = 1 to rounding; double: IEEE ops.
+__device__ inline float rot_params(float app, float aqq, float apq, float& c, float& s) {
+  const float tau = (aqq - app) * 0.5f * __builtin_amdgcn_rcpf(apq);
+  const float at = __builtin_fabsf(tau);
+  float t = __builtin_amdgcn_rcpf(at + __builtin_amdgcn_sqrtf(1.0f + tau * tau));
+  t = tau < 0.0f ? -t : t;
+  c = __builtin_amdgcn_rsqf(1.0f + t * t);
+  s = t * c;
+  const float corr = 1.5f - 0.5f * (c * c + s * s);
+  c *= corr; s *= corr;
+  return t;
+}
+__device__ inline double rot_params(double app, double aqq, double apq, double& c, double& s) {
+  const double tau = (aqq - app) / (2.0 * apq);
+  const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+  c = 1.0 / sqrt(1.0 + t * t);
+  s = t * c;
+  return t;
+}
+
 // Threshold parallel-order Jacobi, symmetric matrix in canonical upper storage.
-// V (nv rows x n) accumulates rotations.  Returns true when a full sweep needed no rotation.
+// V (nv rows x n) accumulates rotations: S_in = V S_out V^T.  Pairs whose relative off-diagonal
+// |a_pq| / sqrt((|a_pp|+shift)(|a_qq|+shift)) is below rot_tol are left alone; sweeping stops as
+// soon as every off-diagonal is below stop_tol (the caller corrects for what is left to first
+// order, so stop_tol ~ sqrt(eps) already gives eps-level results).  stat: bits 0-7 sweeps,
+// bits 8+ rounds that rotated.  Returns false when max_sweeps was hit first.
 template <typename T, int NT>
 __device__ bool jacobi_sym(T* S, T* V, T* cs, const unsigned short* dec, int n, int nv, int lda, T shift,
-                           T tol2, int max_sweeps) {
+                           T rot_tol2, T stop_tol2, int max_sweeps, int& stat) {
+  stat = 0;
   if (n < 2) return true;
   const int tid = threadIdx.x;
   const int nb = n >> 1, n1 = n - 1;
@@ -66,9 +93,18 @@ __device__ bool jacobi_sym(T* S, T* V, T* cs, const unsigned short* dec, int n, 
   const int vstep = NT / nb;
   const int vj = tid % nb, vr0 = tid / nb;
   const bool vact = vr0 < vstep;
-  bool converged = false;
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
-    int rotated = 0;
+    // ---- stopping rule: largest relative off-diagonal element
+    int big = 0;
+    for (int it = tid; it < n * n; it += NT) {
+      const int a = it / n, b = it - a * n;
+      if (a < b) {
+        const T e = S[a * lda + b];
+        big |= (e * e > stop_tol2 * (t_abs(S[a * lda + a]) + shift) * (t_abs(S[b * lda + b]) + shift)) ? 1 : 0;
+      }
+    }
+    if (!__syncthreads_or(big)) return true;
+    stat += 1;
     for (int r = 0; r < n1; ++r) {
       // ---- step 1: rotation of every pair + its diagonal block
       int rot = 0;
@@ -79,11 +115,8 @@ __device__ bool jacobi_sym(T* S, T* V, T* cs, const unsigned short* dec, int n, 
         T& rpq = sym(S, lda, p, q);
         const T apq = rpq;
         T c = T(1), s = T(0);
-        if (apq * apq > tol2 * (t_abs(app) + shift) * (t_abs(aqq) + shift)) {
-          const T tau = (aqq - app) / (T(2) * apq);
-          const T t = (tau >= T(0) ? T(1) : T(-1)) / (t_abs(tau) + t_sqrt(T(1) + tau * tau));
-          c = T(1) / t_sqrt(T(1) + t * t);
-          s = t * c;
+        if (apq * apq > rot_tol2 * (t_abs(app) + shift) * (t_abs(aqq) + shift)) {
+          const T t = rot_params(app, aqq, apq, c, s);
           S[p * lda + p] = app - t * apq;
           S[q * lda + q] = aqq + t * apq;
           rpq = T(0);
@@ -92,7 +125,7 @@ __device__ bool jacobi_sym(T* S, T* V, T* cs, const unsigned short* dec, int n, 
         cs[2 * i] = c; cs[2 * i + 1] = s;
       }
       if (!__syncthreads_or(rot)) continue;   // nothing to rotate in this round (uniform)
-      rotated = 1;
+      stat += 1 << 8;
       // ---- step 2a: off-diagonal 2x2 blocks  B <- R1^T B R2
       for (int it = tid; it < noff; it += NT) {
         const int d = dec[it];
@@ -125,9 +158,8 @@ __device__ bool jacobi_sym(T* S, T* V, T* cs, const unsigned short* dec, int n, 
       }
       __syncthreads();
     }
-    if (!rotated) { converged = true; break; }
   }
-  return converged;
+  return false;
 }
 
 template <typename T, int NT>
@@ -262,29 +294,56 @@ __global__ __launch_bounds__(NT) void letkf_wave_kernel(WaveParams<T> P) {
         __syncthreads();
       }
     }
-    // ---- symmetric eigensolve
-    const bool conv = jacobi_sym<T, NT>(S, V, cs, dec, n, n, lda, reg, P.tol2, P.max_sweeps);
+    // ---- symmetric eigensolve.  S = V (D + E) V^T on return, E = what is left off the diagonal
+    //      (relative size <= stop_tol); every matrix function below is evaluated as
+    //      f(D + E) = f(D) + F o E + O(E^2),  F_pq = (f(d_p) - f(d_q)) / (d_p - d_q)
+    //      (Daleckii-Krein), with the divided differences in cancellation-free closed form.
+    int jstat;
+    const bool conv = jacobi_sym<T, NT>(S, V, cs, dec, n, n, lda, reg, P.rot_tol2, P.stop_tol2, P.max_sweeps, jstat);
     if (!conv) flag |= MIA_FLAG_NOCONV;
-    __syncthreads();
-    // ---- per-mode factors (clamp >= 0 then + reg: core/utils.py:58-59)
+    // ---- per-mode values (clamp >= 0 then + reg: core/utils.py:58-59).  u = sqrt(l + reg)
+    const T ar = t_sqrt(reg);
     for (int r = tid; r < n; r += NT) {
       T lam = S[r * lda + r];
       lam = lam > T(0) ? lam : T(0);
       const T le = lam + reg;
+      const T u = t_sqrt(le);
       T acc = T(0);
       if (P.dual) {
-        const T sl = t_sqrt(le), sr = t_sqrt(reg);
-        gW[r] = (r < ntrue) ? -t_sqrt(km1) / (sl * sr * (sr + sl)) : T(0);
+        gW[r] = (r < ntrue) ? -t_sqrt(km1) / (u * ar * (ar + u)) : T(0);
         for (int b = 0; b < cnt; ++b) acc += V[b * lda + r] * Yt[(size_t)b * kp + k];
       } else {
-        gW[r] = (r < ntrue) ? t_sqrt(km1 / le) : T(0);
+        gW[r] = (r < ntrue) ? t_sqrt(km1) / u : T(0);
         for (int b = 0; b < k; ++b) acc += V[b * lda + r] * zb[b];
       }
       gM[r] = (r < ntrue) ? T(1) / le : T(0);
-      av[r] = acc * gM[r];
+      qb[r] = u;        // kept for the divided differences
+      sb[r] = acc;      // a = V^T rhs
     }
     __syncthreads();
-    for (int b = tid; b < n; b += NT) {   // u = V (gM o V^T rhs)
+    // mean term: (D + E + reg)^-1 a  ~=  gM o (a - E (gM o a))        [F_pq = -gM_p gM_q]
+    for (int r = tid; r < n; r += NT) {
+      T acc = T(0);
+      for (int b = 0; b < n; ++b) if (b != r) acc += sym(S, lda, r, b) * gM[b] * sb[b];
+      av[r] = gM[r] * (sb[r] - acc);
+    }
+    __syncthreads();
+    // square-root term: off-diagonals of S become F o E in place, gW stays the diagonal
+    {
+      const T cdual = t_sqrt(km1) / ar;
+      for (int it = tid; it < n * n; it += NT) {
+        const int a = it / n, b = it - a * n;
+        if (a < b) {
+          const T ua = qb[a], ub = qb[b];
+          T F;
+          if (P.dual) F = cdual * (ar + ua + ub) / ((ua + ub) * ua * ub * (ar + ua) * (ar + ub));
+          else F = -t_sqrt(km1) / (ua * ub * (ua + ub));
+          if (b >= ntrue) F = T(0);
+          S[a * lda + b] *= F;
+        }
+      }
+    }
+    for (int b = tid; b < n; b += NT) {   // u = V av
       T acc = T(0);
       for (int r = 0; r < n; ++r) acc += V[b * lda + r] * av[r];
       uv[b] = acc;
@@ -316,10 +375,16 @@ __global__ __launch_bounds__(NT) void letkf_wave_kernel(WaveParams<T> P) {
         zb[b] = acc;
       }
       __syncthreads();
-      for (int r = tid; r < n; r += NT) {
+      for (int r = tid; r < n; r += NT) {   // zv = V^T z
         T acc = T(0);
         for (int b = 0; b < n; ++b) acc += zb[b] * V[b * lda + r];
-        qb[r] = acc * gW[r];
+        av[r] = acc;
+      }
+      __syncthreads();
+      for (int r = tid; r < n; r += NT) {   // q = (diag(gW) + F o E) zv
+        T acc = gW[r] * av[r];
+        for (int b = 0; b < n; ++b) if (b != r) acc += sym(S, lda, r, b) * av[b];
+        qb[r] = acc;
       }
       __syncthreads();
       T zu = T(0);   // X' w_mean = z . u  (every lane, broadcast reads)
@@ -368,7 +433,7 @@ __global__ __launch_bounds__(NT) void letkf_wave_kernel(WaveParams<T> P) {
       __syncthreads();
       if (flag) atomicOr(&iflag[2], flag);
       __syncthreads();
-      if (tid == 0) P.flags[pt] = iflag[2];
+      if (tid == 0) P.flags[pt] = iflag[2] | (jstat << 8);   // bits 8-15 sweeps, 16+ rotating rounds
     }
   }
 }
@@ -404,8 +469,14 @@ int wave_analysis_launch(const T* X, int64_t ldx, int m, int k, int64_t g0, int6
   ap.lda = ap.nmax + 1;
   ap.rows = ap.dual ? ap.nmax : (p_max > 0 ? p_max : 1);
   ap.max_sweeps = sizeof(T) == 4 ? 16 : 24;
-  const T tol = sizeof(T) == 4 ? T(2.4e-7) : T(9e-16);
-  ap.tol2 = tol * tol;
+  // stop at sqrt(eps): the first-order correction leaves O(stop_tol^2) = O(eps).  The weights
+  // output W uses the diagonal part only, so it asks for full convergence.
+  T stop_tol = sizeof(T) == 4 ? T(2.4e-4) : T(1.5e-8);
+  if (W_opt) stop_tol = sizeof(T) == 4 ? T(2.4e-7) : T(9e-16);
+  if (const char* e = getenv("MIA_JACOBI_STOP_TOL")) stop_tol = T(atof(e));   // experiments only
+  const T rot_tol = stop_tol * T(0.5);
+  ap.stop_tol2 = stop_tol * stop_tol;
+  ap.rot_tol2 = rot_tol * rot_tol;
   const size_t lds = wave_lds_bytes<T>(k, ap.kp, p_max, ap.nmax, ap.lda, ap.rows, W_opt != nullptr && ap.dual);
   if (lds > 160 * 1024) return MIA_ERR_UNSUPPORTED;
   const bool big = ap.nmax > 44;

@@ -50,7 +50,7 @@ class ShardedLetkf:
     collective logic under the gloo backend.
     """
 
-    dominant_kernel_name = "letkf_generic_kernel<float, 64>"
+    dominant_kernel_name = "letkf_sys_kernel<20, 64>"
 
     def __init__(self, device, rank: int = 0, world: int = 1, radii: Sequence[float] = (10.0,),
                  inf_factor: float = 1.0, coord_group: Optional[Sequence[int]] = None, eps: float = 1e-5,
@@ -86,7 +86,7 @@ class ShardedLetkf:
         return gather_blocks(shard, G, self.world, self.group)
 
     def last_flags_ok(self) -> bool:
-        return self._last_flags is None or int(self._last_flags.max().item()) == 0
+        return self._last_flags is None or int((self._last_flags & 0xff).max().item()) == 0
 
     def time_stages(self, X, grid_xyz, obs_xyz, Yb, d, reps: int = 10):
         """HIP-event timing (on torch's current stream = the launch stream) of each stage of this
