@@ -1,0 +1,77 @@
+"""The C-ABI library loads and exports every symbol include/mia_letkf.h declares; the host-only
+entry points (version, status strings, workspace queries, argument validation that returns before
+any HIP call) behave as documented.  No GPU needed."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import torch_assimilate_amd as mia
+    mia.build()
+    from torch_assimilate_amd import _cabi
+    return _cabi.lib()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mia_letkf.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mia_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from torch_assimilate_amd import _cabi
+    decl = declared_symbols()
+    assert len(decl) >= 20
+    for name in decl:
+        assert hasattr(lib, name), name
+    assert sorted(_cabi.EXPORTED_SYMBOLS) == decl
+
+
+def test_version_and_status_strings(lib):
+    assert lib.mia_version() == 100
+    assert lib.mia_status_string(0) == b"ok"
+    for code in (-1, -2, -3, -4, -5, 700):
+        assert len(lib.mia_status_string(code)) > 3
+
+
+def test_workspace_queries(lib):
+    n = C.c_size_t(0)
+    assert lib.mia_letkf_localize_workspace_bytes(50000, 1, C.byref(n)) == 0 and n.value > 4 * 50000
+    assert lib.mia_letkf_localize_workspace_bytes(10, 4, C.byref(n)) == -2        # too many coordinates
+    assert lib.mia_letkf_localize_workspace_bytes(10, 1, None) == -1
+    assert lib.mia_letkf_analysis_workspace_bytes(40, 50000, 4, C.byref(n)) == 0
+    assert n.value >= 50000 * 44 * 4                                              # records of round_up(k+1, 4) floats
+    assert lib.mia_letkf_analysis_workspace_bytes(40, 50000, 2, C.byref(n)) == -2
+    assert lib.mia_etkf_workspace_bytes(20, 40, 8, C.byref(n)) == 0 and n.value >= (20 * 20 + 20) * 8
+    assert lib.mia_etkf_workspace_bytes(1, 40, 8, C.byref(n)) == -2
+
+
+def test_argument_validation_precedes_any_device_work(lib):
+    # invalid sizes / NULL pointers are rejected on the host (negative codes), never reaching HIP
+    assert lib.mia_gaspari_cohn_f64(None, -1, None, None) == -2
+    assert lib.mia_gaspari_cohn_f64(None, 0, None, None) == 0
+    assert lib.mia_gaspari_cohn_f32(None, 5, None, None) == -1
+    assert lib.mia_apply_weights_f32(None, 10, 1, 1, 0, 5, None, None, 10, 0, None) == -2     # k < 2
+    assert lib.mia_apply_weights_f32(None, 10, 1, 4, 0, 0, None, None, 10, 0, None) == 0      # empty shard
+    assert lib.mia_apply_weights_f32(None, 10, 1, 4, 0, 5, None, None, 10, 0, None) == -1
+    assert lib.mia_letkf_pack_obs_f32(None, None, 4, 0, None, None) == 0
+    assert lib.mia_letkf_pack_obs_f32(None, None, 4, 8, None, None) == -1
+    assert lib.mia_letkf_analysis_packed_f32(None, 10, 1, 4, 0, 0, None, 0, None, None, None, 8, 4, 1.0, 0.0,
+                                             None, 10, 0, None, None, None) == 0
+    assert lib.mia_letkf_analysis_packed_f32(None, 10, 1, 4, 0, 5, None, 0, None, None, None, 8, 4, -1.0, 0.0,
+                                             None, 10, 0, None, None, None) == -2             # inf_factor <= 0
+
+
+def test_engine_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import torch_assimilate_amd as mia
+    with pytest.raises(mia.MiaError):
+        mia.LetkfEngine()

@@ -10,10 +10,11 @@ __version__ = "0.1.0"
 
 _LAZY = {
     "LetkfEngine": "engine", "NeighbourLists": "engine",
-    "GaspariCohn": "localization",
+    "GaspariCohn": "localization", "EuclideanMetric": "localization", "AbsoluteDistance": "localization",
+    "ETKFModule": "core", "KETKFModule": "core",
     "LETKF": "interface", "ETKF": "interface", "LKETKF": "interface", "KETKF": "interface",
     "RBFKernel": "kernels", "GaussKernel": "kernels", "LinearKernel": "kernels",
-    "ShardedLetkf": "sharded",
+    "ShardedLetkf": "sharded", "block_partition": "sharded", "gather_blocks": "sharded",
 }
 
 

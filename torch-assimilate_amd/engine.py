@@ -132,6 +132,26 @@ class LetkfEngine:
         p_max = int(stats[0].item())
         return NeighbourLists(cnt, idx, w, cap, p_max, g0, g0 + n)
 
+    def merge_neighbour_lists(self, parts) -> NeighbourLists:
+        """Concatenate consecutive shards' lists (trimmed to the common maximum count)."""
+        p_max = max(p.p_max for p in parts)
+        cap = max(8, (p_max + 7) // 8 * 8)
+        idx, w = [], []
+        for p in parts:
+            if p.p_cap >= cap:
+                idx.append(p.idx[:, :cap])
+                w.append(p.w[:, :cap])
+            else:
+                n = p.idx.shape[0]
+                i = torch.full((n, cap), -1, dtype=torch.int32, device=self.device)
+                ww = torch.zeros((n, cap), dtype=torch.float64, device=self.device)
+                i[:, :p.p_cap] = p.idx
+                ww[:, :p.p_cap] = p.w
+                idx.append(i)
+                w.append(ww)
+        return NeighbourLists(torch.cat([p.cnt for p in parts]), torch.cat(idx).contiguous(),
+                              torch.cat(w).contiguous(), cap, p_max, parts[0].g0, parts[-1].g1)
+
     # ---------------------------------------------------------------- analysis
     def pack_obs(self, Yb: torch.Tensor, d: torch.Tensor, dtype=None) -> torch.Tensor:
         """(k, P) perturbations + (P,) innovations -> obs-major records (P, kp) on the device."""

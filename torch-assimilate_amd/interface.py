@@ -1,0 +1,225 @@
+"""Drivers with the constructor / method surface of pytassim.interface.{ETKF, LETKF, KETKF, LKETKF}
+(pytassim/interface/etkf.py:66-120, letkf.py:72-148, ketkf.py:69-123, lketkf.py:77-115), backed
+by the gfx950 engine.
+
+Two levels:
+
+* array level (always available): ``analyse_arrays`` / ``estimate_weights_arrays`` take the plain
+  arrays the reference hands to its per-grid-point closure -- normalised obs-space perturbations
+  ``Yb (k, P)``, innovations ``d (P,)``, grid / observation coordinates, the prior ensemble
+  ``(..., k, G)`` -- and return the analysis (or the weights ``(G, k, k)`` that
+  ``estimate_weights`` returns, letkf.py:145-146);
+* xarray level (when xarray is importable): ``assimilate(state, observations, pseudo_state,
+  analysis_time)`` with the reference's data model (state dims ``var_name, time, ensemble, grid``;
+  observation Datasets with ``observations`` / ``covariance``), reproducing
+  ``_get_obs_space_variables`` (base.py:359-379), the stacking order of ``_stack_obs``
+  (base.py:223-241), ``state_info`` (mixin_local.py:50-69) and ``_apply_weights`` (base.py:257-278).
+  xarray is not installed in the build / GPU images, so that layer is exercised only where it is.
+
+There is no CPU path: ``gpu`` is accepted for signature compatibility and ignored.
+"""
+from __future__ import annotations
+
+import logging
+import warnings
+from typing import Callable, Iterable, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from .engine import LetkfEngine
+from .kernels import LinearKernel
+from .localization import GaspariCohn
+
+logger = logging.getLogger(__name__)
+
+__all__ = ["ETKF", "LETKF", "KETKF", "LKETKF"]
+
+
+class _NoLocalization:
+    """``localization=None`` in the reference: every observation, weight 1 (wrapper.py:87)."""
+
+
+class ETKF:
+    """Global ensemble transform Kalman filter (interface/etkf.py:33-120)."""
+
+    def __init__(self, inf_factor: float = 1.0, smoother: bool = False, gpu: bool = True,
+                 pre_transform: Optional[Iterable] = None, post_transform: Optional[Iterable] = None,
+                 weight_save_path: Optional[str] = None, forward_model: Optional[Callable] = None,
+                 dtype: torch.dtype = torch.float32, engine: Optional[LetkfEngine] = None):
+        self._inf_factor = float(inf_factor)
+        self.smoother = smoother
+        self.gpu = gpu
+        self.pre_transform = pre_transform
+        self.post_transform = post_transform
+        self.weight_save_path = weight_save_path
+        self.forward_model = forward_model
+        self.dtype = dtype
+        self._engine = engine
+        self._kernel = None
+
+    # ---- properties mirroring the reference ------------------------------------------------
+    @property
+    def inf_factor(self) -> float:
+        return self._inf_factor
+
+    @inf_factor.setter
+    def inf_factor(self, new_factor):
+        self._inf_factor = float(new_factor)
+
+    @property
+    def engine(self) -> LetkfEngine:
+        if self._engine is None:
+            self._engine = LetkfEngine()
+        return self._engine
+
+    @property
+    def _gamma(self) -> Optional[float]:
+        if self._kernel is None or isinstance(self._kernel, LinearKernel):
+            return None
+        g = getattr(self._kernel, "gamma", None)
+        if g is None:
+            raise NotImplementedError("kernel %r is not implemented on the gfx950 path" % (self._kernel,))
+        return float(g)
+
+    def __str__(self):
+        return "Global ETKF(inf_factor={0})".format(self.inf_factor)
+
+    def __repr__(self):
+        return "ETKF({0})".format(self.inf_factor)
+
+    # ---- array level ----------------------------------------------------------------------
+    def _dev(self, a, dtype=None):
+        return torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a).to(
+            device=self.engine.device, dtype=dtype or self.dtype)
+
+    def estimate_weights_arrays(self, yb, d, **_unused) -> torch.Tensor:
+        """(k, P), (P,) -> weights (k, k) (ETKF.estimate_weights, etkf.py:99-120)."""
+        if self._gamma is not None:     # kernelised global solve: one "grid point" seeing every observation
+            from .core import KETKFModule
+            return KETKFModule(self._kernel, self.inf_factor, self.engine)(self._dev(yb), self._dev(d))
+        return self.engine.etkf_weights(self._dev(yb), self._dev(d), self.inf_factor)
+
+    def analyse_arrays(self, state, yb, d, **_unused) -> torch.Tensor:
+        """state (..., k, G) -> analysis of the same shape: weights + _apply_weights (base.py:257-278)."""
+        st = self._dev(state)
+        shp = st.shape
+        W = self.estimate_weights_arrays(yb, d)
+        xa = self.engine.apply_weights(st.reshape(-1, shp[-2], shp[-1]), W)
+        return xa.reshape(shp)
+
+    # ---- xarray level ---------------------------------------------------------------------
+    def assimilate(self, state, observations, pseudo_state=None, analysis_time=None):
+        from . import xr_adapter
+        return xr_adapter.assimilate(self, state, observations, pseudo_state, analysis_time)
+
+
+class LETKF(ETKF):
+    """Localised ETKF (interface/letkf.py:34-148): independent local analysis per grid point."""
+
+    def __init__(self, localization: Optional[GaspariCohn] = None, inf_factor: float = 1.0,
+                 smoother: bool = False, gpu: bool = True, pre_transform=None, post_transform=None,
+                 chunksize: int = 10, weight_save_path=None, forward_model=None,
+                 dtype: torch.dtype = torch.float32, engine: Optional[LetkfEngine] = None):
+        super().__init__(inf_factor=inf_factor, smoother=smoother, gpu=gpu, pre_transform=pre_transform,
+                         post_transform=post_transform, weight_save_path=weight_save_path,
+                         forward_model=forward_model, dtype=dtype, engine=engine)
+        self.localization = localization
+        self.chunksize = chunksize          # dask chunking of the reference; the GPU path does not chunk
+
+    @property
+    def chunks(self):
+        return dict(grid=self.chunksize)
+
+    def __str__(self):
+        return "Localized ETKF(inf_factor={0}, loc={1})".format(self.inf_factor, str(self.localization))
+
+    def __repr__(self):
+        return "LETKF({0},{1})".format(repr(self.inf_factor), repr(self.localization))
+
+    def _lists(self, grid_coords, obs_coords, g0=0, g1=None, grid_info=None, obs_info=None):
+        eng = self.engine
+        G = len(grid_coords)
+        g1 = G if g1 is None else g1
+        if self.localization is None:
+            P = len(obs_coords)
+            cap = max(P, 1)
+            cand = torch.arange(cap, dtype=torch.int32, device=eng.device)[None].expand(g1 - g0, -1).contiguous()
+            if P == 0:
+                cand = cand - 1
+            dist = torch.zeros((1, g1 - g0, cap), dtype=torch.float64, device=eng.device)
+            return eng.localize_from_dist(dist, cand, [1.0], g0=g0)
+        return self.localization.neighbour_lists(eng, grid_coords, obs_coords, g0, g1, grid_info, obs_info)
+
+    def estimate_weights_arrays(self, yb, d, grid_coords=None, obs_coords=None, g0=0, g1=None,
+                                grid_info=None, obs_info=None) -> torch.Tensor:
+        """weights (G, k, k) with [g, i, j] = w_mean_i + W_ij (letkf.py:127-146)."""
+        yb, d = self._dev(yb), self._dev(d)
+        nb = self._lists(grid_coords, obs_coords, g0, g1, grid_info, obs_info)
+        k = yb.shape[0]
+        x = torch.zeros((1, k, nb.g1), dtype=self.dtype, device=self.engine.device)
+        _, W = self.engine.analysis(x, yb, d, nb, self.inf_factor, return_weights=True, rbf_gamma=self._gamma)
+        return W
+
+    def analyse_arrays(self, state, yb, d, grid_coords=None, obs_coords=None, g0=0, g1=None,
+                       grid_info=None, obs_info=None) -> torch.Tensor:
+        """Fused path: the weights never leave the GPU's LDS."""
+        st = self._dev(state)
+        shp = st.shape
+        nb = self._lists(grid_coords, obs_coords, g0, g1, grid_info, obs_info)
+        xa, flags = self.engine.analysis(st.reshape(-1, shp[-2], shp[-1]), self._dev(yb), self._dev(d), nb,
+                                         self.inf_factor, rbf_gamma=self._gamma, return_flags=True)
+        bad = int((flags & 0xff).max().item()) if flags.numel() else 0
+        if bad & 1:
+            raise RuntimeError("LETKF kernel: local observation list overflow (engine bug: lists are sized from counts)")
+        if bad & 4:
+            warnings.warn("LETKF kernel met non-finite values in at least one local block", RuntimeWarning)
+        return xa.reshape(shp[:-1] + (nb.g1 - nb.g0,))
+
+
+class KETKF(ETKF):
+    """Kernelised ETKF (interface/ketkf.py:34-123)."""
+
+    def __init__(self, kernel, inf_factor: float = 1.0, smoother: bool = False, gpu: bool = True,
+                 pre_transform=None, post_transform=None, weight_save_path=None, forward_model=None,
+                 dtype: torch.dtype = torch.float32, engine: Optional[LetkfEngine] = None):
+        super().__init__(inf_factor=inf_factor, smoother=smoother, gpu=gpu, pre_transform=pre_transform,
+                         post_transform=post_transform, weight_save_path=weight_save_path,
+                         forward_model=forward_model, dtype=dtype, engine=engine)
+        self.kernel = kernel
+
+    @property
+    def kernel(self):
+        return self._kernel
+
+    @kernel.setter
+    def kernel(self, new_kernel):
+        self._kernel = new_kernel
+
+    def __str__(self):
+        return "Global KETKF(inf_factor={0}, kernel={1})".format(self.inf_factor, str(self.kernel))
+
+    def __repr__(self):
+        return "KETKF({0})".format(repr(self.kernel))
+
+
+class LKETKF(LETKF):
+    """Localised kernelised ETKF (interface/lketkf.py:37-115; estimate_weights is LETKF's, :77)."""
+
+    def __init__(self, kernel, localization: Optional[GaspariCohn] = None, inf_factor: float = 1.0,
+                 smoother: bool = False, gpu: bool = True, pre_transform=None, post_transform=None,
+                 chunksize: int = 10, weight_save_path=None, forward_model=None,
+                 dtype: torch.dtype = torch.float32, engine: Optional[LetkfEngine] = None):
+        super().__init__(localization=localization, inf_factor=inf_factor, smoother=smoother, gpu=gpu,
+                         pre_transform=pre_transform, post_transform=post_transform, chunksize=chunksize,
+                         weight_save_path=weight_save_path, forward_model=forward_model, dtype=dtype, engine=engine)
+        self._kernel = kernel
+
+    kernel = KETKF.kernel
+
+    def __str__(self):
+        return "Localized KETKF(inf_factor={0}, loc={1}, kernel={2})".format(
+            self.inf_factor, str(self.localization), str(self.kernel))
+
+    def __repr__(self):
+        return "LKETKF({0},{1})".format(repr(self.localization), repr(self.kernel))

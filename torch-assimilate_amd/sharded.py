@@ -37,9 +37,10 @@ def gather_blocks(shard: torch.Tensor, G: int, world: int, group=None) -> torch.
         pad = torch.zeros((m, k, n), dtype=shard.dtype, device=shard.device)
         pad[:, :, :n_r] = shard
         shard = pad
-    gathered = torch.empty((world, m, k, n), dtype=shard.dtype, device=shard.device)
+    # dim-0 concatenation is the layout both RCCL and gloo accept for all_gather_into_tensor
+    gathered = torch.empty((world * m, k, n), dtype=shard.dtype, device=shard.device)
     dist.all_gather_into_tensor(gathered, shard.contiguous(), group=group)
-    return gathered.permute(1, 2, 0, 3).reshape(m, k, world * n)[:, :, :G].contiguous()
+    return gathered.view(world, m, k, n).permute(1, 2, 0, 3).reshape(m, k, world * n)[:, :, :G].contiguous()
 
 
 class ShardedLetkf:
