@@ -45,6 +45,20 @@ def algorithmic_bytes(k, m, P_over_G, n_coord=1):
     return 4.0 * (2 * k * m + (k + 1) * P_over_G + 2 * n_coord * (1 + P_over_G))
 
 
+def traffic_from_profiles(world):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/*traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes on this same
+    workload; bench.py cannot run the profiler on itself).  None when no matching record exists."""
+    path = os.path.join(ROOT, "profiles", "latest_traffic.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        rec = json.load(fh)
+    if rec.get("grid_points") != G_PER_GPU or rec.get("k") != K_ENS:
+        return None
+    return rec
+
+
 def make_case(G, k, stride, device, seed=42):
     """Synthetic inputs generated directly on the device (same distribution as
     oracle.synthetic_case; the seeded numpy version is used wherever values are compared)."""
@@ -172,7 +186,7 @@ def main():
                                    % ("2" if world == 1 else "3-style", G, gpg, K_ENS, P, GC_RADIUS, p_max, INF),
                        "parallelism": "grid-point block shard x%d%s" % (world, " + RCCL all-gather" if world > 1 else "")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic_from_profiles(world),
                          "kernel": runner.dominant_kernel_name, "kernel_ms": kern_ms,
                          "algorithmic_flops_per_analysis": algorithmic_flops(K_ENS, 20, 1),
                          "hbm_algorithmic_GBs": hbm_alg, "hbm_frac": hbm_alg / PEAK_HBM_GBS,

@@ -141,8 +141,14 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 4 : 2)) void letkf_sys_kernel(SysPa
 
   // one grid point per workgroup: no point loop, so nothing per-lane is hoisted and kept live
   // across phases (with a loop the compiler precomputed ~100 address registers and spilled them)
-  const int64_t pt = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-  if (pt >= P.ng) return;
+  // XCD-aware block -> point map: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8
+  // share an L2), so giving XCD x the contiguous point range x*ng/8.. keeps the records shared by
+  // neighbouring grid points in ONE L2 and lets the partial-line X / Xa accesses of consecutive points
+  // merge there (speed / traffic only - any placement is correct).
+  const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+  if (bid >= P.ng) return;
+  const int64_t q8 = P.ng >> 3, r8 = P.ng & 7, xcd = bid & 7;
+  const int64_t pt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   {
     const int64_t g = P.g0 + pt;
     const int cnt = P.cnt[pt];

@@ -30,6 +30,19 @@ class NeighbourLists:
     p_max: int
     g0: int
     g1: int
+    stats: Optional[torch.Tensor] = None   # device [max count, #truncated]; set when the read-back was deferred
+    observed_p_max: Optional[int] = None
+
+    def confirm(self) -> bool:
+        """Deferred check of an assumed ``p_max`` (host sync): True when every list fitted."""
+        if self.stats is None:
+            return True
+        p_max, n_over = (int(v) for v in self.stats.tolist())
+        self.observed_p_max = p_max
+        ok = n_over == 0 and p_max <= self.p_max
+        if ok:
+            self.stats = None
+        return ok
 
 
 class LetkfEngine:
@@ -70,7 +83,12 @@ class LetkfEngine:
 
     def localize(self, grid_xyz, obs_xyz, radii: Sequence[float], coord_group: Optional[Sequence[int]] = None,
                  eps: float = 1e-5, g0: int = 0, g1: Optional[int] = None,
-                 p_cap: Optional[int] = None) -> NeighbourLists:
+                 p_cap: Optional[int] = None, assume_p_max: Optional[int] = None) -> NeighbourLists:
+        """Neighbour lists of grid points [g0, g1).  By default the maximum list length is read back
+        (one 8-byte host sync) to size the analysis launch.  With ``assume_p_max`` (e.g. the value of the
+        previous cycle on the same geometry) nothing is read back here: the returned lists carry the
+        assumption and ``NeighbourLists.confirm()`` checks it later, e.g. after the analysis has been
+        enqueued; the analysis kernel itself flags any point whose list does not fit (never truncates)."""
         grid = self._dev(grid_xyz, torch.float64)
         obs = self._dev(obs_xyz, torch.float64)
         if grid.dim() == 1:
@@ -95,6 +113,16 @@ class LetkfEngine:
         ws = self._workspace("loc", nbytes.value)
         stats = torch.empty(2, dtype=torch.int32, device=self.device)
         cap = int(p_cap) if p_cap is not None else self._p_cap_hint
+        if assume_p_max is not None:
+            cap = max(8, (int(assume_p_max) + 7) // 8 * 8)
+            cnt = torch.empty(n, dtype=torch.int32, device=self.device)
+            idx = torch.empty((n, cap), dtype=torch.int32, device=self.device)
+            w = torch.empty((n, cap), dtype=torch.float64, device=self.device)
+            _cabi.check(self.lib.mia_letkf_localize_f64(
+                _ptr(grid), g0, g1, _ptr(obs), P, nc, cg, rc, n_r, float(eps), cap,
+                _ptr(cnt), _ptr(idx), _ptr(w), _ptr(stats), _ptr(ws), ws.numel(), self._stream()),
+                "mia_letkf_localize_f64")
+            return NeighbourLists(cnt, idx, w, cap, int(assume_p_max), g0, g1, stats)
         while True:
             cnt = torch.empty(n, dtype=torch.int32, device=self.device)
             idx = torch.empty((n, cap), dtype=torch.int32, device=self.device)

@@ -63,6 +63,7 @@ class ShardedLetkf:
         self._engine = None
         self._compute = compute_shard or self._engine_shard
         self.last_p_max = 0
+        self._p_max_hint = None
         self._last_flags = None
 
     @property
@@ -74,9 +75,17 @@ class ShardedLetkf:
 
     def _engine_shard(self, X, grid_xyz, obs_xyz, Yb, d, g0, g1):
         eng = self.engine
-        nb = eng.localize(grid_xyz, obs_xyz, self.radii, self.coord_group, self.eps, g0, g1)
-        self.last_p_max = nb.p_max
+        # the previous cycle's maximum list length is assumed (no host sync before the analysis launch);
+        # the assumption is confirmed AFTER the analysis has been enqueued, while the GPU is busy, and
+        # the shard is redone with the true value in the (rare) case it did not hold
+        nb = eng.localize(grid_xyz, obs_xyz, self.radii, self.coord_group, self.eps, g0, g1,
+                          assume_p_max=self._p_max_hint)
         xa, flags = eng.analysis(X, Yb, d, nb, self.inf_factor, rbf_gamma=self.rbf_gamma, return_flags=True)
+        if not nb.confirm():
+            nb = eng.localize(grid_xyz, obs_xyz, self.radii, self.coord_group, self.eps, g0, g1)
+            xa, flags = eng.analysis(X, Yb, d, nb, self.inf_factor, rbf_gamma=self.rbf_gamma, return_flags=True)
+        self._p_max_hint = nb.observed_p_max if nb.observed_p_max is not None else nb.p_max
+        self.last_p_max = nb.p_max
         self._last_flags = flags
         return xa
 
