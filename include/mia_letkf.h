@@ -45,6 +45,7 @@ extern "C" {
 #define MIA_FLAG_OVERFLOW 1 /* more local observations than p_max: point NOT analysed */
 #define MIA_FLAG_NOCONV 2   /* Jacobi eigensolver hit its sweep cap (result still returned) */
 #define MIA_FLAG_NONFINITE 4 /* non-finite value met in the local block */
+#define MIA_FLAG_RETRY 8    /* matfun route declined this point (spectrum too wide): redo with the eigensolver */
 /* bits 8-15: Jacobi sweeps started, bits 16-31: tournament rounds that rotated (diagnostics) */
 #define MIA_FLAG_MASK 0xff
 
@@ -147,6 +148,26 @@ int mia_letkf_analysis_packed_f64(const double* X, int64_t ldx, int m, int k, in
                                   int p_cap, int p_max, double inf_factor, double gamma,
                                   double* Xa, int64_t ldo, int64_t o0, double* W_opt, int32_t* flags_opt,
                                   void* stream);
+
+/* Eigensolver-free route for few state rows (m small) when the weights are not requested: the two matrix
+ * functions the analysis needs, (C+reg)^-1 and (C+reg)^-1/2 (core/etkf.py:67-76), are applied to the state row
+ * by a Chebyshev expansion whose degree is fixed per grid point from a Gershgorin bound (SURVEY.md section 7
+ * notes such evaluations are valid because W and Pa are functions of A only).  Points that would need a
+ * degree above the built-in cap get MIA_FLAG_RETRY in flags[] (required, not optional here), are counted in
+ * *retry_count (device int32, zeroed by the caller) and are left untouched in Xa; the caller then runs
+ * mia_letkf_analysis_retry_f32 - the eigensolver kernel restricted to the flagged points.
+ * Same argument meaning as mia_letkf_analysis_packed_f32. */
+int mia_letkf_analysis_matfun_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                  const float* rec, int64_t P,
+                                  const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w,
+                                  int p_cap, int p_max, float inf_factor, float gamma,
+                                  float* Xa, int64_t ldo, int64_t o0, int32_t* flags, int32_t* retry_count,
+                                  void* stream);
+int mia_letkf_analysis_retry_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                 const float* rec, int64_t P,
+                                 const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w,
+                                 int p_cap, int p_max, float inf_factor, float gamma,
+                                 float* Xa, int64_t ldo, int64_t o0, int32_t* flags, void* stream);
 
 /* Kernelised variant: KETKFModule with RBFKernel(gamma) (core/ketkf.py:65-94,
  * kernels/rbf.py:75-81,110-111), same localisation and transform (LKETKF,

@@ -211,6 +211,8 @@ def test_large_grid_properties(eng):
     xa = eng.analysis(X, yb, d, nb, 1.1)
     xa2 = eng.analysis(X, yb, d, nb, 1.1)
     assert torch.equal(xa, xa2)
+    xe = eng.analysis(X, yb, d, nb, 1.1, method="eig")           # the two routes agree at full size
+    assert float(torch.linalg.norm(xa - xe) / torch.linalg.norm(xe)) < TOL32
     assert torch.isfinite(xa).all()
     # shard [30000, 30100) equals the same columns of the full run, bit for bit
     nb_s = eng.localize(case["grid_x"], case["obs_x"], [10.0], g0=30000, g1=30100)
@@ -223,3 +225,76 @@ def test_large_grid_properties(eng):
         w = O.localized_weights(dist, case["yb"], case["d"], [10.0], 1.1)
         ref = O.apply_weights(case["state"][:, :, [gi]], w[None])
         assert rel_fro(xa[:, :, gi].cpu().numpy(), ref[:, :, 0]) < TOL32
+
+
+# ---------------------------------------------------------------- eigensolver-free (matfun) route
+@pytest.mark.parametrize("name,c,gamma", [("c2", 10.0, None), ("c4", 16.5, None), ("c2m3", 10.0, None), ("c5", 10.0, 0.5)])
+def test_matfun_route_vs_reference(eng, golden, name, c, gamma):
+    """The Chebyshev matrix-function route against the reference-generated analysis (same gate as the
+    eigensolver route: 1e-5 relative Frobenius, increments within 1e-4) and against the eigensolver route."""
+    g = golden("g7_synthetic_configs.npz")
+    X = g[f"{name}_state"]
+    nb = eng.localize(g[f"{name}_grid_x"], g[f"{name}_obs_x"], [c])
+    xm = X.mean(axis=1, keepdims=True)
+    for inf in (1.0, 1.1):
+        tag = f"{name}_{str(inf).replace('.', 'p')}"
+        args = (dev(X, torch.float32), dev(g[f"{name}_yb"], torch.float32), dev(g[f"{name}_d"], torch.float32), nb, inf)
+        xa, fl = eng.analysis(*args, rbf_gamma=gamma, return_flags=True, method="matfun")
+        xe = eng.analysis(*args, rbf_gamma=gamma, method="eig")
+        f = fl.cpu().numpy()
+        assert int((f & 0xff).max()) == 0
+        ref = g[f"{tag}_analysis"]
+        assert rel_fro(xa.cpu().numpy(), ref) < TOL32
+        assert rel_fro(xa.cpu().numpy() - xm, ref - xm) < 10 * TOL32
+        assert rel_fro(xa.cpu().numpy(), xe.cpu().numpy()) < TOL32
+
+
+def test_matfun_blocks_and_edge_cases(eng, golden):
+    """Random (k, p) blocks of both routes (dual p <= k, primal p > k), the empty observation set and the
+    weights request (which must refuse the matfun route)."""
+    g = golden("g3_g4_core_blocks.npz")
+    for ci, (k, p) in enumerate(g["cases"]):
+        if k > 128 or min(k, p) > 64:
+            continue
+        yb, d = g[f"yb_{ci}"], g[f"d_{ci}"]
+        X = np.random.RandomState(ci).normal(size=(2, k, 1))
+        nb = all_obs_lists(eng, 1, p)
+        xa, fl = eng.analysis(dev(X, torch.float32), dev(yb, torch.float32), dev(d, torch.float32), nb, 1.1,
+                              return_flags=True, method="matfun")
+        assert (int(fl.cpu()[0]) & 0xff) == 0
+        assert rel_fro(xa.cpu().numpy(), O.apply_weights(X, g[f"etkf_{ci}_1p1"][None])) < TOL32, (k, p)
+    X = np.random.RandomState(0).normal(size=(1, 10, 5))
+    nb = eng.localize(np.arange(5.0), np.zeros((0, 1)), [10.0])
+    xa = eng.analysis(dev(X, torch.float32), torch.zeros((10, 0)), torch.zeros(0), nb, 1.1, method="matfun")
+    assert rel_fro(xa.cpu().numpy(), O.apply_weights(X, np.sqrt(1.1) * np.eye(10))) < 1e-6
+    with pytest.raises(ValueError):
+        eng.analysis(dev(X, torch.float32), torch.zeros((10, 0)), torch.zeros(0), nb, 1.1, method="matfun",
+                     return_weights=True)
+
+
+def test_matfun_declines_wide_spectra_and_eigensolver_redoes_them(eng, golden, monkeypatch):
+    """Strong observations (large lambda_max / reg) exceed the degree cap: those grid points are flagged
+    MIA_FLAG_RETRY by the matfun kernel and redone by the eigensolver kernel; the result is the oracle's."""
+    case = O.synthetic_case(300, 40, 2)
+    yb, d = case["yb"] * 12.0, case["d"] * 12.0          # obs error variance / 144: kappa ~ 1e3
+    nb = eng.localize(case["grid_x"], case["obs_x"], [10.0])
+    args = (dev(case["state"], torch.float32), dev(yb, torch.float32), dev(d, torch.float32), nb, 1.1)
+    xa, fl, finish = eng.analysis(*args, return_flags=True, method="matfun", defer_retry=True)
+    f_before = fl.cpu().numpy().copy()
+    n_retry = finish()
+    assert n_retry == int(((f_before & 8) != 0).sum()) and n_retry > 100
+    f_after = fl.cpu().numpy()
+    assert int((f_after & 0xff).max()) == 0                # every declined point was redone
+    ref, _ = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], yb, d, 10.0, 1.1)
+    assert rel_fro(xa.cpu().numpy(), ref) < TOL32
+    xm = case["state"].mean(axis=1, keepdims=True)
+    assert rel_fro(xa.cpu().numpy() - xm, ref - xm) < 10 * TOL32
+    # a moderate case mixes both kernels inside one shard
+    monkeypatch.setenv("MIA_CHEB_DMAX", "17")
+    yb2, d2 = case["yb"], case["d"]
+    xa2, fl2, fin2 = eng.analysis(dev(case["state"], torch.float32), dev(yb2, torch.float32), dev(d2, torch.float32),
+                                  nb, 1.1, return_flags=True, method="matfun", defer_retry=True)
+    n2 = fin2()
+    assert 0 < n2 < 300
+    ref2, _ = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], yb2, d2, 10.0, 1.1)
+    assert rel_fro(xa2.cpu().numpy(), ref2) < TOL32

@@ -1,0 +1,381 @@
+// Fused LETKF analysis without an explicit eigendecomposition: matrix functions applied to
+// vectors by Chebyshev expansion ("matfun" route), float32, one wavefront per grid point.
+//
+// What the reference computes per grid point (core/etkf.py:57-103 + interface/base.py:257-278)
+// depends on the local matrix only through two FUNCTIONS of it,
+//     w_mean = (C + reg)^-1 (Yl d),      W = sqrt(k-1) (C + reg)^-1/2,     C = Yl Yl^T, reg = (k-1)/inf
+// (eigenvalue clamp and shift of core/utils.py:57-60 included: C is positive semi-definite), and the
+// analysis of a state row x only needs their action on ONE vector:
+//     xa = mean + x' w_mean + x' W .
+// SURVEY.md section 7 ("Hard parts") notes that W and Pa being functions of A alone makes
+// eigensolver-free evaluations valid.  On the dual route (p <= k, see letkf_generic.hip) with
+// S = Yl^T Yl, z = Yl^T x' :
+//     x' W      = f0 x' + Yl (phi(S) z),        phi(l) = -sqrt(k-1) / (u a (a + u)),  u = sqrt(l+reg), a = sqrt(reg)
+//     x' w_mean = d_l . (psi(S) z),             psi(l) = 1 / (l + reg)
+// (primal route / RBF-KETKF: S = C or the centred kernel matrix, z = x', phi(l) = sqrt(k-1)/u).
+// phi(S) z and psi(S) z share ONE three-term Chebyshev recurrence t_{j+1} = 2 A t_j - t_{j-1} on
+// A = 2 S / L - I, where L >= lambda_max is the Gershgorin bound of S; both functions are analytic on
+// [0, L] with their nearest singularity at -reg, so the truncation error decays like rho^-d with
+// rho = (sqrt(1+L/reg)+1)/(sqrt(1+L/reg)-1): the degree d is fixed a priori per grid point from L/reg
+// (no convergence loop).  Cost O(d n^2) per state row instead of O(sweeps n^3) for the Jacobi
+// eigensolver, so this route is used when few state rows are transformed and the weights matrix is
+// not requested; grid points whose spectrum would need d > d_max are flagged MIA_FLAG_RETRY and
+// redone by the eigensolver kernel.
+//
+// Mapping: lane r holds row r of S in registers (n <= 64); each recurrence step is n FMAs per lane
+// against the broadcast vector (LDS float4 reads of one address = broadcast), one LDS write of the new
+// vector.  The Gram matrix comes from the matrix cores (v_mfma_f32_16x16x4_f32) as in letkf_sys.hip.
+#include <cstdlib>
+#include "mia_common.h"
+
+namespace mia {
+
+struct ChebParams {
+  const float* X; int64_t ldx; int m; int k;
+  int64_t g0, ng;
+  const float* rec; int kp;
+  const int32_t* cnt; const int32_t* idx; const double* w; int p_cap; int p_max;
+  float reg; float* Xa; int64_t ldo, o0; int32_t* flags;
+  int dual; int rows; int dmax; float log_tol;
+  int kernel_mode; float gamma;
+  int32_t* retry_count;
+};
+
+using f32x4c = __attribute__((ext_vector_type(4))) float;
+
+__device__ inline float wave_sum_c(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max_c(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+template <int NMAX, int KL>
+__global__ __launch_bounds__(64) void letkf_cheb_kernel(ChebParams P) {
+  constexpr int LDA = (NMAX % 8 == 0) ? NMAX + 4 : NMAX;
+  constexpr int N4 = NMAX / 4;
+  constexpr int TT = (NMAX + 15) / 16, NTILE = TT * (TT + 1) / 2;
+  constexpr int DCAP = 64;                       // storage for Chebyshev coefficients
+  static_assert(NMAX % 4 == 0 && NMAX <= 64, "order must be a multiple of 4, one matrix row per lane");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const int k = P.k, kp = P.kp, pm = P.p_max;
+  float* S = reinterpret_cast<float*>(smem_raw);    // [NMAX][LDA] full symmetric
+  float* tv = S + NMAX * LDA;                       // [NMAX] recurrence vector (broadcast source)
+  float* rhs = tv + NMAX;                           // [NMAX]
+  float* uq = rhs + NMAX;                           // [NMAX] scratch (RBF centring)
+  float* cphi = uq + NMAX;                          // [DCAP]
+  float* cpsi = cphi + DCAP;                        // [DCAP]
+  float* fphi = cpsi + DCAP;                        // [DCAP] function samples at the Chebyshev nodes
+  float* fpsi = fphi + DCAP;                        // [DCAP]
+  float* red = fpsi + DCAP;                         // [8]
+  float* xp = red + 8;                              // [kp]
+  float* sw = xp + kp;                              // [NMAX] phi(S) z
+  float* Yt = sw + NMAX;                            // [rows][kp]
+  float* lw = Yt + (size_t)P.rows * kp;             // [pm + 2]
+  int* lidx = reinterpret_cast<int*>(lw + ((pm + 3) & ~1));   // [pm + 2]
+
+  const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+  if (bid >= P.ng) return;
+  const int64_t q8 = P.ng >> 3, r8 = P.ng & 7, xcd = bid & 7;   // XCD-aware block -> point map (letkf_sys.hip)
+  const int64_t pt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int64_t g = P.g0 + pt;
+  const int cnt = P.cnt[pt];
+  int flag = 0;
+  const float km1 = float(k - 1), reg = P.reg;
+  const float ar = sqrtf(reg);
+  const float f0 = P.dual ? sqrtf(km1 / reg) : 0.0f;
+
+  if (cnt > pm || cnt > P.p_cap || (P.dual ? cnt : k) > NMAX) {   // loud failure, never truncate
+    if (P.flags && tid == 0) P.flags[pt] = MIA_FLAG_OVERFLOW;
+    const float nanv = __builtin_nanf("");
+    for (int it = tid; it < P.m * k; it += 64) P.Xa[(int64_t)it * P.ldo + P.o0 + pt] = nanv;
+    return;
+  }
+  float xval[KL];
+#pragma unroll
+  for (int u = 0; u < KL; ++u) { const int i = tid + 64 * u; xval[u] = i < k ? P.X[(int64_t)i * P.ldx + g] : 0.0f; }
+  for (int j = tid; j < cnt; j += 64) {
+    lidx[j] = P.idx[pt * P.p_cap + j];
+    lw[j] = float(P.w[pt * P.p_cap + j]);
+  }
+  __syncthreads();
+  {   // gather + sqrt(rho) scale (wrapper.py:91-97)
+    const int kpv = kp >> 2;
+    for (int it = tid; it < cnt * kpv; it += 64) {
+      const int j = it / kpv, c = it - j * kpv;
+      float4 v = reinterpret_cast<const float4*>(P.rec + (int64_t)lidx[j] * kp)[c];
+      const float wj = lw[j];
+      v.x *= wj; v.y *= wj; v.z *= wj; v.w *= wj;
+      reinterpret_cast<float4*>(Yt + (size_t)j * kp)[c] = v;
+    }
+  }
+  const int ntrue = P.dual ? cnt : k;
+  __syncthreads();
+  // ---- S (full symmetric storage, zero padded)
+  if (P.dual) {
+    const int lr = tid & 15, h = tid >> 4;
+    const int KS = (k + 3) >> 2;
+#pragma unroll
+    for (int tile = 0; tile < NTILE; ++tile) {
+      int tb_ = 0;
+      while ((tb_ + 1) * (tb_ + 2) / 2 <= tile) ++tb_;
+      const int ta_ = tile - tb_ * (tb_ + 1) / 2;
+      const int ra = 16 * ta_ + lr, rb = 16 * tb_ + lr;
+      const float* pa = Yt + (size_t)ra * kp + KS * h;
+      const float* pb = Yt + (size_t)rb * kp + KS * h;
+      f32x4c acc = {0.f, 0.f, 0.f, 0.f};
+      for (int s_ = 0; s_ < KS; ++s_) {
+        const bool kin = KS * h + s_ < k;
+        const float av_ = (ra < cnt && kin) ? pa[s_] : 0.0f;
+        const float bv_ = (rb < cnt && kin) ? pb[s_] : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av_, bv_, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int a = 16 * ta_ + h * 4 + q, b = 16 * tb_ + lr;
+        if (a < NMAX && b < NMAX) { S[a * LDA + b] = acc[q]; if (ta_ != tb_) S[b * LDA + a] = acc[q]; }
+      }
+    }
+  } else {
+    for (int it = tid; it < NMAX * NMAX; it += 64) {
+      const int a = it / NMAX, b = it - a * NMAX;
+      if (a > b) continue;
+      float acc = 0.0f;
+      if (b < k) {
+        if (P.kernel_mode == 0) {
+          for (int j = 0; j < cnt; ++j) acc += Yt[(size_t)j * kp + a] * Yt[(size_t)j * kp + b];
+        } else {   // RBF Gram (kernels/rbf.py:75-81,110-111)
+          for (int j = 0; j < cnt; ++j) { const float df = Yt[(size_t)j * kp + a] - Yt[(size_t)j * kp + b]; acc += df * df; }
+          acc = __expf(-P.gamma * acc);
+        }
+      }
+      S[a * LDA + b] = acc; S[b * LDA + a] = acc;
+    }
+  }
+  __syncthreads();
+  // ---- right-hand side of the mean weights
+  if (P.dual) {
+    if (tid < NMAX) rhs[tid] = tid < cnt ? Yt[(size_t)tid * kp + k] : 0.0f;
+  } else if (P.kernel_mode == 0) {
+    for (int i = tid; i < NMAX; i += 64) {
+      float acc = 0.0f;
+      if (i < k) for (int j = 0; j < cnt; ++j) acc += Yt[(size_t)j * kp + i] * Yt[(size_t)j * kp + k];
+      rhs[i] = acc;
+    }
+  } else {   // double centring of K and centring of k(Yb, d)   (core/ketkf.py:77-89)
+    for (int i = tid; i < k; i += 64) {
+      float acc = 0.0f;
+      for (int j = 0; j < k; ++j) acc += S[i * LDA + j];
+      uq[i] = acc / float(k);
+      float ko = 0.0f;
+      for (int j = 0; j < cnt; ++j) { const float df = Yt[(size_t)j * kp + i] - Yt[(size_t)j * kp + k]; ko += df * df; }
+      rhs[i] = __expf(-P.gamma * ko);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float gm = 0.0f, om = 0.0f;
+      for (int i = 0; i < k; ++i) { gm += uq[i]; om += rhs[i]; }
+      red[0] = gm / float(k); red[1] = om / float(k);
+    }
+    __syncthreads();
+    for (int it = tid; it < k * k; it += 64) {
+      const int a = it / k, b = it - a * k;
+      S[a * LDA + b] = S[a * LDA + b] - uq[b] - (uq[a] - red[0]);
+    }
+    __syncthreads();
+    for (int i = tid; i < NMAX; i += 64) rhs[i] = i < k ? rhs[i] - red[1] - (uq[i] - red[0]) : 0.0f;
+  }
+  __syncthreads();
+  // ---- row r of S into registers; Gershgorin bound L >= lambda_max
+  float srow[NMAX];
+  float rsum = 0.0f;
+  const int r = tid < NMAX ? tid : NMAX - 1;
+#pragma unroll
+  for (int b4 = 0; b4 < N4; ++b4) {
+    const float4 v = reinterpret_cast<const float4*>(S + r * LDA)[b4];
+    srow[4 * b4] = v.x; srow[4 * b4 + 1] = v.y; srow[4 * b4 + 2] = v.z; srow[4 * b4 + 3] = v.w;
+    rsum += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
+  }
+  const float rhs_r = tid < NMAX ? rhs[tid] : 0.0f;
+  float L = wave_max_c(tid < NMAX ? rsum : 0.0f);
+  L = fmaxf(L, 1e-30f * reg) * 1.0001f;
+  // ---- degree from the Bernstein-ellipse parameter of the singularity at -reg
+  const float sq = sqrtf(1.0f + L / reg);
+  const float rho = (sq + 1.0f) / fmaxf(sq - 1.0f, 1e-12f);
+  int deg = (int)ceilf(P.log_tol / __logf(rho)) + 2;
+  deg = deg < 3 ? 3 : deg;
+  if (!(L == L) || !(fabsf(L) < 1e30f)) { flag |= MIA_FLAG_NONFINITE; deg = 3; }
+  if (deg > P.dmax || deg > DCAP - 1) {   // spectrum too wide for the polynomial route: eigensolver redoes this point
+    if (tid == 0) {
+      if (P.flags) P.flags[pt] = MIA_FLAG_RETRY;
+      atomicAdd(P.retry_count, 1);
+    }
+    return;
+  }
+  // ---- Chebyshev coefficients of phi and psi on [0, L]: samples at the N = deg+1 Gauss nodes, then a DCT
+  const int N = deg + 1;
+  {
+    const float invN = 1.0f / float(N);
+    if (tid < N) {
+      const float x = __builtin_amdgcn_cosf(0.5f * (float(tid) + 0.5f) * invN);     // cos(pi (i+1/2)/N), argument in turns
+      const float lam = 0.5f * L * (x + 1.0f);
+      const float le = lam + reg;
+      const float u = __builtin_amdgcn_sqrtf(le);
+      fphi[tid] = P.dual ? -sqrtf(km1) / (u * ar * (ar + u)) : sqrtf(km1) / u;
+      fpsi[tid] = 1.0f / le;
+    }
+    __syncthreads();
+    if (tid < N) {
+      float a1 = 0.0f, a2 = 0.0f;
+      for (int i = 0; i < N; ++i) {
+        const float c = __builtin_amdgcn_cosf(0.5f * float(tid) * (float(i) + 0.5f) * invN);   // cos(j pi (i+1/2)/N)
+        a1 += fphi[i] * c; a2 += fpsi[i] * c;
+      }
+      const float sc = (tid == 0 ? 1.0f : 2.0f) * invN;
+      cphi[tid] = a1 * sc; cpsi[tid] = a2 * sc;
+    }
+    __syncthreads();
+  }
+  const float alpha = 2.0f / L;            // A v = alpha S v - v
+  // ---- per state row: z, the shared recurrence, the output
+  const int k4 = (k + 3) >> 2;
+  for (int mi = 0; mi < P.m; ++mi) {
+    if (mi > 0) {
+#pragma unroll
+      for (int u = 0; u < KL; ++u) { const int i = tid + 64 * u; xval[u] = i < k ? P.X[((int64_t)mi * k + i) * P.ldx + g] : 0.0f; }
+    }
+    float xs = 0.0f;
+#pragma unroll
+    for (int u = 0; u < KL; ++u) xs += xval[u];
+    const float xm = wave_sum_c(xs) / float(k);
+#pragma unroll
+    for (int u = 0; u <= KL; ++u) {         // one pass more than members per lane: zero the d / pad slots
+      const int i = tid + 64 * u;
+      if (i < kp) xp[i] = (u < KL && i < k) ? xval[u < KL ? u : 0] - xm : 0.0f;
+    }
+    __syncthreads();
+    float t0 = 0.0f;                        // z_r
+    if (tid < NMAX) {
+      if (P.dual) {
+        if (tid < cnt) {
+          const float4* yb = reinterpret_cast<const float4*>(Yt + (size_t)tid * kp);
+          const float4* x4 = reinterpret_cast<const float4*>(xp);
+          for (int i = 0; i < k4; ++i) { const float4 y = yb[i], x = x4[i]; t0 += y.x * x.x + y.y * x.y + y.z * x.z + y.w * x.w; }
+        }
+      } else t0 = tid < k ? xp[tid] : 0.0f;
+      tv[tid] = t0;
+    }
+    __syncthreads();
+    // t1 = A t0
+    float y = 0.0f;
+#pragma unroll
+    for (int b4 = 0; b4 < N4; ++b4) {
+      const float4 v = reinterpret_cast<const float4*>(tv)[b4];
+      y += srow[4 * b4] * v.x + srow[4 * b4 + 1] * v.y + srow[4 * b4 + 2] * v.z + srow[4 * b4 + 3] * v.w;
+    }
+    float tprev = t0, tcur = alpha * y - t0;
+    float aphi = cphi[0] * t0 + cphi[1] * tcur, apsi = cpsi[0] * t0 + cpsi[1] * tcur;
+    for (int j = 2; j <= deg; ++j) {
+      __syncthreads();                      // every lane has read tv
+      if (tid < NMAX) tv[tid] = tcur;
+      __syncthreads();
+      y = 0.0f;
+#pragma unroll
+      for (int b4 = 0; b4 < N4; ++b4) {
+        const float4 v = reinterpret_cast<const float4*>(tv)[b4];
+        y += srow[4 * b4] * v.x + srow[4 * b4 + 1] * v.y + srow[4 * b4 + 2] * v.z + srow[4 * b4 + 3] * v.w;
+      }
+      const float tnext = 2.0f * (alpha * y - tcur) - tprev;
+      tprev = tcur; tcur = tnext;
+      aphi += cphi[j] * tcur; apsi += cpsi[j] * tcur;
+    }
+    const bool live = tid < ntrue;
+    const float zu = wave_sum_c(live ? rhs_r * apsi : 0.0f);      // x' w_mean
+    if (tid < NMAX) sw[tid] = live ? aphi : 0.0f;
+    __syncthreads();
+    const float mterm = xm + zu;
+    float* orow = P.Xa + (int64_t)mi * k * P.ldo + P.o0 + pt;
+#pragma unroll
+    for (int u = 0; u < KL; ++u) {
+      const int j = tid + 64 * u;
+      if (j < k) {
+        float acc;
+        if (P.dual) {   // Yl s from the LDS block (still resident on this route; member j contiguous across lanes)
+          acc = f0 * (xval[u] - xm);
+          for (int b = 0; b < cnt; ++b) acc += sw[b] * Yt[(size_t)b * kp + j];
+        } else acc = sw[j];
+        const float out = mterm + acc;
+        if (!(fabsf(out) <= 1e30f)) flag |= MIA_FLAG_NONFINITE;
+        orow[(int64_t)j * P.ldo] = out;
+      }
+    }
+    __syncthreads();
+  }
+  if (P.flags) {
+    const int any = __any(flag != 0) ? MIA_FLAG_NONFINITE : 0;
+    if (tid == 0) P.flags[pt] = any | (deg << 8);     // bits 8-15: polynomial degree used (diagnostics)
+  }
+}
+
+static size_t cheb_lds_bytes(int kp, int p_max, int nmax, int rows) {
+  const int lda = (nmax % 8 == 0) ? nmax + 4 : nmax;
+  size_t e = (size_t)nmax * lda + 4 * (size_t)nmax + 4 * 64 + 8 + (size_t)kp + (size_t)rows * kp + ((p_max + 3) & ~1);
+  return align_up(e * sizeof(float) + (size_t)((p_max + 3) & ~1) * sizeof(int), 16);
+}
+
+template <int NMAX, int KL>
+static int cheb_launch(const ChebParams& ap, size_t lds, dim3 grid, hipStream_t stream) {
+  auto kern = letkf_cheb_kernel<NMAX, KL>;
+  if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  kern<<<grid, dim3(64), lds, stream>>>(ap);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// MIA_ERR_UNSUPPORTED when the shape is outside this route (caller uses the eigensolver kernels)
+int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
+                         const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
+                         float inf_factor, int kernel_mode, float gamma, float* Xa, int64_t ldo, int64_t o0,
+                         int32_t* flags, int32_t* retry_count, hipStream_t stream) {
+  if (!flags || !retry_count) return MIA_ERR_UNSUPPORTED;   // the retry protocol needs both
+  ChebParams ap;
+  ap.X = X; ap.ldx = ldx; ap.m = m; ap.k = k; ap.g0 = g0; ap.ng = ng; ap.rec = rec;
+  ap.kp = (k + 1 + 3) & ~3;
+  ap.cnt = nbr_cnt; ap.idx = nbr_idx; ap.w = nbr_w; ap.p_cap = p_cap; ap.p_max = p_max;
+  ap.reg = float(k - 1) / inf_factor;
+  ap.Xa = Xa; ap.ldo = ldo; ap.o0 = o0; ap.flags = flags; ap.retry_count = retry_count;
+  ap.kernel_mode = kernel_mode; ap.gamma = gamma;
+  ap.dual = (kernel_mode == 0 && p_max <= k) ? 1 : 0;
+  const int ntrue = ap.dual ? p_max : k;
+  static const int buckets[] = {4, 8, 12, 16, 20, 24, 32, 40, 48, 64};
+  int nmax = 0;
+  for (int b : buckets) if (b >= ntrue) { nmax = b; break; }
+  if (nmax == 0 || k > 128) return MIA_ERR_UNSUPPORTED;
+  ap.rows = ap.dual ? nmax : (p_max > 0 ? p_max : 1);
+  ap.dmax = 48;
+  if (const char* e = getenv("MIA_CHEB_DMAX")) ap.dmax = atoi(e);                 // experiments only
+  ap.log_tol = 17.5f;                                                             // ln(1 / 2.5e-8)
+  if (const char* e = getenv("MIA_CHEB_LOGTOL")) ap.log_tol = (float)atof(e);     // experiments only
+  const size_t lds = cheb_lds_bytes(ap.kp, p_max, nmax, ap.rows);
+  if (lds > 160 * 1024) return MIA_ERR_UNSUPPORTED;
+  const int64_t gx = ng < 65536 ? ng : 65536;
+  const int64_t gy = (ng + gx - 1) / gx;
+  if (gy > 65535) return MIA_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)gx, (unsigned)gy);
+  const bool two = k > 64;
+#define MIA_CHEB_CASE(N) case N: return two ? cheb_launch<N, 2>(ap, lds, grid, stream) : cheb_launch<N, 1>(ap, lds, grid, stream);
+  switch (nmax) {
+    MIA_CHEB_CASE(4) MIA_CHEB_CASE(8) MIA_CHEB_CASE(12) MIA_CHEB_CASE(16) MIA_CHEB_CASE(20)
+    MIA_CHEB_CASE(24) MIA_CHEB_CASE(32) MIA_CHEB_CASE(40) MIA_CHEB_CASE(48) MIA_CHEB_CASE(64)
+  }
+#undef MIA_CHEB_CASE
+  return MIA_ERR_UNSUPPORTED;
+}
+
+}  // namespace mia

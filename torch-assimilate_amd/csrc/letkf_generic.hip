@@ -31,12 +31,17 @@ template <typename T>
 int wave_analysis_launch(const T* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const T* rec,
                          const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap,
                          int p_max, T inf_factor, int kernel_mode, T gamma, T* Xa, int64_t ldo, int64_t o0,
-                         T* W_opt, int32_t* flags_opt, hipStream_t stream);
+                         T* W_opt, int32_t* flags_opt, int only_flagged, hipStream_t stream);
+
+int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
+                         const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
+                         float inf_factor, int kernel_mode, float gamma, float* Xa, int64_t ldo, int64_t o0,
+                         int32_t* flags, int32_t* retry_count, hipStream_t stream);
 
 int sys_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
                         const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
                         float inf_factor, int kernel_mode, float gamma, float* Xa, int64_t ldo, int64_t o0,
-                        float* W_opt, int32_t* flags_opt, hipStream_t stream);
+                        float* W_opt, int32_t* flags_opt, int only_flagged, hipStream_t stream);
 
 template <typename T>
 struct AnaParams {
@@ -366,7 +371,7 @@ template <typename T>
 static int analysis_packed_impl(const T* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1, const T* rec,
                                 int64_t P, const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w,
                                 int p_cap, int p_max, T inf_factor, int kernel_mode, T gamma, T* Xa, int64_t ldo,
-                                int64_t o0, T* W_opt, int32_t* flags_opt, hipStream_t stream) {
+                                int64_t o0, T* W_opt, int32_t* flags_opt, hipStream_t stream, int only_flagged = 0) {
   if (g1 < g0 || g0 < 0 || m < 1 || k < 2 || P < 0 || p_cap < 1 || p_max < 0) return MIA_ERR_SIZE;
   if (!(inf_factor > T(0))) return MIA_ERR_SIZE;
   const int64_t ng = g1 - g0;
@@ -380,13 +385,14 @@ static int analysis_packed_impl(const T* X, int64_t ldx, int m, int k, int64_t g
   if constexpr (sizeof(T) == 4) {
     if (!which || which[0] == 's') {
       const int rc = sys_analysis_launch(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
-                                         kernel_mode, gamma, Xa, ldo, o0, W_opt, flags_opt, stream);
+                                         kernel_mode, gamma, Xa, ldo, o0, W_opt, flags_opt, only_flagged, stream);
       if (rc != MIA_ERR_UNSUPPORTED) return rc;
     }
   }
   if (!which || which[0] != 'g')   // runtime-order kernel (letkf_wave.hip): float64 and orders > 64
     return wave_analysis_launch<T>(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
-                                   kernel_mode, gamma, Xa, ldo, o0, W_opt, flags_opt, stream);
+                                   kernel_mode, gamma, Xa, ldo, o0, W_opt, flags_opt, only_flagged, stream);
+  if (only_flagged) return MIA_ERR_UNSUPPORTED;
   AnaParams<T> ap;
   ap.X = X; ap.ldx = ldx; ap.m = m; ap.k = k; ap.g0 = g0; ap.ng = ng; ap.rec = rec; ap.kp = kp;
   ap.cnt = nbr_cnt; ap.idx = nbr_idx; ap.w = nbr_w; ap.p_cap = p_cap; ap.p_max = p_max;
@@ -528,4 +534,32 @@ extern "C" int mia_letkf_analysis_packed_f64(const double* X, int64_t ldx, int m
   (void)hipGetLastError();
   return analysis_packed_impl<double>(X, ldx, m, k, g0, g1, rec, P, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
                                       gamma > 0.0 ? 1 : 0, gamma, Xa, ldo, o0, W_opt, flags_opt, (hipStream_t)stream);
+}
+
+extern "C" int mia_letkf_analysis_matfun_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                             const float* rec, int64_t P, const int32_t* nbr_cnt,
+                                             const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
+                                             float inf_factor, float gamma, float* Xa, int64_t ldo, int64_t o0,
+                                             int32_t* flags, int32_t* retry_count, void* stream) {
+  (void)hipGetLastError();
+  if (g1 < g0 || g0 < 0 || m < 1 || k < 2 || P < 0 || p_cap < 1 || p_max < 0) return MIA_ERR_SIZE;
+  if (!(inf_factor > 0.0f)) return MIA_ERR_SIZE;
+  const int64_t ng = g1 - g0;
+  if (ng == 0) return MIA_OK;
+  if (!X || !Xa || !nbr_cnt || !nbr_idx || !nbr_w || !flags || !retry_count) return MIA_ERR_NULL;
+  if (ldx < g1 || ldo < o0 + ng) return MIA_ERR_SIZE;
+  if (p_max > p_cap) p_max = p_cap;
+  if (P > 0 && !rec) return MIA_ERR_NULL;
+  return cheb_analysis_launch(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
+                              gamma > 0.0f ? 1 : 0, gamma, Xa, ldo, o0, flags, retry_count, (hipStream_t)stream);
+}
+extern "C" int mia_letkf_analysis_retry_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                            const float* rec, int64_t P, const int32_t* nbr_cnt,
+                                            const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
+                                            float inf_factor, float gamma, float* Xa, int64_t ldo, int64_t o0,
+                                            int32_t* flags, void* stream) {
+  (void)hipGetLastError();
+  if (!flags) return MIA_ERR_NULL;
+  return analysis_packed_impl<float>(X, ldx, m, k, g0, g1, rec, P, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
+                                     gamma > 0.0f ? 1 : 0, gamma, Xa, ldo, o0, nullptr, flags, (hipStream_t)stream, 1);
 }

@@ -30,6 +30,7 @@ struct SysParams {
   float reg; float* Xa; int64_t ldo, o0; float* W; int32_t* flags;
   int dual; int rows; int pts_per_block; int max_sweeps; float rot_tol2, stop_tol2;
   int kernel_mode; float gamma;
+  int only_flagged;   // process only points whose flags[] carry MIA_FLAG_RETRY
 };
 
 // round-robin successor of a slot (pair i = slots 2i, 2i+1; slot 0 never moves)
@@ -72,7 +73,7 @@ __device__ inline void tri_decode(int it, int& a, int& b) {
 }
 
 template <int NMAX, int NT>
-__global__ __launch_bounds__(NT, (NT == 64 ? 4 : 2)) void letkf_sys_kernel(SysParams P) {
+__global__ __launch_bounds__(NT, (NT == 64 ? (NMAX >= 32 ? 3 : 4) : 2)) void letkf_sys_kernel(SysParams P) {
   // row stride: a multiple of 4 (float4 rows) that is NOT a multiple of 8, so that consecutive rows
   // start in different LDS banks (stride 64 put every row of a column on one bank)
   constexpr int NB = NMAX / 2, LDA = (NMAX % 8 == 0) ? NMAX + 4 : NMAX, NOFF = NB * (NB - 1) / 2;
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 4 : 2)) void letkf_sys_kernel(SysPa
   constexpr int VSTEP = NT / NB, VP = (NMAX + VSTEP - 1) / VSTEP;
   constexpr int NTRI = NMAX * (NMAX - 1) / 2, TP = (NTRI + NT - 1) / NT;
   constexpr int N4 = NMAX / 4;
+  constexpr int UNR = N4 <= 6 ? N4 : 2;   // full unrolling of the matvec loops only for small orders (register pressure)
   constexpr bool MULTIWAVE = NT > 64;
   constexpr int NWAVE = NT / 64;
   constexpr int TT = (NMAX + 15) / 16, NTILE = TT * (TT + 1) / 2;
@@ -89,9 +91,10 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 4 : 2)) void letkf_sys_kernel(SysPa
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k = P.k, kp = P.kp, pm = P.p_max;
   float* S = reinterpret_cast<float*>(smem_raw);    // [NMAX][LDA] canonical upper / slot order in the sweeps
-  float* V = S + NMAX * LDA;                        // [NMAX][LDA] rows natural, columns slot order
-  float2* cs2 = reinterpret_cast<float2*>(V + NMAX * LDA);   // [NB]
-  float* gWs = reinterpret_cast<float*>(cs2 + NB);  // [NMAX]  (16-byte aligned: NMAX % 4 == 0)
+  // rotations of the round, one private copy per wavefront: every wave derives all NB rotations itself
+  // (reads only), so no barrier is needed between deriving and using them
+  float2* cs2 = reinterpret_cast<float2*>(S + NMAX * LDA) + (size_t)wave * NB;   // [NWAVE][NB]
+  float* gWs = reinterpret_cast<float*>(reinterpret_cast<float2*>(S + NMAX * LDA) + (size_t)NWAVE * NB);  // [NMAX]
   float* tv = gWs + NMAX;                           // [NMAX] scratch vectors, all float4-readable
   float* uq = tv + NMAX;
   float* hq = uq + NMAX;
@@ -103,8 +106,14 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 4 : 2)) void letkf_sys_kernel(SysPa
   int* iflag = reinterpret_cast<int*>(red + 8);     // [4]
   float* xp = reinterpret_cast<float*>(iflag + 4);  // [kp] centred state row (float4-readable)
   float* wbar = xp + kp;                            // [kp]
-  float* Yt = wbar + kp;                            // [rows][kp] obs-major: yb[0..k), d, pad
-  float* lw = Yt + (size_t)P.rows * kp;             // [pm + 2]
+  float* zall = wbar + kp;                          // [m][NMAX]  z = X' B for every state row
+  float* Yt = zall + (size_t)P.m * NMAX;            // [rows][kp] obs-major: yb[0..k), d, pad
+  // The local block is dead once the Gram matrix, the right-hand side and z exist, and V is born only
+  // then: they share one region unless the weights output needs both at once (P.W).
+  float* V = P.W ? Yt + (size_t)P.rows * kp : Yt;   // [NMAX][LDA] rows natural, columns slot order
+  const size_t ureg = P.W ? (size_t)P.rows * kp + NMAX * LDA
+                          : ((size_t)P.rows * kp > (size_t)NMAX * LDA ? (size_t)P.rows * kp : (size_t)NMAX * LDA);
+  float* lw = Yt + ureg;                            // [pm + 2]
   int* lidx = reinterpret_cast<int*>(lw + ((pm + 3) & ~1));   // [pm + 2]
   float* Mq = reinterpret_cast<float*>(lidx + ((pm + 3) & ~1));  // [k][LDA] (W on the dual route)
 
@@ -122,8 +131,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 4 : 2)) void letkf_sys_kernel(SysPa
     wr00[sp] = canon<LDA>(r0, c0); wr01[sp] = canon<LDA>(r0, c1);
     wr10[sp] = canon<LDA>(r1, c0); wr11[sp] = canon<LDA>(r1, c1);
   }
-  const int dg_rd = (2 * tid) * LDA + 2 * tid;
-  const int dg_s0 = slot_next(2 * tid, NB), dg_s1 = slot_next(2 * tid + 1, NB);
+  const int dgi = MULTIWAVE ? lane : tid;   // pair handled in phase 1 (every wave when MULTIWAVE)
+  const int dg_rd = (2 * dgi) * LDA + 2 * dgi;
+  const int dg_s0 = slot_next(2 * dgi, NB), dg_s1 = slot_next(2 * dgi + 1, NB);
   const int dg_w0 = dg_s0 * LDA + dg_s0, dg_w1 = dg_s1 * LDA + dg_s1, dg_we = canon<LDA>(dg_s0, dg_s1);
   const int vj = tid % NB, vr0 = tid / NB;
   const bool vact = vr0 < VSTEP && !(P.max_sweeps & 256);   // bit 8: timing experiment without V
@@ -149,6 +159,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 4 : 2)) void letkf_sys_kernel(SysPa
   if (bid >= P.ng) return;
   const int64_t q8 = P.ng >> 3, r8 = P.ng & 7, xcd = bid & 7;
   const int64_t pt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  if (P.only_flagged && !(P.flags[pt] & MIA_FLAG_RETRY)) return;   // wave-uniform
   {
     const int64_t g = P.g0 + pt;
     const int cnt = P.cnt[pt];
@@ -181,13 +192,6 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 4 : 2)) void letkf_sys_kernel(SysPa
       }
     }
     const int ntrue = P.dual ? cnt : k;
-    // V = I
-    for (int it = tid; it < NMAX * N4; it += NT) {
-      const int a = it / N4, c4 = (it - a * N4) * 4;
-      float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a == c4) e.x = 1.f; else if (a == c4 + 1) e.y = 1.f; else if (a == c4 + 2) e.z = 1.f; else if (a == c4 + 3) e.w = 1.f;
-      reinterpret_cast<float4*>(V + a * LDA)[c4 >> 2] = e;
-    }
     __syncthreads();
     // ---- Gram matrix, canonical upper storage, zero padded to NMAX
     if (xskip & 2) {
@@ -270,6 +274,47 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 4 : 2)) void letkf_sys_kernel(SysPa
       for (int i = tid; i < NMAX; i += NT) tv[i] = i < k ? tv[i] - red[1] - (uq[i] - red[0]) : 0.0f;
     }
     __syncthreads();
+    // ---- z = X' B for every state row while the local block is still in LDS
+    //      (dual: B = Yl -> z_b = sum_i x'_i Yl[i][b]; primal: B = I)
+    {
+      const int k4 = (k + 3) >> 2;
+      for (int mi = 0; mi < P.m; ++mi) {
+        if (mi > 0) { xval = 0.0f; if (tid < k) xval = P.X[((int64_t)mi * k + tid) * P.ldx + g]; }
+        float xm;
+        if (!MULTIWAVE) xm = wave_sum_f(xval) / float(k);
+        else {
+          if (tid < kp) xp[tid] = tid < k ? xval : 0.0f;
+          __syncthreads();
+          xm = 0.0f;
+          for (int i = 0; i < k; ++i) xm += xp[i];
+          xm /= float(k);
+          __syncthreads();
+        }
+        if (tid < kp) xp[tid] = tid < k ? xval - xm : 0.0f;
+        __syncthreads();
+        if (tid < NMAX) {
+          const int b = tid;
+          float z_b = 0.0f;
+          if (P.dual) {
+            if (b < cnt) {
+              const float4* yb = reinterpret_cast<const float4*>(Yt + (size_t)b * kp);
+              const float4* x4 = reinterpret_cast<const float4*>(xp);   // xp is 0 beyond k: d / pad drop out
+              for (int i = 0; i < k4; ++i) { const float4 y = yb[i], x = x4[i]; z_b += y.x * x.x + y.y * x.y + y.z * x.z + y.w * x.w; }
+            }
+          } else z_b = b < k ? xp[b] : 0.0f;
+          zall[mi * NMAX + b] = z_b;
+        }
+        __syncthreads();
+      }
+    }
+    // ---- V = I (overwrites the local block unless the weights output keeps it)
+    for (int it = tid; it < NMAX * N4; it += NT) {
+      const int a = it / N4, c4 = (it - a * N4) * 4;
+      float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a == c4) e.x = 1.f; else if (a == c4 + 1) e.y = 1.f; else if (a == c4 + 2) e.z = 1.f; else if (a == c4 + 3) e.w = 1.f;
+      reinterpret_cast<float4*>(V + a * LDA)[c4 >> 2] = e;
+    }
+    __syncthreads();
 
     // ================================================================ systolic Jacobi
     int sweeps = 0;
@@ -290,7 +335,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 4 : 2)) void letkf_sys_kernel(SysPa
       for (int r = 0; r < NMAX - 1; ++r) {
         // ---- phase 1: rotation of each pair from its diagonal block
         float nd0 = 0.0f, nd1 = 0.0f, nde = 0.0f;
-        if (tid < NB) {
+        if (dgi < NB) {
           const float2 de = *reinterpret_cast<const float2*>(S + dg_rd);
           const float d1 = S[dg_rd + LDA + 1];
           float c = 1.0f, s = 0.0f, t = 0.0f;
@@ -298,9 +343,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 4 : 2)) void letkf_sys_kernel(SysPa
           if (de.y * de.y > P.rot_tol2 * (fabsf(de.x) + reg) * (fabsf(d1) + reg)) { rot_params_f(de.x, d1, de.y, c, s, t); nde = 0.0f; }
           nd0 = de.x - t * de.y;
           nd1 = d1 + t * de.y;
-          cs2[tid] = make_float2(c, s);
+          cs2[dgi] = make_float2(c, s);
         }
-        if (MULTIWAVE) __syncthreads(); else MIA_LDS_ORDER();
+        MIA_LDS_ORDER();   // same-wave LDS write -> read: in-order, no barrier
         // ---- phase 2: every read of the round, rotate in registers
         float o00[SP], o01[SP], o10[SP], o11[SP];
 #pragma unroll
@@ -368,7 +413,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 4 : 2)) void letkf_sys_kernel(SysPa
         gM_r = live ? 1.0f / le : 0.0f;
         // a = V^T rhs : column r of V (stride LDA, conflict-free across lanes) against the broadcast rhs
         float acc = 0.0f;
-#pragma unroll
+#pragma unroll UNR
         for (int b4 = 0; b4 < N4; ++b4) {
           const float4 t4 = reinterpret_cast<const float4*>(tv)[b4];
           acc += V[(4 * b4 + 0) * LDA + r] * t4.x + V[(4 * b4 + 1) * LDA + r] * t4.y +
@@ -412,7 +457,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 4 : 2)) void letkf_sys_kernel(SysPa
       if (tid < NMAX) {
         const int b = tid;
         float acc = 0.0f;
-#pragma unroll
+#pragma unroll UNR
         for (int r4 = 0; r4 < N4; ++r4) {
           const float4 vv = reinterpret_cast<const float4*>(V + b * LDA)[r4];
           const float4 a4 = reinterpret_cast<const float4*>(zb)[r4];
@@ -431,44 +476,16 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 4 : 2)) void letkf_sys_kernel(SysPa
       }
     }
     // ---- ensemble transform (interface/base.py:257-278), one state row at a time
-    const int k4 = (k + 3) >> 2;
     for (int mi = 0; mi < ((xskip & 8) ? 0 : P.m); ++mi) {
-      if (mi > 0) { xval = 0.0f; if (tid < k) xval = P.X[((int64_t)mi * k + tid) * P.ldx + g]; }
-      float xm;
-      if (!MULTIWAVE) xm = wave_sum_f(xval) / float(k);
-      else {
-        if (tid < kp) xp[tid] = tid < k ? xval : 0.0f;
-        __syncthreads();
-        xm = 0.0f;
-        for (int i = 0; i < k; ++i) xm += xp[i];
-        xm /= float(k);
-        __syncthreads();
-      }
-      const float xc = xval - xm;                          // centred member value (lanes < k)
-      if (tid < kp) xp[tid] = tid < k ? xc : 0.0f;
-      __syncthreads();
-      // z = X' B  (dual: B = Yl -> z_b = sum_i x'_i Yl[i][b]; primal: B = I)
-      float z_b = 0.0f;
-      if (tid < NMAX) {
-        const int b = tid;
-        if (P.dual) {
-          if (b < cnt) {
-            const float4* yb = reinterpret_cast<const float4*>(Yt + (size_t)b * kp);
-            const float4* x4 = reinterpret_cast<const float4*>(xp);
-            for (int i = 0; i < k4; ++i) { const float4 y = yb[i], x = x4[i]; z_b += y.x * x.x + y.y * x.y + y.z * x.z + y.w * x.w; }
-            if (k & 3) {   // the record's d / pad entries follow the members inside the last float4: xp is 0 there
-            }
-          }
-        } else z_b = b < k ? xp[b] : 0.0f;
-        zb[b] = z_b;
-      }
-      __syncthreads();
-      float zv_r = 0.0f;
+      xval = 0.0f;
+      if (tid < k) xval = P.X[((int64_t)mi * k + tid) * P.ldx + g];     // L2-resident re-read
+      float zv_r = 0.0f, z_b = 0.0f;
       if (tid < NMAX) {   // zv = V^T z
         const int r = tid;
-#pragma unroll
+        z_b = zall[mi * NMAX + r];
+#pragma unroll UNR
         for (int b4 = 0; b4 < N4; ++b4) {
-          const float4 z4 = reinterpret_cast<const float4*>(zb)[b4];
+          const float4 z4 = reinterpret_cast<const float4*>(zall + mi * NMAX)[b4];
           zv_r += V[(4 * b4 + 0) * LDA + r] * z4.x + V[(4 * b4 + 1) * LDA + r] * z4.y +
                   V[(4 * b4 + 2) * LDA + r] * z4.z + V[(4 * b4 + 3) * LDA + r] * z4.w;
         }
@@ -478,7 +495,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 4 : 2)) void letkf_sys_kernel(SysPa
       if (tid < NMAX) {   // q = (diag(gW) + F o E) zv : row r of the symmetric matrix against the broadcast zv
         const int r = tid;
         float acc = 0.0f;
-#pragma unroll
+#pragma unroll UNR
         for (int b4 = 0; b4 < N4; ++b4) {
           const float4 s4 = reinterpret_cast<const float4*>(S + r * LDA)[b4];
           const float4 z4 = reinterpret_cast<const float4*>(tv)[b4];
@@ -487,28 +504,38 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 4 : 2)) void letkf_sys_kernel(SysPa
         qb[r] = acc;
       }
       __syncthreads();
-      float zu;   // X' w_mean = z . u
-      if (!MULTIWAVE) zu = wave_sum_f(tid < NMAX ? z_b * uvs[tid] : 0.0f);
-      else { zu = 0.0f; for (int b = 0; b < NMAX; ++b) zu += zb[b] * uvs[b]; }
-      if (tid < NMAX) {   // s = V q
+      float zu, xm;   // X' w_mean = z . u ; ensemble mean of this row
+      if (!MULTIWAVE) {
+        zu = wave_sum_f(tid < NMAX ? z_b * uvs[tid] : 0.0f);
+        xm = wave_sum_f(xval) / float(k);
+      } else {
+        zu = 0.0f;
+        for (int b = 0; b < NMAX; ++b) zu += zall[mi * NMAX + b] * uvs[b];
+        if (tid < kp) xp[tid] = tid < k ? xval : 0.0f;
+        __syncthreads();
+        xm = 0.0f;
+        for (int i = 0; i < k; ++i) xm += xp[i];
+        xm /= float(k);
+      }
+      if (tid < NMAX) {   // s = V q, pre-multiplied by the localisation weight of its observation
         const int b = tid;
         float acc = 0.0f;
-#pragma unroll
+#pragma unroll UNR
         for (int r4 = 0; r4 < N4; ++r4) {
           const float4 vv = reinterpret_cast<const float4*>(V + b * LDA)[r4];
           const float4 q4 = reinterpret_cast<const float4*>(qb)[r4];
           acc += vv.x * q4.x + vv.y * q4.y + vv.z * q4.z + vv.w * q4.w;
         }
-        sb[b] = acc;
+        sb[b] = P.dual ? (b < cnt ? acc * lw[b] : 0.0f) : acc;
       }
       __syncthreads();
       const float mterm = xm + zu;
       float* orow = P.Xa + (int64_t)mi * k * P.ldo + P.o0 + pt;
       for (int j = tid; j < k; j += NT) {
         float acc;
-        if (P.dual) {
-          acc = f0 * xp[j];
-          for (int b = 0; b < cnt; ++b) acc += sb[b] * Yt[(size_t)b * kp + j];
+        if (P.dual) {   // Yl s straight from the (L2-resident) records: member j is contiguous across lanes
+          acc = f0 * (xval - xm);
+          for (int b = 0; b < cnt; ++b) acc += sb[b] * P.rec[(int64_t)lidx[b] * kp + j];
         } else acc = sb[j];
         const float out = mterm + acc;
         if (!(fabsf(out) <= 1e30f)) flag |= MIA_FLAG_NONFINITE;
@@ -547,12 +574,15 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 4 : 2)) void letkf_sys_kernel(SysPa
   }
 }
 
-static size_t sys_lds_bytes(int k, int kp, int p_max, int nmax, int rows, bool want_mq) {
+static size_t sys_lds_bytes(int k, int kp, int m, int p_max, int nmax, int rows, bool want_w, bool dual) {
   const int lda = (nmax % 8 == 0) ? nmax + 4 : nmax;
-  size_t e = 2 * (size_t)nmax * lda + nmax /*cs2*/ + 8 * (size_t)nmax + 8 + 2 * (size_t)kp + (size_t)rows * kp +
+  const size_t yt = (size_t)rows * kp, vv = (size_t)nmax * lda;
+  const size_t ureg = want_w ? yt + vv : (yt > vv ? yt : vv);
+  const int nwave = nmax > 32 ? 4 : 1;
+  size_t e = (size_t)nmax * lda + (size_t)nwave * nmax /*cs2*/ + 8 * (size_t)nmax + 8 + 2 * (size_t)kp + (size_t)m * nmax + ureg +
              ((p_max + 3) & ~1);
   size_t b = e * sizeof(float) + 4 * sizeof(int) + (size_t)((p_max + 3) & ~1) * sizeof(int);
-  if (want_mq) b += (size_t)k * lda * sizeof(float);
+  if (want_w && dual) b += (size_t)k * lda * sizeof(float);
   return align_up(b, 16);
 }
 
@@ -569,8 +599,10 @@ static int sys_launch(const SysParams& ap, size_t lds, dim3 grid, hipStream_t st
 int sys_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
                         const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
                         float inf_factor, int kernel_mode, float gamma, float* Xa, int64_t ldo, int64_t o0,
-                        float* W_opt, int32_t* flags_opt, hipStream_t stream) {
+                        float* W_opt, int32_t* flags_opt, int only_flagged, hipStream_t stream) {
   SysParams ap;
+  ap.only_flagged = only_flagged;
+  if (only_flagged && !flags_opt) return MIA_ERR_NULL;
   ap.X = X; ap.ldx = ldx; ap.m = m; ap.k = k; ap.g0 = g0; ap.ng = ng; ap.rec = rec;
   ap.kp = (k + 1 + 3) & ~3;
   ap.cnt = nbr_cnt; ap.idx = nbr_idx; ap.w = nbr_w; ap.p_cap = p_cap; ap.p_max = p_max;
@@ -595,7 +627,8 @@ int sys_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, i
   const float rot_tol = 1e-7f;
   ap.stop_tol2 = stop_tol * stop_tol;
   ap.rot_tol2 = rot_tol * rot_tol;
-  const size_t lds = sys_lds_bytes(k, ap.kp, p_max, nmax, ap.rows, W_opt != nullptr && ap.dual);
+  const size_t lds = sys_lds_bytes(k, ap.kp, m, p_max, nmax, ap.rows, W_opt != nullptr, ap.dual != 0);
+  if ((k > 64 && nmax <= 32) || k > 256) return MIA_ERR_UNSUPPORTED;   // one member per lane
   if (lds > 160 * 1024) return MIA_ERR_UNSUPPORTED;
   // one grid point per workgroup (measured on MI355X, C2: 1-2 points per workgroup beat 4-10 by 5-12 %:
   // the dispatcher's dynamic placement balances the data-dependent sweep counts)

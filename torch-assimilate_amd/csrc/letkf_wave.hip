@@ -34,6 +34,7 @@ struct WaveParams {
   T reg; T* Xa; int64_t ldo, o0; T* W; int32_t* flags;
   int dual; int nmax; int lda; int rows; int pts_per_block; int max_sweeps; T rot_tol2, stop_tol2;
   int kernel_mode; T gamma;
+  int only_flagged;
 };
 
 template <typename T> struct Vec4 { T x, y, z, w; };
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(NT) void letkf_wave_kernel(WaveParams<T> P) {
     const int cnt = P.cnt[pt];
     int flag = 0;
     __syncthreads();
+    if (P.only_flagged && !(P.flags[pt] & MIA_FLAG_RETRY)) continue;
     if (cnt > pm || cnt > P.p_cap) {   // loud failure: never analyse with a truncated list
       if (P.flags && tid == 0) P.flags[pt] = MIA_FLAG_OVERFLOW;
       const T nanv = T(__builtin_nanf(""));
@@ -453,8 +455,10 @@ template <typename T>
 int wave_analysis_launch(const T* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const T* rec,
                          const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap,
                          int p_max, T inf_factor, int kernel_mode, T gamma, T* Xa, int64_t ldo, int64_t o0,
-                         T* W_opt, int32_t* flags_opt, hipStream_t stream) {
+                         T* W_opt, int32_t* flags_opt, int only_flagged, hipStream_t stream) {
   WaveParams<T> ap;
+  ap.only_flagged = only_flagged;
+  if (only_flagged && !flags_opt) return MIA_ERR_NULL;
   ap.X = X; ap.ldx = ldx; ap.m = m; ap.k = k; ap.g0 = g0; ap.ng = ng; ap.rec = rec;
   ap.kp = (k + 1 + 3) & ~3;
   ap.cnt = nbr_cnt; ap.idx = nbr_idx; ap.w = nbr_w; ap.p_cap = p_cap; ap.p_max = p_max;
@@ -501,9 +505,9 @@ int wave_analysis_launch(const T* X, int64_t ldx, int m, int k, int64_t g0, int6
 
 template int wave_analysis_launch<float>(const float*, int64_t, int, int, int64_t, int64_t, const float*,
                                          const int32_t*, const int32_t*, const double*, int, int, float, int, float,
-                                         float*, int64_t, int64_t, float*, int32_t*, hipStream_t);
+                                         float*, int64_t, int64_t, float*, int32_t*, int, hipStream_t);
 template int wave_analysis_launch<double>(const double*, int64_t, int, int, int64_t, int64_t, const double*,
                                           const int32_t*, const int32_t*, const double*, int, int, double, int, double,
-                                          double*, int64_t, int64_t, double*, int32_t*, hipStream_t);
+                                          double*, int64_t, int64_t, double*, int32_t*, int, hipStream_t);
 
 }  // namespace mia

@@ -200,13 +200,22 @@ class LetkfEngine:
         _cabi.check(fn(_ptr(Yb), _ptr(d), k, P, _ptr(rec), self._stream()), "mia_letkf_pack_obs_" + sfx)
         return rec[:P]
 
+    MATFUN_MAX_ROWS = 4     # state rows per grid point up to which the eigensolver-free route is preferred
+
     def analysis(self, X: torch.Tensor, Yb: Optional[torch.Tensor], d: Optional[torch.Tensor],
                  nbrs: NeighbourLists, inf_factor: float = 1.0, return_weights: bool = False,
                  rbf_gamma: Optional[float] = None, out: Optional[torch.Tensor] = None, out_offset: int = 0,
-                 return_flags: bool = False, rec: Optional[torch.Tensor] = None):
+                 return_flags: bool = False, rec: Optional[torch.Tensor] = None, method: str = "auto",
+                 defer_retry: bool = False):
         """X (m, k, G) prior ensemble (grid fastest), Yb (k, P), d (P,) [or their packed records
         ``rec`` from :meth:`pack_obs`]: analysis of the shard described by ``nbrs``.
-        Returns Xa (m, k, n) [, W (n, k, k)] [, flags (n,)]."""
+        Returns Xa (m, k, n) [, W (n, k, k)] [, flags (n,)].
+
+        ``method``: "eig" = fused Jacobi eigensolver kernel (always available, the only one that can
+        return the weights); "matfun" = eigensolver-free Chebyshev matrix-function route (float32, few
+        state rows, no weights), with the eigensolver redoing the grid points it declines; "auto" picks
+        matfun when it applies.  With ``defer_retry`` the (8-byte, synchronising) read of the decline
+        counter is left to the caller: the return value gains a trailing callable that must be invoked."""
         if X.dim() == 2:
             X = X[None]
         X = X.to(self.device).contiguous()
@@ -220,6 +229,8 @@ class LetkfEngine:
             rec = self.pack_obs(Yb, d, dtype)
         if rec.dtype != dtype or rec.shape[1] != (k + 1 + 3) // 4 * 4:
             raise ValueError("packed records do not match the state's dtype / ensemble size")
+        if method not in ("auto", "eig", "matfun"):
+            raise ValueError("method must be 'auto', 'eig' or 'matfun'")
         P = rec.shape[0]
         n = nbrs.g1 - nbrs.g0
         if out is None:
@@ -229,17 +240,41 @@ class LetkfEngine:
         W = torch.empty((n, k, k), dtype=dtype, device=self.device) if return_weights else None
         flags = torch.empty(n, dtype=torch.int32, device=self.device)
         sfx = "f32" if dtype == torch.float32 else "f64"
-        fn = getattr(self.lib, "mia_letkf_analysis_packed_" + sfx)
-        _cabi.check(fn(_ptr(X), G, m, k, nbrs.g0, nbrs.g1, _ptr(rec), P, _ptr(nbrs.cnt), _ptr(nbrs.idx),
-                       _ptr(nbrs.w), nbrs.p_cap, nbrs.p_max, float(inf_factor),
-                       float(rbf_gamma) if rbf_gamma is not None else 0.0,
-                       _ptr(out), ldo, out_offset, _ptr(W), _ptr(flags), self._stream()),
-                    "mia_letkf_analysis_packed_" + sfx)
+        gamma = float(rbf_gamma) if rbf_gamma is not None else 0.0
+        args = (_ptr(X), G, m, k, nbrs.g0, nbrs.g1, _ptr(rec), P, _ptr(nbrs.cnt), _ptr(nbrs.idx),
+                _ptr(nbrs.w), nbrs.p_cap, nbrs.p_max, float(inf_factor), gamma, _ptr(out), ldo, out_offset)
+        can_matfun = dtype == torch.float32 and not return_weights and n > 0
+        if method == "matfun" and not can_matfun:
+            raise ValueError("the matfun route needs float32 and cannot return the weights")
+        use_matfun = can_matfun and (method == "matfun" or (method == "auto" and m <= self.MATFUN_MAX_ROWS))
+        finish = None
+        if use_matfun:
+            retry = torch.zeros(1, dtype=torch.int32, device=self.device)
+            rc = self.lib.mia_letkf_analysis_matfun_f32(*args, _ptr(flags), _ptr(retry), self._stream())
+            if rc == -3:              # shape outside the matfun kernels: eigensolver route
+                use_matfun = False
+            else:
+                _cabi.check(rc, "mia_letkf_analysis_matfun_f32")
+
+                def finish():
+                    n_retry = int(retry.item())          # host sync (8 bytes)
+                    if n_retry:
+                        _cabi.check(self.lib.mia_letkf_analysis_retry_f32(*args, _ptr(flags), self._stream()),
+                                    "mia_letkf_analysis_retry_f32")
+                    return n_retry
+        if not use_matfun:
+            fn = getattr(self.lib, "mia_letkf_analysis_packed_" + sfx)
+            _cabi.check(fn(*args, _ptr(W), _ptr(flags), self._stream()), "mia_letkf_analysis_packed_" + sfx)
+        if finish is not None and not defer_retry:
+            finish()
+            finish = None
         res = [out]
         if return_weights:
             res.append(W)
         if return_flags:
             res.append(flags)
+        if defer_retry:
+            res.append(finish if finish is not None else (lambda: 0))
         return res[0] if len(res) == 1 else tuple(res)
 
     # ------------------------------------------------------------- global ETKF

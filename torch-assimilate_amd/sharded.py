@@ -51,14 +51,19 @@ class ShardedLetkf:
     collective logic under the gloo backend.
     """
 
-    dominant_kernel_name = "letkf_sys_kernel<20, 64>"
+    @property
+    def dominant_kernel_name(self):
+        return "letkf_sys_kernel<20, 64>" if self.method == "eig" else "letkf_cheb_kernel<20, 1>"
 
     def __init__(self, device, rank: int = 0, world: int = 1, radii: Sequence[float] = (10.0,),
                  inf_factor: float = 1.0, coord_group: Optional[Sequence[int]] = None, eps: float = 1e-5,
-                 rbf_gamma: Optional[float] = None, compute_shard: Optional[Callable] = None, group=None):
+                 rbf_gamma: Optional[float] = None, compute_shard: Optional[Callable] = None, group=None,
+                 method: str = "auto"):
         self.device, self.rank, self.world = device, rank, world
         self.radii, self.inf_factor, self.coord_group, self.eps = list(radii), inf_factor, coord_group, eps
         self.rbf_gamma = rbf_gamma
+        self.method = method
+        self.last_retries = 0
         self.group = group
         self._engine = None
         self._compute = compute_shard or self._engine_shard
@@ -80,10 +85,13 @@ class ShardedLetkf:
         # the shard is redone with the true value in the (rare) case it did not hold
         nb = eng.localize(grid_xyz, obs_xyz, self.radii, self.coord_group, self.eps, g0, g1,
                           assume_p_max=self._p_max_hint)
-        xa, flags = eng.analysis(X, Yb, d, nb, self.inf_factor, rbf_gamma=self.rbf_gamma, return_flags=True)
+        xa, flags, finish = eng.analysis(X, Yb, d, nb, self.inf_factor, rbf_gamma=self.rbf_gamma,
+                                         return_flags=True, method=self.method, defer_retry=True)
         if not nb.confirm():
             nb = eng.localize(grid_xyz, obs_xyz, self.radii, self.coord_group, self.eps, g0, g1)
-            xa, flags = eng.analysis(X, Yb, d, nb, self.inf_factor, rbf_gamma=self.rbf_gamma, return_flags=True)
+            xa, flags, finish = eng.analysis(X, Yb, d, nb, self.inf_factor, rbf_gamma=self.rbf_gamma,
+                                             return_flags=True, method=self.method, defer_retry=True)
+        self.last_retries = finish()      # (the stream is already drained by confirm(): no extra wait)
         self._p_max_hint = nb.observed_p_max if nb.observed_p_max is not None else nb.p_max
         self.last_p_max = nb.p_max
         self._last_flags = flags
@@ -113,8 +121,10 @@ class ShardedLetkf:
             e[1].record()
             nb = eng.localize(grid_xyz, obs_xyz, self.radii, self.coord_group, self.eps, g0, g1)
             e[2].record()
-            eng.analysis(X, None, None, nb, self.inf_factor, rbf_gamma=self.rbf_gamma, rec=rec)
+            _, fin = eng.analysis(X, None, None, nb, self.inf_factor, rbf_gamma=self.rbf_gamma, rec=rec,
+                                  method=self.method, defer_retry=True)
             e[3].record()
+            fin()
             torch.cuda.synchronize()
             for name, a, b in zip(acc, e[:-1], e[1:]):
                 acc[name] += a.elapsed_time(b)
