@@ -41,6 +41,18 @@ def algorithmic_flops(k, p, m):
     return k * k * p + 2 * k * p + 9 * k ** 3 + k ** 3 + 5 * k * k + 2 * k * k * m + 25 * p
 
 
+def executed_flops(k, p, m, deg):
+    """What the matfun kernel really executes per analysis (dual route): Gram on 16x16x4 MFMA tiles over
+    the padded order (upper tiles), z and output products, Chebyshev coefficients and recurrence."""
+    if not deg:
+        return None
+    tt = (max(p, 1) + 15) // 16
+    ks = (k + 3) // 4
+    gram = tt * (tt + 1) // 2 * ks * 2048
+    n = (p + 3) // 4 * 4
+    return gram + m * (2 * k * n * 2 + deg * 2 * n * n) + 4 * (deg + 1) ** 2 + 25 * p
+
+
 def algorithmic_bytes(k, m, P_over_G, n_coord=1):
     return 4.0 * (2 * k * m + (k + 1) * P_over_G + 2 * n_coord * (1 + P_over_G))
 
@@ -116,6 +128,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grid-per-gpu", type=int, default=G_PER_GPU)
+    ap.add_argument("--method", default="auto", choices=["auto", "eig", "matfun"],
+                    help="analysis route: auto = eigensolver-free matfun kernel for m <= 4 (default), eig = fused Jacobi")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,7 +157,7 @@ def main():
     G = gpg * world
     X, grid_x, obs_x, Yb, d = make_case(G, K_ENS, OBS_STRIDE, device)
     P = obs_x.shape[0]
-    runner = ShardedLetkf(device, rank, world, radii=[GC_RADIUS], inf_factor=INF)
+    runner = ShardedLetkf(device, rank, world, radii=[GC_RADIUS], inf_factor=INF, method=args.method)
 
     def step():
         return runner.assimilate(X, grid_x, obs_x, Yb, d)
@@ -174,6 +188,14 @@ def main():
     achieved = flops / (kern_ms * 1e-3) / 1e12
     hbm_alg = algorithmic_bytes(K_ENS, 1, P / G) * gpg / (kern_ms * 1e-3) / 1e9
 
+    # secondary figure: the fused Jacobi-eigensolver route on the same shard (kernel only)
+    eig_ms = None
+    if args.method != "eig":
+        r2 = ShardedLetkf(device, rank, world, radii=[GC_RADIUS], inf_factor=INF, method="eig")
+        r2._engine = runner.engine
+        eig_ms, _ = r2.time_stages(X, grid_x, obs_x, Yb, d, reps=5)
+    deg = runner.mean_degree()
+
     if rank == 0:
         value = G * args.steps / elapsed
         line = {
@@ -190,8 +212,15 @@ def main():
                          "kernel": runner.dominant_kernel_name, "kernel_ms": kern_ms,
                          "algorithmic_flops_per_analysis": algorithmic_flops(K_ENS, 20, 1),
                          "hbm_algorithmic_GBs": hbm_alg, "hbm_frac": hbm_alg / PEAK_HBM_GBS,
-                         "note": "fp32 peak: vector = f32-MFMA = 157.3 TFLOP/s; flops credited at the "
-                                 "SURVEY 8(d) count (9k^3 eigensolve) whatever the method"},
+                         "executed_flops_per_analysis": executed_flops(K_ENS, 20, 1, deg),
+                         "executed_frac": executed_flops(K_ENS, 20, 1, deg) * gpg / (kern_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                         "note": "fp32 peak: vector = f32-MFMA = 157.3 TFLOP/s; `achieved`/`frac` credit the SURVEY 8(d) "
+                                 "flop count of the reference algorithm (9k^3 symmetric-QR eigensolve) whatever the method; "
+                                 "the matfun route executes far fewer flops (executed_*: 16x16x4 MFMA Gram tiles incl. "
+                                 "padding + Chebyshev recurrence of the measured mean degree), so frac can exceed 1"},
+            "route": {"method": args.method, "mean_chebyshev_degree": deg, "declined_points_last_step": runner.last_retries,
+                      "eigensolver_route_kernel_ms": eig_ms,
+                      "eigensolver_route_kernel_analyses_per_s": (gpg / (eig_ms * 1e-3)) if eig_ms else None},
             "stages_ms": stage_ms,
         }
         if cpu is not None:

@@ -103,6 +103,12 @@ class ShardedLetkf:
         shard = self._compute(X, grid_xyz, obs_xyz, Yb, d, g0, g1)
         return gather_blocks(shard, G, self.world, self.group)
 
+    def mean_degree(self):
+        """Mean Chebyshev degree of the last matfun launch (flags bits 8-15), None for the eigensolver route."""
+        if self._last_flags is None or self.method == "eig":
+            return None
+        return float(((self._last_flags >> 8) & 0xff).float().mean().item())
+
     def last_flags_ok(self) -> bool:
         return self._last_flags is None or int((self._last_flags & 0xff).max().item()) == 0
 
