@@ -90,6 +90,11 @@ int mia_letkf_localize_f64(const double* grid_xyz, int64_t g0, int64_t g1,
                            int p_cap, int32_t* nbr_cnt, int32_t* nbr_idx, double* nbr_w,
                            int32_t* stats, void* ws, size_t ws_bytes, void* stream);
 
+/* The observation cell index alone (what mia_letkf_localize_f64 builds first), for the fused route below. */
+int mia_letkf_index_build_f64(const double* obs_xyz, int64_t P, int n_coord,
+                              const int32_t* coord_group /* host */, const double* gc_c /* host */, int n_r,
+                              void* ws, size_t ws_bytes /* mia_letkf_localize_workspace_bytes */, void* stream);
+
 /* Same lists from caller-evaluated distances (an arbitrary Python dist_func evaluated on
  * the host in batch): dist [n_r][g1-g0][p_cap] f64, cand_idx [g1-g0][p_cap] (-1 = pad).
  * Compacts in place the candidates whose weight product exceeds gc_eps. */
@@ -163,6 +168,19 @@ int mia_letkf_analysis_matfun_f32(const float* X, int64_t ldx, int m, int k, int
                                   int p_cap, int p_max, float inf_factor, float gamma,
                                   float* Xa, int64_t ldo, int64_t o0, int32_t* flags, int32_t* retry_count,
                                   void* stream);
+/* matfun route with the Gaspari-Cohn localisation fused in: every wavefront scans the observation index
+ * (mia_letkf_index_build_f64) for its grid point itself, so no neighbour lists are written or read.
+ * p_max_assumed sizes the launch (e.g. stats[0] of an earlier call on the same geometry); a grid point with
+ * more local observations gets MIA_FLAG_OVERFLOW and NaN output, stats[0] = true maximum, stats[1] = number
+ * of such points: when stats[1] != 0 the caller redoes the shard with the larger value (or the list route). */
+int mia_letkf_analysis_matfun_fused_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                        const float* rec, int64_t P,
+                                        const double* grid_xyz, int n_coord, const int32_t* coord_group /* host */,
+                                        const double* gc_c /* host */, int n_r, double gc_eps,
+                                        void* index_ws, size_t index_ws_bytes,
+                                        int p_max_assumed, float inf_factor, float gamma,
+                                        float* Xa, int64_t ldo, int64_t o0, int32_t* flags, int32_t* retry_count,
+                                        int32_t* stats, void* stream);
 int mia_letkf_analysis_retry_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
                                  const float* rec, int64_t P,
                                  const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w,

@@ -290,7 +290,7 @@ def test_matfun_declines_wide_spectra_and_eigensolver_redoes_them(eng, golden, m
     xm = case["state"].mean(axis=1, keepdims=True)
     assert rel_fro(xa.cpu().numpy() - xm, ref - xm) < 10 * TOL32
     # a moderate case mixes both kernels inside one shard
-    monkeypatch.setenv("MIA_CHEB_DMAX", "17")
+    monkeypatch.setenv("MIA_CHEB_DMAX", "14")
     yb2, d2 = case["yb"], case["d"]
     xa2, fl2, fin2 = eng.analysis(dev(case["state"], torch.float32), dev(yb2, torch.float32), dev(d2, torch.float32),
                                   nb, 1.1, return_flags=True, method="matfun", defer_retry=True)
@@ -298,3 +298,34 @@ def test_matfun_declines_wide_spectra_and_eigensolver_redoes_them(eng, golden, m
     assert 0 < n2 < 300
     ref2, _ = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], yb2, d2, 10.0, 1.1)
     assert rel_fro(xa2.cpu().numpy(), ref2) < TOL32
+
+
+def test_fused_localisation_equals_list_route_bitwise(eng, golden):
+    """The kernel that scans the observation index itself must reproduce the explicit-list route bit for bit
+    (same scan code, same order), in 1-D and with two radii in 3-D; an under-estimated list bound is reported."""
+    rs = np.random.RandomState(11)
+    cases = [(np.arange(3000.0)[:, None], np.arange(0, 3000, 2.0)[:, None], [10.0], [0]),
+             (rs.uniform(0, 1, size=(1500, 3)), rs.uniform(0, 1, size=(4000, 3)), [0.12, 0.25], [0, 0, 1])]
+    for grid, obs, radii, groups in cases:
+        k = 24
+        P = obs.shape[0]
+        X = dev(rs.normal(size=(2, k, grid.shape[0])), torch.float32)
+        yb = rs.normal(size=(k, P)); yb -= yb.mean(axis=0)
+        d = rs.normal(size=P)
+        nb = eng.localize(grid, obs, radii, coord_group=groups)
+        rec = eng.pack_obs(dev(yb, torch.float32), dev(d, torch.float32))
+        ref = eng.analysis(X, None, None, nb, 1.1, rec=rec, method="matfun")
+        index = eng.build_index(obs, radii, groups)
+        xa, flags, finish = eng.analysis_fused(X, rec, grid, index, nb.p_max, 1.1)
+        ok, p_max, n_retry = finish()
+        assert ok and p_max == nb.p_max
+        assert torch.equal(xa, ref)
+        assert int((flags & 0xff).max().cpu()) == 0
+        # shard of the same problem
+        xs, _, fin = eng.analysis_fused(X, rec, grid, index, nb.p_max, 1.1, g0=100, g1=900)
+        assert fin()[0] and torch.equal(xs, ref[:, :, 100:900])
+        # assumed bound too small: reported, never silently truncated
+        xb, fb, finb = eng.analysis_fused(X, rec, grid, index, max(nb.p_max - 3, 1), 1.1)
+        okb, pb, _ = finb()
+        assert not okb and pb == nb.p_max
+        assert int((fb & 1).max().cpu()) == 1

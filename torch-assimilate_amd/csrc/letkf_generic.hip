@@ -22,6 +22,7 @@
 // off-diagonal mass below eps*(l + reg) is already below rounding of the reference result.
 #include "mia_common.h"
 #include "mia_jacobi.h"
+#include "mia_localize_dev.h"
 
 #include <cstdlib>
 
@@ -36,7 +37,8 @@ int wave_analysis_launch(const T* X, int64_t ldx, int m, int k, int64_t g0, int6
 int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
                          const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
                          float inf_factor, int kernel_mode, float gamma, float* Xa, int64_t ldo, int64_t o0,
-                         int32_t* flags, int32_t* retry_count, hipStream_t stream);
+                         int32_t* flags, int32_t* retry_count, const ScanParams* scan, int32_t* stats,
+                         hipStream_t stream);
 
 int sys_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
                         const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
@@ -551,7 +553,8 @@ extern "C" int mia_letkf_analysis_matfun_f32(const float* X, int64_t ldx, int m,
   if (p_max > p_cap) p_max = p_cap;
   if (P > 0 && !rec) return MIA_ERR_NULL;
   return cheb_analysis_launch(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
-                              gamma > 0.0f ? 1 : 0, gamma, Xa, ldo, o0, flags, retry_count, (hipStream_t)stream);
+                              gamma > 0.0f ? 1 : 0, gamma, Xa, ldo, o0, flags, retry_count, nullptr, nullptr,
+                              (hipStream_t)stream);
 }
 extern "C" int mia_letkf_analysis_retry_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
                                             const float* rec, int64_t P, const int32_t* nbr_cnt,
@@ -562,4 +565,33 @@ extern "C" int mia_letkf_analysis_retry_f32(const float* X, int64_t ldx, int m, 
   if (!flags) return MIA_ERR_NULL;
   return analysis_packed_impl<float>(X, ldx, m, k, g0, g1, rec, P, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
                                      gamma > 0.0f ? 1 : 0, gamma, Xa, ldo, o0, nullptr, flags, (hipStream_t)stream, 1);
+}
+
+extern "C" int mia_letkf_analysis_matfun_fused_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                                   const float* rec, int64_t P, const double* grid_xyz, int n_coord,
+                                                   const int32_t* coord_group, const double* gc_c, int n_r,
+                                                   double gc_eps, void* index_ws, size_t index_ws_bytes,
+                                                   int p_max_assumed, float inf_factor, float gamma, float* Xa,
+                                                   int64_t ldo, int64_t o0, int32_t* flags, int32_t* retry_count,
+                                                   int32_t* stats, void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (g1 < g0 || g0 < 0 || m < 1 || k < 2 || P < 1 || p_max_assumed < 0) return MIA_ERR_SIZE;
+  if (!(inf_factor > 0.0f)) return MIA_ERR_SIZE;
+  const int64_t ng = g1 - g0;
+  if (!stats) return MIA_ERR_NULL;
+  MIA_HIP_TRY(hipMemsetAsync(stats, 0, 2 * sizeof(int32_t), stream));
+  if (ng == 0) return MIA_OK;
+  if (!X || !Xa || !rec || !flags || !retry_count || !index_ws) return MIA_ERR_NULL;
+  if (ldx < g1 || ldo < o0 + ng) return MIA_ERR_SIZE;
+  size_t need = 0;
+  int rc = mia_letkf_localize_workspace_bytes(P, n_coord, &need);
+  if (rc != MIA_OK) return rc;
+  if (index_ws_bytes < need) return MIA_ERR_WORKSPACE;
+  ScanParams sp;
+  rc = make_scan_params(&sp, grid_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, index_ws);
+  if (rc != MIA_OK) return rc;
+  return cheb_analysis_launch(X, ldx, m, k, g0, ng, rec, nullptr, nullptr, nullptr, p_max_assumed > 0 ? p_max_assumed : 1,
+                              p_max_assumed, inf_factor, gamma > 0.0f ? 1 : 0, gamma, Xa, ldo, o0, flags, retry_count,
+                              &sp, stats, stream);
 }

@@ -9,15 +9,9 @@
 // reference's dtype, so `weight > eps` takes the reference's decision) and compacts the
 // survivors with a wave ballot.  Integer/byte work, HBM/L2-bound: no MFMA here.
 #include "mia_common.h"
+#include "mia_localize_dev.h"
 
 namespace mia {
-
-struct IndexHeader {        // lives at the start of the workspace, written on device
-  double mn[MIA_MAX_COORD];
-  double invh[MIA_MAX_COORD];
-  int n[MIA_MAX_COORD];
-  int ncell;
-};
 
 struct IndexParams {
   const double* obs;  // [P][nc]
@@ -28,64 +22,76 @@ struct IndexParams {
   IndexHeader* hdr;
   int* start;    // [cell_cap + 1]  counts -> exclusive starts
   int* cursor;   // [cell_cap]
-  int* sorted;   // [P]
+  int* sorted;   // [P]      observation index, cell-major, ascending inside a cell
   int* cell_of;  // [P]
+  double* sxyz;  // [P][nc]  coordinates in the same order (no second indirection in the scan)
 };
 
-__device__ inline int cell_coord(double x, double mn, double invh, int n) {
-  double f = floor((x - mn) * invh);
-  f = f < -2.0 ? -2.0 : f;
-  f = f > double(n) + 1.0 ? double(n) + 1.0 : f;
-  return (f == f) ? int(f) : -2;  // NaN coordinate -> no cell
+__device__ inline unsigned long long dkey(double x) {     // total order of doubles as unsigned integers
+  const long long b = __double_as_longlong(x);
+  return b < 0 ? ~(unsigned long long)b : ((unsigned long long)b | 0x8000000000000000ull);
+}
+__device__ inline double dkey_inv(unsigned long long k) {
+  const unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)b);
 }
 
-// one workgroup: bounding box of the observations, then the cell grid dimensions
-__global__ __launch_bounds__(1024) void index_bbox_kernel(IndexParams p) {
-  __shared__ double smn[MIA_MAX_COORD][16], smx[MIA_MAX_COORD][16];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+// bounding box of the observations: wave + workgroup reduction, one pair of 64-bit atomics per
+// workgroup and coordinate
+__global__ __launch_bounds__(256) void index_bbox_kernel(IndexParams p) {
+  __shared__ unsigned long long sx[4], sn[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int c = 0; c < p.nc; ++c) {
-    double mn = 1e300, mx = -1e300;
-    for (int64_t j = tid; j < p.P; j += blockDim.x) {
-      double x = p.obs[j * p.nc + c];
-      if (x == x) { mn = x < mn ? x : mn; mx = x > mx ? x : mx; }
+    unsigned long long kx = 0ull, kn = 0ull;
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < p.P; j += stride) {
+      const double x = p.obs[j * p.nc + c];
+      if (x == x) { const unsigned long long k = dkey(x); kx = k > kx ? k : kx; kn = ~k > kn ? ~k : kn; }
     }
     for (int o = 32; o > 0; o >>= 1) {
-      double a = __shfl_xor(mn, o, 64), b = __shfl_xor(mx, o, 64);
-      mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+      const unsigned long long a = __shfl_xor(kx, o, 64), b = __shfl_xor(kn, o, 64);
+      kx = a > kx ? a : kx; kn = b > kn ? b : kn;
     }
-    if (lane == 0) { smn[c][wv] = mn; smx[c][wv] = mx; }
+    if (lane == 0) { sx[wv] = kx; sn[wv] = kn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w) { kx = sx[w] > kx ? sx[w] : kx; kn = sn[w] > kn ? sn[w] : kn; }
+      if (kx != 0ull) { atomicMax(&p.hdr->kmax[c], kx); atomicMax(&p.hdr->kmin_inv[c], kn); }
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if (tid == 0) {
-    double ext[MIA_MAX_COORD], h[MIA_MAX_COORD];
-    long long n[MIA_MAX_COORD];
-    for (int c = 0; c < MIA_MAX_COORD; ++c) { n[c] = 1; h[c] = 1.0; ext[c] = 0.0; p.hdr->mn[c] = 0.0; }
-    for (int c = 0; c < p.nc; ++c) {
-      double mn = 1e300, mx = -1e300;
-      for (int w = 0; w < 16; ++w) { mn = smn[c][w] < mn ? smn[c][w] : mn; mx = smx[c][w] > mx ? smx[c][w] : mx; }
-      if (mn > mx) { mn = 0.0; mx = 0.0; }
-      p.hdr->mn[c] = mn;
-      ext[c] = mx - mn;
-      h[c] = p.cutoff[c] > 0.0 ? p.cutoff[c] : 1.0;
-      double nn = floor(ext[c] / h[c]) + 1.0;
-      n[c] = nn > 1048576.0 ? 1048576 : (long long)nn;
-    }
-    // shrink until the table fits: halve the longest axis (cells only grow, so the
-    // +-1 cell neighbourhood still covers the taper's support)
-    while (n[0] * n[1] * n[2] > (long long)p.cell_cap) {
-      int big = 0;
-      for (int c = 1; c < p.nc; ++c) if (n[c] > n[big]) big = c;
-      n[big] = (n[big] + 1) / 2;
-    }
-    for (int c = 0; c < p.nc; ++c) {
-      double hc = ext[c] / double(n[c]);
-      if (hc < h[c]) hc = h[c]; else hc *= (1.0 + 1e-12);
-      p.hdr->invh[c] = 1.0 / hc;
-      p.hdr->n[c] = int(n[c]);
-    }
-    for (int c = p.nc; c < MIA_MAX_COORD; ++c) { p.hdr->invh[c] = 1.0; p.hdr->n[c] = 1; }
-    p.hdr->ncell = int(n[0] * n[1] * n[2]);
+}
+
+// one thread: cell grid dimensions from the bounding box
+__global__ void index_dims_kernel(IndexParams p) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double ext[MIA_MAX_COORD], h[MIA_MAX_COORD];
+  long long n[MIA_MAX_COORD];
+  for (int c = 0; c < MIA_MAX_COORD; ++c) { n[c] = 1; h[c] = 1.0; ext[c] = 0.0; p.hdr->mn[c] = 0.0; }
+  for (int c = 0; c < p.nc; ++c) {
+    double mn = 0.0, mx = 0.0;
+    if (p.hdr->kmax[c] != 0ull) { mx = dkey_inv(p.hdr->kmax[c]); mn = dkey_inv(~p.hdr->kmin_inv[c]); }
+    p.hdr->mn[c] = mn;
+    ext[c] = mx - mn;
+    h[c] = p.cutoff[c] > 0.0 ? p.cutoff[c] : 1.0;
+    double nn = floor(ext[c] / h[c]) + 1.0;
+    n[c] = nn > 1048576.0 ? 1048576 : (long long)nn;
   }
+  // shrink until the table fits: halve the longest axis (cells only grow, so the
+  // +-1 cell neighbourhood still covers the taper's support)
+  while (n[0] * n[1] * n[2] > (long long)p.cell_cap) {
+    int big = 0;
+    for (int c = 1; c < p.nc; ++c) if (n[c] > n[big]) big = c;
+    n[big] = (n[big] + 1) / 2;
+  }
+  for (int c = 0; c < p.nc; ++c) {
+    double hc = ext[c] / double(n[c]);
+    if (hc < h[c]) hc = h[c]; else hc *= (1.0 + 1e-12);
+    p.hdr->invh[c] = 1.0 / hc;
+    p.hdr->n[c] = int(n[c]);
+  }
+  for (int c = p.nc; c < MIA_MAX_COORD; ++c) { p.hdr->invh[c] = 1.0; p.hdr->n[c] = 1; }
+  p.hdr->ncell = int(n[0] * n[1] * n[2]);
 }
 
 __device__ inline int obs_cell(const IndexHeader* h, const double* x, int nc) {
@@ -138,8 +144,9 @@ __global__ void index_scatter_kernel(IndexParams p) {
   p.sorted[pos] = int(j);
 }
 
-// the scatter order inside a cell depends on atomic arrival: sort each cell's slice by
-// observation index so that neighbour lists (and therefore summation order) are reproducible
+// the scatter order inside a cell depends on atomic arrival: sort each cell's slice by observation
+// index so that neighbour lists (and therefore summation order) are reproducible; then lay the
+// coordinates out in that order
 __global__ void index_sortcell_kernel(IndexParams p) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= p.hdr->ncell) return;
@@ -149,95 +156,99 @@ __global__ void index_sortcell_kernel(IndexParams p) {
     while (j >= lo && p.sorted[j] > v) { p.sorted[j + 1] = p.sorted[j]; --j; }
     p.sorted[j + 1] = v;
   }
+  for (int i = lo; i < hi; ++i) {
+    const int64_t j = p.sorted[i];
+    for (int q = 0; q < p.nc; ++q) p.sxyz[(int64_t)i * p.nc + q] = p.obs[j * p.nc + q];
+  }
 }
 
 struct LocalizeParams {
-  const double* grid;  // [G][nc]
-  const double* obs;   // [P][nc]
-  int64_t g0, ng, P;
-  int nc, n_r;
-  int group[MIA_MAX_COORD];
-  double inv_c[MIA_MAX_RADII];
-  double eps;
+  ScanParams scan;
+  int64_t g0, ng;
   int p_cap;
-  const IndexHeader* hdr;
-  const int* start;
-  const int* sorted;
   int* cnt; int* idx; double* w; int* stats;
 };
 
-// one wavefront per grid point
+// One THREAD per grid point.  A wavefront-per-point version of this kernel (the scan_neighbours device
+// function, still used by the fused analysis route) took 83 us for 1e5 points on MI355X although it
+// executes only ~400 instructions per wavefront: every wavefront runs a chain of four dependent memory
+// round trips (header -> cell range -> index -> coordinates) of ~1.5 us each and only 32 wavefronts fit
+// a CU.  With one point per lane the same chain is amortised over 64 points and the candidate loop
+// (~30 candidates x ~50 float64 operations) runs with all lanes busy.
 __global__ __launch_bounds__(256) void localize_kernel(LocalizeParams p) {
-  const int lane = threadIdx.x & 63;
-  const int64_t pt = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (pt >= p.ng) return;   // whole wave leaves together
-  const IndexHeader* h = p.hdr;
-  double gx[MIA_MAX_COORD];
-  int cg[MIA_MAX_COORD];
-  for (int c = 0; c < MIA_MAX_COORD; ++c) { gx[c] = 0.0; cg[c] = 0; }
-  for (int c = 0; c < p.nc; ++c) {
-    gx[c] = p.grid[(p.g0 + pt) * p.nc + c];
-    cg[c] = cell_coord(gx[c], h->mn[c], h->invh[c], h->n[c]);
-  }
-  int* my_idx = p.idx + pt * p.p_cap;
-  double* my_w = p.w + pt * p.p_cap;
+  const int64_t pt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int count = 0;
-  // outer coordinates: -1..+1 each; the innermost (fastest) coordinate's three cells are
-  // contiguous in the table and are scanned as one range
-  const int nc = p.nc;
-  const int n_outer = nc == 1 ? 1 : (nc == 2 ? 3 : 9);
-  const int last = nc - 1;
-  int lo_l = cg[last] - 1, hi_l = cg[last] + 1;
-  lo_l = lo_l < 0 ? 0 : lo_l;
-  hi_l = hi_l > h->n[last] - 1 ? h->n[last] - 1 : hi_l;
-  for (int o = 0; o < n_outer; ++o) {
-    int base_cell = 0;
-    bool ok = lo_l <= hi_l;
-    if (nc >= 2) {
-      int d0 = (nc == 2) ? (o - 1) : (o / 3 - 1);
-      int c0 = cg[0] + d0;
-      ok = ok && c0 >= 0 && c0 < h->n[0];
-      base_cell = c0;
-      if (nc == 3) {
-        int c1 = cg[1] + (o % 3 - 1);
-        ok = ok && c1 >= 0 && c1 < h->n[1];
-        base_cell = base_cell * h->n[1] + c1;
-      }
-      base_cell *= h->n[last];
+  if (pt < p.ng) {
+    const ScanParams& q = p.scan;
+    const IndexHeader* h = q.hdr;
+    const int nc = q.nc;
+    double gx[MIA_MAX_COORD];
+    int cg[MIA_MAX_COORD];
+    for (int c = 0; c < MIA_MAX_COORD; ++c) { gx[c] = 0.0; cg[c] = 0; }
+    for (int c = 0; c < nc; ++c) {
+      gx[c] = q.grid[(p.g0 + pt) * nc + c];
+      cg[c] = cell_coord(gx[c], h->mn[c], h->invh[c], h->n[c]);
     }
-    if (!ok) continue;
-    const int beg = p.start[base_cell + lo_l], end = p.start[base_cell + hi_l + 1];
-    for (int b = beg; b < end; b += 64) {
-      const int pos = b + lane;
-      bool use = false;
-      int j = -1;
-      double wgt = 0.0;
-      if (pos < end) {
-        j = p.sorted[pos];
-        double d2[MIA_MAX_RADII] = {0.0, 0.0, 0.0};
-        for (int c = 0; c < nc; ++c) {
-          double dx = p.obs[(int64_t)j * nc + c] - gx[c];
-          d2[p.group[c]] += dx * dx;
+    int* my_idx = p.idx + pt * p.p_cap;
+    double* my_w = p.w + pt * p.p_cap;
+    const int n_outer = nc == 1 ? 1 : (nc == 2 ? 3 : 9);
+    const int last = nc - 1;
+    int lo_l = cg[last] - 1, hi_l = cg[last] + 1;
+    lo_l = lo_l < 0 ? 0 : lo_l;
+    hi_l = hi_l > h->n[last] - 1 ? h->n[last] - 1 : hi_l;
+    for (int o = 0; o < n_outer; ++o) {
+      int base_cell = 0;
+      bool ok = lo_l <= hi_l;
+      if (nc >= 2) {
+        const int d0 = (nc == 2) ? (o - 1) : (o / 3 - 1);
+        const int c0 = cg[0] + d0;
+        ok = ok && c0 >= 0 && c0 < h->n[0];
+        base_cell = c0;
+        if (nc == 3) {
+          const int c1 = cg[1] + (o % 3 - 1);
+          ok = ok && c1 >= 0 && c1 < h->n[1];
+          base_cell = base_cell * h->n[1] + c1;
         }
-        wgt = 1.0;
-        for (int r = 0; r < p.n_r; ++r) wgt *= gc_taper<double>(sqrt(d2[r]) * p.inv_c[r]);
-        use = wgt > p.eps;
+        base_cell *= h->n[last];
       }
-      const unsigned long long mask = __ballot(use);
-      if (use) {
-        const int slot = count + __popcll(mask & ((1ull << lane) - 1ull));
-        if (slot < p.p_cap) { my_idx[slot] = j; my_w[slot] = sqrt(wgt); }
+      if (!ok) continue;
+      const int beg = q.start[base_cell + lo_l], end = q.start[base_cell + hi_l + 1];
+      // four candidates per trip: their (independent) loads are issued together, so the ~1.5 us memory
+      // latency is paid once per four candidates instead of once per candidate
+      for (int pos0 = beg; pos0 < end; pos0 += 4) {
+        double wg[4];
+        int oj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int pos = pos0 + u < end ? pos0 + u : end - 1;
+          oj[u] = q.sorted[pos];
+          double d2[MIA_MAX_RADII] = {0.0, 0.0, 0.0};
+          for (int c = 0; c < nc; ++c) {
+            const double dx = q.sxyz[(int64_t)pos * nc + c] - gx[c];
+            d2[q.group[c]] += dx * dx;
+          }
+          double wgt = 1.0;
+          for (int r = 0; r < q.n_r; ++r) wgt *= gc_taper_d2(d2[r], q.inv_c[r], q.cc[r]);
+          wg[u] = pos0 + u < end ? wgt : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (wg[u] > q.eps) {
+            if (count < p.p_cap) { my_idx[count] = oj[u]; my_w[count] = wg[u] * rsqrt_f64(wg[u]); }
+            ++count;
+          }
+        }
       }
-      count += __popcll(mask);
     }
-  }
-  for (int s = count + lane; s < p.p_cap; s += 64) { my_idx[s] = -1; my_w[s] = 0.0; }
-  if (lane == 0) {
+    for (int s_ = count; s_ < p.p_cap; ++s_) { my_idx[s_] = -1; my_w[s_] = 0.0; }
     p.cnt[pt] = count;
-    // same-address atomics serialise at ~11 ns each (1e5 points -> 1 ms): the running maximum only
-    // grows, so a relaxed look first lets almost every wavefront skip the atomic
-    if (count > __hip_atomic_load(&p.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&p.stats[0], count);
-    if (count > p.p_cap) atomicAdd(&p.stats[1], 1);
+  }
+  // statistics: one (conditional) atomic per wavefront
+  int mx = count, over = (pt < p.ng && count > p.p_cap) ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) { const int a = __shfl_xor(mx, o, 64); mx = a > mx ? a : mx; over += __shfl_xor(over, o, 64); }
+  if ((threadIdx.x & 63) == 0) {
+    if (mx > __hip_atomic_load(&p.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&p.stats[0], mx);
+    if (over) atomicAdd(&p.stats[1], over);
   }
 }
 
@@ -291,11 +302,53 @@ __global__ void gc_kernel(const T* r, int64_t n, T* w) {
   for (; i < n; i += stride) w[i] = gc_taper<T>(r[i]);
 }
 
-static int cell_cap_for(int64_t P) {
-  int64_t cap = 2 * P;
-  if (cap < 1024) cap = 1024;
-  if (cap > (int64_t)1 << 24) cap = (int64_t)1 << 24;
-  return int(cap);
+// builds the cell index of the observations in ws (all kernels enqueued on stream)
+int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_t* coord_group,
+                     const double* gc_c, int n_r, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (P < 0 || n_coord < 1 || n_coord > MIA_MAX_COORD || n_r < 1 || n_r > MIA_MAX_RADII) return MIA_ERR_SIZE;
+  if (P > 2000000000LL) return MIA_ERR_UNSUPPORTED;
+  if (!coord_group || !gc_c) return MIA_ERR_NULL;
+  for (int c = 0; c < n_coord; ++c) if (coord_group[c] < 0 || coord_group[c] >= n_r) return MIA_ERR_SIZE;
+  for (int r = 0; r < n_r; ++r) if (!(gc_c[r] > 0.0)) return MIA_ERR_SIZE;
+  if (P == 0) return MIA_OK;
+  if (!obs_xyz || !ws) return MIA_ERR_NULL;
+  if (((uintptr_t)ws) & 255) return MIA_ERR_ALIGN;
+  const IndexLayout L = index_layout(ws, P, n_coord);
+  if (ws_bytes < L.bytes) return MIA_ERR_WORKSPACE;
+  IndexParams ip;
+  ip.obs = obs_xyz; ip.P = P; ip.nc = n_coord; ip.cell_cap = (int)L.cap;
+  for (int c = 0; c < MIA_MAX_COORD; ++c) ip.cutoff[c] = c < n_coord ? 2.0 * gc_c[coord_group[c]] : 1.0;
+  ip.hdr = L.hdr; ip.start = L.start; ip.cursor = L.cursor; ip.sorted = L.sorted; ip.cell_of = L.cell_of; ip.sxyz = L.sxyz;
+  // header, start and cursor are adjacent: one fill clears all three
+  MIA_HIP_TRY(hipMemsetAsync(ip.hdr, 0, (char*)ip.sorted - (char*)ip.hdr, stream));
+  const unsigned nbP = (unsigned)((P + 255) / 256);
+  index_bbox_kernel<<<dim3(nbP < 64 ? nbP : 64), dim3(256), 0, stream>>>(ip);
+  MIA_LAUNCH_CHECK();
+  index_dims_kernel<<<dim3(1), dim3(64), 0, stream>>>(ip);
+  MIA_LAUNCH_CHECK();
+  index_count_kernel<<<dim3(nbP), dim3(256), 0, stream>>>(ip);
+  MIA_LAUNCH_CHECK();
+  index_scan_kernel<<<dim3(1), dim3(1024), 0, stream>>>(ip);
+  MIA_LAUNCH_CHECK();
+  index_scatter_kernel<<<dim3(nbP), dim3(256), 0, stream>>>(ip);
+  MIA_LAUNCH_CHECK();
+  index_sortcell_kernel<<<dim3((unsigned)((L.cap + 255) / 256)), dim3(256), 0, stream>>>(ip);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// scan parameters over an already built index
+int make_scan_params(ScanParams* sp, const double* grid_xyz, int64_t P, int n_coord, const int32_t* coord_group,
+                     const double* gc_c, int n_r, double gc_eps, void* ws) {
+  if (n_coord < 1 || n_coord > MIA_MAX_COORD || n_r < 1 || n_r > MIA_MAX_RADII) return MIA_ERR_SIZE;
+  if (!coord_group || !gc_c || !grid_xyz || !ws) return MIA_ERR_NULL;
+  const IndexLayout L = index_layout(ws, P, n_coord);
+  sp->grid = grid_xyz; sp->sxyz = L.sxyz; sp->hdr = L.hdr; sp->start = L.start; sp->sorted = L.sorted;
+  sp->nc = n_coord; sp->n_r = n_r;
+  for (int c = 0; c < MIA_MAX_COORD; ++c) sp->group[c] = c < n_coord ? coord_group[c] : 0;
+  for (int r = 0; r < MIA_MAX_RADII; ++r) { sp->inv_c[r] = r < n_r ? 1.0 / gc_c[r] : 1.0; sp->cc[r] = r < n_r ? gc_c[r] : 1.0; }
+  sp->eps = gc_eps;
+  return MIA_OK;
 }
 
 }  // namespace mia
@@ -330,14 +383,14 @@ extern "C" int mia_letkf_localize_workspace_bytes(int64_t P, int n_coord, size_t
   if (!bytes) return MIA_ERR_NULL;
   if (P < 0 || n_coord < 1 || n_coord > MIA_MAX_COORD) return MIA_ERR_SIZE;
   if (P > 2000000000LL) return MIA_ERR_UNSUPPORTED;
-  const size_t cap = (size_t)cell_cap_for(P);
-  size_t b = align_up(sizeof(IndexHeader), 256);
-  b += align_up((cap + 1) * sizeof(int), 256);  // start
-  b += align_up(cap * sizeof(int), 256);        // cursor
-  b += align_up((size_t)P * sizeof(int) + 4, 256);  // sorted
-  b += align_up((size_t)P * sizeof(int) + 4, 256);  // cell_of
-  *bytes = b;
+  *bytes = index_layout(nullptr, P, n_coord).bytes;
   return MIA_OK;
+}
+
+extern "C" int mia_letkf_index_build_f64(const double* obs_xyz, int64_t P, int n_coord, const int32_t* coord_group,
+                                         const double* gc_c, int n_r, void* ws, size_t ws_bytes, void* stream) {
+  (void)hipGetLastError();
+  return index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int mia_letkf_localize_f64(const double* grid_xyz, int64_t g0, int64_t g1,
@@ -363,44 +416,14 @@ extern "C" int mia_letkf_localize_f64(const double* grid_xyz, int64_t g0, int64_
     MIA_HIP_TRY(hipMemsetAsync(nbr_w, 0, ng * (size_t)p_cap * sizeof(double), stream));
     return MIA_OK;
   }
-  if (!obs_xyz || !ws) return MIA_ERR_NULL;
-  size_t need = 0;
-  int rc = mia_letkf_localize_workspace_bytes(P, n_coord, &need);
+  int rc = index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, ws, ws_bytes, stream);
   if (rc != MIA_OK) return rc;
-  if (ws_bytes < need) return MIA_ERR_WORKSPACE;
-  if (((uintptr_t)ws) & 255) return MIA_ERR_ALIGN;
-
-  const size_t cap = (size_t)cell_cap_for(P);
-  IndexParams ip;
-  ip.obs = obs_xyz; ip.P = P; ip.nc = n_coord; ip.cell_cap = (int)cap;
-  for (int c = 0; c < MIA_MAX_COORD; ++c) ip.cutoff[c] = c < n_coord ? 2.0 * gc_c[coord_group[c]] : 1.0;
-  char* base = (char*)ws;
-  ip.hdr = (IndexHeader*)base; base += align_up(sizeof(IndexHeader), 256);
-  ip.start = (int*)base; base += align_up((cap + 1) * sizeof(int), 256);
-  ip.cursor = (int*)base; base += align_up(cap * sizeof(int), 256);
-  ip.sorted = (int*)base; base += align_up((size_t)P * sizeof(int) + 4, 256);
-  ip.cell_of = (int*)base;
-  // start and cursor are adjacent: one memset clears both
-  MIA_HIP_TRY(hipMemsetAsync(ip.start, 0, (char*)ip.sorted - (char*)ip.start, stream));
-  index_bbox_kernel<<<dim3(1), dim3(1024), 0, stream>>>(ip);
-  MIA_LAUNCH_CHECK();
-  const unsigned nbP = (unsigned)((P + 255) / 256);
-  index_count_kernel<<<dim3(nbP), dim3(256), 0, stream>>>(ip);
-  MIA_LAUNCH_CHECK();
-  index_scan_kernel<<<dim3(1), dim3(1024), 0, stream>>>(ip);
-  MIA_LAUNCH_CHECK();
-  index_scatter_kernel<<<dim3(nbP), dim3(256), 0, stream>>>(ip);
-  MIA_LAUNCH_CHECK();
-  index_sortcell_kernel<<<dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, stream>>>(ip);
-  MIA_LAUNCH_CHECK();
-
   LocalizeParams lp;
-  lp.grid = grid_xyz; lp.obs = obs_xyz; lp.g0 = g0; lp.ng = ng; lp.P = P; lp.nc = n_coord; lp.n_r = n_r;
-  for (int c = 0; c < MIA_MAX_COORD; ++c) lp.group[c] = c < n_coord ? coord_group[c] : 0;
-  for (int r = 0; r < MIA_MAX_RADII; ++r) lp.inv_c[r] = r < n_r ? 1.0 / gc_c[r] : 1.0;
-  lp.eps = gc_eps; lp.p_cap = p_cap; lp.hdr = ip.hdr; lp.start = ip.start; lp.sorted = ip.sorted;
+  rc = make_scan_params(&lp.scan, grid_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, ws);
+  if (rc != MIA_OK) return rc;
+  lp.g0 = g0; lp.ng = ng; lp.p_cap = p_cap;
   lp.cnt = nbr_cnt; lp.idx = nbr_idx; lp.w = nbr_w; lp.stats = stats;
-  const int64_t nb = (ng + 3) / 4;
+  const int64_t nb = (ng + 255) / 256;
   if (nb > 2147483647LL) return MIA_ERR_UNSUPPORTED;
   localize_kernel<<<dim3((unsigned)nb), dim3(256), 0, stream>>>(lp);
   MIA_LAUNCH_CHECK();

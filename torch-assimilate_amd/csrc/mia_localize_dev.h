@@ -1,0 +1,156 @@
+// Device-side pieces of the Gaspari-Cohn localisation shared by the stand-alone neighbour-list kernel
+// (localize.hip) and the analysis kernels that scan the observation index themselves (fused route).
+// Reference: GaspariCohn.localize_obs, pytassim/localization/gaspari_cohn.py:97-136.
+#pragma once
+#include "mia_common.h"
+
+namespace mia {
+
+struct IndexHeader {        // lives at the start of the workspace, written on device
+  // order-preserving integer keys of the coordinate extrema, both kept as running MAXIMA so that a
+  // plain zero fill initialises them: kmax = max key(x), kmin_inv = max ~key(x)
+  unsigned long long kmax[MIA_MAX_COORD];
+  unsigned long long kmin_inv[MIA_MAX_COORD];
+  double mn[MIA_MAX_COORD];
+  double invh[MIA_MAX_COORD];
+  int n[MIA_MAX_COORD];
+  int ncell;
+};
+
+__device__ inline int cell_coord(double x, double mn, double invh, int n) {
+  double f = floor((x - mn) * invh);
+  f = f < -2.0 ? -2.0 : f;
+  f = f > double(n) + 1.0 ? double(n) + 1.0 : f;
+  return (f == f) ? int(f) : -2;  // NaN coordinate -> no cell
+}
+
+// 1/sqrt(x) in float64 without the (slow, correctly rounded) library sqrt/div: float seed, two Newton
+// steps (relative error ~1e-15, far inside what the `weight > eps` decision can resolve)
+__device__ inline double rsqrt_f64(double x) {
+  double y = (double)__builtin_amdgcn_rsqf((float)x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+
+// Gaspari-Cohn taper from the squared distance: r = sqrt(d2)/c and 1/r = c/sqrt(d2) both come from
+// one reciprocal square root, so the -2/(3r) term of the outer branch needs no division
+__device__ inline double gc_taper_d2(double d2, double inv_c, double c) {
+  if (!(d2 > 0.0)) return d2 == 0.0 ? 1.0 : 0.0;            // r = 0 -> 1; NaN -> 0 (as gc_taper)
+  const double y = rsqrt_f64(d2);
+  const double r = d2 * y * inv_c, rinv = c * y;
+  const double f1 = (((-0.25 * r + 0.5) * r + 0.625) * r - 5.0 / 3.0) * r * r + 1.0;
+  const double f2 = ((((r * (1.0 / 12.0) - 0.5) * r + 0.625) * r + 5.0 / 3.0) * r - 5.0) * r + 4.0 - (2.0 / 3.0) * rinv;
+  return r < 1.0 ? f1 : (r < 2.0 ? f2 : 0.0);
+}
+
+// what a wavefront needs to find the local observations of one grid point
+struct ScanParams {
+  const double* grid;   // [G][nc]
+  const double* sxyz;   // [P][nc] observation coordinates in cell order
+  const IndexHeader* hdr;
+  const int* start;     // [ncell + 1]
+  const int* sorted;    // [P] observation index in cell order
+  int nc, n_r;
+  int group[MIA_MAX_COORD];
+  double inv_c[MIA_MAX_RADII];
+  double cc[MIA_MAX_RADII];
+  double eps;
+};
+
+// One wavefront scans the 3^d cells around grid point g (the innermost coordinate's three cells are one
+// contiguous range), evaluates distance and taper in float64 and compacts the observations whose weight
+// exceeds eps with a wave ballot, in cell order, ascending index inside a cell.  The first `cap` survivors
+// are written as (index, sqrt(weight)); the return value is the true count (may exceed cap).
+template <typename WT>
+__device__ inline int scan_neighbours(const ScanParams& p, int64_t g, int lane, int cap, int* oidx, WT* ow) {
+  const IndexHeader* h = p.hdr;
+  double gx[MIA_MAX_COORD];
+  int cg[MIA_MAX_COORD];
+  for (int c = 0; c < MIA_MAX_COORD; ++c) { gx[c] = 0.0; cg[c] = 0; }
+  for (int c = 0; c < p.nc; ++c) {
+    gx[c] = p.grid[g * p.nc + c];
+    cg[c] = cell_coord(gx[c], h->mn[c], h->invh[c], h->n[c]);
+  }
+  int count = 0;
+  const int nc = p.nc;
+  const int n_outer = nc == 1 ? 1 : (nc == 2 ? 3 : 9);
+  const int last = nc - 1;
+  int lo_l = cg[last] - 1, hi_l = cg[last] + 1;
+  lo_l = lo_l < 0 ? 0 : lo_l;
+  hi_l = hi_l > h->n[last] - 1 ? h->n[last] - 1 : hi_l;
+  for (int o = 0; o < n_outer; ++o) {
+    int base_cell = 0;
+    bool ok = lo_l <= hi_l;
+    if (nc >= 2) {
+      int d0 = (nc == 2) ? (o - 1) : (o / 3 - 1);
+      int c0 = cg[0] + d0;
+      ok = ok && c0 >= 0 && c0 < h->n[0];
+      base_cell = c0;
+      if (nc == 3) {
+        int c1 = cg[1] + (o % 3 - 1);
+        ok = ok && c1 >= 0 && c1 < h->n[1];
+        base_cell = base_cell * h->n[1] + c1;
+      }
+      base_cell *= h->n[last];
+    }
+    if (!ok) continue;
+    const int beg = p.start[base_cell + lo_l], end = p.start[base_cell + hi_l + 1];
+    for (int b = beg; b < end; b += 64) {
+      const int pos = b + lane;
+      bool use = false;
+      int j = -1;
+      double wgt = 0.0;
+      if (pos < end) {
+        j = p.sorted[pos];
+        double d2[MIA_MAX_RADII] = {0.0, 0.0, 0.0};
+        for (int c = 0; c < nc; ++c) {
+          double dx = p.sxyz[(int64_t)pos * nc + c] - gx[c];
+          d2[p.group[c]] += dx * dx;
+        }
+        wgt = 1.0;
+        for (int r = 0; r < p.n_r; ++r) wgt *= gc_taper_d2(d2[r], p.inv_c[r], p.cc[r]);
+        use = wgt > p.eps;
+      }
+      const unsigned long long mask = __ballot(use);
+      if (use) {
+        const int slot = count + __popcll(mask & ((1ull << lane) - 1ull));
+        if (slot < cap) { oidx[slot] = j; ow[slot] = WT(wgt * rsqrt_f64(wgt)); }
+      }
+      count += __popcll(mask);
+    }
+  }
+  return count;
+}
+
+// layout of the index workspace (built by mia_letkf_index_build_f64)
+struct IndexLayout {
+  IndexHeader* hdr; int* start; int* cursor; int* sorted; int* cell_of; double* sxyz; size_t bytes; size_t cap;
+};
+static inline size_t index_cell_cap(int64_t P) {
+  int64_t cap = 2 * P;
+  if (cap < 1024) cap = 1024;
+  if (cap > (int64_t)1 << 24) cap = (int64_t)1 << 24;
+  return (size_t)cap;
+}
+static inline IndexLayout index_layout(void* ws, int64_t P, int nc) {
+  IndexLayout L;
+  L.cap = index_cell_cap(P);
+  char* base = (char*)ws;
+  L.hdr = (IndexHeader*)base; base += align_up(sizeof(IndexHeader), 256);
+  L.start = (int*)base; base += align_up((L.cap + 1) * sizeof(int), 256);
+  L.cursor = (int*)base; base += align_up(L.cap * sizeof(int), 256);
+  L.sorted = (int*)base; base += align_up((size_t)P * sizeof(int) + 4, 256);
+  L.cell_of = (int*)base; base += align_up((size_t)P * sizeof(int) + 4, 256);
+  L.sxyz = (double*)base; base += align_up((size_t)P * (size_t)nc * sizeof(double) + 8, 256);
+  L.bytes = (size_t)(base - (char*)ws);
+  return L;
+}
+
+// host side, defined in localize.hip
+int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_t* coord_group,
+                     const double* gc_c, int n_r, void* ws, size_t ws_bytes, hipStream_t stream);
+int make_scan_params(ScanParams* sp, const double* grid_xyz, int64_t P, int n_coord, const int32_t* coord_group,
+                     const double* gc_c, int n_r, double gc_eps, void* ws);
+
+}  // namespace mia

@@ -13,7 +13,7 @@ import torch
 
 from . import _cabi
 
-__all__ = ["LetkfEngine", "NeighbourLists"]
+__all__ = ["LetkfEngine", "NeighbourLists", "ObsIndex"]
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -43,6 +43,17 @@ class NeighbourLists:
         if ok:
             self.stats = None
         return ok
+
+
+@dataclass
+class ObsIndex:
+    """Cell index of one observation set for one localisation (built by mia_letkf_index_build_f64)."""
+    ws: torch.Tensor
+    obs: torch.Tensor          # (P, nc) float64, kept alive: the index refers to it
+    radii: list
+    coord_group: list
+    P: int
+    nc: int
 
 
 class LetkfEngine:
@@ -137,6 +148,68 @@ class LetkfEngine:
             cap = (p_max + 7) // 8 * 8          # lists were truncated: retry with room for all
         self._p_cap_hint = max(8, (p_max + 7) // 8 * 8)
         return NeighbourLists(cnt, idx, w, cap, p_max, g0, g1)
+
+    def build_index(self, obs_xyz, radii: Sequence[float], coord_group: Optional[Sequence[int]] = None) -> ObsIndex:
+        """Bin the observations into the uniform cell grid used by the fused-localisation analysis."""
+        obs = self._dev(obs_xyz, torch.float64)
+        if obs.dim() == 1:
+            obs = obs[:, None].contiguous()
+        P, nc = obs.shape
+        radii = [float(r) for r in (radii if hasattr(radii, "__len__") else [radii])]
+        coord_group = [0] * nc if coord_group is None else [int(c) for c in coord_group]
+        nbytes = C.c_size_t(0)
+        _cabi.check(self.lib.mia_letkf_localize_workspace_bytes(P, nc, C.byref(nbytes)), "localize_workspace_bytes")
+        ws = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=self.device)
+        cg = (C.c_int32 * nc)(*coord_group)
+        rc = (C.c_double * len(radii))(*radii)
+        _cabi.check(self.lib.mia_letkf_index_build_f64(_ptr(obs), P, nc, cg, rc, len(radii), _ptr(ws), ws.numel(),
+                                                       self._stream()), "mia_letkf_index_build_f64")
+        return ObsIndex(ws, obs, radii, coord_group, P, nc)
+
+    def analysis_fused(self, X: torch.Tensor, rec: torch.Tensor, grid_xyz, index: ObsIndex, p_max_assumed: int,
+                       inf_factor: float = 1.0, eps: float = 1e-5, rbf_gamma: Optional[float] = None,
+                       g0: int = 0, g1: Optional[int] = None):
+        """matfun analysis with the localisation fused into the kernel (no neighbour lists).  Returns
+        (Xa (m, k, n), flags, finish); ``finish()`` performs the single host sync of the step and returns
+        (ok, observed p_max, declined points): ok False means some grid point has more local observations
+        than assumed and the shard must be redone (list route); declined points are redone by the
+        eigensolver kernel inside ``finish``."""
+        if X.dim() == 2:
+            X = X[None]
+        X = X.to(self.device).contiguous()
+        if X.dtype != torch.float32 or rec.dtype != torch.float32:
+            raise TypeError("the fused matfun route is float32 only")
+        m, k, G = X.shape
+        grid = self._dev(grid_xyz, torch.float64)
+        if grid.dim() == 1:
+            grid = grid[:, None].contiguous()
+        g1 = G if g1 is None else g1
+        n = g1 - g0
+        out = torch.empty((m, k, n), dtype=torch.float32, device=self.device)
+        flags = torch.empty(n, dtype=torch.int32, device=self.device)
+        retry = torch.zeros(1, dtype=torch.int32, device=self.device)
+        stats = torch.empty(2, dtype=torch.int32, device=self.device)
+        cg = (C.c_int32 * index.nc)(*index.coord_group)
+        rc = (C.c_double * len(index.radii))(*index.radii)
+        gamma = float(rbf_gamma) if rbf_gamma is not None else 0.0
+        _cabi.check(self.lib.mia_letkf_analysis_matfun_fused_f32(
+            _ptr(X), G, m, k, g0, g1, _ptr(rec), index.P, _ptr(grid), index.nc, cg, rc, len(index.radii), float(eps),
+            _ptr(index.ws), index.ws.numel(), int(p_max_assumed), float(inf_factor), gamma, _ptr(out), n, 0,
+            _ptr(flags), _ptr(retry), _ptr(stats), self._stream()), "mia_letkf_analysis_matfun_fused_f32")
+
+        def finish():
+            p_max, n_over = (int(v) for v in stats.tolist())        # host sync
+            n_retry = int(retry.item())
+            if n_over:
+                return False, p_max, n_retry
+            if n_retry:     # rare: the eigensolver kernel redoes the declined points and needs explicit lists
+                nb = self.localize(grid, index.obs, index.radii, index.coord_group, eps, g0, g1)
+                _cabi.check(self.lib.mia_letkf_analysis_retry_f32(
+                    _ptr(X), G, m, k, g0, g1, _ptr(rec), index.P, _ptr(nb.cnt), _ptr(nb.idx), _ptr(nb.w), nb.p_cap,
+                    nb.p_max, float(inf_factor), gamma, _ptr(out), n, 0, _ptr(flags), self._stream()),
+                    "mia_letkf_analysis_retry_f32")
+            return True, p_max, n_retry
+        return out, flags, finish
 
     def localize_from_dist(self, dist, cand_idx, radii: Sequence[float], eps: float = 1e-5,
                            g0: int = 0) -> NeighbourLists:

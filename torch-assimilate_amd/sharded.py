@@ -53,16 +53,17 @@ class ShardedLetkf:
 
     @property
     def dominant_kernel_name(self):
-        return "letkf_sys_kernel<20, 64>" if self.method == "eig" else "letkf_cheb_kernel<20, 1>"
+        return "letkf_sys_kernel<20, 64>" if self.method == "eig" else "letkf_cheb_kernel<20, 1, false>"
 
     def __init__(self, device, rank: int = 0, world: int = 1, radii: Sequence[float] = (10.0,),
                  inf_factor: float = 1.0, coord_group: Optional[Sequence[int]] = None, eps: float = 1e-5,
                  rbf_gamma: Optional[float] = None, compute_shard: Optional[Callable] = None, group=None,
-                 method: str = "auto"):
+                 method: str = "auto", fused_localization: bool = False):
         self.device, self.rank, self.world = device, rank, world
         self.radii, self.inf_factor, self.coord_group, self.eps = list(radii), inf_factor, coord_group, eps
         self.rbf_gamma = rbf_gamma
         self.method = method
+        self.fused_localization = fused_localization
         self.last_retries = 0
         self.group = group
         self._engine = None
@@ -80,9 +81,23 @@ class ShardedLetkf:
 
     def _engine_shard(self, X, grid_xyz, obs_xyz, Yb, d, g0, g1):
         eng = self.engine
-        # the previous cycle's maximum list length is assumed (no host sync before the analysis launch);
-        # the assumption is confirmed AFTER the analysis has been enqueued, while the GPU is busy, and
-        # the shard is redone with the true value in the (rare) case it did not hold
+        fusable = (self.fused_localization and self.method != "eig" and self._p_max_hint is not None and X.dtype == torch.float32
+                   and X.shape[0] <= eng.MATFUN_MAX_ROWS and len(obs_xyz) > 0)
+        if fusable:
+            # steady state: index build -> one fused kernel (localisation + analysis), then ONE host sync
+            # that confirms the assumed list bound while the GPU is already busy / done
+            rec = eng.pack_obs(Yb, d, X.dtype)
+            index = eng.build_index(obs_xyz, self.radii, self.coord_group)
+            xa, flags, finish = eng.analysis_fused(X, rec, grid_xyz, index, self._p_max_hint, self.inf_factor,
+                                                   self.eps, self.rbf_gamma, g0, g1)
+            ok, p_max, n_retry = finish()
+            self._p_max_hint = p_max
+            if ok:
+                self.last_p_max, self.last_retries, self._last_flags = p_max, n_retry, flags
+                return xa
+        # explicit neighbour lists.  After the first call on a geometry the previous maximum list length is
+        # assumed, so nothing is read back before the analysis launch; the assumption is confirmed right
+        # after the launch (the one host sync of the step) and the shard redone if it did not hold
         nb = eng.localize(grid_xyz, obs_xyz, self.radii, self.coord_group, self.eps, g0, g1,
                           assume_p_max=self._p_max_hint)
         xa, flags, finish = eng.analysis(X, Yb, d, nb, self.inf_factor, rbf_gamma=self.rbf_gamma,
@@ -91,7 +106,7 @@ class ShardedLetkf:
             nb = eng.localize(grid_xyz, obs_xyz, self.radii, self.coord_group, self.eps, g0, g1)
             xa, flags, finish = eng.analysis(X, Yb, d, nb, self.inf_factor, rbf_gamma=self.rbf_gamma,
                                              return_flags=True, method=self.method, defer_retry=True)
-        self.last_retries = finish()      # (the stream is already drained by confirm(): no extra wait)
+        self.last_retries = finish()
         self._p_max_hint = nb.observed_p_max if nb.observed_p_max is not None else nb.p_max
         self.last_p_max = nb.p_max
         self._last_flags = flags
@@ -119,20 +134,29 @@ class ShardedLetkf:
         G = X.shape[-1]
         g0, g1 = block_partition(G, self.world)[self.rank]
         ev = lambda: torch.cuda.Event(enable_timing=True)
-        acc = {"pack_obs": 0.0, "localize(index+lists, incl. host sync)": 0.0, "analysis_kernel": 0.0}
+        fused = (self.fused_localization and self.method != "eig" and self._p_max_hint is not None
+                 and X.dtype == torch.float32)
+        names = ["pack_obs", "obs_index_build" if fused else "localize(index+lists, incl. host sync)", "analysis_kernel"]
+        acc = dict.fromkeys(names, 0.0)
         for _ in range(reps):
             e = [ev() for _ in range(4)]
             e[0].record()
             rec = eng.pack_obs(Yb, d, X.dtype)
             e[1].record()
-            nb = eng.localize(grid_xyz, obs_xyz, self.radii, self.coord_group, self.eps, g0, g1)
-            e[2].record()
-            _, fin = eng.analysis(X, None, None, nb, self.inf_factor, rbf_gamma=self.rbf_gamma, rec=rec,
-                                  method=self.method, defer_retry=True)
+            if fused:
+                index = eng.build_index(obs_xyz, self.radii, self.coord_group)
+                e[2].record()
+                _, _, fin = eng.analysis_fused(X, rec, grid_xyz, index, self._p_max_hint, self.inf_factor, self.eps,
+                                               self.rbf_gamma, g0, g1)
+            else:
+                nb = eng.localize(grid_xyz, obs_xyz, self.radii, self.coord_group, self.eps, g0, g1)
+                e[2].record()
+                _, fin = eng.analysis(X, None, None, nb, self.inf_factor, rbf_gamma=self.rbf_gamma, rec=rec,
+                                      method=self.method, defer_retry=True)
             e[3].record()
             fin()
             torch.cuda.synchronize()
-            for name, a, b in zip(acc, e[:-1], e[1:]):
+            for name, a, b in zip(names, e[:-1], e[1:]):
                 acc[name] += a.elapsed_time(b)
         stage = {k: v / reps for k, v in acc.items()}
         return stage["analysis_kernel"], stage
