@@ -300,6 +300,7 @@ class LetkfEngine:
             if Yb.dim() != 2 or Yb.shape[0] != k:
                 raise ValueError("Yb must be (k, P) with the state's ensemble size")
             rec = self.pack_obs(Yb, d, dtype)
+            self._keep_rec = rec      # (a record buffer packed during HIP-graph capture must outlive the capture)
         if rec.dtype != dtype or rec.shape[1] != (k + 1 + 3) // 4 * 4:
             raise ValueError("packed records do not match the state's dtype / ensemble size")
         if method not in ("auto", "eig", "matfun"):
