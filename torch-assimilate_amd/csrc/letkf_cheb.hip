@@ -42,20 +42,11 @@ struct ChebParams {
   int32_t* retry_count;
   // fused localisation: the wavefront scans the observation index itself instead of reading lists
   int fused; ScanParams scan; int32_t* stats;
+  int xskip;   // timing experiments only (MIA_EXPERIMENT_SKIP), 0 in production
+  int lds_per_wave;
 };
 
 using f32x4c = __attribute__((ext_vector_type(4))) float;
-
-__device__ inline float wave_sum_c(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ inline float wave_max_c(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
 
 // one row of S (registers) against the broadcast vector in LDS: four independent FMA chains
 // (written with explicit fmaf: the default contraction/SLP of hipcc turned the plain expression into
@@ -74,18 +65,25 @@ __device__ inline float matvec_row(const float (&srow)[NMAX], const float* tv) {
   return (y0 + y1) + (y2 + y3);
 }
 
-template <int NMAX, int KL, bool FUSED>
-__global__ __launch_bounds__(64) void letkf_cheb_kernel(ChebParams P) {
+// wave-local ordering of LDS traffic: all LDS operations of this wavefront issued so far have completed
+// and the compiler may not move memory operations across (the waves of a workgroup are independent here)
+#define MIA_WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+template <int NMAX, int KL, bool FUSED, int WPB>
+__global__ __launch_bounds__(64 * WPB, (NMAX <= 24 ? 5 : (NMAX <= 40 ? 4 : 2))) void letkf_cheb_kernel(ChebParams P) {
   constexpr int LDA = (NMAX % 8 == 0) ? NMAX + 4 : NMAX;
   constexpr int N4 = NMAX / 4;
   constexpr int TT = (NMAX + 15) / 16, NTILE = TT * (TT + 1) / 2;
   constexpr int DCAP = 64;                       // storage for Chebyshev coefficients
   static_assert(NMAX % 4 == 0 && NMAX <= 64, "order must be a multiple of 4, one matrix row per lane");
 
+  // WPB wavefronts per workgroup, each with its own grid point and its own LDS slice (no barrier between
+  // them): 1e5 single-wave workgroups cost ~0.11 ms in dispatch alone on MI355X (measured with all phases
+  // skipped), four points per workgroup cut that to a quarter
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = P.k, kp = P.kp, pm = P.p_max;
-  float* S = reinterpret_cast<float*>(smem_raw);    // [NMAX][LDA] full symmetric
+  float* S = reinterpret_cast<float*>(smem_raw + (size_t)wave * P.lds_per_wave);    // [NMAX][LDA] full symmetric
   float* tv = S + NMAX * LDA;                       // [NMAX] recurrence vector (broadcast source)
   float* rhs = tv + NMAX;                           // [NMAX]
   float* uq = rhs + NMAX;                           // [NMAX] scratch (RBF centring)
@@ -97,14 +95,20 @@ __global__ __launch_bounds__(64) void letkf_cheb_kernel(ChebParams P) {
   float* xp = red + 8;                              // [kp]
   float* sw = xp + kp;                              // [NMAX] phi(S) z
   float* Yt = sw + NMAX;                            // [rows][kp]
-  float* lw = Yt + (size_t)P.rows * kp;             // [pm + 2]
+  float* lw = Yt + (size_t)(P.rows + 1) * kp;       // [pm + 2]   (Yt has one extra, all-zero row)
   int* lidx = reinterpret_cast<int*>(lw + ((pm + 3) & ~1));   // [pm + 2]
 
+  // XCD-aware block -> point map (letkf_sys.hip): block b's XCD group x = b % 8 owns a contiguous range of
+  // point groups; the WPB waves of a block take consecutive points
   const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-  if (bid >= P.ng) return;
-  const int64_t q8 = P.ng >> 3, r8 = P.ng & 7, xcd = bid & 7;   // XCD-aware block -> point map (letkf_sys.hip)
-  const int64_t pt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int64_t nblk = (P.ng + WPB - 1) / WPB;
+  if (bid >= nblk) return;
+  const int64_t q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const int64_t grp = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int64_t pt = grp * WPB + wave;
+  if (pt >= P.ng) return;
   const int64_t g = P.g0 + pt;
+  if (P.xskip & 16) return;            // experiment: dispatch floor
   int flag = 0;
   const float km1 = float(k - 1), reg = P.reg;
   const float ar = sqrtf(reg);
@@ -121,6 +125,13 @@ __global__ __launch_bounds__(64) void letkf_cheb_kernel(ChebParams P) {
       if (cnt > pm) atomicAdd(&P.stats[1], 1);
     }
   } else {
+    // count, list entries and the state row are all requested before anything is waited for: one memory
+    // round trip instead of a count -> entries chain (entries beyond the count are loaded and ignored)
+    const int nl = pm < P.p_cap ? pm : P.p_cap;
+    for (int j = tid; j < nl; j += 64) {       // (one trip for the dual route: p_max <= 64)
+      lidx[j] = P.idx[pt * P.p_cap + j];
+      lw[j] = float(P.w[pt * P.p_cap + j]);
+    }
     cnt = P.cnt[pt];
   }
   if (cnt > pm || (!FUSED && cnt > P.p_cap) || (P.dual ? cnt : k) > NMAX) {   // loud failure, never truncate
@@ -129,16 +140,11 @@ __global__ __launch_bounds__(64) void letkf_cheb_kernel(ChebParams P) {
     for (int it = tid; it < P.m * k; it += 64) P.Xa[(int64_t)it * P.ldo + P.o0 + pt] = nanv;
     return;
   }
-  if constexpr (!FUSED) {
-    for (int j = tid; j < cnt; j += 64) {
-      lidx[j] = P.idx[pt * P.p_cap + j];
-      lw[j] = float(P.w[pt * P.p_cap + j]);
-    }
-  }
-  __syncthreads();
+  if (P.xskip & 32) return;            // experiment: after the list / state loads
+  MIA_WAVE_SYNC();
   {   // gather + sqrt(rho) scale (wrapper.py:91-97)
     const int kpv = kp >> 2;
-    for (int it = tid; it < cnt * kpv; it += 64) {
+    for (int it = tid; it < ((P.xskip & 1) ? 0 : cnt * kpv); it += 64) {
       const int j = it / kpv, c = it - j * kpv;
       float4 v = reinterpret_cast<const float4*>(P.rec + (int64_t)lidx[j] * kp)[c];
       const float wj = lw[j];
@@ -146,33 +152,49 @@ __global__ __launch_bounds__(64) void letkf_cheb_kernel(ChebParams P) {
       reinterpret_cast<float4*>(Yt + (size_t)j * kp)[c] = v;
     }
   }
+  for (int i = tid; i < kp; i += 64) Yt[(size_t)P.rows * kp + i] = 0.0f;   // the zero row of the Gram panels
   const int ntrue = P.dual ? cnt : k;
-  __syncthreads();
+  MIA_WAVE_SYNC();
   // ---- S (full symmetric storage, zero padded)
-  if (P.dual) {
+  if (P.xskip & 2) {
+    for (int it = tid; it < NMAX * LDA; it += 64) S[it] = 0.0f;
+  } else if (P.dual) {
+    // S = Yl^T Yl on the matrix cores (v_mfma_f32_16x16x4_f32, exact f32).  All TT row panels are loaded
+    // once per K step and feed the NTILE upper tiles, whose accumulators are independent (back-to-back
+    // MFMA issue).  A[row][kk] = Yt[16*t + (lane&15)][KS*(lane>>4) + s]: any K order sums the same Gram
+    // entry.  Panel rows beyond the local observation count read an all-zero row.
     const int lr = tid & 15, h = tid >> 4;
     const int KS = (k + 3) >> 2;
+    const float* prow[TT];
 #pragma unroll
-    for (int tile = 0; tile < NTILE; ++tile) {
-      int tb_ = 0;
-      while ((tb_ + 1) * (tb_ + 2) / 2 <= tile) ++tb_;
-      const int ta_ = tile - tb_ * (tb_ + 1) / 2;
-      const int ra = 16 * ta_ + lr, rb = 16 * tb_ + lr;
-      const float* pa = Yt + (size_t)ra * kp + KS * h;
-      const float* pb = Yt + (size_t)rb * kp + KS * h;
-      f32x4c acc = {0.f, 0.f, 0.f, 0.f};
-      for (int s_ = 0; s_ < KS; ++s_) {
-        const bool kin = KS * h + s_ < k;
-        const float av_ = (ra < cnt && kin) ? pa[s_] : 0.0f;
-        const float bv_ = (rb < cnt && kin) ? pb[s_] : 0.0f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av_, bv_, acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int a = 16 * ta_ + h * 4 + q, b = 16 * tb_ + lr;
-        if (a < NMAX && b < NMAX) { S[a * LDA + b] = acc[q]; if (ta_ != tb_) S[b * LDA + a] = acc[q]; }
-      }
+    for (int t = 0; t < TT; ++t) {
+      const int row = 16 * t + lr;
+      prow[t] = Yt + (size_t)(row < cnt ? row : P.rows) * kp + KS * h;     // row P.rows = zero row
     }
+    f32x4c acc[NTILE];
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) acc[t] = f32x4c{0.f, 0.f, 0.f, 0.f};
+    const bool kfull = (k & 3) == 0;
+#pragma unroll 5
+    for (int s_ = 0; s_ < KS; ++s_) {
+      float av_[TT];
+#pragma unroll
+      for (int t = 0; t < TT; ++t) av_[t] = (kfull || KS * h + s_ < k) ? prow[t][s_] : 0.0f;
+#pragma unroll
+      for (int tb_ = 0, tile = 0; tb_ < TT; ++tb_)
+#pragma unroll
+        for (int ta_ = 0; ta_ <= tb_; ++ta_, ++tile)
+          acc[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[ta_], av_[tb_], acc[tile], 0, 0, 0);
+    }
+#pragma unroll
+    for (int tb_ = 0, tile = 0; tb_ < TT; ++tb_)
+#pragma unroll
+      for (int ta_ = 0; ta_ <= tb_; ++ta_, ++tile)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int a = 16 * ta_ + h * 4 + q, b = 16 * tb_ + lr;   // D[row = 4*(lane>>4)+q][col = lane&15]
+          if (a < NMAX && b < NMAX) { S[a * LDA + b] = acc[tile][q]; if (ta_ != tb_) S[b * LDA + a] = acc[tile][q]; }
+        }
   } else {
     for (int it = tid; it < NMAX * NMAX; it += 64) {
       const int a = it / NMAX, b = it - a * NMAX;
@@ -189,7 +211,7 @@ __global__ __launch_bounds__(64) void letkf_cheb_kernel(ChebParams P) {
       S[a * LDA + b] = acc; S[b * LDA + a] = acc;
     }
   }
-  __syncthreads();
+  MIA_WAVE_SYNC();
   // ---- right-hand side of the mean weights
   if (P.dual) {
     if (tid < NMAX) rhs[tid] = tid < cnt ? Yt[(size_t)tid * kp + k] : 0.0f;
@@ -208,21 +230,21 @@ __global__ __launch_bounds__(64) void letkf_cheb_kernel(ChebParams P) {
       for (int j = 0; j < cnt; ++j) { const float df = Yt[(size_t)j * kp + i] - Yt[(size_t)j * kp + k]; ko += df * df; }
       rhs[i] = __expf(-P.gamma * ko);
     }
-    __syncthreads();
+    MIA_WAVE_SYNC();
     if (tid == 0) {
       float gm = 0.0f, om = 0.0f;
       for (int i = 0; i < k; ++i) { gm += uq[i]; om += rhs[i]; }
       red[0] = gm / float(k); red[1] = om / float(k);
     }
-    __syncthreads();
+    MIA_WAVE_SYNC();
     for (int it = tid; it < k * k; it += 64) {
       const int a = it / k, b = it - a * k;
       S[a * LDA + b] = S[a * LDA + b] - uq[b] - (uq[a] - red[0]);
     }
-    __syncthreads();
+    MIA_WAVE_SYNC();
     for (int i = tid; i < NMAX; i += 64) rhs[i] = i < k ? rhs[i] - red[1] - (uq[i] - red[0]) : 0.0f;
   }
-  __syncthreads();
+  MIA_WAVE_SYNC();
   // ---- row r of S into registers; Gershgorin bound L >= lambda_max
   float srow[NMAX];
   float rsum = 0.0f;
@@ -234,13 +256,14 @@ __global__ __launch_bounds__(64) void letkf_cheb_kernel(ChebParams P) {
     rsum += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
   }
   const float rhs_r = tid < NMAX ? rhs[tid] : 0.0f;
-  float L = wave_max_c(tid < NMAX ? rsum : 0.0f);
+  float L = wave_max_dpp(tid < NMAX ? rsum : 0.0f);
   L = fmaxf(L, 1e-30f * reg) * 1.0001f;
   // ---- degree from the Bernstein-ellipse parameter of the singularity at -reg
   const float sq = sqrtf(1.0f + L / reg);
   const float rho = (sq + 1.0f) / fmaxf(sq - 1.0f, 1e-12f);
   int deg = (int)ceilf(P.log_tol / __logf(rho)) + 2;
   deg = deg < 3 ? 3 : deg;
+  if (P.xskip & 4) deg = 3;
   if (!(L == L) || !(fabsf(L) < 1e30f)) { flag |= MIA_FLAG_NONFINITE; deg = 3; }
   if (deg > P.dmax || deg > DCAP - 1) {   // spectrum too wide for the polynomial route: eigensolver redoes this point
     if (tid == 0) {
@@ -261,7 +284,7 @@ __global__ __launch_bounds__(64) void letkf_cheb_kernel(ChebParams P) {
       fphi[tid] = P.dual ? -sqrtf(km1) / (u * ar * (ar + u)) : sqrtf(km1) / u;
       fpsi[tid] = 1.0f / le;
     }
-    __syncthreads();
+    MIA_WAVE_SYNC();
     if (tid < N) {
       float a1 = 0.0f, a2 = 0.0f;
       for (int i = 0; i < N; ++i) {
@@ -271,7 +294,7 @@ __global__ __launch_bounds__(64) void letkf_cheb_kernel(ChebParams P) {
       const float sc = (tid == 0 ? 1.0f : 2.0f) * invN;
       cphi[tid] = a1 * sc; cpsi[tid] = a2 * sc;
     }
-    __syncthreads();
+    MIA_WAVE_SYNC();
   }
   const float alpha = 2.0f / L;            // A v = alpha S v - v
   // ---- per state row: z, the shared recurrence, the output
@@ -284,13 +307,13 @@ __global__ __launch_bounds__(64) void letkf_cheb_kernel(ChebParams P) {
     float xs = 0.0f;
 #pragma unroll
     for (int u = 0; u < KL; ++u) xs += xval[u];
-    const float xm = wave_sum_c(xs) / float(k);
+    const float xm = wave_sum_dpp(xs) / float(k);
 #pragma unroll
     for (int u = 0; u <= KL; ++u) {         // one pass more than members per lane: zero the d / pad slots
       const int i = tid + 64 * u;
       if (i < kp) xp[i] = (u < KL && i < k) ? xval[u < KL ? u : 0] - xm : 0.0f;
     }
-    __syncthreads();
+    MIA_WAVE_SYNC();
     float t0 = 0.0f;                        // z_r
     if (tid < NMAX) {
       if (P.dual) {
@@ -302,24 +325,24 @@ __global__ __launch_bounds__(64) void letkf_cheb_kernel(ChebParams P) {
       } else t0 = tid < k ? xp[tid] : 0.0f;
       tv[tid] = t0;
     }
-    __syncthreads();
+    MIA_WAVE_SYNC();
     // t1 = A t0
     float y = matvec_row<NMAX>(srow, tv);
     float tprev = t0, tcur = alpha * y - t0;
     float aphi = cphi[0] * t0 + cphi[1] * tcur, apsi = cpsi[0] * t0 + cpsi[1] * tcur;
     for (int j = 2; j <= deg; ++j) {
-      __syncthreads();                      // every lane has read tv
+      MIA_WAVE_SYNC();                      // every lane has read tv
       if (tid < NMAX) tv[tid] = tcur;
-      __syncthreads();
+      MIA_WAVE_SYNC();
       y = matvec_row<NMAX>(srow, tv);
       const float tnext = 2.0f * (alpha * y - tcur) - tprev;
       tprev = tcur; tcur = tnext;
       aphi += cphi[j] * tcur; apsi += cpsi[j] * tcur;
     }
     const bool live = tid < ntrue;
-    const float zu = wave_sum_c(live ? rhs_r * apsi : 0.0f);      // x' w_mean
+    const float zu = wave_sum_dpp(live ? rhs_r * apsi : 0.0f);      // x' w_mean
     if (tid < NMAX) sw[tid] = live ? aphi : 0.0f;
-    __syncthreads();
+    MIA_WAVE_SYNC();
     const float mterm = xm + zu;
     float* orow = P.Xa + (int64_t)mi * k * P.ldo + P.o0 + pt;
 #pragma unroll
@@ -329,14 +352,14 @@ __global__ __launch_bounds__(64) void letkf_cheb_kernel(ChebParams P) {
         float acc;
         if (P.dual) {   // Yl s from the LDS block (still resident on this route; member j contiguous across lanes)
           acc = f0 * (xval[u] - xm);
-          for (int b = 0; b < cnt; ++b) acc += sw[b] * Yt[(size_t)b * kp + j];
+          for (int b = 0; b < ((P.xskip & 8) ? 0 : cnt); ++b) acc += sw[b] * Yt[(size_t)b * kp + j];
         } else acc = sw[j];
         const float out = mterm + acc;
         if (!(fabsf(out) <= 1e30f)) flag |= MIA_FLAG_NONFINITE;
         orow[(int64_t)j * P.ldo] = out;
       }
     }
-    __syncthreads();
+    MIA_WAVE_SYNC();
   }
   if (P.flags) {
     const int any = __any(flag != 0) ? MIA_FLAG_NONFINITE : 0;
@@ -346,17 +369,29 @@ __global__ __launch_bounds__(64) void letkf_cheb_kernel(ChebParams P) {
 
 static size_t cheb_lds_bytes(int kp, int p_max, int nmax, int rows) {
   const int lda = (nmax % 8 == 0) ? nmax + 4 : nmax;
-  size_t e = (size_t)nmax * lda + 4 * (size_t)nmax + 4 * 64 + 8 + (size_t)kp + (size_t)rows * kp + ((p_max + 3) & ~1);
+  size_t e = (size_t)nmax * lda + 4 * (size_t)nmax + 4 * 64 + 8 + (size_t)kp + (size_t)(rows + 1) * kp + ((p_max + 3) & ~1);
   return align_up(e * sizeof(float) + (size_t)((p_max + 3) & ~1) * sizeof(int), 16);
 }
 
-template <int NMAX, int KL, bool FUSED>
-static int cheb_launch(const ChebParams& ap, size_t lds, dim3 grid, hipStream_t stream) {
-  auto kern = letkf_cheb_kernel<NMAX, KL, FUSED>;
-  if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  kern<<<grid, dim3(64), lds, stream>>>(ap);
+template <int NMAX, int KL, bool FUSED, int WPB>
+static int cheb_launch_w(const ChebParams& ap, size_t lds, hipStream_t stream) {
+  auto kern = letkf_cheb_kernel<NMAX, KL, FUSED, WPB>;
+  const size_t tot = lds * WPB;
+  if (tot > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tot));
+  const int64_t nblk = (ap.ng + WPB - 1) / WPB;
+  const int64_t gx = nblk < 65536 ? nblk : 65536;
+  const int64_t gy = (nblk + gx - 1) / gx;
+  if (gy > 65535) return MIA_ERR_UNSUPPORTED;
+  kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64 * WPB), tot, stream>>>(ap);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
+}
+
+template <int NMAX, int KL, bool FUSED>
+static int cheb_launch(const ChebParams& ap, size_t lds, dim3, hipStream_t stream) {
+  // four independent points per workgroup when their LDS slices fit comfortably
+  if (getenv("MIA_CHEB_WPB4") && lds * 4 <= 40 * 1024) return cheb_launch_w<NMAX, KL, FUSED, 4>(ap, lds, stream);   // experiment
+  return cheb_launch_w<NMAX, KL, FUSED, 1>(ap, lds, stream);
 }
 
 // MIA_ERR_UNSUPPORTED when the shape is outside this route (caller uses the eigensolver kernels)
@@ -384,10 +419,13 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
   ap.rows = ap.dual ? nmax : (p_max > 0 ? p_max : 1);
   ap.dmax = 48;
   if (const char* e = getenv("MIA_CHEB_DMAX")) ap.dmax = atoi(e);                 // experiments only
+  ap.xskip = 0;
+  if (const char* e = getenv("MIA_EXPERIMENT_SKIP")) ap.xskip = atoi(e);
   ap.log_tol = 14.5f;   // ln(1 / 5e-7): a-priori truncation bound; measured error is flat (2.5e-7..7e-7 vs the reference) for 11 <= log_tol <= 17.5
   if (const char* e = getenv("MIA_CHEB_LOGTOL")) ap.log_tol = (float)atof(e);     // experiments only
   const size_t lds = cheb_lds_bytes(ap.kp, p_max, nmax, ap.rows);
   if (lds > 160 * 1024) return MIA_ERR_UNSUPPORTED;
+  ap.lds_per_wave = (int)lds;
   const int64_t gx = ng < 65536 ? ng : 65536;
   const int64_t gy = (ng + gx - 1) / gx;
   if (gy > 65535) return MIA_ERR_UNSUPPORTED;

@@ -58,12 +58,6 @@ __device__ inline void rot_params_f(float app, float aqq, float apq, float& c, f
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-__device__ inline float wave_sum_f(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
 // strictly-upper element (a < b) number `it` in b-major order: it = b(b-1)/2 + a
 __device__ inline void tri_decode(int it, int& a, int& b) {
   b = (int)((1.0f + __builtin_amdgcn_sqrtf(1.0f + 8.0f * (float)it)) * 0.5f);
@@ -281,7 +275,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? (NMAX >= 32 ? 3 : 4) : 2)) void let
       for (int mi = 0; mi < P.m; ++mi) {
         if (mi > 0) { xval = 0.0f; if (tid < k) xval = P.X[((int64_t)mi * k + tid) * P.ldx + g]; }
         float xm;
-        if (!MULTIWAVE) xm = wave_sum_f(xval) / float(k);
+        if (!MULTIWAVE) xm = wave_sum_dpp(xval) / float(k);
         else {
           if (tid < kp) xp[tid] = tid < k ? xval : 0.0f;
           __syncthreads();
@@ -506,8 +500,8 @@ __global__ __launch_bounds__(NT, (NT == 64 ? (NMAX >= 32 ? 3 : 4) : 2)) void let
       __syncthreads();
       float zu, xm;   // X' w_mean = z . u ; ensemble mean of this row
       if (!MULTIWAVE) {
-        zu = wave_sum_f(tid < NMAX ? z_b * uvs[tid] : 0.0f);
-        xm = wave_sum_f(xval) / float(k);
+        zu = wave_sum_dpp(tid < NMAX ? z_b * uvs[tid] : 0.0f);
+        xm = wave_sum_dpp(xval) / float(k);
       } else {
         zu = 0.0f;
         for (int b = 0; b < NMAX; ++b) zu += zall[mi * NMAX + b] * uvs[b];
