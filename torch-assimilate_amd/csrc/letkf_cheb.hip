@@ -48,21 +48,22 @@ struct ChebParams {
 
 using f32x4c = __attribute__((ext_vector_type(4))) float;
 
-// one row of S (registers) against the broadcast vector in LDS: four independent FMA chains
-// (written with explicit fmaf: the default contraction/SLP of hipcc turned the plain expression into
-// v_pk_mul + v_pk_add + moves, ~2.5x the instructions)
+// one row of S (registers, kept as float2 pairs) against the broadcast vector in LDS.  Written on 2-vectors
+// so that hipcc emits v_pk_fma_f32 with operands already in place (the scalar form compiled to v_pk_mul /
+// v_pk_add plus ~17 v_mov per step: 45 VALU instead of 12); two accumulators for instruction-level parallelism
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
 template <int NMAX>
-__device__ inline float matvec_row(const float (&srow)[NMAX], const float* tv) {
-  float y0 = 0.0f, y1 = 0.0f, y2 = 0.0f, y3 = 0.0f;
+__device__ inline float matvec_row(const f2v (&srow2)[NMAX / 2], const float* tv) {
+  f2v acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};
 #pragma unroll
   for (int b4 = 0; b4 < NMAX / 4; ++b4) {
-    const float4 v = reinterpret_cast<const float4*>(tv)[b4];
-    y0 = __builtin_fmaf(srow[4 * b4], v.x, y0);
-    y1 = __builtin_fmaf(srow[4 * b4 + 1], v.y, y1);
-    y2 = __builtin_fmaf(srow[4 * b4 + 2], v.z, y2);
-    y3 = __builtin_fmaf(srow[4 * b4 + 3], v.w, y3);
+    const f4v v = reinterpret_cast<const f4v*>(tv)[b4];
+    acc0 = srow2[2 * b4] * v.xy + acc0;
+    acc1 = srow2[2 * b4 + 1] * v.zw + acc1;
   }
-  return (y0 + y1) + (y2 + y3);
+  const f2v a = acc0 + acc1;
+  return a.x + a.y;
 }
 
 // wave-local ordering of LDS traffic: all LDS operations of this wavefront issued so far have completed
@@ -87,11 +88,9 @@ __global__ __launch_bounds__(64 * WPB, (NMAX <= 24 ? 5 : (NMAX <= 40 ? 4 : 2))) 
   float* tv = S + NMAX * LDA;                       // [NMAX] recurrence vector (broadcast source)
   float* rhs = tv + NMAX;                           // [NMAX]
   float* uq = rhs + NMAX;                           // [NMAX] scratch (RBF centring)
-  float* cphi = uq + NMAX;                          // [DCAP]
-  float* cpsi = cphi + DCAP;                        // [DCAP]
-  float* fphi = cpsi + DCAP;                        // [DCAP] function samples at the Chebyshev nodes
-  float* fpsi = fphi + DCAP;                        // [DCAP]
-  float* red = fpsi + DCAP;                         // [8]
+  f2v* c2 = reinterpret_cast<f2v*>(uq + NMAX);      // [DCAP] Chebyshev coefficients (phi_j, psi_j)
+  f2v* f2s = c2 + DCAP;                             // [DCAP] function samples (phi, psi) at the Chebyshev nodes
+  float* red = reinterpret_cast<float*>(f2s + DCAP);   // [8]
   float* xp = red + 8;                              // [kp]
   float* sw = xp + kp;                              // [NMAX] phi(S) z
   float* Yt = sw + NMAX;                            // [rows][kp]
@@ -246,14 +245,14 @@ __global__ __launch_bounds__(64 * WPB, (NMAX <= 24 ? 5 : (NMAX <= 40 ? 4 : 2))) 
   }
   MIA_WAVE_SYNC();
   // ---- row r of S into registers; Gershgorin bound L >= lambda_max
-  float srow[NMAX];
+  f2v srow2[NMAX / 2];
   float rsum = 0.0f;
   const int r = tid < NMAX ? tid : NMAX - 1;
 #pragma unroll
   for (int b4 = 0; b4 < N4; ++b4) {
-    const float4 v = reinterpret_cast<const float4*>(S + r * LDA)[b4];
-    srow[4 * b4] = v.x; srow[4 * b4 + 1] = v.y; srow[4 * b4 + 2] = v.z; srow[4 * b4 + 3] = v.w;
-    rsum += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
+    const f4v v = reinterpret_cast<const f4v*>(S + r * LDA)[b4];
+    srow2[2 * b4] = v.xy; srow2[2 * b4 + 1] = v.zw;
+    rsum += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
   }
   const float rhs_r = tid < NMAX ? rhs[tid] : 0.0f;
   float L = wave_max_dpp(tid < NMAX ? rsum : 0.0f);
@@ -277,22 +276,31 @@ __global__ __launch_bounds__(64 * WPB, (NMAX <= 24 ? 5 : (NMAX <= 40 ? 4 : 2))) 
   {
     const float invN = 1.0f / float(N);
     if (tid < N) {
-      const float x = __builtin_amdgcn_cosf(0.5f * (float(tid) + 0.5f) * invN);     // cos(pi (i+1/2)/N), argument in turns
+      const float x = __builtin_amdgcn_cosf(float(2 * tid + 1) * 0.25f * invN);     // cos(pi (i+1/2)/N), argument in turns
       const float lam = 0.5f * L * (x + 1.0f);
       const float le = lam + reg;
       const float u = __builtin_amdgcn_sqrtf(le);
-      fphi[tid] = P.dual ? -sqrtf(km1) / (u * ar * (ar + u)) : sqrtf(km1) / u;
-      fpsi[tid] = 1.0f / le;
+      f2v f;
+      f.x = P.dual ? -sqrtf(km1) / (u * ar * (ar + u)) : sqrtf(km1) / u;
+      f.y = 1.0f / le;
+      f2s[tid] = f;
     }
     MIA_WAVE_SYNC();
     if (tid < N) {
-      float a1 = 0.0f, a2 = 0.0f;
+      f2v a = {0.0f, 0.0f};
+      // cos(j pi (i+1/2)/N) = cos(2 pi m / 4N), m = j (2i+1) mod 4N kept as an exact integer phase
+      // (a float phase accumulated over i loses ~N*eps turns: 2e-5 in the analysis at degree 40)
+      const int n4 = 4 * N;
+      const float inv4n = 0.25f * invN;
+      int ph = tid;                       // i = 0: j * 1
       for (int i = 0; i < N; ++i) {
-        const float c = __builtin_amdgcn_cosf(0.5f * float(tid) * (float(i) + 0.5f) * invN);   // cos(j pi (i+1/2)/N)
-        a1 += fphi[i] * c; a2 += fpsi[i] * c;
+        const float c = __builtin_amdgcn_cosf(float(ph) * inv4n);
+        ph += 2 * tid;
+        ph = ph >= n4 ? ph - n4 : ph;
+        a = f2s[i] * c + a;
       }
       const float sc = (tid == 0 ? 1.0f : 2.0f) * invN;
-      cphi[tid] = a1 * sc; cpsi[tid] = a2 * sc;
+      c2[tid] = a * sc;
     }
     MIA_WAVE_SYNC();
   }
@@ -327,18 +335,19 @@ __global__ __launch_bounds__(64 * WPB, (NMAX <= 24 ? 5 : (NMAX <= 40 ? 4 : 2))) 
     }
     MIA_WAVE_SYNC();
     // t1 = A t0
-    float y = matvec_row<NMAX>(srow, tv);
+    float y = matvec_row<NMAX>(srow2, tv);
     float tprev = t0, tcur = alpha * y - t0;
-    float aphi = cphi[0] * t0 + cphi[1] * tcur, apsi = cpsi[0] * t0 + cpsi[1] * tcur;
+    f2v ap = c2[0] * t0 + c2[1] * tcur;       // (phi(S) z, psi(S) z) row r, accumulated together
     for (int j = 2; j <= deg; ++j) {
       MIA_WAVE_SYNC();                      // every lane has read tv
       if (tid < NMAX) tv[tid] = tcur;
       MIA_WAVE_SYNC();
-      y = matvec_row<NMAX>(srow, tv);
+      y = matvec_row<NMAX>(srow2, tv);
       const float tnext = 2.0f * (alpha * y - tcur) - tprev;
       tprev = tcur; tcur = tnext;
-      aphi += cphi[j] * tcur; apsi += cpsi[j] * tcur;
+      ap = c2[j] * tcur + ap;
     }
+    const float aphi = ap.x, apsi = ap.y;
     const bool live = tid < ntrue;
     const float zu = wave_sum_dpp(live ? rhs_r * apsi : 0.0f);      // x' w_mean
     if (tid < NMAX) sw[tid] = live ? aphi : 0.0f;
