@@ -8,7 +8,7 @@ eng = mia.LetkfEngine(dev)
 X, gx, ox, Yb, d = bench.make_case(100000, 40, 2, dev)
 nb = eng.localize(gx, ox, [10.0])
 rec = eng.pack_obs(Yb, d, torch.float32)
-for skip in (0, 15, 16, 32):
+for skip in (0, 1, 4, 8, 15, 32):
     os.environ["MIA_EXPERIMENT_SKIP"] = str(skip)
     ts = []
     for b in range(6):
