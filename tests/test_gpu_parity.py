@@ -329,3 +329,40 @@ def test_fused_localisation_equals_list_route_bitwise(eng, golden):
         okb, pb, _ = finb()
         assert not okb and pb == nb.p_max
         assert int((fb & 1).max().cpu()) == 1
+
+
+@pytest.mark.parametrize("scale", [0.01, 1.0, 3.0, 6.0])
+@pytest.mark.parametrize("inf", [0.8, 1.0, 1.5])
+def test_both_routes_across_observation_strength_and_inflation(eng, scale, inf):
+    """Spectra from nearly zero (weak observations: analysis ~ inflated prior) to lambda_max/reg ~ 100 (strong
+    observations: matfun declines, eigensolver takes over), deflation (inf < 1) and inflation, both routes
+    against the oracle on every grid point incl. the ragged domain edges."""
+    case = O.synthetic_case(160, 24, 2, seed=5)
+    yb, d = case["yb"] * scale, case["d"] * scale
+    nb = eng.localize(case["grid_x"], case["obs_x"], [6.0])
+    ref, _ = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], yb, d, 6.0, inf)
+    xm = case["state"].mean(axis=1, keepdims=True)
+    for method in ("matfun", "eig"):
+        xa, fl = eng.analysis(dev(case["state"], torch.float32), dev(yb, torch.float32), dev(d, torch.float32), nb, inf,
+                              return_flags=True, method=method)
+        assert int((fl & 0xff).max().cpu()) == 0
+        assert rel_fro(xa.cpu().numpy(), ref) < TOL32, (method, scale, inf)
+        assert rel_fro(xa.cpu().numpy() - xm, ref - xm) < 20 * TOL32, (method, scale, inf)
+
+
+def test_degenerate_ensembles(eng):
+    """All members equal in observation space (S = 0) and a single member perturbed: no division by zero, the
+    result is the oracle's (prior perturbations inflated by sqrt(inf), mean shifted by nothing / by the gain)."""
+    rs = np.random.RandomState(2)
+    G, k = 64, 16
+    state = rs.normal(size=(1, k, G))
+    grid_x = np.arange(G, dtype=np.float64); obs_x = np.arange(0, G, 2, dtype=np.float64)
+    yb0 = np.zeros((k, obs_x.size)); d0 = rs.normal(size=obs_x.size)
+    yb1 = yb0.copy(); yb1[3] = 1.0; yb1 -= yb1.mean(axis=0)
+    nb = eng.localize(grid_x, obs_x, [5.0])
+    for yb in (yb0, yb1):
+        ref, _ = O.letkf_analysis(state, grid_x, obs_x, yb, d0, 5.0, 1.2)
+        for method in ("matfun", "eig"):
+            xa = eng.analysis(dev(state, torch.float32), dev(yb, torch.float32), dev(d0, torch.float32), nb, 1.2, method=method)
+            assert torch.isfinite(xa).all()
+            assert rel_fro(xa.cpu().numpy(), ref) < TOL32
