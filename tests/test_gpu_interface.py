@@ -124,3 +124,40 @@ def test_sharded_runner_single_gpu_matches_oracle(mia):
         w = O.localized_weights(dist, case["yb"], case["d"], [10.0], 1.1)
         ref = O.apply_weights(case["state"][:, :, [gi]], w[None])
         assert rel_fro(out[:, :, gi].cpu().numpy(), ref[:, :, 0]) < 1e-5
+
+
+@pytest.mark.parametrize("G,chunks,strong", [(2000, 4, False), (1999, 3, False), (1000, 4, True)])
+def test_overlapped_exchange_path_on_one_gpu(mia, G, chunks, strong):
+    """The compute / all-gather overlap route of the multi-GPU runner (side stream, events, one RCCL
+    all-gather per chunk, final permute), driven on ONE GPU through a single-rank RCCL group: must give the
+    same ensemble as the plain route, twice in a row (second call uses the assumed list bound).  `strong`:
+    accurate observations make the matfun kernel decline points, exercising the re-exchange of redone chunks."""
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    own = not dist.is_initialized()
+    if own:
+        import os, socket
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        case = O.synthetic_case(G, 40, 2)
+        scale = 12.0 if strong else 1.0
+        args = (torch.as_tensor(case["state"], dtype=torch.float32, device=dev), torch.as_tensor(case["grid_x"], device=dev),
+                torch.as_tensor(case["obs_x"], device=dev),
+                torch.as_tensor(case["yb"] * scale, dtype=torch.float32, device=dev),
+                torch.as_tensor(case["d"] * scale, dtype=torch.float32, device=dev))
+        plain = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1)
+        ref = plain.assimilate(*args)
+        over = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1, comm_chunks=chunks)
+        for _ in range(2):
+            out = over._assimilate_overlapped(*args, G, 0, G)
+            torch.cuda.synchronize()
+            assert out.shape == ref.shape
+            assert over.last_flags_ok()
+            assert rel_fro(out.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+        if strong:
+            assert plain.last_retries > 0 and over.last_retries == plain.last_retries
+    finally:
+        if own:
+            dist.destroy_process_group()

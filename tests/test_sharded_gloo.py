@@ -28,7 +28,12 @@ def _oracle_shard(X, grid_x, obs_x, Yb, d, g0, g1):
     return torch.from_numpy(ana)
 
 
-def _worker(rank, world, port, G, out_path):
+def _oracle_chunk(X, grid_x, obs_x, Yb, d, c0, c1, state):
+    state.setdefault("calls", []).append((c0, c1))
+    return _oracle_shard(X, grid_x, obs_x, Yb, d, c0, c1), (lambda: 0)
+
+
+def _worker(rank, world, port, G, out_path, chunks=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -36,7 +41,8 @@ def _worker(rank, world, port, G, out_path):
     import torch_assimilate_amd as mia
     case = O.synthetic_case(G, 12, 2)
     X = torch.from_numpy(case["state"])
-    runner = mia.ShardedLetkf("cpu", rank, world, radii=[10.0], inf_factor=1.1, compute_shard=_oracle_shard)
+    runner = mia.ShardedLetkf("cpu", rank, world, radii=[10.0], inf_factor=1.1, compute_shard=_oracle_shard,
+                              comm_chunks=chunks, chunk_compute=_oracle_chunk if chunks > 1 else None)
     full = runner.assimilate(X, torch.from_numpy(case["grid_x"]), torch.from_numpy(case["obs_x"]),
                              torch.from_numpy(case["yb"]), torch.from_numpy(case["d"]))
     assert full.shape == X.shape
@@ -50,10 +56,12 @@ def _worker(rank, world, port, G, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("G", [64, 51])      # 51: uneven tail block exercises the padding
-def test_two_rank_shard_and_allgather(tmp_path, G):
+@pytest.mark.parametrize("G,chunks", [(64, 1), (51, 1), (64, 4), (51, 4), (37, 3)])
+def test_two_rank_shard_and_allgather(tmp_path, G, chunks):
+    """chunks == 1: one all-gather of the whole block; chunks > 1: the compute / exchange-overlap path
+    (block analysed in pieces, one all-gather per piece, uneven tails padded) -- same result."""
     out = str(tmp_path / "full.npy")
-    mp.spawn(_worker, args=(2, _free_port(), G, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), G, out, chunks), nprocs=2, join=True)
     got = np.load(out)
     case = O.synthetic_case(G, 12, 2)
     ref, _ = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], case["yb"], case["d"], 10.0, 1.1)

@@ -58,13 +58,17 @@ class ShardedLetkf:
     def __init__(self, device, rank: int = 0, world: int = 1, radii: Sequence[float] = (10.0,),
                  inf_factor: float = 1.0, coord_group: Optional[Sequence[int]] = None, eps: float = 1e-5,
                  rbf_gamma: Optional[float] = None, compute_shard: Optional[Callable] = None, group=None,
-                 method: str = "auto", fused_localization: bool = False, use_graph: bool = False):
+                 method: str = "auto", fused_localization: bool = False, use_graph: bool = False,
+                 comm_chunks: int = 4, chunk_compute: Optional[Callable] = None):
         self.device, self.rank, self.world = device, rank, world
         self.radii, self.inf_factor, self.coord_group, self.eps = list(radii), inf_factor, coord_group, eps
         self.rbf_gamma = rbf_gamma
         self.method = method
         self.fused_localization = fused_localization
         self.use_graph = use_graph
+        self.comm_chunks = int(comm_chunks)
+        self._chunk_compute = chunk_compute
+        self._comm_stream = None
         self._graph = None
         self.graph_replays = 0
         self.last_retries = 0
@@ -164,8 +168,101 @@ class ShardedLetkf:
     def assimilate(self, X, grid_xyz, obs_xyz, Yb, d) -> torch.Tensor:
         G = X.shape[-1]
         g0, g1 = block_partition(G, self.world)[self.rank]
+        if self.world > 1 and self.comm_chunks > 1:
+            return self._assimilate_overlapped(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1)
         shard = self._compute(X, grid_xyz, obs_xyz, Yb, d, g0, g1)
         return gather_blocks(shard, G, self.world, self.group)
+
+    # ------------------------------------------------------------------ compute / exchange overlap
+    def _chunk_engine(self, X, grid_xyz, obs_xyz, Yb, d, g0, g1, state):
+        """Analysis of sub-range [g0, g1) of this rank's block with the shard-wide preparation (packed
+        records, neighbour lists) done once and kept in ``state``.  Returns (Xa chunk, finish)."""
+        eng = self.engine
+        if "nb" not in state:
+            b0, b1 = state["block"]
+            state["rec"] = eng.pack_obs(Yb, d, X.dtype)
+            nb = eng.localize(grid_xyz, obs_xyz, self.radii, self.coord_group, self.eps, b0, b1,
+                              assume_p_max=self._p_max_hint)
+            state["nb"] = nb
+        nb, (b0, _) = state["nb"], state["block"]
+        from .engine import NeighbourLists
+        sub = NeighbourLists(nb.cnt[g0 - b0:g1 - b0], nb.idx[g0 - b0:g1 - b0], nb.w[g0 - b0:g1 - b0],
+                             nb.p_cap, nb.p_max, g0, g1)
+        xa, flags, finish = eng.analysis(X, None, None, sub, self.inf_factor, rbf_gamma=self.rbf_gamma,
+                                         rec=state["rec"], return_flags=True, method=self.method, defer_retry=True)
+        state.setdefault("flags", []).append(flags)
+        return xa, finish
+
+    def _assimilate_overlapped(self, X, grid_xyz, obs_xyz, Yb, d, G, g0, g1):
+        """The rank's block is analysed in ``comm_chunks`` pieces; the all-gather of piece c (RCCL, on a side
+        stream) runs while piece c+1 is being analysed, so at 8 GPUs the 16 MB-per-rank exchange hides behind
+        the compute instead of adding to it.  One permute-copy at the end restores (m, k, G)."""
+        import torch.distributed as dist
+        world, C = self.world, self.comm_chunks
+        n = (G + world - 1) // world                 # common block length
+        nc = (n + C - 1) // C                        # common chunk length
+        m, k = X.shape[0], X.shape[1]
+        cuda = X.is_cuda
+        chunk_fn = self._chunk_compute or self._chunk_engine
+        gath = torch.empty((C, world * m, k, nc), dtype=X.dtype, device=X.device)
+        state = {"block": (g0, g1)}
+        finishes, bufs = [], []
+        if cuda:
+            comp = torch.cuda.current_stream(X.device)
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=X.device)
+            comm = self._comm_stream
+            comm.wait_stream(comp)
+        for c in range(C):
+            c0, c1 = min(g1, g0 + c * nc), min(g1, g0 + (c + 1) * nc)
+            buf = torch.zeros((m, k, nc), dtype=X.dtype, device=X.device) if c1 - c0 < nc else None
+            xa = None
+            if c1 > c0:
+                xa, fin = chunk_fn(X, grid_xyz, obs_xyz, Yb, d, c0, c1, state)
+                finishes.append(fin)
+                if buf is None:
+                    buf = xa
+                else:
+                    buf[:, :, :c1 - c0] = xa
+            bufs.append((buf, xa))
+            if cuda:
+                ev = torch.cuda.Event()
+                ev.record(comp)
+                with torch.cuda.stream(comm):
+                    comm.wait_event(ev)
+                    dist.all_gather_into_tensor(gath[c], buf.contiguous(), group=self.group)
+            else:
+                dist.all_gather_into_tensor(gath[c], buf.contiguous(), group=self.group)
+        nb = state.get("nb")
+        redo = 0
+        if nb is not None and not nb.confirm():
+            redo = 1                                  # list bound broken somewhere in this block
+        n_retry = sum(f() for f in finishes)          # (host sync; declined points were redone in place)
+        self.last_retries = n_retry
+        if cuda:
+            comp.wait_stream(comm)
+        # rare paths must be agreed on by all ranks: redone chunks need a second exchange
+        if self._chunk_compute is None:
+            flag = torch.tensor([redo, 1 if n_retry else 0], dtype=torch.int32, device=X.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            any_redo, any_retry = (int(v) for v in flag.tolist())
+            if any_redo:
+                self._p_max_hint = None
+                shard = self._engine_shard(X, grid_xyz, obs_xyz, Yb, d, g0, g1)
+                return gather_blocks(shard, G, world, self.group)
+            if any_retry:                             # buffers were updated in place by the retry kernels
+                for c, (buf, xa) in enumerate(bufs):
+                    if xa is not None and xa is not buf:
+                        buf[:, :, :xa.shape[-1]] = xa
+                    dist.all_gather_into_tensor(gath[c], buf.contiguous(), group=self.group)
+            if nb is not None:
+                self._p_max_hint = nb.observed_p_max if nb.observed_p_max is not None else nb.p_max
+                self.last_p_max = nb.p_max
+                self._last_flags = torch.cat(state["flags"]) if state.get("flags") else None
+        out = gath.view(C, world, m, k, nc).permute(2, 3, 1, 0, 4).reshape(m, k, world * C * nc)
+        if C * nc != n:                               # chunk padding inside each rank's block
+            out = out.view(m, k, world, C * nc)[:, :, :, :n].reshape(m, k, world * n)
+        return out[:, :, :G].contiguous()
 
     def mean_degree(self):
         """Mean Chebyshev degree of the last matfun launch (flags bits 8-15), None for the eigensolver route."""
