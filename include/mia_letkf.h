@@ -40,6 +40,7 @@ extern "C" {
 #define MIA_ERR_UNSUPPORTED (-3) /* shape outside what the kernels are built for (e.g. LDS) */
 #define MIA_ERR_WORKSPACE (-4)   /* workspace too small */
 #define MIA_ERR_ALIGN (-5)       /* pointer not aligned as documented */
+#define MIA_ERR_COMM (-6)        /* RCCL / communicator failure: see mia_comm_last_error() */
 
 /* per-grid-point flag bits written to `flags_opt` */
 #define MIA_FLAG_OVERFLOW 1 /* more local observations than p_max: point NOT analysed */
@@ -217,6 +218,54 @@ int mia_apply_weights_f32(const float* X, int64_t ldx, int m, int k, int64_t g0,
                           const float* W, float* Xa, int64_t ldo, int64_t o0, void* stream);
 int mia_apply_weights_f64(const double* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
                           const double* W, double* Xa, int64_t ldo, int64_t o0, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * One assimilation step of one rank's block of grid points as ONE call (native driver; the per-step
+ * orchestration of the entries above costs more host time than the GPU work it enqueues).
+ *
+ * Distribution: the reference distributes the same per-grid-point work as dask chunks of grid points
+ * (interface/letkf.py:118-131, DaskLocalization) on one host; here rank r of `world` owns the block
+ * [r*n, min(G,(r+1)*n)), n = ceil(G/world), analyses it in n_chunks pieces and every piece is all-gathered
+ * (RCCL, on `comm_stream`) and placed into the full (m, k, G) result while the next piece is analysed on
+ * `stream`.  comm == NULL: single rank, Xa is written directly, no second stream needed.
+ *
+ * Communicator: mia_comm_load(path of the RCCL library the process already uses), rank 0 draws
+ * mia_comm_unique_id (128 bytes) which the host distributes by any means (e.g. torch.distributed broadcast),
+ * every rank calls mia_comm_create on its device.  mia_comm_create_custom substitutes caller callbacks for
+ * the two collectives (used by the tests to emulate a second rank on a one-GPU box).
+ *
+ * method: 0 auto (matfun for m <= 4), 1 eigensolver kernel, 2 matfun.   p_max_assumed: bound of the local
+ * observation count the launch is sized for (lists capacity = round_up(., 8)).
+ * counters [8] i32 (device): [0] longest list of the block, [1] lists longer than the capacity, [2] grid points
+ * the matfun kernel declined; [4..6] the same, max-reduced over all ranks.  The host reads [4..6] once after
+ * the call (the only synchronisation of the step):
+ *   [5] != 0 or [4] > p_max_assumed  -> the bound did not hold on some rank: repeat the step (phase 0) on ALL
+ *                                       ranks with p_max_assumed >= [4];
+ *   [6] != 0                          -> call again with phase = 1 on ALL ranks: the eigensolver kernel redoes
+ *                                       the declined points in place (no-op where none) and the pieces are
+ *                                       exchanged again.  The workspace must be untouched between the phases.
+ * flags [block length] i32: MIA_FLAG_* per grid point of the block.
+ * ---------------------------------------------------------------------------------- */
+typedef struct mia_comm mia_comm_t;
+typedef int (*mia_allgather_fn)(void* ctx, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+typedef int (*mia_allreduce_max_i32_fn)(void* ctx, int32_t* buf, int n, void* stream);
+int mia_comm_load(const char* rccl_library_path /* NULL: "librccl.so" */);
+int mia_comm_unique_id(void* id128);
+int mia_comm_create(const void* id128, int rank, int world, mia_comm_t** comm);
+int mia_comm_create_custom(int rank, int world, mia_allgather_fn allgather, mia_allreduce_max_i32_fn allreduce_max,
+                           void* ctx, mia_comm_t** comm);
+int mia_comm_destroy(mia_comm_t* comm);
+const char* mia_comm_last_error(void);
+int mia_letkf_sharded_step_workspace_bytes(int64_t G, int m, int k, int64_t P, int n_coord, int world,
+                                           int n_chunks, int p_max_assumed, size_t* bytes);
+int mia_letkf_sharded_step_f32(const float* X /* [m][k][G] */, int64_t G, int m, int k,
+                               const float* Yb /* [k][P] */, const float* d /* [P] */, int64_t P,
+                               const double* grid_xyz /* [G][n_coord] */, const double* obs_xyz /* [P][n_coord] */,
+                               int n_coord, const int32_t* coord_group /* host */, const double* gc_c /* host */,
+                               int n_r, double gc_eps, float inf_factor, float gamma, int method,
+                               int p_max_assumed, mia_comm_t* comm, int n_chunks, int phase,
+                               float* Xa /* [m][k][G] */, int32_t* flags, int32_t* counters,
+                               void* ws, size_t ws_bytes, void* stream, void* comm_stream);
 
 #ifdef __cplusplus
 }

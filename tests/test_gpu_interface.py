@@ -161,3 +161,122 @@ def test_overlapped_exchange_path_on_one_gpu(mia, G, chunks, strong):
     finally:
         if own:
             dist.destroy_process_group()
+
+
+def _emulated_peer_comm(mia, runner, rank, ref_full, G, chunks):
+    """mia_comm_create_custom communicator that plays a 2-rank world on one GPU: the all-gather callback puts
+    this rank's piece into its slot and the peer's piece -- cut from a reference analysis of the whole grid --
+    into the other slot, on the stream the driver passes."""
+    import ctypes as C
+    from torch_assimilate_amd import _cabi
+    world = 2
+    m, k = ref_full.shape[0], ref_full.shape[1]
+    n = (G + world - 1) // world
+    nc = ((n + chunks - 1) // chunks + 7) // 8 * 8
+    peer = 1 - rank
+    pieces = []
+    for c in range(chunks):
+        lo = min(G, peer * n + c * nc)
+        hi = min(G, peer * n + min(n, (c + 1) * nc))
+        t = torch.zeros((m, k, nc), dtype=torch.float32, device=ref_full.device)
+        t[:, :, :hi - lo] = ref_full[:, :, lo:hi]
+        pieces.append(t.contiguous())
+    calls = {"n": 0}
+
+    def allgather(ctx, send, recv, nbytes, stream):
+        ws = runner._native["ws"]
+        c = calls["n"] % chunks
+        calls["n"] += 1
+        data = m * k * nc * 4
+        assert nbytes == data + 16                         # piece + counter trailer
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+            off_r = recv - ws.data_ptr()
+            off_s = send - ws.data_ptr()
+            slots = ws[off_r:off_r + 2 * nbytes].view(2, nbytes)
+            slots[rank].copy_(ws[off_s:off_s + nbytes])
+            slots[peer, :data].view(torch.float32).view(m, k, nc).copy_(pieces[c])
+            slots[peer, data:].zero_()
+        return 0
+
+    def allreduce(ctx, buf, cnt, stream):
+        return 0
+
+    cb = (_cabi.ALLGATHER_FN(allgather), _cabi.ALLREDUCE_MAX_I32_FN(allreduce))
+    handle = C.c_void_p()
+    _cabi.check(_cabi.lib().mia_comm_create_custom(rank, world, C.cast(cb[0], C.c_void_p), C.cast(cb[1], C.c_void_p),
+                                                   None, C.byref(handle)), "mia_comm_create_custom")
+    return handle, cb, calls
+
+
+@pytest.mark.parametrize("G,chunks,strong", [(2000, 4, False), (1999, 3, False), (1203, 1, False), (1000, 4, True),
+                                             (40000, 8, False)])
+@pytest.mark.parametrize("rank", [0, 1])
+@pytest.mark.parametrize("signal", ["1", "0"])
+def test_native_step_driver_two_rank_layout_on_one_gpu(mia, G, chunks, strong, rank, signal, monkeypatch):
+    """mia_letkf_sharded_step_f32 as rank 0 and as rank 1 of a 2-rank world (peer emulated, see above): block /
+    chunk partition, per-chunk exchange on the side stream, placement into (m, k, G) incl. ragged tails and the
+    unaligned scalar path, and the phase-1 redo after declined points.  Must reproduce the single-rank result."""
+    monkeypatch.setenv("MIA_SEGMENT_SIGNAL", signal)   # "1": one segmented launch + device-side segment counters
+    dev = torch.device("cuda:0")
+    case = O.synthetic_case(G, 40, 2)
+    scale = 12.0 if strong else 1.0
+    args = (torch.as_tensor(case["state"], dtype=torch.float32, device=dev), torch.as_tensor(case["grid_x"], device=dev),
+            torch.as_tensor(case["obs_x"], device=dev),
+            torch.as_tensor(case["yb"] * scale, dtype=torch.float32, device=dev),
+            torch.as_tensor(case["d"] * scale, dtype=torch.float32, device=dev))
+    plain = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1, native_step=False)
+    ref = plain.assimilate(*args)
+    single = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1)
+    for _ in range(3):                                 # call 1: exact lists; calls 2, 3: the native driver
+        out1 = single.assimilate(*args)
+    assert single.native_steps == 2 and torch.equal(out1, ref) and single.last_flags_ok()
+    if strong:
+        assert single.last_retries == plain.last_retries > 0
+
+    runner = mia.ShardedLetkf(dev, rank, 2, radii=[10.0], inf_factor=1.1, comm_chunks=chunks)
+    runner._p_max_hint = plain._p_max_hint
+    handle, keep, calls = _emulated_peer_comm(mia, runner, rank, ref, G, chunks)
+    runner._native = dict(comm=handle, custom=True, ws=None, stream=torch.cuda.Stream(device=dev), key=None)
+    try:
+        for _ in range(2):
+            out = runner.assimilate(*args)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref)
+            assert runner.last_flags_ok()
+        assert runner.native_steps == 2
+        assert calls["n"] == 2 * chunks * (2 if strong else 1)
+    finally:
+        from torch_assimilate_amd import _cabi
+        _cabi.lib().mia_comm_destroy(handle)
+        runner._native = None
+
+
+def test_native_step_driver_through_real_rccl_single_rank(mia):
+    """The library-owned RCCL communicator (unique id over torch.distributed, ncclCommInitRank, per-chunk
+    ncclAllGather on the side stream, ncclAllReduce of the counters) on a one-rank world."""
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    own = not dist.is_initialized()
+    if own:
+        import os, socket
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        G = 3000
+        case = O.synthetic_case(G, 40, 2)
+        args = (torch.as_tensor(case["state"], dtype=torch.float32, device=dev), torch.as_tensor(case["grid_x"], device=dev),
+                torch.as_tensor(case["obs_x"], device=dev), torch.as_tensor(case["yb"], dtype=torch.float32, device=dev),
+                torch.as_tensor(case["d"], dtype=torch.float32, device=dev))
+        ref = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1, native_step=False).assimilate(*args)
+        r = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1, comm_chunks=4)
+        r._force_comm = True
+        for _ in range(4):
+            out = r.assimilate(*args)
+        torch.cuda.synchronize()
+        assert r.native_steps == 3 and r._native["comm"] is not None
+        assert torch.equal(out, ref) and r.last_flags_ok()
+        r.close()
+    finally:
+        if own:
+            dist.destroy_process_group()

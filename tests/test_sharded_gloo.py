@@ -28,12 +28,36 @@ def _oracle_shard(X, grid_x, obs_x, Yb, d, g0, g1):
     return torch.from_numpy(ana)
 
 
-def _oracle_chunk(X, grid_x, obs_x, Yb, d, c0, c1, state):
-    state.setdefault("calls", []).append((c0, c1))
-    return _oracle_shard(X, grid_x, obs_x, Yb, d, c0, c1), (lambda: 0)
+def _oracle_chunk(X, grid_x, obs_x, Yb, d, c0, c1, state, buf):
+    buf[:, :, :c1 - c0] = _oracle_shard(X, grid_x, obs_x, Yb, d, c0, c1)
+    return lambda: 0
 
 
-def _worker(rank, world, port, G, out_path, chunks=1):
+class _DecliningChunk:
+    """Stand-in for a kernel that declines grid points: rank 1's first piece is written wrong and the
+    declined-points counter raised; the deferred retry repairs the piece.  Every rank must then take the
+    second exchange (agreement through the reduced counters), or the ranks dead-lock / keep the wrong data."""
+
+    def __init__(self, rank):
+        self.rank, self.fired, self.repaired = rank, False, 0
+
+    def __call__(self, X, grid_x, obs_x, Yb, d, c0, c1, state, buf):
+        good = _oracle_shard(X, grid_x, obs_x, Yb, d, c0, c1)
+        if self.rank == 1 and not self.fired:
+            self.fired = True
+            buf[:, :, :c1 - c0] = 0.0
+            state["vec"][2] += 3
+
+            def finish():
+                buf[:, :, :c1 - c0] = good
+                self.repaired += 1
+                return 3
+            return finish
+        buf[:, :, :c1 - c0] = good
+        return lambda: 0
+
+
+def _worker(rank, world, port, G, out_path, chunks=1, declining=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -42,10 +66,13 @@ def _worker(rank, world, port, G, out_path, chunks=1):
     case = O.synthetic_case(G, 12, 2)
     X = torch.from_numpy(case["state"])
     runner = mia.ShardedLetkf("cpu", rank, world, radii=[10.0], inf_factor=1.1, compute_shard=_oracle_shard,
-                              comm_chunks=chunks, chunk_compute=_oracle_chunk if chunks > 1 else None)
+                              comm_chunks=chunks,
+                              chunk_compute=(_DecliningChunk(rank) if declining else _oracle_chunk) if chunks > 1 else None)
     full = runner.assimilate(X, torch.from_numpy(case["grid_x"]), torch.from_numpy(case["obs_x"]),
                              torch.from_numpy(case["yb"]), torch.from_numpy(case["d"]))
     assert full.shape == X.shape
+    if declining:
+        assert runner.last_retries == (3 if rank == 1 else 0)
     gathered = [torch.empty_like(full) for _ in range(world)]
     dist.all_gather(gathered, full)
     for t in gathered:                      # every rank holds the same full analysis
@@ -56,12 +83,14 @@ def _worker(rank, world, port, G, out_path, chunks=1):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("G,chunks", [(64, 1), (51, 1), (64, 4), (51, 4), (37, 3)])
-def test_two_rank_shard_and_allgather(tmp_path, G, chunks):
+@pytest.mark.parametrize("G,chunks,declining", [(64, 1, False), (51, 1, False), (64, 4, False), (51, 4, False),
+                                                 (37, 3, False), (51, 4, True)])
+def test_two_rank_shard_and_allgather(tmp_path, G, chunks, declining):
     """chunks == 1: one all-gather of the whole block; chunks > 1: the compute / exchange-overlap path
-    (block analysed in pieces, one all-gather per piece, uneven tails padded) -- same result."""
+    (block analysed in pieces, one all-gather per piece, uneven tails padded) -- same result.  declining:
+    one rank's piece needs the deferred retry; both ranks must agree on the second exchange."""
     out = str(tmp_path / "full.npy")
-    mp.spawn(_worker, args=(2, _free_port(), G, out, chunks), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), G, out, chunks, declining), nprocs=2, join=True)
     got = np.load(out)
     case = O.synthetic_case(G, 12, 2)
     ref, _ = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], case["yb"], case["d"], 10.0, 1.1)

@@ -14,8 +14,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmia_letkf.so")
 STAMP = os.path.join(LIB_DIR, "libmia_letkf.stamp")
-SOURCES = ["localize.hip", "letkf_generic.hip", "etkf_global.hip", "letkf_wave.hip", "letkf_sys.hip", "letkf_cheb.hip", "api.cc"]
-HEADERS = ["mia_common.h", "mia_jacobi.h", os.path.join(ROOT, "include", "mia_letkf.h")]
+SOURCES = ["localize.hip", "letkf_generic.hip", "etkf_global.hip", "letkf_wave.hip", "letkf_sys.hip", "letkf_cheb.hip", "sharded_step.hip", "api.cc"]
+HEADERS = ["mia_common.h", "mia_jacobi.h", "mia_localize_dev.h", "mia_kernels.h", os.path.join(ROOT, "include", "mia_letkf.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
@@ -37,20 +37,57 @@ def hipcc_path():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+def _object_digest(src):
+    h = hashlib.sha256()
+    for f in [src] + [f if os.path.isabs(f) else os.path.join(CSRC, f) for f in HEADERS]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:24]
+
+
+def _compile(job):
+    src, obj, verbose = job
+    cmd = [hipcc_path()] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", obj + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed on %s:\n%s%s" % (os.path.basename(src), res.stdout, res.stderr))
+    os.replace(obj + ".tmp", obj)
+    return obj
+
+
 def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 into lib/libmia_letkf.so (skipped if up to date)."""
+    """Compile every HIP source for gfx950 into lib/libmia_letkf.so (skipped if up to date).  One object per
+    source, cached under lib/obj by content digest and compiled in parallel, then one link."""
     os.makedirs(LIB_DIR, exist_ok=True)
     dig = _digest()
     if not force and os.path.exists(LIB_PATH) and os.path.exists(STAMP):
         with open(STAMP) as fh:
             if fh.read().strip() == dig:
                 return LIB_PATH
-    cmd = [hipcc_path()] + FLAGS + _sources() + ["-o", LIB_PATH + ".tmp"]
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    jobs, objs = [], []
+    for src in _sources():
+        obj = os.path.join(obj_dir, "%s.%s.o" % (os.path.basename(src), _object_digest(src)))
+        objs.append(obj)
+        if force or not os.path.exists(obj):
+            jobs.append((src, obj, verbose))
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:
+            list(pool.map(_compile, jobs))
+    for f in os.listdir(obj_dir):                      # drop objects of older source versions
+        if os.path.join(obj_dir, f) not in objs:
+            os.remove(os.path.join(obj_dir, f))
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-ldl", "-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     with open(STAMP, "w") as fh:
         fh.write(dig)

@@ -47,8 +47,20 @@ _PROTOS = {
     "mia_etkf_weights_f64": ([vp, vp, i32, i64, f64, vp, vp, vp, sz, vp], i32),
     "mia_apply_weights_f32": ([vp, i64, i32, i32, i64, i64, vp, vp, i64, i64, vp], i32),
     "mia_apply_weights_f64": ([vp, i64, i32, i32, i64, i64, vp, vp, i64, i64, vp], i32),
+    "mia_comm_load": ([C.c_char_p], i32),
+    "mia_comm_unique_id": ([vp], i32),
+    "mia_comm_create": ([vp, i32, i32, C.POINTER(vp)], i32),
+    "mia_comm_create_custom": ([i32, i32, vp, vp, vp, C.POINTER(vp)], i32),
+    "mia_comm_destroy": ([vp], i32),
+    "mia_comm_last_error": ([], C.c_char_p),
+    "mia_letkf_sharded_step_workspace_bytes": ([i64, i32, i32, i64, i32, i32, i32, i32, C.POINTER(sz)], i32),
+    "mia_letkf_sharded_step_f32": ([vp, i64, i32, i32, vp, vp, i64, vp, vp, i32, C.POINTER(C.c_int32), C.POINTER(f64),
+                                    i32, f64, f32, f32, i32, i32, vp, i32, i32, vp, vp, vp, vp, sz, vp, vp], i32),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
+# callbacks of mia_comm_create_custom
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, vp, vp, vp, sz, vp)
+ALLREDUCE_MAX_I32_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_int, vp)
 
 
 class MiaError(RuntimeError):
@@ -78,4 +90,6 @@ def lib():
 def check(status, what):
     if status != 0:
         msg = lib().mia_status_string(status).decode()
+        if status == -6:
+            msg += ": " + lib().mia_comm_last_error().decode()
         raise MiaError("%s failed with status %d: %s" % (what, status, msg))

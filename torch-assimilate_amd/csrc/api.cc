@@ -11,6 +11,7 @@ extern "C" const char* mia_status_string(int status) {
     case MIA_ERR_UNSUPPORTED: return "shape not supported by the gfx950 kernels (LDS capacity / index range)";
     case MIA_ERR_WORKSPACE: return "workspace too small (use the *_workspace_bytes query)";
     case MIA_ERR_ALIGN: return "workspace pointer must be 256-byte aligned";
+    case MIA_ERR_COMM: return "RCCL / communicator failure (mia_comm_last_error has the detail)";
     default: return status > 0 ? "HIP runtime error (value is the hipError_t)" : "unknown status";
   }
 }

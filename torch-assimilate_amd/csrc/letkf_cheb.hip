@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include "mia_common.h"
 #include "mia_localize_dev.h"
+#include "mia_kernels.h"
 
 namespace mia {
 
@@ -44,6 +45,9 @@ struct ChebParams {
   int fused; ScanParams scan; int32_t* stats;
   int xskip;   // timing experiments only (MIA_EXPERIMENT_SKIP), 0 in production
   int lds_per_wave;
+  // segmented launch (native step driver): the ng points are seg_len-sized segments; segment s writes
+  // its own (m*k, seg_len) buffer at Xa + s * seg_stride and counts its finished points in done[s*64 + ..]
+  int seg_len; int64_t seg_stride; int32_t* done;
 };
 
 using f32x4c = __attribute__((ext_vector_type(4))) float;
@@ -70,8 +74,8 @@ __device__ inline float matvec_row(const f2v (&srow2)[NMAX / 2], const float* tv
 // and the compiler may not move memory operations across (the waves of a workgroup are independent here)
 #define MIA_WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-template <int NMAX, int KL, bool FUSED, int WPB>
-__global__ __launch_bounds__(64 * WPB, (NMAX <= 24 ? 5 : (NMAX <= 40 ? 4 : 2))) void letkf_cheb_kernel(ChebParams P) {
+template <int NMAX, int KL, bool FUSED, int WPB, bool SEG>
+__device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
   constexpr int LDA = (NMAX % 8 == 0) ? NMAX + 4 : NMAX;
   constexpr int N4 = NMAX / 4;
   constexpr int TT = (NMAX + 15) / 16, NTILE = TT * (TT + 1) / 2;
@@ -99,12 +103,22 @@ __global__ __launch_bounds__(64 * WPB, (NMAX <= 24 ? 5 : (NMAX <= 40 ? 4 : 2))) 
 
   // XCD-aware block -> point map (letkf_sys.hip): block b's XCD group x = b % 8 owns a contiguous range of
   // point groups; the WPB waves of a block take consecutive points
-  const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-  const int64_t nblk = (P.ng + WPB - 1) / WPB;
+  int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+  int64_t nblk = (P.ng + WPB - 1) / WPB;
   if (bid >= nblk) return;
+  int64_t seg0 = 0;
+  float* Xab = P.Xa;
+  if constexpr (SEG) {     // the same map inside every segment (seg_len % 8 == 0 keeps bid & 7 the XCD)
+    const unsigned sg = (unsigned)bid / (unsigned)P.seg_len;
+    seg0 = (int64_t)sg * P.seg_len;
+    Xab += (int64_t)sg * P.seg_stride;
+    bid -= seg0;
+    nblk = nblk - seg0 < P.seg_len ? nblk - seg0 : P.seg_len;
+  }
   const int64_t q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
   const int64_t grp = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int64_t pt = grp * WPB + wave;
+  const int64_t pt = seg0 + grp * WPB + wave;
+  const int64_t ocol = SEG ? grp : P.o0 + pt;          // output column of this point
   if (pt >= P.ng) return;
   const int64_t g = P.g0 + pt;
   if (P.xskip & 16) return;            // experiment: dispatch floor
@@ -136,7 +150,10 @@ __global__ __launch_bounds__(64 * WPB, (NMAX <= 24 ? 5 : (NMAX <= 40 ? 4 : 2))) 
   if (cnt > pm || (!FUSED && cnt > P.p_cap) || (P.dual ? cnt : k) > NMAX) {   // loud failure, never truncate
     if (P.flags && tid == 0) P.flags[pt] = MIA_FLAG_OVERFLOW;
     const float nanv = __builtin_nanf("");
-    for (int it = tid; it < P.m * k; it += 64) P.Xa[(int64_t)it * P.ldo + P.o0 + pt] = nanv;
+    for (int it = tid; it < P.m * k; it += 64) {
+      if constexpr (SEG) __hip_atomic_store(&Xab[(int64_t)it * P.ldo + ocol], nanv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else Xab[(int64_t)it * P.ldo + ocol] = nanv;
+    }
     return;
   }
   if (P.xskip & 32) return;            // experiment: after the list / state loads
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(64 * WPB, (NMAX <= 24 ? 5 : (NMAX <= 40 ? 4 : 2))) 
     if (tid < NMAX) sw[tid] = live ? aphi : 0.0f;
     MIA_WAVE_SYNC();
     const float mterm = xm + zu;
-    float* orow = P.Xa + (int64_t)mi * k * P.ldo + P.o0 + pt;
+    float* orow = Xab + (int64_t)mi * k * P.ldo + ocol;
 #pragma unroll
     for (int u = 0; u < KL; ++u) {
       const int j = tid + 64 * u;
@@ -365,7 +382,12 @@ __global__ __launch_bounds__(64 * WPB, (NMAX <= 24 ? 5 : (NMAX <= 40 ? 4 : 2))) 
         } else acc = sw[j];
         const float out = mterm + acc;
         if (!(fabsf(out) <= 1e30f)) flag |= MIA_FLAG_NONFINITE;
-        orow[(int64_t)j * P.ldo] = out;
+        // segmented launch: write-through (agent-scope) stores, so that the segment counter below can
+        // publish them without a cache-wide release (a __threadfence per point costs 18x the kernel)
+        if constexpr (SEG) {
+          if (P.xskip & 128) orow[(int64_t)j * P.ldo] = out;    // experiment
+          else __hip_atomic_store(&orow[(int64_t)j * P.ldo], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else orow[(int64_t)j * P.ldo] = out;
       }
     }
     MIA_WAVE_SYNC();
@@ -374,6 +396,37 @@ __global__ __launch_bounds__(64 * WPB, (NMAX <= 24 ? 5 : (NMAX <= 40 ? 4 : 2))) 
     const int any = __any(flag != 0) ? MIA_FLAG_NONFINITE : 0;
     if (tid == 0) P.flags[pt] = any | (deg << 8);     // bits 8-15: polynomial degree used (diagnostics)
   }
+}
+
+template <int NMAX, int KL, bool FUSED, int WPB>
+__global__ __launch_bounds__(64 * WPB, (NMAX <= 24 ? 5 : (NMAX <= 40 ? 4 : 2))) void letkf_cheb_kernel(ChebParams P) {
+  letkf_cheb_point<NMAX, KL, FUSED, WPB, false>(P);
+}
+
+// Segmented launch: one grid over the whole block; every workgroup (= one grid point), whatever path it left
+// the analysis on, has its output written through to memory and then counts itself in its segment's slot counters.
+// A waiter on another stream (segment_wait_kernel) sees a segment complete while later segments still run.
+template <int NMAX, int KL>
+__global__ __launch_bounds__(64, (NMAX <= 24 ? 5 : (NMAX <= 40 ? 4 : 2))) void letkf_cheb_seg_kernel(ChebParams P) {
+  letkf_cheb_point<NMAX, KL, false, 1, true>(P);
+  const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+  if (bid >= P.ng) return;
+  // all output stores of this wavefront (write-through, see above) have been acknowledged before it counts
+  if (!(P.xskip & 64)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned sg = (unsigned)bid / (unsigned)P.seg_len;
+    __hip_atomic_fetch_add(P.done + ((size_t)sg * 64 + (unsigned)(bid & 63)) * kSlotStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ void __launch_bounds__(64) segment_wait_kernel(const int32_t* done, int expected, int32_t* err, int max_polls) {
+  const int lane = threadIdx.x;
+  for (int poll = 0; poll < max_polls; ++poll) {
+    const int v = __hip_atomic_load(done + (size_t)lane * kSlotStride, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave_sum(v) >= expected) return;
+    __builtin_amdgcn_s_sleep(64);
+  }
+  if (lane == 0) atomicOr(err, 1);      // exit condition every wave reaches: ~seconds, then report
 }
 
 static size_t cheb_lds_bytes(int kp, int p_max, int nmax, int rows) {
@@ -403,14 +456,35 @@ static int cheb_launch(const ChebParams& ap, size_t lds, dim3, hipStream_t strea
   return cheb_launch_w<NMAX, KL, FUSED, 1>(ap, lds, stream);
 }
 
-// MIA_ERR_UNSUPPORTED when the shape is outside this route (caller uses the eigensolver kernels)
+template <int NMAX, int KL>
+static int cheb_launch_seg(const ChebParams& ap, size_t lds, hipStream_t stream) {
+  auto kern = letkf_cheb_seg_kernel<NMAX, KL>;
+  if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int64_t gx = ap.ng < 65536 ? ap.ng : 65536;
+  const int64_t gy = (ap.ng + gx - 1) / gx;
+  if (gy > 65535) return MIA_ERR_UNSUPPORTED;
+  kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64), lds, stream>>>(ap);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+int segment_wait_launch(const int32_t* done64, int expected, int32_t* err, hipStream_t stream) {
+  segment_wait_kernel<<<1, 64, 0, stream>>>(done64, expected, err, 1 << 21);   // ~1 us per poll
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// MIA_ERR_UNSUPPORTED when the shape is outside this route (caller uses the eigensolver kernels).
+// seg_len > 0: segmented launch (see letkf_cheb_seg_kernel); Xa = first segment buffer, ldo = seg_len.
 int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
                          const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
                          float inf_factor, int kernel_mode, float gamma, float* Xa, int64_t ldo, int64_t o0,
                          int32_t* flags, int32_t* retry_count, const ScanParams* scan, int32_t* stats,
-                         hipStream_t stream) {
+                         hipStream_t stream, int seg_len, int64_t seg_stride, int32_t* done) {
   if (!flags || !retry_count) return MIA_ERR_UNSUPPORTED;   // the retry protocol needs both
+  if (seg_len > 0 && (scan || !done || seg_len % 8 || ng >= (int64_t)1 << 31)) return MIA_ERR_UNSUPPORTED;
   ChebParams ap;
+  ap.seg_len = seg_len; ap.seg_stride = seg_stride; ap.done = done;
   ap.fused = scan != nullptr;
   if (scan) { ap.scan = *scan; ap.stats = stats; if (!stats) return MIA_ERR_NULL; } else ap.stats = nullptr;
   ap.X = X; ap.ldx = ldx; ap.m = m; ap.k = k; ap.g0 = g0; ap.ng = ng; ap.rec = rec;
@@ -440,6 +514,15 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
   if (gy > 65535) return MIA_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)gx, (unsigned)gy);
   const bool two = k > 64;
+  if (seg_len > 0) {
+#define MIA_CHEB_SEG(N) case N: return two ? cheb_launch_seg<N, 2>(ap, lds, stream) : cheb_launch_seg<N, 1>(ap, lds, stream);
+    switch (nmax) {
+      MIA_CHEB_SEG(4) MIA_CHEB_SEG(8) MIA_CHEB_SEG(12) MIA_CHEB_SEG(16) MIA_CHEB_SEG(20)
+      MIA_CHEB_SEG(24) MIA_CHEB_SEG(32) MIA_CHEB_SEG(40) MIA_CHEB_SEG(48) MIA_CHEB_SEG(64)
+    }
+#undef MIA_CHEB_SEG
+    return MIA_ERR_UNSUPPORTED;
+  }
 #define MIA_CHEB_CASE(N) case N: return ap.fused ? (two ? cheb_launch<N, 2, true>(ap, lds, grid, stream) : cheb_launch<N, 1, true>(ap, lds, grid, stream)) \
                                         : (two ? cheb_launch<N, 2, false>(ap, lds, grid, stream) : cheb_launch<N, 1, false>(ap, lds, grid, stream));
   switch (nmax) {

@@ -23,6 +23,7 @@
 #include "mia_common.h"
 #include "mia_jacobi.h"
 #include "mia_localize_dev.h"
+#include "mia_kernels.h"
 
 #include <cstdlib>
 
@@ -33,12 +34,6 @@ int wave_analysis_launch(const T* X, int64_t ldx, int m, int k, int64_t g0, int6
                          const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap,
                          int p_max, T inf_factor, int kernel_mode, T gamma, T* Xa, int64_t ldo, int64_t o0,
                          T* W_opt, int32_t* flags_opt, int only_flagged, hipStream_t stream);
-
-int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
-                         const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
-                         float inf_factor, int kernel_mode, float gamma, float* Xa, int64_t ldo, int64_t o0,
-                         int32_t* flags, int32_t* retry_count, const ScanParams* scan, int32_t* stats,
-                         hipStream_t stream);
 
 int sys_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
                         const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,

@@ -1,0 +1,26 @@
+// Internal launchers shared between translation units (not part of the C ABI).
+#pragma once
+#include "mia_common.h"
+#include "mia_localize_dev.h"
+
+namespace mia {
+
+// a segment's 64 slot counters sit kSlotStride ints apart (one per 256 bytes): atomics that share a cache line
+// are serialised by the L2 channel that owns it (25 000 on one line cost more than the whole analysis)
+constexpr int kSlotStride = 64;
+
+// letkf_cheb.hip.  MIA_ERR_UNSUPPORTED when the shape is outside the matfun route.
+// seg_len > 0: one segmented launch over the ng points (native step driver): segment s = points
+// [s*seg_len, (s+1)*seg_len) writes the (m*k, seg_len) buffer at Xa + s*seg_stride (ldo = seg_len) and counts
+// its finished points in the 64 slot counters done[(s*64 + j) * kSlotStride] (zeroed by the caller); needs seg_len % 8 == 0.
+int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
+                         const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
+                         float inf_factor, int kernel_mode, float gamma, float* Xa, int64_t ldo, int64_t o0,
+                         int32_t* flags, int32_t* retry_count, const ScanParams* scan, int32_t* stats,
+                         hipStream_t stream, int seg_len = 0, int64_t seg_stride = 0, int32_t* done = nullptr);
+
+// one-wave kernel on `stream` that returns once the 64 slot counters at done64[j * kSlotStride] sum to `expected` (bounded
+// polling: after ~seconds it sets bit 0 of *err and returns, so the grid always drains)
+int segment_wait_launch(const int32_t* done64, int expected, int32_t* err, hipStream_t stream);
+
+}  // namespace mia

@@ -94,7 +94,8 @@ class LetkfEngine:
 
     def localize(self, grid_xyz, obs_xyz, radii: Sequence[float], coord_group: Optional[Sequence[int]] = None,
                  eps: float = 1e-5, g0: int = 0, g1: Optional[int] = None,
-                 p_cap: Optional[int] = None, assume_p_max: Optional[int] = None) -> NeighbourLists:
+                 p_cap: Optional[int] = None, assume_p_max: Optional[int] = None,
+                 stats_out: Optional[torch.Tensor] = None) -> NeighbourLists:
         """Neighbour lists of grid points [g0, g1).  By default the maximum list length is read back
         (one 8-byte host sync) to size the analysis launch.  With ``assume_p_max`` (e.g. the value of the
         previous cycle on the same geometry) nothing is read back here: the returned lists carry the
@@ -122,7 +123,7 @@ class LetkfEngine:
         nbytes = C.c_size_t(0)
         _cabi.check(self.lib.mia_letkf_localize_workspace_bytes(P, nc, C.byref(nbytes)), "localize_workspace_bytes")
         ws = self._workspace("loc", nbytes.value)
-        stats = torch.empty(2, dtype=torch.int32, device=self.device)
+        stats = stats_out if stats_out is not None else torch.empty(2, dtype=torch.int32, device=self.device)
         cap = int(p_cap) if p_cap is not None else self._p_cap_hint
         if assume_p_max is not None:
             cap = max(8, (int(assume_p_max) + 7) // 8 * 8)
@@ -279,7 +280,8 @@ class LetkfEngine:
                  nbrs: NeighbourLists, inf_factor: float = 1.0, return_weights: bool = False,
                  rbf_gamma: Optional[float] = None, out: Optional[torch.Tensor] = None, out_offset: int = 0,
                  return_flags: bool = False, rec: Optional[torch.Tensor] = None, method: str = "auto",
-                 defer_retry: bool = False):
+                 defer_retry: bool = False, retry: Optional[torch.Tensor] = None,
+                 flags: Optional[torch.Tensor] = None):
         """X (m, k, G) prior ensemble (grid fastest), Yb (k, P), d (P,) [or their packed records
         ``rec`` from :meth:`pack_obs`]: analysis of the shard described by ``nbrs``.
         Returns Xa (m, k, n) [, W (n, k, k)] [, flags (n,)].
@@ -288,7 +290,9 @@ class LetkfEngine:
         return the weights); "matfun" = eigensolver-free Chebyshev matrix-function route (float32, few
         state rows, no weights), with the eigensolver redoing the grid points it declines; "auto" picks
         matfun when it applies.  With ``defer_retry`` the (8-byte, synchronising) read of the decline
-        counter is left to the caller: the return value gains a trailing callable that must be invoked."""
+        counter is left to the caller: the return value gains a trailing callable that must be invoked.
+        ``retry`` (1 int32, zeroed by the caller) / ``flags`` (n int32): caller-owned counter and flag
+        buffers, e.g. one counter shared by the launches of several sub-ranges."""
         if X.dim() == 2:
             X = X[None]
         X = X.to(self.device).contiguous()
@@ -312,7 +316,10 @@ class LetkfEngine:
             out_offset = 0
         ldo = out.shape[-1]
         W = torch.empty((n, k, k), dtype=dtype, device=self.device) if return_weights else None
-        flags = torch.empty(n, dtype=torch.int32, device=self.device)
+        if flags is None:
+            flags = torch.empty(n, dtype=torch.int32, device=self.device)
+        elif flags.numel() != n or flags.dtype != torch.int32 or not flags.is_contiguous():
+            raise ValueError("flags must be a contiguous int32 tensor with one entry per grid point")
         sfx = "f32" if dtype == torch.float32 else "f64"
         gamma = float(rbf_gamma) if rbf_gamma is not None else 0.0
         args = (_ptr(X), G, m, k, nbrs.g0, nbrs.g1, _ptr(rec), P, _ptr(nbrs.cnt), _ptr(nbrs.idx),
@@ -323,7 +330,8 @@ class LetkfEngine:
         use_matfun = can_matfun and (method == "matfun" or (method == "auto" and m <= self.MATFUN_MAX_ROWS))
         finish = None
         if use_matfun:
-            retry = torch.zeros(1, dtype=torch.int32, device=self.device)
+            if retry is None:
+                retry = torch.zeros(1, dtype=torch.int32, device=self.device)
             rc = self.lib.mia_letkf_analysis_matfun_f32(*args, _ptr(flags), _ptr(retry), self._stream())
             if rc == -3:              # shape outside the matfun kernels: eigensolver route
                 use_matfun = False

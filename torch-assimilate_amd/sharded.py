@@ -59,7 +59,7 @@ class ShardedLetkf:
                  inf_factor: float = 1.0, coord_group: Optional[Sequence[int]] = None, eps: float = 1e-5,
                  rbf_gamma: Optional[float] = None, compute_shard: Optional[Callable] = None, group=None,
                  method: str = "auto", fused_localization: bool = False, use_graph: bool = False,
-                 comm_chunks: int = 4, chunk_compute: Optional[Callable] = None):
+                 comm_chunks: int = 4, chunk_compute: Optional[Callable] = None, native_step: bool = True):
         self.device, self.rank, self.world = device, rank, world
         self.radii, self.inf_factor, self.coord_group, self.eps = list(radii), inf_factor, coord_group, eps
         self.rbf_gamma = rbf_gamma
@@ -69,6 +69,11 @@ class ShardedLetkf:
         self.comm_chunks = int(comm_chunks)
         self._chunk_compute = chunk_compute
         self._comm_stream = None
+        self._obuf = None
+        self.native_step = native_step
+        self._native = None
+        self._force_comm = False      # tests / tools: a one-rank RCCL communicator drives the exchange route
+        self.native_steps = 0
         self._graph = None
         self.graph_replays = 0
         self.last_retries = 0
@@ -168,35 +173,188 @@ class ShardedLetkf:
     def assimilate(self, X, grid_xyz, obs_xyz, Yb, d) -> torch.Tensor:
         G = X.shape[-1]
         g0, g1 = block_partition(G, self.world)[self.rank]
+        if (self.native_step and self._compute == self._engine_shard and self._chunk_compute is None
+                and torch.is_tensor(X) and X.is_cuda and X.dtype == torch.float32 and X.dim() == 3
+                and not self.fused_localization and not self.use_graph):
+            return self._assimilate_native(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1)
         if self.world > 1 and self.comm_chunks > 1:
             return self._assimilate_overlapped(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1)
         shard = self._compute(X, grid_xyz, obs_xyz, Yb, d, g0, g1)
         return gather_blocks(shard, G, self.world, self.group)
 
-    # ------------------------------------------------------------------ compute / exchange overlap
-    def _chunk_engine(self, X, grid_xyz, obs_xyz, Yb, d, g0, g1, state):
-        """Analysis of sub-range [g0, g1) of this rank's block with the shard-wide preparation (packed
-        records, neighbour lists) done once and kept in ``state``.  Returns (Xa chunk, finish)."""
+    # ------------------------------------------------------------------ native step driver
+    def _native_comm(self):
+        """RCCL communicator owned by the C library (created once): rank 0 of the group draws the unique id,
+        torch.distributed carries its 128 bytes to the others, every rank joins on its own device."""
+        import ctypes as C
+        import os
+        import torch.distributed as dist
+        from . import _cabi
+        lib = self.engine.lib
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        _cabi.check(lib.mia_comm_load(path.encode() if os.path.exists(path) else None), "mia_comm_load")
+        buf = C.create_string_buffer(128)
+        if self.rank == 0:
+            _cabi.check(lib.mia_comm_unique_id(buf), "mia_comm_unique_id")
+        box = [buf.raw]
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        dist.broadcast_object_list(box, src=src, group=self.group)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _cabi.check(lib.mia_comm_create(C.create_string_buffer(box[0], 128), self.rank, self.world,
+                                            C.byref(handle)), "mia_comm_create")
+        return handle
+
+    def _native_state(self):
+        if self._native is None:
+            st = dict(comm=None, ws=None, stream=None, key=None)
+            if self.world > 1 or self._force_comm:
+                st["comm"] = self._native_comm()
+                st["stream"] = torch.cuda.Stream(device=self.device)
+            self._native = st
+        return self._native
+
+    def close(self):
+        """Release the library-owned communicator (idempotent)."""
+        if self._native is not None and self._native.get("comm") is not None and not self._native.get("custom"):
+            self.engine.lib.mia_comm_destroy(self._native["comm"])
+        self._native = None
+
+    def _assimilate_native(self, X, grid_xyz, obs_xyz, Yb, d, G, g0, g1):
+        """Steady state: ONE library call enqueues the whole step (mia_letkf_sharded_step_f32: records,
+        cell index, neighbour lists, analysis chunks, per-chunk RCCL all-gather + placement on a second
+        stream, 16-byte max-reduce of the redo counters), then one 32-byte read-back decides -- identically
+        on every rank -- whether anything has to be redone.  The first call on a geometry (no bound for the
+        local observation count yet) takes the exact-list route through torch.distributed."""
+        import ctypes as C
+        import torch.distributed as dist
+        from . import _cabi
+        from .engine import _ptr
         eng = self.engine
+        if self._p_max_hint is None:
+            shard = self._engine_shard(X, grid_xyz, obs_xyz, Yb, d, g0, g1)
+            if self.world > 1:
+                t = torch.tensor([self._p_max_hint], dtype=torch.int32, device=X.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                self._p_max_hint = int(t.item())                  # one bound for all ranks
+            return gather_blocks(shard, G, self.world, self.group)
+        st = self._native_state()
+        lib = eng.lib
+        X = X.contiguous()
+        m, k = X.shape[0], X.shape[1]
+        grid = eng._dev(grid_xyz, torch.float64)
+        obs = eng._dev(obs_xyz, torch.float64)
+        if grid.dim() == 1:
+            grid = grid[:, None]
+        if obs.dim() == 1:
+            obs = obs[:, None]
+        nc = grid.shape[1]
+        P = obs.shape[0]
+        Yb = Yb.to(device=X.device, dtype=torch.float32).contiguous()
+        d = d.to(device=X.device, dtype=torch.float32).contiguous().reshape(-1)
+        if Yb.shape != (k, P) or d.shape[0] != P or grid.shape[0] != G:
+            raise ValueError("inconsistent shapes: X (m,k,G), Yb (k,P), d (P,), grid (G,nc), obs (P,nc)")
+        hint = int(self._p_max_hint)
+        C_chunks = self.comm_chunks if st["comm"] is not None else 1
+        key = (G, m, k, P, nc, hint, C_chunks)
+        if st["key"] != key:
+            nbytes = C.c_size_t(0)
+            _cabi.check(lib.mia_letkf_sharded_step_workspace_bytes(G, m, k, P, nc, self.world, C_chunks, hint,
+                                                                   C.byref(nbytes)), "sharded_step_workspace_bytes")
+            if st["ws"] is None or st["ws"].numel() < nbytes.value:
+                st["ws"] = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=X.device)
+            cg = [0] * nc if self.coord_group is None else [int(c) for c in self.coord_group]
+            st["cg"] = (C.c_int32 * nc)(*cg)
+            st["rc"] = (C.c_double * len(self.radii))(*[float(r) for r in self.radii])
+            st["counters"] = torch.zeros(8, dtype=torch.int32, device=X.device)
+            st["key"] = key
+        out = torch.empty((m, k, G), dtype=torch.float32, device=X.device)
+        flags = torch.empty(max(g1 - g0, 1), dtype=torch.int32, device=X.device)
+        method = {"auto": 0, "eig": 1, "matfun": 2}[self.method]
+        gamma = float(self.rbf_gamma) if self.rbf_gamma is not None else 0.0
+        comp = torch.cuda.current_stream(X.device)
+        side = st["stream"].cuda_stream if st["stream"] is not None else None
+
+        def call(phase):
+            _cabi.check(lib.mia_letkf_sharded_step_f32(
+                _ptr(X), G, m, k, _ptr(Yb), _ptr(d), P, _ptr(grid), _ptr(obs), nc, st["cg"], st["rc"], len(self.radii),
+                float(self.eps), float(self.inf_factor), gamma, method, hint, st["comm"], C_chunks, phase,
+                _ptr(out), _ptr(flags), _ptr(st["counters"]), _ptr(st["ws"]), st["ws"].numel(),
+                C.c_void_p(comp.cuda_stream), C.c_void_p(side) if side is not None else None),
+                "mia_letkf_sharded_step_f32")
+
+        call(0)
+        cnt = st["counters"].tolist()                         # the one host sync of the step
+        p_seen, n_over, n_retry = cnt[4], cnt[5], cnt[6]
+        if cnt[7]:
+            # a segment waiter gave up (the analysis launch and the exchange stream must be able to run
+            # concurrently: e.g. more HIP streams than hardware queues): all ranks switch to one launch + one
+            # event per piece and repeat the step
+            import os
+            import warnings
+            if os.environ.get("MIA_SEGMENT_SIGNAL") == "0":
+                raise _cabi.MiaError("native step driver: exchange error bits %d" % cnt[7])
+            warnings.warn("segmented launch timed out waiting for a segment; falling back to per-piece launches",
+                          RuntimeWarning)
+            os.environ["MIA_SEGMENT_SIGNAL"] = "0"
+            return self._assimilate_native(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1)
+        if n_over or p_seen > hint:
+            self._p_max_hint = None                            # bound broken on some rank: all ranks redo
+            return self._assimilate_native(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1)
+        if n_retry:
+            call(1)                                            # eigensolver redoes declined points; re-exchange
+        self.native_steps += 1
+        self.last_retries = cnt[2]
+        self._p_max_hint = p_seen if self.world > 1 else max(p_seen, 0)
+        self.last_p_max = hint
+        self._last_flags = flags[:g1 - g0]
+        return out
+
+    # ------------------------------------------------------------------ compute / exchange overlap
+    def _chunk_engine(self, X, grid_xyz, obs_xyz, Yb, d, c0, c1, state, buf):
+        """Analysis of sub-range [c0, c1) of this rank's block into ``buf[:, :, :c1-c0]``.  The shard-wide
+        preparation (packed records, neighbour lists of the whole block) is enqueued with the first chunk
+        and kept in ``state``.  state["vec"] = device int32 [max list length, #truncated lists, #declined
+        points]: written by the kernels, never read here.  Returns the deferred retry launcher."""
+        eng = self.engine
+        b0, b1 = state["block"]
+        vec = state["vec"]
         if "nb" not in state:
-            b0, b1 = state["block"]
             state["rec"] = eng.pack_obs(Yb, d, X.dtype)
             nb = eng.localize(grid_xyz, obs_xyz, self.radii, self.coord_group, self.eps, b0, b1,
-                              assume_p_max=self._p_max_hint)
+                              assume_p_max=self._p_max_hint, stats_out=vec[:2])
+            if nb.stats is None:            # exact lists (first call on a geometry): publish their maximum
+                vec[:2].copy_(torch.tensor([nb.p_max, 0], dtype=torch.int32), non_blocking=True)
             state["nb"] = nb
-        nb, (b0, _) = state["nb"], state["block"]
+            state["flags"] = torch.empty(b1 - b0, dtype=torch.int32, device=X.device)
+        nb = state["nb"]
         from .engine import NeighbourLists
-        sub = NeighbourLists(nb.cnt[g0 - b0:g1 - b0], nb.idx[g0 - b0:g1 - b0], nb.w[g0 - b0:g1 - b0],
-                             nb.p_cap, nb.p_max, g0, g1)
-        xa, flags, finish = eng.analysis(X, None, None, sub, self.inf_factor, rbf_gamma=self.rbf_gamma,
-                                         rec=state["rec"], return_flags=True, method=self.method, defer_retry=True)
-        state.setdefault("flags", []).append(flags)
-        return xa, finish
+        sub = NeighbourLists(nb.cnt[c0 - b0:c1 - b0], nb.idx[c0 - b0:c1 - b0], nb.w[c0 - b0:c1 - b0],
+                             nb.p_cap, nb.p_max, c0, c1)
+        _, finish = eng.analysis(X, None, None, sub, self.inf_factor, rbf_gamma=self.rbf_gamma, rec=state["rec"],
+                                 out=buf, out_offset=0, method=self.method, defer_retry=True,
+                                 retry=vec[2:3], flags=state["flags"][c0 - b0:c1 - b0])
+        return finish
+
+    def _overlap_buffers(self, X, world, C, n, nc):
+        m, k = X.shape[0], X.shape[1]
+        key = (X.dtype, X.device, m, k, world, C, n, nc)
+        if self._obuf is None or self._obuf["key"] != key:
+            self._obuf = dict(key=key,
+                              gath=torch.empty((C, world * m, k, nc), dtype=X.dtype, device=X.device),
+                              bufs=[torch.zeros((m, k, nc), dtype=X.dtype, device=X.device) for _ in range(C)],
+                              vec=torch.zeros(3, dtype=torch.int32, device=X.device))
+        return self._obuf
 
     def _assimilate_overlapped(self, X, grid_xyz, obs_xyz, Yb, d, G, g0, g1):
-        """The rank's block is analysed in ``comm_chunks`` pieces; the all-gather of piece c (RCCL, on a side
-        stream) runs while piece c+1 is being analysed, so at 8 GPUs the 16 MB-per-rank exchange hides behind
-        the compute instead of adding to it.  One permute-copy at the end restores (m, k, G)."""
+        """The rank's block is analysed in ``comm_chunks`` pieces; the all-gather of piece c (RCCL) and its
+        copy into the (m, k, G) result run on a side stream while piece c+1 is being analysed, so at 8 GPUs
+        the 16 MB-per-rank exchange hides behind the compute instead of adding to it.
+
+        Nothing is read back by the host until everything is enqueued.  The three counters that can demand a
+        redo (longest neighbour list vs the assumed bound, truncated lists, grid points the matfun kernel
+        declined) stay on the device, are max-reduced over the ranks with one 12-byte all-reduce and read
+        once: every rank takes the same decision, so the rare second exchange cannot dead-lock."""
         import torch.distributed as dist
         world, C = self.world, self.comm_chunks
         n = (G + world - 1) // world                 # common block length
@@ -204,65 +362,78 @@ class ShardedLetkf:
         m, k = X.shape[0], X.shape[1]
         cuda = X.is_cuda
         chunk_fn = self._chunk_compute or self._chunk_engine
-        gath = torch.empty((C, world * m, k, nc), dtype=X.dtype, device=X.device)
-        state = {"block": (g0, g1)}
-        finishes, bufs = [], []
+        ob = self._overlap_buffers(X, world, C, n, nc)
+        gath, bufs, vec = ob["gath"], ob["bufs"], ob["vec"]
+        out = torch.empty((m, k, world, C * nc), dtype=X.dtype, device=X.device)
+        hint = self._p_max_hint
+        state = {"block": (g0, g1), "vec": vec}
         if cuda:
             comp = torch.cuda.current_stream(X.device)
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=X.device)
             comm = self._comm_stream
-            comm.wait_stream(comp)
+            comm.wait_stream(comp)                   # the buffers' previous readers are done
+        vec.zero_()
+
+        def exchange(c):
+            dist.all_gather_into_tensor(gath[c], bufs[c], group=self.group)
+            out[:, :, :, c * nc:(c + 1) * nc].copy_(gath[c].view(world, m, k, nc).permute(1, 2, 0, 3))
+
+        def exchange_all():
+            for c in range(C):
+                if cuda:
+                    ev = torch.cuda.Event()
+                    ev.record(comp)
+                    with torch.cuda.stream(comm):
+                        comm.wait_event(ev)
+                        exchange(c)
+                else:
+                    exchange(c)
+
+        finishes = []
         for c in range(C):
             c0, c1 = min(g1, g0 + c * nc), min(g1, g0 + (c + 1) * nc)
-            buf = torch.zeros((m, k, nc), dtype=X.dtype, device=X.device) if c1 - c0 < nc else None
-            xa = None
             if c1 > c0:
-                xa, fin = chunk_fn(X, grid_xyz, obs_xyz, Yb, d, c0, c1, state)
-                finishes.append(fin)
-                if buf is None:
-                    buf = xa
-                else:
-                    buf[:, :, :c1 - c0] = xa
-            bufs.append((buf, xa))
+                finishes.append(chunk_fn(X, grid_xyz, obs_xyz, Yb, d, c0, c1, state, bufs[c]))
             if cuda:
                 ev = torch.cuda.Event()
                 ev.record(comp)
                 with torch.cuda.stream(comm):
                     comm.wait_event(ev)
-                    dist.all_gather_into_tensor(gath[c], buf.contiguous(), group=self.group)
+                    exchange(c)
             else:
-                dist.all_gather_into_tensor(gath[c], buf.contiguous(), group=self.group)
-        nb = state.get("nb")
-        redo = 0
-        if nb is not None and not nb.confirm():
-            redo = 1                                  # list bound broken somewhere in this block
-        n_retry = sum(f() for f in finishes)          # (host sync; declined points were redone in place)
-        self.last_retries = n_retry
+                exchange(c)
         if cuda:
+            with torch.cuda.stream(comm):
+                red = vec.clone()
+                dist.all_reduce(red, op=dist.ReduceOp.MAX, group=self.group)
             comp.wait_stream(comm)
-        # rare paths must be agreed on by all ranks: redone chunks need a second exchange
+        else:
+            red = vec.clone()
+            dist.all_reduce(red, op=dist.ReduceOp.MAX, group=self.group)
+        p_seen, n_over, n_retry = (int(v) for v in red.tolist())      # the one host sync of the step
+        self.last_retries = 0
+        if n_over or (hint is not None and p_seen > hint):
+            # some rank's assumed list bound did not hold: all ranks redo the step with exact lists
+            self._p_max_hint = None
+            shard = self._compute(X, grid_xyz, obs_xyz, Yb, d, g0, g1)
+            return gather_blocks(shard, G, world, self.group)
+        if n_retry:
+            # some rank's matfun kernel declined grid points: the eigensolver redoes them in place
+            # (no-op launches elsewhere) and all ranks exchange again
+            self.last_retries = max([f() for f in finishes if f is not None] + [0])   # (one shared counter)
+            exchange_all()
+            if cuda:
+                comp.wait_stream(comm)
         if self._chunk_compute is None:
-            flag = torch.tensor([redo, 1 if n_retry else 0], dtype=torch.int32, device=X.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-            any_redo, any_retry = (int(v) for v in flag.tolist())
-            if any_redo:
-                self._p_max_hint = None
-                shard = self._engine_shard(X, grid_xyz, obs_xyz, Yb, d, g0, g1)
-                return gather_blocks(shard, G, world, self.group)
-            if any_retry:                             # buffers were updated in place by the retry kernels
-                for c, (buf, xa) in enumerate(bufs):
-                    if xa is not None and xa is not buf:
-                        buf[:, :, :xa.shape[-1]] = xa
-                    dist.all_gather_into_tensor(gath[c], buf.contiguous(), group=self.group)
-            if nb is not None:
-                self._p_max_hint = nb.observed_p_max if nb.observed_p_max is not None else nb.p_max
-                self.last_p_max = nb.p_max
-                self._last_flags = torch.cat(state["flags"]) if state.get("flags") else None
-        out = gath.view(C, world, m, k, nc).permute(2, 3, 1, 0, 4).reshape(m, k, world * C * nc)
+            self._p_max_hint = p_seen
+            self.last_p_max = state["nb"].p_max if "nb" in state else p_seen
+            self._last_flags = state.get("flags")
+        out = out.view(m, k, world, C * nc)
         if C * nc != n:                               # chunk padding inside each rank's block
-            out = out.view(m, k, world, C * nc)[:, :, :, :n].reshape(m, k, world * n)
-        return out[:, :, :G].contiguous()
+            out = out[:, :, :, :n]
+        out = out.reshape(m, k, world * n)
+        return out if world * n == G else out[:, :, :G].contiguous()
 
     def mean_degree(self):
         """Mean Chebyshev degree of the last matfun launch (flags bits 8-15), None for the eigensolver route."""
