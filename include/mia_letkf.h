@@ -227,7 +227,7 @@ int mia_apply_weights_f64(const double* X, int64_t ldx, int m, int k, int64_t g0
  * (interface/letkf.py:118-131, DaskLocalization) on one host; here rank r of `world` owns the block
  * [r*n, min(G,(r+1)*n)), n = ceil(G/world), analyses it in n_chunks pieces and every piece is all-gathered
  * (RCCL, on `comm_stream`) and placed into the full (m, k, G) result while the next piece is analysed on
- * `stream`.  comm == NULL: single rank, Xa is written directly, no second stream needed.
+ * `stream`.  comm == NULL: single rank, Xa is written directly, comm_stream unused.  n_chunks <= 15.
  *
  * Communicator: mia_comm_load(path of the RCCL library the process already uses), rank 0 draws
  * mia_comm_unique_id (128 bytes) which the host distributes by any means (e.g. torch.distributed broadcast),
@@ -237,8 +237,9 @@ int mia_apply_weights_f64(const double* X, int64_t ldx, int m, int k, int64_t g0
  * method: 0 auto (matfun for m <= 4), 1 eigensolver kernel, 2 matfun.   p_max_assumed: bound of the local
  * observation count the launch is sized for (lists capacity = round_up(., 8)).
  * counters [8] i32 (device): [0] longest list of the block, [1] lists longer than the capacity, [2] grid points
- * the matfun kernel declined; [4..6] the same, max-reduced over all ranks.  The host reads [4..6] once after
- * the call (the only synchronisation of the step):
+ * the matfun kernel declined, [3] error bits (bit 0: a segment waiter timed out); [4..7] the same, max- (or-)
+ * reduced over all ranks (comm == NULL: left zero, [0..3] are the whole story).  The host reads them once
+ * after the call (the only synchronisation of the step):
  *   [5] != 0 or [4] > p_max_assumed  -> the bound did not hold on some rank: repeat the step (phase 0) on ALL
  *                                       ranks with p_max_assumed >= [4];
  *   [6] != 0                          -> call again with phase = 1 on ALL ranks: the eigensolver kernel redoes

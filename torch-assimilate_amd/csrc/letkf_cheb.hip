@@ -48,6 +48,7 @@ struct ChebParams {
   // segmented launch (native step driver): the ng points are seg_len-sized segments; segment s writes
   // its own (m*k, seg_len) buffer at Xa + s * seg_stride and counts its finished points in done[s*64 + ..]
   int seg_len; int64_t seg_stride; int32_t* done;
+  int kpv_magic;   // ceil(2^20 / (kp / 4))
 };
 
 using f32x4c = __attribute__((ext_vector_type(4))) float;
@@ -158,14 +159,31 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
   }
   if (P.xskip & 32) return;            // experiment: after the list / state loads
   MIA_WAVE_SYNC();
-  {   // gather + sqrt(rho) scale (wrapper.py:91-97)
+  {   // gather + sqrt(rho) scale (wrapper.py:91-97).  Four record quads per lane are requested before any is
+      // consumed (one memory round trip for the usual <= 256 quads instead of one per 64), and the quad ->
+      // (observation, column) split is a multiply-shift (P.kpv_magic = ceil(2^20 / kpv), exact below 2^20 / kpv
+      // quads) instead of an integer division per quad
     const int kpv = kp >> 2;
-    for (int it = tid; it < ((P.xskip & 1) ? 0 : cnt * kpv); it += 64) {
-      const int j = it / kpv, c = it - j * kpv;
-      float4 v = reinterpret_cast<const float4*>(P.rec + (int64_t)lidx[j] * kp)[c];
-      const float wj = lw[j];
-      v.x *= wj; v.y *= wj; v.z *= wj; v.w *= wj;
-      reinterpret_cast<float4*>(Yt + (size_t)j * kp)[c] = v;
+    const int total = (P.xskip & 1) ? 0 : cnt * kpv;
+    for (int base = 0; base < total; base += 256) {
+      float4 v[4];
+      int jj[4], cc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int it = base + 64 * u + tid;
+        const int j = (int)(((unsigned long long)(unsigned)it * (unsigned)P.kpv_magic) >> 20);
+        jj[u] = j; cc[u] = it - j * kpv;
+        if (it < total) v[u] = reinterpret_cast<const float4*>(P.rec + (int64_t)lidx[j] * kp)[cc[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (base + 64 * u + tid < total) {
+          const float wj = lw[jj[u]];
+          float4 t = v[u];
+          t.x *= wj; t.y *= wj; t.z *= wj; t.w *= wj;
+          reinterpret_cast<float4*>(Yt + (size_t)jj[u] * kp)[cc[u]] = t;
+        }
+      }
     }
   }
   for (int i = tid; i < kp; i += 64) Yt[(size_t)P.rows * kp + i] = 0.0f;   // the zero row of the Gram panels
@@ -489,6 +507,7 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
   if (scan) { ap.scan = *scan; ap.stats = stats; if (!stats) return MIA_ERR_NULL; } else ap.stats = nullptr;
   ap.X = X; ap.ldx = ldx; ap.m = m; ap.k = k; ap.g0 = g0; ap.ng = ng; ap.rec = rec;
   ap.kp = (k + 1 + 3) & ~3;
+  ap.kpv_magic = ((1 << 20) + (ap.kp >> 2) - 1) / (ap.kp >> 2);
   ap.cnt = nbr_cnt; ap.idx = nbr_idx; ap.w = nbr_w; ap.p_cap = p_cap; ap.p_max = p_max;
   ap.reg = float(k - 1) / inf_factor;
   ap.Xa = Xa; ap.ldo = ldo; ap.o0 = o0; ap.flags = flags; ap.retry_count = retry_count;

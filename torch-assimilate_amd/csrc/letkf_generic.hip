@@ -24,6 +24,7 @@
 #include "mia_jacobi.h"
 #include "mia_localize_dev.h"
 #include "mia_kernels.h"
+#include "mia_pack_dev.h"
 
 #include <cstdlib>
 
@@ -323,22 +324,7 @@ __global__ __launch_bounds__(NT) void letkf_generic_kernel(AnaParams<T> P) {
 template <typename T>
 __global__ __launch_bounds__(256) void pack_obs_kernel(const T* Yb, const T* d, int k, int64_t P, int kp, T* rec) {
   __shared__ T tile[32][33];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  const int64_t j0 = (int64_t)blockIdx.x * 32;
-  for (int i0 = 0; i0 < kp; i0 += 32) {
-    for (int r = ty; r < 32; r += 8) {
-      const int i = i0 + r; const int64_t j = j0 + tx;
-      T v = T(0);
-      if (j < P) { if (i < k) v = Yb[(int64_t)i * P + j]; else if (i == k) v = d[j]; }
-      tile[r][tx] = v;
-    }
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-      const int64_t j = j0 + r; const int i = i0 + tx;
-      if (j < P && i < kp) rec[j * kp + i] = tile[tx][r];
-    }
-    __syncthreads();
-  }
+  pack_obs_tile<T>(Yb, d, k, P, kp, rec, (int64_t)blockIdx.x, tile);
 }
 
 template <typename T>

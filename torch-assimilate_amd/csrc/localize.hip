@@ -10,6 +10,7 @@
 // survivors with a wave ballot.  Integer/byte work, HBM/L2-bound: no MFMA here.
 #include "mia_common.h"
 #include "mia_localize_dev.h"
+#include "mia_pack_dev.h"
 
 namespace mia {
 
@@ -25,6 +26,8 @@ struct IndexParams {
   int* sorted;   // [P]      observation index, cell-major, ascending inside a cell
   int* cell_of;  // [P]
   double* sxyz;  // [P][nc]  coordinates in the same order (no second indirection in the scan)
+  unsigned nb_bbox;      // workgroups of the first kernel that reduce the bounding box ...
+  PackJob pack;          // ... the others (if any) pack observation records (pack.rec != nullptr)
 };
 
 __device__ inline unsigned long long dkey(double x) {     // total order of doubles as unsigned integers
@@ -36,41 +39,17 @@ __device__ inline double dkey_inv(unsigned long long k) {
   return __longlong_as_double((long long)b);
 }
 
-// bounding box of the observations: wave + workgroup reduction, one pair of 64-bit atomics per
-// workgroup and coordinate
-__global__ __launch_bounds__(256) void index_bbox_kernel(IndexParams p) {
-  __shared__ unsigned long long sx[4], sn[4];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int c = 0; c < p.nc; ++c) {
-    unsigned long long kx = 0ull, kn = 0ull;
-    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < p.P; j += stride) {
-      const double x = p.obs[j * p.nc + c];
-      if (x == x) { const unsigned long long k = dkey(x); kx = k > kx ? k : kx; kn = ~k > kn ? ~k : kn; }
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-      const unsigned long long a = __shfl_xor(kx, o, 64), b = __shfl_xor(kn, o, 64);
-      kx = a > kx ? a : kx; kn = b > kn ? b : kn;
-    }
-    if (lane == 0) { sx[wv] = kx; sn[wv] = kn; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int w = 1; w < 4; ++w) { kx = sx[w] > kx ? sx[w] : kx; kn = sn[w] > kn ? sn[w] : kn; }
-      if (kx != 0ull) { atomicMax(&p.hdr->kmax[c], kx); atomicMax(&p.hdr->kmin_inv[c], kn); }
-    }
-    __syncthreads();
-  }
-}
-
 // one thread: cell grid dimensions from the bounding box
-__global__ void index_dims_kernel(IndexParams p) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ inline void index_dims(const IndexParams& p) {
   double ext[MIA_MAX_COORD], h[MIA_MAX_COORD];
   long long n[MIA_MAX_COORD];
   for (int c = 0; c < MIA_MAX_COORD; ++c) { n[c] = 1; h[c] = 1.0; ext[c] = 0.0; p.hdr->mn[c] = 0.0; }
   for (int c = 0; c < p.nc; ++c) {
     double mn = 0.0, mx = 0.0;
-    if (p.hdr->kmax[c] != 0ull) { mx = dkey_inv(p.hdr->kmax[c]); mn = dkey_inv(~p.hdr->kmin_inv[c]); }
+    // (the extrema were produced by other workgroups' atomics: read them at the same scope)
+    const unsigned long long kmax_c = __hip_atomic_load(&p.hdr->kmax[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long kmin_c = __hip_atomic_load(&p.hdr->kmin_inv[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (kmax_c != 0ull) { mx = dkey_inv(kmax_c); mn = dkey_inv(~kmin_c); }
     p.hdr->mn[c] = mn;
     ext[c] = mx - mn;
     h[c] = p.cutoff[c] > 0.0 ? p.cutoff[c] : 1.0;
@@ -94,6 +73,43 @@ __global__ void index_dims_kernel(IndexParams p) {
   p.hdr->ncell = int(n[0] * n[1] * n[2]);
 }
 
+// bounding box of the observations: wave + workgroup reduction, one pair of 64-bit atomics per
+// workgroup and coordinate; the workgroup that finishes last derives the cell grid from it (a separate
+// one-thread launch cost as much as this whole kernel: ~5 us of dispatch latency each)
+__global__ __launch_bounds__(256) void index_bbox_dims_kernel(IndexParams p) {
+  if (blockIdx.x >= p.nb_bbox) {        // independent passenger: observation records for the analysis kernel
+    __shared__ float tile[32][33];
+    pack_obs_tile<float>(p.pack.Yb, p.pack.d, p.pack.k, p.P, p.pack.kp, p.pack.rec, (int64_t)(blockIdx.x - p.nb_bbox), tile);
+    return;
+  }
+  __shared__ unsigned long long sx[4], sn[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t stride = (int64_t)p.nb_bbox * blockDim.x;
+  for (int c = 0; c < p.nc; ++c) {
+    unsigned long long kx = 0ull, kn = 0ull;
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < p.P; j += stride) {
+      const double x = p.obs[j * p.nc + c];
+      if (x == x) { const unsigned long long k = dkey(x); kx = k > kx ? k : kx; kn = ~k > kn ? ~k : kn; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long a = __shfl_xor(kx, o, 64), b = __shfl_xor(kn, o, 64);
+      kx = a > kx ? a : kx; kn = b > kn ? b : kn;
+    }
+    if (lane == 0) { sx[wv] = kx; sn[wv] = kn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w) { kx = sx[w] > kx ? sx[w] : kx; kn = sn[w] > kn ? sn[w] : kn; }
+      if (kx != 0ull) { atomicMax(&p.hdr->kmax[c], kx); atomicMax(&p.hdr->kmin_inv[c], kn); }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    // the atomics above are performed (returning atomics: their results are back) before this one is issued
+    const unsigned done = __hip_atomic_fetch_add(&p.hdr->done_bbox, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == p.nb_bbox - 1) index_dims(p);
+  }
+}
+
 __device__ inline int obs_cell(const IndexHeader* h, const double* x, int nc) {
   int id = 0;
   for (int c = 0; c < nc; ++c) {
@@ -104,36 +120,49 @@ __device__ inline int obs_cell(const IndexHeader* h, const double* x, int nc) {
   return id;
 }
 
-__global__ void index_count_kernel(IndexParams p) {
-  int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (j >= p.P) return;
-  int c = obs_cell(p.hdr, p.obs + j * p.nc, p.nc);
-  p.cell_of[j] = c;
-  atomicAdd(&p.start[c], 1);
+// exclusive scan of start[0 .. ncell] by one workgroup (entry ncell receives the total).  Every thread owns a
+// contiguous run of entries: all loads of the first pass are independent (one memory round trip, instead of
+// one per 256-entry slab with a carried dependency)
+__device__ inline void index_scan_block(const IndexParams& p, int* wsum) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nt = blockDim.x;
+  const int n = p.hdr->ncell + 1;
+  const int run = (n + nt - 1) / nt;
+  const int lo = tid * run < n ? tid * run : n, hi = lo + run < n ? lo + run : n;
+  int sum = 0;
+  // counts were accumulated by other workgroups' atomics: read them at the same scope
+  for (int i = lo; i < hi; ++i)
+    sum += (i < n - 1) ? __hip_atomic_load(&p.start[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+  int x = sum;
+  for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+  if (lane == 63) wsum[wv] = x;
+  __syncthreads();
+  int off = x - sum;
+  for (int w = 0; w < wv; ++w) off += wsum[w];
+  for (int i = lo; i < hi; ++i) {
+    const int v = (i < n - 1) ? __hip_atomic_load(&p.start[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    p.start[i] = off;
+    off += v;
+  }
 }
 
-// one workgroup: in-place exclusive scan of start[0 .. ncell]
-__global__ __launch_bounds__(1024) void index_scan_kernel(IndexParams p) {
-  __shared__ int wsum[16];
-  __shared__ int carry;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int n = p.hdr->ncell + 1;
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    int i = base + tid;
-    int v = (i < n - 1) ? p.start[i] : 0;   // entry ncell holds the total
-    int x = v;
-    for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-    if (lane == 63) wsum[wv] = x;
-    __syncthreads();
-    int off = carry;
-    for (int w = 0; w < wv; ++w) off += wsum[w];
-    if (i < n) p.start[i] = off + x - v;
-    __syncthreads();
-    if (tid == 1023) carry = off + x;
-    __syncthreads();
+// cell of every observation + per-cell counts; the workgroup that finishes last turns the counts into
+// exclusive starts (saves the dispatch of a one-workgroup scan kernel)
+__global__ __launch_bounds__(256) void index_count_scan_kernel(IndexParams p) {
+  __shared__ int wsum[4];
+  __shared__ int is_last;
+  const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (j < p.P) {
+    const int c = obs_cell(p.hdr, p.obs + j * p.nc, p.nc);
+    p.cell_of[j] = c;
+    atomicAdd(&p.start[c], 1);          // (returning atomic: performed before the wave goes on)
   }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned done = __hip_atomic_fetch_add(&p.hdr->done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = done == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (is_last) index_scan_block(p, wsum);
 }
 
 __global__ void index_scatter_kernel(IndexParams p) {
@@ -304,7 +333,7 @@ __global__ void gc_kernel(const T* r, int64_t n, T* w) {
 
 // builds the cell index of the observations in ws (all kernels enqueued on stream)
 int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_t* coord_group,
-                     const double* gc_c, int n_r, void* ws, size_t ws_bytes, hipStream_t stream) {
+                     const double* gc_c, int n_r, void* ws, size_t ws_bytes, hipStream_t stream, const PackJob* pack) {
   if (P < 0 || n_coord < 1 || n_coord > MIA_MAX_COORD || n_r < 1 || n_r > MIA_MAX_RADII) return MIA_ERR_SIZE;
   if (P > 2000000000LL) return MIA_ERR_UNSUPPORTED;
   if (!coord_group || !gc_c) return MIA_ERR_NULL;
@@ -322,13 +351,17 @@ int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_
   // header, start and cursor are adjacent: one fill clears all three
   MIA_HIP_TRY(hipMemsetAsync(ip.hdr, 0, (char*)ip.sorted - (char*)ip.hdr, stream));
   const unsigned nbP = (unsigned)((P + 255) / 256);
-  index_bbox_kernel<<<dim3(nbP < 64 ? nbP : 64), dim3(256), 0, stream>>>(ip);
+  ip.nb_bbox = nbP < 64 ? nbP : 64;
+  ip.pack = PackJob{nullptr, nullptr, nullptr, 0, 0};
+  unsigned nb_pack = 0;
+  if (pack && pack->rec) {
+    if ((P + 31) / 32 > 2000000000LL) return MIA_ERR_UNSUPPORTED;
+    ip.pack = *pack;
+    nb_pack = (unsigned)((P + 31) / 32);
+  }
+  index_bbox_dims_kernel<<<dim3(ip.nb_bbox + nb_pack), dim3(256), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
-  index_dims_kernel<<<dim3(1), dim3(64), 0, stream>>>(ip);
-  MIA_LAUNCH_CHECK();
-  index_count_kernel<<<dim3(nbP), dim3(256), 0, stream>>>(ip);
-  MIA_LAUNCH_CHECK();
-  index_scan_kernel<<<dim3(1), dim3(1024), 0, stream>>>(ip);
+  index_count_scan_kernel<<<dim3(nbP), dim3(256), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
   index_scatter_kernel<<<dim3(nbP), dim3(256), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
@@ -348,6 +381,39 @@ int make_scan_params(ScanParams* sp, const double* grid_xyz, int64_t P, int n_co
   for (int c = 0; c < MIA_MAX_COORD; ++c) sp->group[c] = c < n_coord ? coord_group[c] : 0;
   for (int r = 0; r < MIA_MAX_RADII; ++r) { sp->inv_c[r] = r < n_r ? 1.0 / gc_c[r] : 1.0; sp->cc[r] = r < n_r ? gc_c[r] : 1.0; }
   sp->eps = gc_eps;
+  return MIA_OK;
+}
+
+int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* obs_xyz, int64_t P, int n_coord,
+                  const int32_t* coord_group, const double* gc_c, int n_r, double gc_eps, int p_cap,
+                  int32_t* nbr_cnt, int32_t* nbr_idx, double* nbr_w, int32_t* stats, void* ws, size_t ws_bytes,
+                  hipStream_t stream, const PackJob* pack, bool stats_zeroed) {
+  if (g1 < g0 || g0 < 0 || P < 0) return MIA_ERR_SIZE;
+  if (n_coord < 1 || n_coord > MIA_MAX_COORD || n_r < 1 || n_r > MIA_MAX_RADII || p_cap < 1) return MIA_ERR_SIZE;
+  if (!coord_group || !gc_c || !stats) return MIA_ERR_NULL;
+  for (int c = 0; c < n_coord; ++c) if (coord_group[c] < 0 || coord_group[c] >= n_r) return MIA_ERR_SIZE;
+  for (int r = 0; r < n_r; ++r) if (!(gc_c[r] > 0.0)) return MIA_ERR_SIZE;
+  const int64_t ng = g1 - g0;
+  if (!stats_zeroed) MIA_HIP_TRY(hipMemsetAsync(stats, 0, 2 * sizeof(int32_t), stream));
+  if (ng == 0) return MIA_OK;
+  if (!nbr_cnt || !nbr_idx || !nbr_w || !grid_xyz) return MIA_ERR_NULL;
+  if (P == 0) {  // no observations at all: every list is empty (-> prior weights downstream)
+    MIA_HIP_TRY(hipMemsetAsync(nbr_cnt, 0, ng * sizeof(int32_t), stream));
+    MIA_HIP_TRY(hipMemsetAsync(nbr_idx, 0xff, ng * (size_t)p_cap * sizeof(int32_t), stream));
+    MIA_HIP_TRY(hipMemsetAsync(nbr_w, 0, ng * (size_t)p_cap * sizeof(double), stream));
+    return MIA_OK;
+  }
+  int rc = index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, ws, ws_bytes, stream, pack);
+  if (rc != MIA_OK) return rc;
+  LocalizeParams lp;
+  rc = make_scan_params(&lp.scan, grid_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, ws);
+  if (rc != MIA_OK) return rc;
+  lp.g0 = g0; lp.ng = ng; lp.p_cap = p_cap;
+  lp.cnt = nbr_cnt; lp.idx = nbr_idx; lp.w = nbr_w; lp.stats = stats;
+  const int64_t nb = (ng + 255) / 256;
+  if (nb > 2147483647LL) return MIA_ERR_UNSUPPORTED;
+  localize_kernel<<<dim3((unsigned)nb), dim3(256), 0, stream>>>(lp);
+  MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
 
@@ -398,36 +464,10 @@ extern "C" int mia_letkf_localize_f64(const double* grid_xyz, int64_t g0, int64_
                                       const int32_t* coord_group, const double* gc_c, int n_r,
                                       double gc_eps, int p_cap, int32_t* nbr_cnt, int32_t* nbr_idx,
                                       double* nbr_w, int32_t* stats, void* ws, size_t ws_bytes,
-                                      void* stream_) {
+                                      void* stream) {
   (void)hipGetLastError();  // drop stale per-thread error state left by other users of the runtime
-  hipStream_t stream = (hipStream_t)stream_;
-  if (g1 < g0 || g0 < 0 || P < 0) return MIA_ERR_SIZE;
-  if (n_coord < 1 || n_coord > MIA_MAX_COORD || n_r < 1 || n_r > MIA_MAX_RADII || p_cap < 1) return MIA_ERR_SIZE;
-  if (!coord_group || !gc_c || !stats) return MIA_ERR_NULL;
-  for (int c = 0; c < n_coord; ++c) if (coord_group[c] < 0 || coord_group[c] >= n_r) return MIA_ERR_SIZE;
-  for (int r = 0; r < n_r; ++r) if (!(gc_c[r] > 0.0)) return MIA_ERR_SIZE;
-  const int64_t ng = g1 - g0;
-  MIA_HIP_TRY(hipMemsetAsync(stats, 0, 2 * sizeof(int32_t), stream));
-  if (ng == 0) return MIA_OK;
-  if (!nbr_cnt || !nbr_idx || !nbr_w || !grid_xyz) return MIA_ERR_NULL;
-  if (P == 0) {  // no observations at all: every list is empty (-> prior weights downstream)
-    MIA_HIP_TRY(hipMemsetAsync(nbr_cnt, 0, ng * sizeof(int32_t), stream));
-    MIA_HIP_TRY(hipMemsetAsync(nbr_idx, 0xff, ng * (size_t)p_cap * sizeof(int32_t), stream));
-    MIA_HIP_TRY(hipMemsetAsync(nbr_w, 0, ng * (size_t)p_cap * sizeof(double), stream));
-    return MIA_OK;
-  }
-  int rc = index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, ws, ws_bytes, stream);
-  if (rc != MIA_OK) return rc;
-  LocalizeParams lp;
-  rc = make_scan_params(&lp.scan, grid_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, ws);
-  if (rc != MIA_OK) return rc;
-  lp.g0 = g0; lp.ng = ng; lp.p_cap = p_cap;
-  lp.cnt = nbr_cnt; lp.idx = nbr_idx; lp.w = nbr_w; lp.stats = stats;
-  const int64_t nb = (ng + 255) / 256;
-  if (nb > 2147483647LL) return MIA_ERR_UNSUPPORTED;
-  localize_kernel<<<dim3((unsigned)nb), dim3(256), 0, stream>>>(lp);
-  MIA_LAUNCH_CHECK();
-  return MIA_OK;
+  return mia::localize_impl(grid_xyz, g0, g1, obs_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, p_cap, nbr_cnt,
+                            nbr_idx, nbr_w, stats, ws, ws_bytes, (hipStream_t)stream, nullptr, false);
 }
 
 extern "C" int mia_letkf_localize_from_dist_f64(const double* dist, const int32_t* cand_idx,

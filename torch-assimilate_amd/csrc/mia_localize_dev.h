@@ -15,6 +15,7 @@ struct IndexHeader {        // lives at the start of the workspace, written on d
   double invh[MIA_MAX_COORD];
   int n[MIA_MAX_COORD];
   int ncell;
+  unsigned done_bbox, done_count;   // workgroups finished (the last one runs the serial follow-up stage)
 };
 
 __device__ inline int cell_coord(double x, double mn, double invh, int n) {
@@ -148,8 +149,16 @@ static inline IndexLayout index_layout(void* ws, int64_t P, int nc) {
 }
 
 // host side, defined in localize.hip
+struct PackJob;
 int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_t* coord_group,
-                     const double* gc_c, int n_r, void* ws, size_t ws_bytes, hipStream_t stream);
+                     const double* gc_c, int n_r, void* ws, size_t ws_bytes, hipStream_t stream,
+                     const PackJob* pack = nullptr);
+// neighbour lists of grid points [g0, g1) (mia_letkf_localize_f64 without the argument checks of the C entry);
+// pack: float32 record packing job executed inside the first index kernel; stats_zeroed: caller cleared stats
+int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* obs_xyz, int64_t P, int n_coord,
+                  const int32_t* coord_group, const double* gc_c, int n_r, double gc_eps, int p_cap,
+                  int32_t* nbr_cnt, int32_t* nbr_idx, double* nbr_w, int32_t* stats, void* ws, size_t ws_bytes,
+                  hipStream_t stream, const PackJob* pack, bool stats_zeroed);
 int make_scan_params(ScanParams* sp, const double* grid_xyz, int64_t P, int n_coord, const int32_t* coord_group,
                      const double* gc_c, int n_r, double gc_eps, void* ws);
 

@@ -18,6 +18,7 @@
 
 #include "mia_common.h"
 #include "mia_kernels.h"
+#include "mia_pack_dev.h"
 
 // ---- the few RCCL declarations needed (ABI of rccl.h 2.x: opaque comm, 128-byte id, C enums)
 typedef struct ncclComm* ncclComm_t;
@@ -49,7 +50,7 @@ void set_error(const char* what, int code) {
   snprintf(g_comm_error, sizeof(g_comm_error), "%s (code %d) %s", what, code, msg);
 }
 
-constexpr int kMaxChunks = 16;
+constexpr int kMaxChunks = 16;   // pieces per block; events: [c] piece c, [kMaxChunks-1] records packed (pieces <= 15)
 
 }  // namespace
 
@@ -132,7 +133,7 @@ struct StepLayout {
 
 int step_layout(int64_t G, int m, int k, int64_t P, int n_coord, int world, int n_chunks, int p_max_assumed,
                 StepLayout* L) {
-  if (G < 0 || m <= 0 || k <= 0 || P < 0 || n_coord <= 0 || world <= 0 || n_chunks <= 0 || n_chunks > kMaxChunks ||
+  if (G < 0 || m <= 0 || k <= 0 || P < 0 || n_coord <= 0 || world <= 0 || n_chunks <= 0 || n_chunks > kMaxChunks - 1 ||
       p_max_assumed < 0)
     return MIA_ERR_SIZE;
   const int kp = (k + 1 + 3) / 4 * 4;
@@ -296,17 +297,16 @@ extern "C" int mia_letkf_sharded_step_f32(const float* X, int64_t G, int m, int 
     if (exch) {
       MIA_HIP_TRY(hipMemsetAsync(ctr, 0, 4 * sizeof(int32_t), s));
       MIA_HIP_TRY(hipMemsetAsync(done, 0, (size_t)n_chunks * 64 * mia::kSlotStride * sizeof(int32_t), s));
-      // the side stream starts after everything already enqueued (incl. the zeroing above)
+    }
+    if (exch) {   // the side stream starts after everything already enqueued (incl. the zeroing above)
       MIA_HIP_TRY(hipEventRecord(comm->ev[kMaxChunks], s));
       MIA_HIP_TRY(hipStreamWaitEvent(cs, comm->ev[kMaxChunks], 0));
     }
-    if (P > 0) {
-      rc = mia_letkf_pack_obs_f32(Yb, d, k, P, rec, stream);
-      if (rc != MIA_OK) return rc;
-    }
     if (b1 > b0) {
-      rc = mia_letkf_localize_f64(grid_xyz, b0, b1, obs_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, L.cap,
-                                  cnt, idx, w, ctr, base + L.loc, L.loc_bytes, stream);
+      // the record packing rides inside the first index kernel (independent work, no launch of its own)
+      const mia::PackJob job{Yb, d, rec, k, (k + 1 + 3) / 4 * 4};
+      rc = mia::localize_impl(grid_xyz, b0, b1, obs_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, L.cap,
+                              cnt, idx, w, ctr, base + L.loc, L.loc_bytes, s, P > 0 ? &job : nullptr, true);
       if (rc != MIA_OK) return rc;
     }
     // one launch over the whole block whose segments are exchanged as they complete (no kernel boundary, no
@@ -375,8 +375,7 @@ extern "C" int mia_letkf_sharded_step_f32(const float* X, int64_t G, int m, int 
     }
   }
 
-  if (phase == 0 && !exch)     // single rank: the reduced copy is the rank's own
-    MIA_HIP_TRY(hipMemcpyAsync(counters + 4, counters, 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  // (without the exchange route counters[4..7] stay zero: the rank's own [0..3] are the whole story)
   if (exch) {                              // the caller's stream continues after the exchange
     MIA_HIP_TRY(hipEventRecord(comm->ev[kMaxChunks + 1], cs));
     MIA_HIP_TRY(hipStreamWaitEvent(s, comm->ev[kMaxChunks + 1], 0));

@@ -210,7 +210,7 @@ class ShardedLetkf:
             st = dict(comm=None, ws=None, stream=None, key=None)
             if self.world > 1 or self._force_comm:
                 st["comm"] = self._native_comm()
-                st["stream"] = torch.cuda.Stream(device=self.device)
+            st["stream"] = torch.cuda.Stream(device=self.device)
             self._native = st
         return self._native
 
@@ -285,6 +285,8 @@ class ShardedLetkf:
 
         call(0)
         cnt = st["counters"].tolist()                         # the one host sync of the step
+        if st["comm"] is None or (self.world == 1 and C_chunks == 1):
+            cnt[4:8] = cnt[0:4]                                # no exchange route: the rank's own counters
         p_seen, n_over, n_retry = cnt[4], cnt[5], cnt[6]
         if cnt[7]:
             # a segment waiter gave up (the analysis launch and the exchange stream must be able to run
