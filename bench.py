@@ -12,7 +12,9 @@ ensemble is all-gathered over RCCL.
 
 One step = one full pass of the hot path with inputs resident in HBM: pack obs records,
 build the observation cell index, Gaspari-Cohn neighbour lists, fused local analysis
-(Gram, eigensolve, weights, transform) [, all-gather].  Prints ONE JSON line on rank 0.
+(Gram, matrix functions / eigensolve, weights, transform) [, all-gather], enqueued by ONE call
+into the C-ABI library (mia_letkf_sharded_step_f32) and ended by the one host read-back that
+validates it.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -124,8 +126,8 @@ def cpu_baseline(n_points_total=16000):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grid-per-gpu", type=int, default=G_PER_GPU)
     ap.add_argument("--method", default="auto", choices=["auto", "eig", "matfun"],
@@ -157,7 +159,9 @@ def main():
     G = gpg * world
     X, grid_x, obs_x, Yb, d = make_case(G, K_ENS, OBS_STRIDE, device)
     P = obs_x.shape[0]
-    runner = ShardedLetkf(device, rank, world, radii=[GC_RADIUS], inf_factor=INF, method=args.method)
+    runner = ShardedLetkf(device, rank, world, radii=[GC_RADIUS], inf_factor=INF, method=args.method,
+                          comm_chunks=int(os.environ.get("MIA_COMM_CHUNKS", "4")),
+                          native_step=os.environ.get("MIA_NATIVE_STEP", "1") != "0")
 
     def step():
         return runner.assimilate(X, grid_x, obs_x, Yb, d)
@@ -222,6 +226,8 @@ def main():
                       "eigensolver_route_kernel_ms": eig_ms,
                       "eigensolver_route_kernel_analyses_per_s": (gpg / (eig_ms * 1e-3)) if eig_ms else None},
             "stages_ms": stage_ms,
+            "step_driver": ("native: mia_letkf_sharded_step_f32, %d of %d timed+warmup steps" % (runner.native_steps, args.steps + args.warmup))
+                           if runner.native_steps else "python (engine entries one by one)",
         }
         if cpu is not None:
             line["cpu_baseline"] = cpu

@@ -28,6 +28,7 @@ struct IndexParams {
   double* sxyz;  // [P][nc]  coordinates in the same order (no second indirection in the scan)
   unsigned nb_bbox;      // workgroups of the first kernel that reduce the bounding box ...
   PackJob pack;          // ... the others (if any) pack observation records (pack.rec != nullptr)
+  ZeroJob zero;          // small caller buffers cleared by the first kernel (saves their fill launches)
 };
 
 __device__ inline unsigned long long dkey(double x) {     // total order of doubles as unsigned integers
@@ -85,6 +86,8 @@ __global__ __launch_bounds__(256) void index_bbox_dims_kernel(IndexParams p) {
   __shared__ unsigned long long sx[4], sn[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t stride = (int64_t)p.nb_bbox * blockDim.x;
+  for (int q = 0; q < 3; ++q)
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < p.zero.n[q]; i += stride) p.zero.ptr[q][i] = 0;
   for (int c = 0; c < p.nc; ++c) {
     unsigned long long kx = 0ull, kn = 0ull;
     for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < p.P; j += stride) {
@@ -121,40 +124,58 @@ __device__ inline int obs_cell(const IndexHeader* h, const double* x, int nc) {
 }
 
 // exclusive scan of start[0 .. ncell] by one workgroup (entry ncell receives the total).  Every thread owns a
-// contiguous run of entries: all loads of the first pass are independent (one memory round trip, instead of
-// one per 256-entry slab with a carried dependency)
+// contiguous run of entries; runs of up to 8 stay in registers (independent loads: one memory round trip)
 __device__ inline void index_scan_block(const IndexParams& p, int* wsum) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nt = blockDim.x;
   const int n = p.hdr->ncell + 1;
   const int run = (n + nt - 1) / nt;
   const int lo = tid * run < n ? tid * run : n, hi = lo + run < n ? lo + run : n;
   int sum = 0;
+  int vals[8];
   // counts were accumulated by other workgroups' atomics: read them at the same scope
-  for (int i = lo; i < hi; ++i)
-    sum += (i < n - 1) ? __hip_atomic_load(&p.start[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+  if (run <= 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = lo + u;
+      vals[u] = (i < hi && i < n - 1) ? __hip_atomic_load(&p.start[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += vals[u];
+  } else {
+    for (int i = lo; i < hi; ++i)
+      sum += (i < n - 1) ? __hip_atomic_load(&p.start[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+  }
   int x = sum;
   for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
   if (lane == 63) wsum[wv] = x;
   __syncthreads();
   int off = x - sum;
   for (int w = 0; w < wv; ++w) off += wsum[w];
-  for (int i = lo; i < hi; ++i) {
-    const int v = (i < n - 1) ? __hip_atomic_load(&p.start[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    p.start[i] = off;
-    off += v;
+  if (run <= 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (lo + u < hi) p.start[lo + u] = off;
+      off += vals[u];
+    }
+  } else {
+    for (int i = lo; i < hi; ++i) {
+      const int v = (i < n - 1) ? __hip_atomic_load(&p.start[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      p.start[i] = off;
+      off += v;
+    }
   }
 }
 
 // cell of every observation + per-cell counts; the workgroup that finishes last turns the counts into
 // exclusive starts (saves the dispatch of a one-workgroup scan kernel)
-__global__ __launch_bounds__(256) void index_count_scan_kernel(IndexParams p) {
-  __shared__ int wsum[4];
+__global__ __launch_bounds__(1024) void index_count_scan_kernel(IndexParams p) {
+  __shared__ int wsum[16];
   __shared__ int is_last;
   const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (j < p.P) {
     const int c = obs_cell(p.hdr, p.obs + j * p.nc, p.nc);
     p.cell_of[j] = c;
-    atomicAdd(&p.start[c], 1);          // (returning atomic: performed before the wave goes on)
+    atomicAdd(&p.start[c], 1);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -175,19 +196,39 @@ __global__ void index_scatter_kernel(IndexParams p) {
 
 // the scatter order inside a cell depends on atomic arrival: sort each cell's slice by observation
 // index so that neighbour lists (and therefore summation order) are reproducible; then lay the
-// coordinates out in that order
-__global__ void index_sortcell_kernel(IndexParams p) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= p.hdr->ncell) return;
-  int lo = p.start[c], hi = p.start[c + 1];
-  for (int i = lo + 1; i < hi; ++i) {
-    int v = p.sorted[i], j = i - 1;
-    while (j >= lo && p.sorted[j] > v) { p.sorted[j + 1] = p.sorted[j]; --j; }
-    p.sorted[j + 1] = v;
-  }
-  for (int i = lo; i < hi; ++i) {
-    const int64_t j = p.sorted[i];
-    for (int q = 0; q < p.nc; ++q) p.sxyz[(int64_t)i * p.nc + q] = p.obs[j * p.nc + q];
+// coordinates out in that order.  One WAVE per cell (grid-stride over the cells): a cell of up to 64
+// observations is ranked in registers (ids are distinct: rank = number of smaller ids) with one load and one
+// store per lane; the thread-per-cell insertion sort this replaces spent 16 us in dependent global round trips.
+__global__ __launch_bounds__(256) void index_sortcell_kernel(IndexParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = (gridDim.x * blockDim.x) >> 6;
+  const int ncell = p.hdr->ncell;
+  for (int c = wave; c < ncell; c += nwave) {
+    const int lo = p.start[c], hi = p.start[c + 1], n = hi - lo;
+    if (n <= 0) continue;
+    if (n <= 64) {
+      const int v = lane < n ? p.sorted[lo + lane] : 0x7fffffff;
+      int rank = 0;
+      for (int l = 0; l < n; ++l) rank += __shfl(v, l, 64) < v ? 1 : 0;
+      if (lane < n) {
+        p.sorted[lo + rank] = v;
+        for (int q = 0; q < p.nc; ++q) p.sxyz[(int64_t)(lo + rank) * p.nc + q] = p.obs[(int64_t)v * p.nc + q];
+      }
+    } else {
+      if (lane == 0) {
+        for (int i = lo + 1; i < hi; ++i) {
+          int v = p.sorted[i], j = i - 1;
+          while (j >= lo && p.sorted[j] > v) { p.sorted[j + 1] = p.sorted[j]; --j; }
+          p.sorted[j + 1] = v;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int i = lo + lane; i < hi; i += 64) {
+        const int64_t j = __hip_atomic_load(&p.sorted[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        for (int q = 0; q < p.nc; ++q) p.sxyz[(int64_t)i * p.nc + q] = p.obs[j * p.nc + q];
+      }
+    }
   }
 }
 
@@ -333,7 +374,8 @@ __global__ void gc_kernel(const T* r, int64_t n, T* w) {
 
 // builds the cell index of the observations in ws (all kernels enqueued on stream)
 int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_t* coord_group,
-                     const double* gc_c, int n_r, void* ws, size_t ws_bytes, hipStream_t stream, const PackJob* pack) {
+                     const double* gc_c, int n_r, void* ws, size_t ws_bytes, hipStream_t stream, const PackJob* pack,
+                     const ZeroJob* zero) {
   if (P < 0 || n_coord < 1 || n_coord > MIA_MAX_COORD || n_r < 1 || n_r > MIA_MAX_RADII) return MIA_ERR_SIZE;
   if (P > 2000000000LL) return MIA_ERR_UNSUPPORTED;
   if (!coord_group || !gc_c) return MIA_ERR_NULL;
@@ -353,6 +395,7 @@ int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_
   const unsigned nbP = (unsigned)((P + 255) / 256);
   ip.nb_bbox = nbP < 64 ? nbP : 64;
   ip.pack = PackJob{nullptr, nullptr, nullptr, 0, 0};
+  ip.zero = zero ? *zero : ZeroJob{{nullptr, nullptr, nullptr}, {0, 0, 0}};
   unsigned nb_pack = 0;
   if (pack && pack->rec) {
     if ((P + 31) / 32 > 2000000000LL) return MIA_ERR_UNSUPPORTED;
@@ -361,11 +404,12 @@ int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_
   }
   index_bbox_dims_kernel<<<dim3(ip.nb_bbox + nb_pack), dim3(256), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
-  index_count_scan_kernel<<<dim3(nbP), dim3(256), 0, stream>>>(ip);
+  index_count_scan_kernel<<<dim3((unsigned)((P + 1023) / 1024)), dim3(1024), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
   index_scatter_kernel<<<dim3(nbP), dim3(256), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
-  index_sortcell_kernel<<<dim3((unsigned)((L.cap + 255) / 256)), dim3(256), 0, stream>>>(ip);
+  const size_t sort_blocks = (L.cap + 3) / 4 < 2048 ? (L.cap + 3) / 4 : 2048;      // 4 waves (cells) per workgroup
+  index_sortcell_kernel<<<dim3((unsigned)sort_blocks), dim3(256), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
@@ -387,7 +431,7 @@ int make_scan_params(ScanParams* sp, const double* grid_xyz, int64_t P, int n_co
 int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* obs_xyz, int64_t P, int n_coord,
                   const int32_t* coord_group, const double* gc_c, int n_r, double gc_eps, int p_cap,
                   int32_t* nbr_cnt, int32_t* nbr_idx, double* nbr_w, int32_t* stats, void* ws, size_t ws_bytes,
-                  hipStream_t stream, const PackJob* pack, bool stats_zeroed) {
+                  hipStream_t stream, const PackJob* pack, bool stats_zeroed, const ZeroJob* zero) {
   if (g1 < g0 || g0 < 0 || P < 0) return MIA_ERR_SIZE;
   if (n_coord < 1 || n_coord > MIA_MAX_COORD || n_r < 1 || n_r > MIA_MAX_RADII || p_cap < 1) return MIA_ERR_SIZE;
   if (!coord_group || !gc_c || !stats) return MIA_ERR_NULL;
@@ -403,7 +447,7 @@ int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* 
     MIA_HIP_TRY(hipMemsetAsync(nbr_w, 0, ng * (size_t)p_cap * sizeof(double), stream));
     return MIA_OK;
   }
-  int rc = index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, ws, ws_bytes, stream, pack);
+  int rc = index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, ws, ws_bytes, stream, pack, zero);
   if (rc != MIA_OK) return rc;
   LocalizeParams lp;
   rc = make_scan_params(&lp.scan, grid_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, ws);
@@ -467,7 +511,7 @@ extern "C" int mia_letkf_localize_f64(const double* grid_xyz, int64_t g0, int64_
                                       void* stream) {
   (void)hipGetLastError();  // drop stale per-thread error state left by other users of the runtime
   return mia::localize_impl(grid_xyz, g0, g1, obs_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, p_cap, nbr_cnt,
-                            nbr_idx, nbr_w, stats, ws, ws_bytes, (hipStream_t)stream, nullptr, false);
+                            nbr_idx, nbr_w, stats, ws, ws_bytes, (hipStream_t)stream, nullptr, false, nullptr);
 }
 
 extern "C" int mia_letkf_localize_from_dist_f64(const double* dist, const int32_t* cand_idx,

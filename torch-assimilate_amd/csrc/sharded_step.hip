@@ -292,22 +292,31 @@ extern "C" int mia_letkf_sharded_step_f32(const float* X, int64_t G, int m, int 
 
   bool segmented = false;
   if (phase == 0) {
-    // counters[0..3] = {longest list, truncated lists, declined points, error bits} of this rank; [4..7] = max over ranks
-    MIA_HIP_TRY(hipMemsetAsync(counters, 0, 8 * sizeof(int32_t), s));
-    if (exch) {
-      MIA_HIP_TRY(hipMemsetAsync(ctr, 0, 4 * sizeof(int32_t), s));
-      MIA_HIP_TRY(hipMemsetAsync(done, 0, (size_t)n_chunks * 64 * mia::kSlotStride * sizeof(int32_t), s));
-    }
-    if (exch) {   // the side stream starts after everything already enqueued (incl. the zeroing above)
-      MIA_HIP_TRY(hipEventRecord(comm->ev[kMaxChunks], s));
-      MIA_HIP_TRY(hipStreamWaitEvent(cs, comm->ev[kMaxChunks], 0));
+    // counters[0..3] = {longest list, truncated lists, declined points, error bits} of this rank; [4..7] = max over ranks.
+    // They, the trailer copy and the segment slots are cleared by the first index kernel when it runs
+    // (every fill launch of its own costs ~5-8 us of the ~100 us this phase takes)
+    const bool zero_in_kernel = P > 0 && b1 > b0;
+    const size_t done_ints = (size_t)n_chunks * 64 * mia::kSlotStride;
+    if (!zero_in_kernel) {
+      MIA_HIP_TRY(hipMemsetAsync(counters, 0, 8 * sizeof(int32_t), s));
+      if (exch) {
+        MIA_HIP_TRY(hipMemsetAsync(ctr, 0, 4 * sizeof(int32_t), s));
+        MIA_HIP_TRY(hipMemsetAsync(done, 0, done_ints * sizeof(int32_t), s));
+      }
     }
     if (b1 > b0) {
-      // the record packing rides inside the first index kernel (independent work, no launch of its own)
+      // the record packing rides inside the first index kernel too (independent work, no launch of its own)
       const mia::PackJob job{Yb, d, rec, k, (k + 1 + 3) / 4 * 4};
+      const mia::ZeroJob zj{{counters, exch ? ctr : nullptr, exch ? done : nullptr},
+                            {8, exch ? 4 : 0, exch ? (int64_t)done_ints : 0}};
       rc = mia::localize_impl(grid_xyz, b0, b1, obs_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, L.cap,
-                              cnt, idx, w, ctr, base + L.loc, L.loc_bytes, s, P > 0 ? &job : nullptr, true);
+                              cnt, idx, w, ctr, base + L.loc, L.loc_bytes, s, P > 0 ? &job : nullptr, true,
+                              zero_in_kernel ? &zj : nullptr);
       if (rc != MIA_OK) return rc;
+    }
+    if (exch) {   // the side stream starts once the lists exist (and the slots it polls have been cleared)
+      MIA_HIP_TRY(hipEventRecord(comm->ev[kMaxChunks], s));
+      MIA_HIP_TRY(hipStreamWaitEvent(cs, comm->ev[kMaxChunks], 0));
     }
     // one launch over the whole block whose segments are exchanged as they complete (no kernel boundary, no
     // event between the pieces: a 1e5-point block in 4 launches costs 292 us instead of 245 us on MI355X)

@@ -457,7 +457,9 @@ class ShardedLetkf:
                  and X.dtype == torch.float32)
         names = ["pack_obs", "obs_index_build" if fused else "localize(index+lists, incl. host sync)", "analysis_kernel"]
         acc = dict.fromkeys(names, 0.0)
+        burst = 5
         for _ in range(reps):
+            nk = 1
             e = [ev() for _ in range(4)]
             e[0].record()
             rec = eng.pack_obs(Yb, d, X.dtype)
@@ -469,13 +471,18 @@ class ShardedLetkf:
                                                self.rbf_gamma, g0, g1)
             else:
                 nb = eng.localize(grid_xyz, obs_xyz, self.radii, self.coord_group, self.eps, g0, g1)
+                # the list step ends in a host read-back, so the GPU is idle here: launch the analysis kernel
+                # `burst` times back to back and divide, otherwise the interval between the two events measures
+                # the host's launch latency (~40 us from Python) on top of the kernel
                 e[2].record()
-                _, fin = eng.analysis(X, None, None, nb, self.inf_factor, rbf_gamma=self.rbf_gamma, rec=rec,
-                                      method=self.method, defer_retry=True)
+                for _ in range(burst):
+                    _, fin = eng.analysis(X, None, None, nb, self.inf_factor, rbf_gamma=self.rbf_gamma, rec=rec,
+                                          method=self.method, defer_retry=True)
+                nk = burst
             e[3].record()
             fin()
             torch.cuda.synchronize()
             for name, a, b in zip(names, e[:-1], e[1:]):
-                acc[name] += a.elapsed_time(b)
+                acc[name] += a.elapsed_time(b) / (nk if name == "analysis_kernel" else 1)
         stage = {k: v / reps for k, v in acc.items()}
         return stage["analysis_kernel"], stage
