@@ -220,6 +220,33 @@ int mia_apply_weights_f64(const double* X, int64_t ldx, int m, int k, int64_t g0
                           const double* W, double* Xa, int64_t ldo, int64_t o0, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Observation-space preparation, the step immediately upstream of the analysis
+ * (AssimilationInterface._get_obs_space_variables, interface/base.py:359-379): from the ensemble in observation
+ * space hx [k][P] (row stride ldh) and the observations y [P] of one observation subset
+ *     mean_j = mean_i hx[i][j]              (state.split_mean_perts, base.py:367-369)
+ *     d      = (y  - mean) R^-1/2           (base.py:370-371, Observation.mul_rcinv, observation.py:290-295)
+ *     Yb[i]  = (hx[i] - mean) R^-1/2        (base.py:372)
+ * uncorr: R = diag(var), value * (1 / sqrt(var))                     (observation.py:241-245, 276-278)
+ * corr:   R = cov [P][P] (symmetric positive definite, lower triangle read), value @ inv(cholesky(R).T)
+ *         (observation.py:247-275) computed as a blocked Cholesky sweep over [R; values] - no inverse formed;
+ *         *info_opt (device) = 0, or j+1 if the leading minor of order j+1 is not positive definite.
+ * Outputs, each optional: Yb [k][P] (row stride ldy), d [P], rec [P][kp] = the packed records of
+ * mia_letkf_pack_obs_*.  Several subsets are stacked (base.py:374-377 _stack_obs) by pointing Yb/d/rec at the
+ * subset's offset inside the stacked arrays (ldy = total number of observations).
+ * ---------------------------------------------------------------------------------- */
+int mia_obs_space_uncorr_f32(const float* hx, int64_t ldh, const float* y, const float* var, int k, int64_t P,
+                             float* Yb_opt, int64_t ldy, float* d_opt, float* rec_opt, void* stream);
+int mia_obs_space_uncorr_f64(const double* hx, int64_t ldh, const double* y, const double* var, int k, int64_t P,
+                             double* Yb_opt, int64_t ldy, double* d_opt, double* rec_opt, void* stream);
+int mia_obs_space_corr_workspace_bytes(int k, int64_t P, int elem_bytes, size_t* bytes);
+int mia_obs_space_corr_f32(const float* hx, int64_t ldh, const float* y, const float* cov, int k, int64_t P,
+                           float* Yb_opt, int64_t ldy, float* d_opt, float* rec_opt, int32_t* info_opt,
+                           void* ws, size_t ws_bytes, void* stream);
+int mia_obs_space_corr_f64(const double* hx, int64_t ldh, const double* y, const double* cov, int k, int64_t P,
+                           double* Yb_opt, int64_t ldy, double* d_opt, double* rec_opt, int32_t* info_opt,
+                           void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * One assimilation step of one rank's block of grid points as ONE call (native driver; the per-step
  * orchestration of the entries above costs more host time than the GPU work it enqueues).
  *

@@ -280,3 +280,59 @@ def test_native_step_driver_through_real_rccl_single_rank(mia):
     finally:
         if own:
             dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------- observation-space preparation
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-13), (torch.float32, 2e-6)])
+@pytest.mark.parametrize("k,P", [(10, 40), (40, 1000), (7, 33), (80, 257)])
+def test_obs_space_uncorrelated_vs_oracle(mia, dtype, tol, k, P):
+    rnd = np.random.RandomState(k * 1000 + P)
+    hx = rnd.normal(size=(k, P)) + 3.0
+    y = rnd.normal(size=P) + 3.0
+    var = rnd.uniform(0.2, 4.0, size=P)
+    yb_ref, d_ref = O.obs_space_uncorr(hx, y, var)
+    eng = mia.LetkfEngine("cuda:0")
+    yb, d, rec = eng.obs_space(hx, y, var=var, dtype=dtype, want_rec=True)
+    assert rel_fro(yb.cpu().numpy(), yb_ref) < tol and rel_fro(d.cpu().numpy(), d_ref) < tol
+    # the records emitted by the same kernel are the packed form of (Yb, d), bit for bit
+    assert torch.equal(rec, eng.pack_obs(yb, d, dtype))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 2e-4)])
+@pytest.mark.parametrize("k,P", [(10, 40), (12, 31), (20, 200), (8, 97)])
+def test_obs_space_correlated_vs_oracle(mia, dtype, tol, k, P):
+    rnd = np.random.RandomState(k * 1000 + P)
+    hx = rnd.normal(size=(k, P)) + 1.0
+    y = rnd.normal(size=P) + 1.0
+    a = rnd.normal(size=(P, P))
+    xg = np.arange(P)
+    cov = np.exp(-np.abs(xg[:, None] - xg[None, :]) / 3.0) + 0.05 * (a @ a.T) / P + 0.1 * np.eye(P)
+    yb_ref, d_ref = O.obs_space_corr(hx, y, cov)
+    eng = mia.LetkfEngine("cuda:0")
+    yb, d, rec = eng.obs_space(hx, y, cov=cov, dtype=dtype, want_rec=True)
+    assert rel_fro(yb.cpu().numpy(), yb_ref) < tol and rel_fro(d.cpu().numpy(), d_ref) < tol
+    assert torch.equal(rec, eng.pack_obs(yb, d, dtype))
+    bad = cov.copy(); bad[P // 2, P // 2] = -1.0
+    with pytest.raises(ValueError):
+        eng.obs_space(hx, y, cov=bad, dtype=dtype)
+
+
+def test_obs_space_reference_fixture_and_stacking(mia, golden):
+    """The reference's own correlated-R fixture (yb, d generated by importing the reference, tools/gen_golden.py)
+    and the stacking of two subsets (one correlated, one uncorrelated) into one observation axis."""
+    g = golden("g6_reference_fixture_letkf.npz")
+    ti = int(g["time_index"])
+    hx, y, cov = g["state"][0, ti], g["obs"][ti], g["cov"]
+    f = mia.ETKF(inf_factor=1.1, dtype=torch.float64)
+    d, yb = f.get_obs_space_variables([hx], [y], covariances=[cov])
+    np.testing.assert_allclose(yb.cpu().numpy(), g["yb"], atol=1e-12)
+    np.testing.assert_allclose(d.cpu().numpy(), g["d"], atol=1e-12)
+    rnd = np.random.RandomState(3)
+    hx2, y2, var2 = rnd.normal(size=(hx.shape[0], 17)), rnd.normal(size=17), rnd.uniform(0.5, 2.0, size=17)
+    d_s, yb_s = f.get_obs_space_variables([hx, hx2], [y, y2], variances=[None, var2], covariances=[cov, None])
+    yb2, d2 = O.obs_space_uncorr(hx2, y2, var2)
+    np.testing.assert_allclose(yb_s.cpu().numpy(), np.concatenate([g["yb"], yb2], axis=1), atol=1e-12)
+    np.testing.assert_allclose(d_s.cpu().numpy(), np.concatenate([g["d"], d2]), atol=1e-12)
+    # ... and straight into the global ETKF of the fixture
+    w = f.estimate_weights_arrays(yb, d).cpu().numpy()
+    assert rel_fro(w, g["weights_global_1p1"]) < 1e-9

@@ -47,6 +47,11 @@ _PROTOS = {
     "mia_etkf_weights_f64": ([vp, vp, i32, i64, f64, vp, vp, vp, sz, vp], i32),
     "mia_apply_weights_f32": ([vp, i64, i32, i32, i64, i64, vp, vp, i64, i64, vp], i32),
     "mia_apply_weights_f64": ([vp, i64, i32, i32, i64, i64, vp, vp, i64, i64, vp], i32),
+    "mia_obs_space_uncorr_f32": ([vp, i64, vp, vp, i32, i64, vp, i64, vp, vp, vp], i32),
+    "mia_obs_space_uncorr_f64": ([vp, i64, vp, vp, i32, i64, vp, i64, vp, vp, vp], i32),
+    "mia_obs_space_corr_workspace_bytes": ([i32, i64, i32, C.POINTER(sz)], i32),
+    "mia_obs_space_corr_f32": ([vp, i64, vp, vp, i32, i64, vp, i64, vp, vp, vp, vp, sz, vp], i32),
+    "mia_obs_space_corr_f64": ([vp, i64, vp, vp, i32, i64, vp, i64, vp, vp, vp, vp, sz, vp], i32),
     "mia_comm_load": ([C.c_char_p], i32),
     "mia_comm_unique_id": ([vp], i32),
     "mia_comm_create": ([vp, i32, i32, C.POINTER(vp)], i32),

@@ -274,6 +274,68 @@ class LetkfEngine:
         _cabi.check(fn(_ptr(Yb), _ptr(d), k, P, _ptr(rec), self._stream()), "mia_letkf_pack_obs_" + sfx)
         return rec[:P]
 
+    def obs_space(self, hx, y, var=None, cov=None, dtype=None, out=None, offset: int = 0, want_rec: bool = False):
+        """Observation-space variables of ONE observation subset on the device
+        (AssimilationInterface._get_obs_space_variables, interface/base.py:359-379):
+        hx (k, P) ensemble in observation space, y (P,) observations and either var (P,) [uncorrelated R,
+        observation.py:241-245] or cov (P, P) [correlated R, observation.py:247-275].
+        Returns (Yb (k, P), d (P,)) [+ rec (P, kp) with ``want_rec``].  ``out=(Yb_all, d_all[, rec_all])`` with
+        ``offset`` writes into the subset's slice of the stacked arrays instead (base.py:374-377)."""
+        if (var is None) == (cov is None):
+            raise ValueError("give exactly one of var (uncorrelated R) and cov (correlated R)")
+        hx = torch.as_tensor(hx)
+        dtype = dtype or (hx.dtype if hx.dtype in (torch.float32, torch.float64) else torch.float64)
+        hx = hx.to(device=self.device, dtype=dtype).contiguous()
+        if hx.dim() != 2:
+            raise ValueError("hx must be (k, P)")
+        k, P = hx.shape
+        y = torch.as_tensor(y).to(device=self.device, dtype=dtype).contiguous().reshape(-1)
+        if y.shape[0] != P:
+            raise ValueError("Observational size between ensemble ({0:d}) and observations ({1:d}) do not match!".format(
+                P, y.shape[0]))
+        kp = (k + 1 + 3) // 4 * 4
+        if out is None:
+            Yb = torch.empty((k, P), dtype=dtype, device=self.device)
+            d = torch.empty(P, dtype=dtype, device=self.device)
+            rec = torch.empty((max(P, 1), kp), dtype=dtype, device=self.device) if want_rec else None
+            yb_v, d_v, rec_v, ldy = Yb, d, rec, P
+        else:
+            Yb, d = out[0], out[1]
+            rec = out[2] if len(out) > 2 else None
+            if Yb.dtype != dtype or d.dtype != dtype or not Yb.is_contiguous() or Yb.shape[0] != k:
+                raise ValueError("stacked outputs must be contiguous, of the working dtype and (k, P_total)")
+            if offset < 0 or offset + P > Yb.shape[1] or d.shape[0] != Yb.shape[1]:
+                raise ValueError("subset does not fit the stacked arrays")
+            ldy = Yb.shape[1]
+            yb_v, d_v = Yb[:, offset:], d[offset:]
+            rec_v = rec[offset:] if rec is not None else None
+        sfx = "f32" if dtype == torch.float32 else "f64"
+        if var is not None:
+            var = torch.as_tensor(var).to(device=self.device, dtype=dtype).contiguous().reshape(-1)
+            if var.shape[0] != P:
+                raise ValueError("var must have one entry per observation")
+            fn = getattr(self.lib, "mia_obs_space_uncorr_" + sfx)
+            _cabi.check(fn(_ptr(hx), P, _ptr(y), _ptr(var), k, P, _ptr(yb_v), ldy, _ptr(d_v), _ptr(rec_v),
+                           self._stream()), "mia_obs_space_uncorr_" + sfx)
+        else:
+            cov = torch.as_tensor(cov).to(device=self.device, dtype=dtype).contiguous()
+            if cov.shape != (P, P):
+                raise ValueError("cov must be (P, P)")
+            nbytes = C.c_size_t(0)
+            _cabi.check(self.lib.mia_obs_space_corr_workspace_bytes(k, P, 4 if dtype == torch.float32 else 8,
+                                                                    C.byref(nbytes)), "obs_space_corr_workspace_bytes")
+            ws = self._workspace("obs_corr", nbytes.value)
+            info = torch.zeros(1, dtype=torch.int32, device=self.device)
+            fn = getattr(self.lib, "mia_obs_space_corr_" + sfx)
+            _cabi.check(fn(_ptr(hx), P, _ptr(y), _ptr(cov), k, P, _ptr(yb_v), ldy, _ptr(d_v), _ptr(rec_v), _ptr(info),
+                           _ptr(ws), ws.numel(), self._stream()), "mia_obs_space_corr_" + sfx)
+            bad = int(info.item())
+            if bad:        # numpy.linalg.cholesky raises LinAlgError here (observation.py:249)
+                raise ValueError("observation covariance is not positive definite (leading minor of order %d)" % bad)
+        if out is not None:
+            return None
+        return (Yb, d, rec[:P]) if want_rec else (Yb, d)
+
     MATFUN_MAX_ROWS = 4     # state rows per grid point up to which the eigensolver-free route is preferred
 
     def analysis(self, X: torch.Tensor, Yb: Optional[torch.Tensor], d: Optional[torch.Tensor],

@@ -100,6 +100,28 @@ class ETKF:
             return KETKFModule(self._kernel, self.inf_factor, self.engine)(self._dev(yb), self._dev(d))
         return self.engine.etkf_weights(self._dev(yb), self._dev(d), self.inf_factor)
 
+    def get_obs_space_variables(self, ens_obs, observations, variances=None, covariances=None):
+        """Array-level ``_get_obs_space_variables`` (interface/base.py:359-379) on the device: for every
+        observation subset j, ``ens_obs[j]`` (k, P_j) = H_j(x) of the ensemble, ``observations[j]`` (P_j,) and
+        its R as ``variances[j]`` (P_j,) (uncorrelated, observation.py:241-245) or ``covariances[j]``
+        (P_j, P_j) (correlated, observation.py:247-275; None entries fall back to the variance).
+        Returns the stacked (innovations (P,), ens_obs_perts (k, P)) -- the order of the reference's return."""
+        n = len(ens_obs)
+        if len(observations) != n:
+            raise ValueError("one observation vector per ensemble-in-observation-space array")
+        sizes = [int(torch.as_tensor(h).shape[-1]) for h in ens_obs]
+        k = int(torch.as_tensor(ens_obs[0]).shape[0])
+        total = sum(sizes)
+        Yb = torch.empty((k, total), dtype=self.dtype, device=self.engine.device)
+        d = torch.empty(total, dtype=self.dtype, device=self.engine.device)
+        off = 0
+        for j in range(n):
+            cov = covariances[j] if covariances is not None else None
+            var = variances[j] if (variances is not None and cov is None) else None
+            self.engine.obs_space(ens_obs[j], observations[j], var=var, cov=cov, dtype=self.dtype, out=(Yb, d), offset=off)
+            off += sizes[j]
+        return d, Yb
+
     def analyse_arrays(self, state, yb, d, **_unused) -> torch.Tensor:
         """state (..., k, G) -> analysis of the same shape: weights + _apply_weights (base.py:257-278)."""
         st = self._dev(state)
