@@ -50,6 +50,10 @@ extern "C" {
 /* bits 8-15: Jacobi sweeps started, bits 16-31: tournament rounds that rotated (diagnostics) */
 #define MIA_FLAG_MASK 0xff
 
+/* taper of the localisation */
+#define MIA_TAPER_GC 0     /* GaspariCohn,    pytassim/localization/gaspari_cohn.py:40-136 */
+#define MIA_TAPER_GC_INF 1 /* GaspariCohnInf, pytassim/localization/gaspari_cohn.py:139-254 (one radius) */
+
 #define MIA_MAX_COORD 3
 #define MIA_MAX_RADII 3
 
@@ -63,6 +67,10 @@ const char* mia_status_string(int status);
  * ---------------------------------------------------------------------------------- */
 int mia_gaspari_cohn_f64(const double* r, int64_t n, double* w, void* stream);
 int mia_gaspari_cohn_f32(const float* r, int64_t n, float* w, void* stream);
+/* Form-factor-infinity variant: GaspariCohnInf._f1.._f4 and the branch assembly of
+ * gaspari_cohn.py:176-215,244-251 (thresholds 0.5, 1, 1.5, 2, strict `<`). */
+int mia_gaspari_cohn_inf_f64(const double* r, int64_t n, double* w, void* stream);
+int mia_gaspari_cohn_inf_f32(const float* r, int64_t n, float* w, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Localisation: for every grid point g in [g0, g1) the list of observations with
@@ -91,6 +99,13 @@ int mia_letkf_localize_f64(const double* grid_xyz, int64_t g0, int64_t g1,
                            int p_cap, int32_t* nbr_cnt, int32_t* nbr_idx, double* nbr_w,
                            int32_t* stats, void* ws, size_t ws_bytes, void* stream);
 
+/* The same with the taper selectable (MIA_TAPER_*): GaspariCohnInf.localize_obs, gaspari_cohn.py:217-254. */
+int mia_letkf_localize_taper_f64(int taper, const double* grid_xyz, int64_t g0, int64_t g1,
+                                 const double* obs_xyz, int64_t P, int n_coord,
+                                 const int32_t* coord_group /* host */, const double* gc_c /* host */, int n_r,
+                                 double gc_eps, int p_cap, int32_t* nbr_cnt, int32_t* nbr_idx, double* nbr_w,
+                                 int32_t* stats, void* ws, size_t ws_bytes, void* stream);
+
 /* The observation cell index alone (what mia_letkf_localize_f64 builds first), for the fused route below. */
 int mia_letkf_index_build_f64(const double* obs_xyz, int64_t P, int n_coord,
                               const int32_t* coord_group /* host */, const double* gc_c /* host */, int n_r,
@@ -103,6 +118,11 @@ int mia_letkf_localize_from_dist_f64(const double* dist, const int32_t* cand_idx
                                      int p_cap, const double* gc_c /* host */, int n_r,
                                      double gc_eps, int32_t* nbr_cnt, int32_t* nbr_idx,
                                      double* nbr_w, int32_t* stats, void* stream);
+
+int mia_letkf_localize_from_dist_taper_f64(int taper, const double* dist, const int32_t* cand_idx, int64_t n_pts,
+                                           int p_cap, const double* gc_c /* host */, int n_r,
+                                           double gc_eps, int32_t* nbr_cnt, int32_t* nbr_idx,
+                                           double* nbr_w, int32_t* stats, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Local analysis for grid points [g0, g1): mask & sqrt(rho)-scale (wrapper.py:91-97),
@@ -203,6 +223,50 @@ int mia_lketkf_rbf_analysis_f64(const double* X, int64_t ldx, int m, int k, int6
                                 int p_cap, int p_max, double inf_factor, double gamma,
                                 double* Xa, int64_t ldo, int64_t o0, double* W_opt, int32_t* flags_opt,
                                 void* ws, size_t ws_bytes, void* stream);
+
+/* Any other reference kernel, and the compositions of pytassim/kernels/base_kernels.py:61-161, as a kernel
+ * EXPRESSION in reverse Polish form evaluated per element of K(Yb, Yb) and K(Yb, d) inside the analysis kernel.
+ * Every reference kernel is a function of three pair statistics of two rows x, y of the localised block:
+ *   x.y (kernels/utils.py:38-58), |x - y|_2^2 (utils.py:93-110), |x - y|_1 (utils.py:61-90, norm = 1):
+ *   LinearKernel   linear.py:66-67       DOT
+ *   PolyKernel     polynomial.py:78-81   DOT CONST(c) ADD CONST(p) POW
+ *   TanhKernel     tanh.py:82-86         DOT CONST(a) MUL CONST(c) ADD TANH
+ *   GaussKernel    rbf.py:75-81          SQDIST CONST(-1/(2 l^2)) MUL EXP        (scalar lengthscale)
+ *   RationalKernel rational.py:81-87     SQDIST CONST(1/(2 a l^2)) MUL CONST(1) ADD CONST(-a) POW
+ *   PeriodicKernel periodic.py:81-84     L1DIST CONST(pi/p) MUL SIN CONST(2) POW CONST(-2/l^2) MUL EXP
+ *   OrnsteinUhlenbeckKernel orn_uhl.py:72-75   L1DIST CONST(-1/l) MUL EXP
+ *   ScaleKernel    scale.py:70-73        CONST(c)
+ *   DiagKernel     diag.py:64-72         DIAG(c)   (c where x and y are the same sample of a square Gram, else 0)
+ *   Additive / Multiplicative / PowerKernel   base_kernels.py:98-161   <k1> <k2> ADD | MUL | POW
+ * Same argument meaning as mia_letkf_analysis_packed_*; prog is a HOST array. */
+#define MIA_KOP_DOT 1
+#define MIA_KOP_SQDIST 2
+#define MIA_KOP_L1DIST 3
+#define MIA_KOP_CONST 4 /* push value */
+#define MIA_KOP_DIAG 5  /* push value on the diagonal of K(Yb, Yb), 0 elsewhere and in K(Yb, d) */
+#define MIA_KOP_ADD 6   /* binary operators pop y, pop x, push x op y */
+#define MIA_KOP_MUL 7
+#define MIA_KOP_POW 8
+#define MIA_KOP_EXP 9   /* unary operators replace the top */
+#define MIA_KOP_TANH 10
+#define MIA_KOP_SIN 11
+#define MIA_KERNEL_MAX_OPS 24
+#define MIA_KERNEL_MAX_DEPTH 6
+typedef struct { int32_t op; int32_t reserved; double value; } mia_kernel_op_t;
+int mia_lketkf_kernel_analysis_packed_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                          const float* rec, int64_t P,
+                                          const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w,
+                                          int p_cap, int p_max, float inf_factor,
+                                          const mia_kernel_op_t* prog /* host */, int n_ops,
+                                          float* Xa, int64_t ldo, int64_t o0, float* W_opt, int32_t* flags_opt,
+                                          void* stream);
+int mia_lketkf_kernel_analysis_packed_f64(const double* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                          const double* rec, int64_t P,
+                                          const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w,
+                                          int p_cap, int p_max, double inf_factor,
+                                          const mia_kernel_op_t* prog /* host */, int n_ops,
+                                          double* Xa, int64_t ldo, int64_t o0, double* W_opt, int32_t* flags_opt,
+                                          void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Global (unlocalised) ETKF: one (k, P) solve, ETKF.estimate_weights

@@ -57,6 +57,26 @@ def test_argument_validation_precedes_any_device_work(lib):
     assert lib.mia_gaspari_cohn_f64(None, -1, None, None) == -2
     assert lib.mia_gaspari_cohn_f64(None, 0, None, None) == 0
     assert lib.mia_gaspari_cohn_f32(None, 5, None, None) == -1
+    assert lib.mia_gaspari_cohn_inf_f64(None, -1, None, None) == -2
+    assert lib.mia_gaspari_cohn_inf_f32(None, 5, None, None) == -1
+    # kernel expressions are validated on the host: NULL program, unknown opcode, operator without operands,
+    # two values left on the stack, deeper than the device's operand stack
+    from torch_assimilate_amd._cabi import KernelOp
+    def prog(*ops):
+        arr = (KernelOp * len(ops))()
+        for i, (op, val) in enumerate(ops):
+            arr[i].op, arr[i].value = op, val
+        return arr
+    def call(p, n):
+        return lib.mia_lketkf_kernel_analysis_packed_f64(None, 10, 1, 4, 0, 5, None, 0, None, None, None, 8, 8, 1.0,
+                                                         p, n, None, 10, 0, None, None, None)
+    assert call(None, 1) == -1
+    assert call(prog((99, 0.0)), 1) == -2
+    assert call(prog((6, 0.0)), 1) == -2
+    assert call(prog((1, 0.0), (2, 0.0)), 2) == -2
+    assert call(prog(*[(4, 1.0)] * 7 + [(6, 0.0)] * 6), 13) == -3
+    assert call(prog((1, 0.0), (4, 1.0), (6, 0.0)), 3) == -1          # well formed: fails later, on the NULL state
+    assert lib.mia_letkf_localize_from_dist_taper_f64(7, None, None, 0, 8, None, 1, 1e-5, None, None, None, None, None) == -2
     assert lib.mia_apply_weights_f32(None, 10, 1, 1, 0, 5, None, None, 10, 0, None) == -2     # k < 2
     assert lib.mia_apply_weights_f32(None, 10, 1, 4, 0, 0, None, None, 10, 0, None) == 0      # empty shard
     assert lib.mia_apply_weights_f32(None, 10, 1, 4, 0, 5, None, None, 10, 0, None) == -1

@@ -1,0 +1,128 @@
+"""GPU parity for SURVEY.md section 8 rows f2 / f4: the form-factor-infinity Gaspari-Cohn taper
+(GaspariCohnInf, gaspari_cohn.py:139-254) and every reference kernel / kernel composition through the
+kernel-expression route of the fused analysis kernel, against golden vectors the reference itself produced
+(tests/golden/g8_kernels_gcinf.npz, tools/gen_golden.py) and against the CPU oracle.
+
+Tolerances: float64 <= 1e-9 on weights (kernel matrices go through exp / pow / tanh / sin whose device
+implementations differ from libm in the last ulps, amplified by the (k-1)/inf-regularised inverse), float32
+<= 1e-5 relative Frobenius error on the analysis ensemble (BASELINE.json north_star) and <= 5e-5 on raw weights.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_fro
+from kernel_cases import KERNEL_NAMES, oracle_kernels, product_kernels
+from oracle import letkf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mia():
+    import torch_assimilate_amd as m
+    m.build()
+    return m
+
+
+@pytest.fixture(scope="module")
+def eng(mia):
+    return mia.LetkfEngine("cuda:0")
+
+
+def dev(a, dtype):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(device="cuda:0", dtype=dtype)
+
+
+def test_gaspari_cohn_inf_taper(eng, golden):
+    g = golden("g8_kernels_gcinf.npz")
+    r = g["r"]
+    w64 = eng.gaspari_cohn(dev(r, torch.float64), taper=1).cpu().numpy()
+    np.testing.assert_allclose(w64, g["inf_w_c1.0"], rtol=0, atol=2e-14)
+    assert w64[r >= 2.0].max() == 0.0 and w64[r == 0.0].min() == 1.0
+    w32 = eng.gaspari_cohn(dev(r, torch.float32), taper=1).cpu().numpy()
+    np.testing.assert_allclose(w32, g["inf_w_c1.0"], rtol=0, atol=5e-6)
+    # NaN distance -> weight 0 (every comparison of gaspari_cohn.py:244 is False)
+    assert eng.gaspari_cohn(dev([np.nan], torch.float64), taper=1).item() == 0.0
+
+
+def test_gaspari_cohn_inf_localize_obs_api(mia, golden):
+    g = golden("g8_kernels_gcinf.npz")
+    r = g["r"]
+    loc = mia.GaspariCohnInf(10.0, lambda gi, o: np.abs(o - gi))
+    use, w = loc.localize_obs(0.0, r * 10.0)
+    np.testing.assert_array_equal(use, g["inf_use_c10.0"])
+    np.testing.assert_allclose(w, g["inf_w_c10.0"], rtol=0, atol=2e-14)
+
+
+@pytest.mark.parametrize("nc,groups", [(1, [0]), (2, [0, 0])])
+def test_gcinf_cell_index_lists_match_oracle_mask(eng, nc, groups):
+    rs = np.random.RandomState(5)
+    grid, obs = rs.uniform(0, 1, size=(300, nc)), rs.uniform(0, 1, size=(700, nc))
+    c = 0.06
+    nb = eng.localize(grid, obs, [c], groups, taper=1)
+    cnt, idx, w = nb.cnt.cpu().numpy(), nb.idx.cpu().numpy(), nb.w.cpu().numpy()
+    for gi in range(len(grid)):
+        dist = O.grouped_euclid_distance(grid[gi], obs, groups, 1)[0]
+        use, wt = O.localize_obs(dist, c, taper="gc_inf")
+        ref = np.nonzero(use)[0]
+        assert cnt[gi] == len(ref)
+        order = np.argsort(idx[gi, :cnt[gi]])
+        np.testing.assert_array_equal(idx[gi, :cnt[gi]][order], ref)
+        np.testing.assert_allclose(w[gi, :cnt[gi]][order] ** 2, wt[ref], rtol=1e-12, atol=1e-13)   # cancellation in the polynomials near r = 2
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 1e-5)])
+def test_letkf_under_gaspari_cohn_inf_vs_reference(mia, golden, dtype, tol):
+    g = golden("g8_kernels_gcinf.npz")
+    for metric in (mia.AbsoluteDistance(), lambda gi, o: np.abs(np.asarray(o).reshape(-1) - np.asarray(gi).reshape(-1)[-1])):
+        a = mia.LETKF(localization=mia.GaspariCohnInf(10.0, metric), inf_factor=1.1, dtype=dtype)
+        xa = a.analyse_arrays(g["loc_state"], g["loc_yb"], g["loc_d"], grid_coords=g["loc_grid_x"],
+                              obs_coords=g["loc_obs_x"])
+        assert rel_fro(xa.cpu().numpy(), g["letkf_gcinf_analysis"]) < tol
+        W = a.estimate_weights_arrays(g["loc_yb"], g["loc_d"], grid_coords=g["loc_grid_x"], obs_coords=g["loc_obs_x"])
+        assert rel_fro(W.cpu().numpy()[::8], g["letkf_gcinf_weights"]) < 5 * tol
+
+
+@pytest.mark.parametrize("name", KERNEL_NAMES)
+def test_ketkf_every_kernel_vs_reference(mia, golden, name):
+    g = golden("g8_kernels_gcinf.npz")
+    kern = product_kernels()[name]
+    for bi in range(len(g["blocks"])):
+        for inf in (1.0, 1.1):
+            ref = g[f"ketkf_{name}_{bi}_{str(inf).replace('.', 'p')}"]
+            mod = mia.KETKFModule(kern, inf)
+            w64 = mod(torch.tensor(g[f"yb_{bi}"]), torch.tensor(g[f"d_{bi}"])).cpu().numpy()
+            assert rel_fro(w64, ref) < 1e-9, (name, bi, inf)
+            w32 = mod(torch.tensor(g[f"yb_{bi}"], dtype=torch.float32),
+                      torch.tensor(g[f"d_{bi}"], dtype=torch.float32)).cpu().numpy()
+            assert rel_fro(w32, ref) < 5e-5, (name, bi, inf)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 1e-5)])
+@pytest.mark.parametrize("name", ["poly2", "ornuhl"])
+def test_lketkf_expression_route_vs_reference(mia, golden, name, dtype, tol):
+    g = golden("g8_kernels_gcinf.npz")
+    a = mia.LKETKF(product_kernels()[name], localization=mia.GaspariCohn(10.0, mia.AbsoluteDistance()),
+                   inf_factor=1.1, dtype=dtype)
+    xa = a.analyse_arrays(g["loc_state"], g["loc_yb"], g["loc_d"], grid_coords=g["loc_grid_x"],
+                          obs_coords=g["loc_obs_x"])
+    assert rel_fro(xa.cpu().numpy(), g[f"lketkf_{name}_analysis"]) < tol
+    W = a.estimate_weights_arrays(g["loc_yb"], g["loc_d"], grid_coords=g["loc_grid_x"], obs_coords=g["loc_obs_x"])
+    assert rel_fro(W.cpu().numpy()[::8], g[f"lketkf_{name}_weights"]) < 5 * tol
+
+
+def test_expression_route_agrees_with_the_specialised_rbf_and_linear_kernels(mia, eng):
+    """the RBF and linear kernels written as expressions must reproduce the specialised routes"""
+    from torch_assimilate_amd import kernels as K
+    case = O.synthetic_case(200, 40, 2, seed=3)
+    nb = eng.localize(case["grid_x"], case["obs_x"], [10.0])
+    X, yb, d = (dev(case[n], torch.float64) for n in ("state", "yb", "d"))
+    ref_rbf = eng.analysis(X, yb, d, nb, 1.1, rbf_gamma=0.5)
+    got_rbf = eng.analysis(X, yb, d, nb, 1.1, kernel_program=K.RBFKernel(0.5).program())
+    assert rel_fro(got_rbf.cpu().numpy(), ref_rbf.cpu().numpy()) < 1e-12
+    ref_lin = eng.analysis(X, yb, d, nb, 1.1)
+    got_lin = eng.analysis(X, yb, d, nb, 1.1, kernel_program=K.LinearKernel().program())
+    assert rel_fro(got_lin.cpu().numpy(), ref_lin.cpu().numpy()) < 1e-9      # KETKF(linear) == ETKF
+    with pytest.raises(ValueError):
+        eng.analysis(X, yb, d, nb, 1.1, rbf_gamma=0.5, kernel_program=K.PolyKernel().program())

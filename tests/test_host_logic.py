@@ -53,7 +53,76 @@ def test_interface_constructor_surface():
     assert a.inf_factor == 1.3
     assert repr(mia.ETKF(1.0)) == "ETKF(1.0)"
     k = mia.LKETKF(mia.RBFKernel(0.5), localization=loc)
-    assert k._gamma == 0.5
+    assert k._kernel_args() == dict(rbf_gamma=0.5, kernel_program=None)
     k.kernel = mia.LinearKernel()
-    assert k._gamma is None
-    assert mia.KETKF(mia.GaussKernel(2.0))._gamma == pytest.approx(0.125)
+    assert k._kernel_args() == dict(rbf_gamma=None, kernel_program=None)
+    assert mia.KETKF(mia.GaussKernel(2.0))._kernel_args()["rbf_gamma"] == pytest.approx(0.125)
+    k.kernel = mia.PolyKernel(2.0, 1.0)
+    assert k._kernel_args()["rbf_gamma"] is None and len(k._kernel_args()["kernel_program"]) == 5
+    inf = mia.GaspariCohnInf(10.0, mia.AbsoluteDistance())
+    assert str(inf) == "GaspariCohnInf(l=[10.])" and repr(inf) == "GaspariCohnInf" and inf._thres == [2, 1.5, 1, 0.5]
+    with pytest.raises(ValueError):
+        mia.GaspariCohnInf((10.0, 2.0), mia.AbsoluteDistance())
+
+
+def run_program(prog, dot, sq, l1, same):
+    """Pure-Python evaluator of a kernel expression with the device's semantics (csrc/letkf_wave.hip kprog_eval)."""
+    from torch_assimilate_amd import kernels as K
+    st = []
+    for op, val in prog:
+        if op == K.KOP_DOT:
+            st.append(dot)
+        elif op == K.KOP_SQDIST:
+            st.append(sq)
+        elif op == K.KOP_L1DIST:
+            st.append(l1)
+        elif op == K.KOP_CONST:
+            st.append(np.full_like(dot, val))
+        elif op == K.KOP_DIAG:
+            st.append(np.where(same, val, 0.0))
+        elif op in (K.KOP_ADD, K.KOP_MUL, K.KOP_POW):
+            y, x = st.pop(), st.pop()
+            st.append(x + y if op == K.KOP_ADD else (x * y if op == K.KOP_MUL else np.power(x, y)))
+        elif op == K.KOP_EXP:
+            st.append(np.exp(st.pop()))
+        elif op == K.KOP_TANH:
+            st.append(np.tanh(st.pop()))
+        elif op == K.KOP_SIN:
+            st.append(np.sin(st.pop()))
+        else:
+            raise AssertionError(op)
+    assert len(st) == 1
+    return st[0]
+
+
+def test_kernel_programs_reproduce_the_reference_kernels(golden):
+    """every kernel descriptor's expression, evaluated on the three pair statistics, gives the kernel matrices the
+    reference's kernel classes produced (golden g8: K(x, x) and K(x, y) with a single y row, as in the KETKF)."""
+    import torch
+    from kernel_cases import product_kernels, oracle_kernels
+    from torch_assimilate_amd import kernels as K
+    g = golden("g8_kernels_gcinf.npz")
+    x, y = g["kern_x"], g["kern_y"]
+    for name, kern in product_kernels().items():
+        gamma, prog = K.kernel_route(kern)
+        assert gamma is None and prog
+        for other, same, key in ((x, np.eye(len(x), dtype=bool), "kxx"), (y, np.zeros((len(x), len(y)), bool), "kxy")):
+            diff = x[:, None, :] - other[None, :, :]
+            got = run_program(prog, x @ other.T, (diff ** 2).sum(-1), np.abs(diff).sum(-1), same)
+            np.testing.assert_allclose(got, g[f"{key}_{name}"], rtol=1e-12, atol=1e-13, err_msg=name)
+        ora = oracle_kernels()[name](torch.tensor(x), torch.tensor(x)).numpy()
+        np.testing.assert_allclose(ora, g[f"kxx_{name}"], rtol=1e-13, atol=1e-13)
+    assert K.kernel_route(None) == (None, None) and K.kernel_route(K.LinearKernel()) == (None, None)
+    assert K.kernel_route(K.RBFKernel(10.0)) == (10.0, None)
+    with pytest.raises(NotImplementedError):
+        K.kernel_route(torch.nn.Linear(2, 2))          # ModuleKernel-style user code is not mirrored
+    with pytest.raises(NotImplementedError):
+        K.GaussKernel(torch.ones(3))                    # per-feature lengthscale
+    with pytest.raises(TypeError):
+        K.PolyKernel() + 3.0
+    deep = K.ScaleKernel(1.0)
+    for _ in range(12):
+        deep = deep + K.PolyKernel()
+    with pytest.raises(ValueError):
+        K.kernel_route(deep)                            # more operations than the device evaluates
+    assert str(K.PolyKernel(2.0, 1.0) + K.RBFKernel(0.5)) == "PolynomialKernel(2.0, 1.0)+RBFKernel(γ=0.5)"

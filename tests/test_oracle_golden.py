@@ -122,3 +122,47 @@ def test_g7_c1_global(golden):
         ana, w = O.etkf_analysis(st, g["c1_yb"], g["c1_d"], inf)
         assert rel_fro(w, g[f"{tag}_weights"][0]) < 1e-10
         assert rel_fro(ana, g[f"{tag}_analysis"]) < 1e-10
+
+
+def test_g8_gaspari_cohn_inf(golden):
+    g = golden("g8_kernels_gcinf.npz")
+    r = g["r"]
+    with np.errstate(all="ignore"):
+        for i, fn in enumerate((O.gc_inf_f1, O.gc_inf_f2, O.gc_inf_f3, O.gc_inf_f4)):
+            np.testing.assert_array_equal(fn(r[r > 0]), g[f"inf_f{i + 1}"])
+    for c in (1.0, 10.0):
+        use, w = O.localize_obs(r * c, c, taper="gc_inf")
+        np.testing.assert_array_equal(use, g[f"inf_use_c{c}"])
+        np.testing.assert_array_equal(w, g[f"inf_w_c{c}"])
+    # C_0(0) = 1, continuity at the three inner knots, compact support
+    w = O.gaspari_cohn_inf(np.array([0.0, 0.5 - 1e-12, 0.5, 1 - 1e-12, 1.0, 1.5 - 1e-12, 1.5, 2.0]))
+    assert w[0] == 1.0 and w[-1] == 0.0
+    np.testing.assert_allclose(w[1::2][:3], w[2::2][:3], atol=1e-10)
+
+
+def test_g8_kernels_and_ketkf(golden):
+    from kernel_cases import oracle_kernels
+    g = golden("g8_kernels_gcinf.npz")
+    x, y = torch.tensor(g["kern_x"]), torch.tensor(g["kern_y"])
+    for name, kern in oracle_kernels().items():
+        np.testing.assert_allclose(kern(x, x).numpy(), g[f"kxx_{name}"], rtol=1e-13, atol=1e-13, err_msg=name)
+        np.testing.assert_allclose(kern(x, y).numpy(), g[f"kxy_{name}"], rtol=1e-13, atol=1e-13, err_msg=name)
+        for bi in range(len(g["blocks"])):
+            for inf in (1.0, 1.1):
+                tag = f"{name}_{bi}_{str(inf).replace('.', 'p')}"
+                got = O.ketkf_weights(g[f"yb_{bi}"], g[f"d_{bi}"], kern, inf).numpy()
+                assert rel_fro(got, g[f"ketkf_{tag}"]) < 1e-10, tag
+
+
+def test_g8_localised(golden):
+    from kernel_cases import oracle_kernels
+    g = golden("g8_kernels_gcinf.npz")
+    st, gx, ox, yb, d = g["loc_state"], g["loc_grid_x"], g["loc_obs_x"], g["loc_yb"], g["loc_d"]
+    kerns = oracle_kernels()
+    for tag, core, taper in (
+            ("lketkf_poly2", lambda a, b, inf: O.ketkf_weights(a, b, kerns["poly2"], inf), "gc"),
+            ("lketkf_ornuhl", lambda a, b, inf: O.ketkf_weights(a, b, kerns["ornuhl"], inf), "gc"),
+            ("letkf_gcinf", O.etkf_weights, "gc_inf")):
+        ana, w = O.letkf_analysis(st, gx, ox, yb, d, 10.0, 1.1, core=core, taper=taper)
+        assert rel_fro(w[::8], g[f"{tag}_weights"]) < 1e-10, tag
+        assert rel_fro(ana, g[f"{tag}_analysis"]) < 1e-10, tag

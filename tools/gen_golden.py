@@ -42,6 +42,8 @@ def import_reference():
         linear=importlib.import_module("pytassim.kernels.linear"),
         wrapper=importlib.import_module("pytassim.interface.wrapper"),
     )
+    for name in ("polynomial", "tanh", "periodic", "rational", "orn_uhl", "scale", "diag", "base_kernels"):
+        mods[name] = importlib.import_module("pytassim.kernels." + name)
     return mods
 
 
@@ -194,6 +196,59 @@ def main():
             g7[f"{tag}_weights"] = w[widx]
             g7[f"{tag}_analysis"] = apply_weights(st, w)
     np.savez_compressed(os.path.join(OUT, "g7_synthetic_configs.npz"), **g7)
+    # ---- G8: rows f2 / f4 of SURVEY.md section 8: GaspariCohnInf and the remaining kernels + compositions
+    GaspariCohnInf = R["gc"].GaspariCohnInf
+    g8 = {"r": r}
+    with np.errstate(all="ignore"):
+        for i, fn in enumerate((GaspariCohnInf._f1, GaspariCohnInf._f2, GaspariCohnInf._f3, GaspariCohnInf._f4)):
+            g8[f"inf_f{i + 1}"] = fn(r[r > 0].copy())
+    for c in (1.0, 10.0):
+        gci = GaspariCohnInf(c, dist_func=lambda g, o: np.abs(o - g))
+        use, w = gci.localize_obs(0.0, r * c)
+        g8[f"inf_use_c{c}"], g8[f"inf_w_c{c}"] = use, w
+    kernels = dict(
+        poly2=R["polynomial"].PolyKernel(t64(2.0), t64(1.0)),
+        poly3=R["polynomial"].PolyKernel(t64(3.0), t64(0.5)),
+        tanh=R["tanh"].TanhKernel(t64(0.05), t64(0.1)),
+        periodic=R["periodic"].PeriodicKernel(t64(7.0), t64(1.5)),
+        rational=R["rational"].RationalKernel(t64(2.0), t64(1.5)),
+        ornuhl=R["orn_uhl"].OrnsteinUhlenbeckKernel(t64(6.0)),
+    )
+    kernels["rbf_plus_diag"] = RBFKernel(t64(0.5)) + R["diag"].DiagKernel(t64(0.3))
+    kernels["scale_times_rbf"] = R["scale"].ScaleKernel(t64(2.5)) * GaussKernel(t64(2.0))
+    kernels["linear_plus_scale"] = LinearKernel() + R["scale"].ScaleKernel(t64(0.7))
+    kernels["rational_pow_scale"] = R["rational"].RationalKernel(t64(1.0), t64(1.0)) ** R["scale"].ScaleKernel(t64(2.0))
+    kernels["poly_plus_ornuhl_times_scale"] = (R["polynomial"].PolyKernel(t64(2.0), t64(1.0))
+                                               + R["orn_uhl"].OrnsteinUhlenbeckKernel(t64(4.0)) * R["scale"].ScaleKernel(t64(3.0)))
+    rk = np.random.RandomState(7)
+    xk, yk = rk.normal(size=(6, 4)), rk.normal(size=(1, 4))
+    g8["kern_x"], g8["kern_y"] = xk, yk
+    blocks = [(40, 20), (10, 40), (20, 7)]
+    for bi, (k, p) in enumerate(blocks):
+        yb = rk.normal(size=(k, p)) * 0.6
+        yb -= yb.mean(axis=0)
+        g8[f"yb_{bi}"], g8[f"d_{bi}"] = yb, rk.normal(size=(p,)) * 0.6
+    g8["blocks"] = np.array(blocks)
+    for name, kern in kernels.items():
+        g8[f"kxx_{name}"] = kern(t64(xk), t64(xk)).numpy()
+        g8[f"kxy_{name}"] = kern(t64(xk), t64(yk)).numpy()
+        for bi in range(len(blocks)):
+            for inf in (1.0, 1.1):
+                tag = f"{name}_{bi}_{str(inf).replace('.', 'p')}"
+                g8[f"ketkf_{tag}"] = KETKFModule(kern, t64(inf))(t64(g8[f"yb_{bi}"]), t64(g8[f"d_{bi}"])).numpy()
+    # localised: LKETKF with a polynomial kernel and LETKF under GaspariCohnInf, G = 64 (synthetic recipe of G7)
+    st, gx, ox, yb, dd = synth(64, 40, 2, seed=11)
+    g8.update(loc_state=st, loc_grid_x=gx, loc_obs_x=ox, loc_yb=yb, loc_d=dd)
+    for tag, core, loc in (
+            ("lketkf_poly2", KETKFModule(kernels["poly2"], t64(1.1)), GaspariCohn(10.0, lambda g, o: np.abs(o - g[1]))),
+            ("lketkf_ornuhl", KETKFModule(kernels["ornuhl"], t64(1.1)), GaspariCohn(10.0, lambda g, o: np.abs(o - g[1]))),
+            ("letkf_gcinf", ETKFModule(t64(1.1)), GaspariCohnInf(10.0, lambda g, o: np.abs(o - g[1])))):
+        f_loc = wrapper_localization(wrapper_bridge(core, torch.device("cpu"), torch.float64), loc)
+        w = np.stack([f_loc(np.array([0.0, x]), yb, dd, obs_info=ox) for x in gx])
+        g8[f"{tag}_weights"] = w[::8]
+        g8[f"{tag}_analysis"] = apply_weights(st, w)
+    np.savez_compressed(os.path.join(OUT, "g8_kernels_gcinf.npz"), **g8)
+
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
 

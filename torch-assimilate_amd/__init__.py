@@ -13,7 +13,11 @@ _LAZY = {
     "GaspariCohn": "localization", "EuclideanMetric": "localization", "AbsoluteDistance": "localization",
     "ETKFModule": "core", "KETKFModule": "core",
     "LETKF": "interface", "ETKF": "interface", "LKETKF": "interface", "KETKF": "interface",
-    "RBFKernel": "kernels", "GaussKernel": "kernels", "LinearKernel": "kernels",
+    "GaspariCohnInf": "localization",
+    "RBFKernel": "kernels", "GaussKernel": "kernels", "LinearKernel": "kernels", "PolyKernel": "kernels",
+    "TanhKernel": "kernels", "PeriodicKernel": "kernels", "RationalKernel": "kernels",
+    "OrnsteinUhlenbeckKernel": "kernels", "ScaleKernel": "kernels", "DiagKernel": "kernels",
+    "AdditiveKernel": "kernels", "MultiplicativeKernel": "kernels", "PowerKernel": "kernels",
     "ShardedLetkf": "sharded", "block_partition": "sharded", "gather_blocks": "sharded",
 }
 

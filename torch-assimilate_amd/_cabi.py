@@ -10,11 +10,28 @@ from ._build import LIB_PATH
 _lib = None
 
 i32, i64, f32, f64, vp, sz = C.c_int, C.c_int64, C.c_float, C.c_double, C.c_void_p, C.c_size_t
+
+
+class KernelOp(C.Structure):
+    """mia_kernel_op_t"""
+    _fields_ = [("op", C.c_int32), ("reserved", C.c_int32), ("value", C.c_double)]
+
+
 _PROTOS = {
     "mia_version": ([], i32),
     "mia_status_string": ([i32], C.c_char_p),
     "mia_gaspari_cohn_f64": ([vp, i64, vp, vp], i32),
     "mia_gaspari_cohn_f32": ([vp, i64, vp, vp], i32),
+    "mia_gaspari_cohn_inf_f64": ([vp, i64, vp, vp], i32),
+    "mia_gaspari_cohn_inf_f32": ([vp, i64, vp, vp], i32),
+    "mia_letkf_localize_taper_f64": ([i32, vp, i64, i64, vp, i64, i32, C.POINTER(C.c_int32), C.POINTER(f64), i32, f64,
+                                      i32, vp, vp, vp, vp, vp, sz, vp], i32),
+    "mia_letkf_localize_from_dist_taper_f64": ([i32, vp, vp, i64, i32, C.POINTER(f64), i32, f64, vp, vp, vp, vp, vp],
+                                               i32),
+    "mia_lketkf_kernel_analysis_packed_f32": ([vp, i64, i32, i32, i64, i64, vp, i64, vp, vp, vp, i32, i32, f32,
+                                               C.POINTER(KernelOp), i32, vp, i64, i64, vp, vp, vp], i32),
+    "mia_lketkf_kernel_analysis_packed_f64": ([vp, i64, i32, i32, i64, i64, vp, i64, vp, vp, vp, i32, i32, f64,
+                                               C.POINTER(KernelOp), i32, vp, i64, i64, vp, vp, vp], i32),
     "mia_letkf_localize_workspace_bytes": ([i64, i32, C.POINTER(sz)], i32),
     "mia_letkf_localize_f64": ([vp, i64, i64, vp, i64, i32, C.POINTER(C.c_int32), C.POINTER(f64), i32, f64,
                                 i32, vp, vp, vp, vp, vp, sz, vp], i32),

@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from .engine import LetkfEngine
-from .kernels import LinearKernel
+from .kernels import kernel_route
 
 __all__ = ["ETKFModule", "KETKFModule"]
 
@@ -38,7 +38,7 @@ class ETKFModule:
     def __repr__(self) -> str:
         return "ETKFCore"
 
-    _gamma = None
+    kernel = None
 
     @property
     def engine(self) -> LetkfEngine:
@@ -66,29 +66,21 @@ class ETKFModule:
             cand = cand - 1
         nbrs = eng.localize_from_dist(torch.zeros((1, 1, cap), dtype=torch.float64, device=eng.device), cand, [1.0])
         x = torch.zeros((1, k, 1), dtype=dtype, device=eng.device)
-        _, w = eng.analysis(x, perts, obs, nbrs, self.inf_factor, return_weights=True, rbf_gamma=self._gamma)
+        gamma, prog = kernel_route(self.kernel)
+        _, w = eng.analysis(x, perts, obs, nbrs, self.inf_factor, return_weights=True, rbf_gamma=gamma,
+                            kernel_program=prog)
         return w[0]
 
     forward = __call__
 
 
 class KETKFModule(ETKFModule):
-    """core/ketkf.py:29-94 for the kernels of :mod:`.kernels`."""
+    """core/ketkf.py:29-94 for the kernels of :mod:`.kernels` (every reference kernel and composition except
+    ModuleKernel; NotImplementedError for anything else)."""
 
     def __init__(self, kernel, inf_factor: float = 1.0, engine: Optional[LetkfEngine] = None):
         super().__init__(inf_factor, engine)
         self.kernel = kernel
-
-    @property
-    def _gamma(self):
-        if isinstance(self.kernel, LinearKernel):
-            return None
-        g = getattr(self.kernel, "gamma", None)
-        if g is None:
-            raise NotImplementedError(
-                "only RBFKernel / GaussKernel (scalar lengthscale) and LinearKernel are implemented "
-                "on the gfx950 path; got %r" % (self.kernel,))
-        return float(g)
 
     def __str__(self):
         return "KETKFModule({0:s}, {1})".format(str(self.kernel), self.inf_factor)

@@ -34,7 +34,8 @@ template <typename T>
 int wave_analysis_launch(const T* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const T* rec,
                          const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap,
                          int p_max, T inf_factor, int kernel_mode, T gamma, T* Xa, int64_t ldo, int64_t o0,
-                         T* W_opt, int32_t* flags_opt, int only_flagged, hipStream_t stream);
+                         T* W_opt, int32_t* flags_opt, int only_flagged, hipStream_t stream,
+                         const mia_kernel_op_t* prog = nullptr, int n_ops = 0);
 
 int sys_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
                         const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
@@ -354,7 +355,8 @@ template <typename T>
 static int analysis_packed_impl(const T* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1, const T* rec,
                                 int64_t P, const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w,
                                 int p_cap, int p_max, T inf_factor, int kernel_mode, T gamma, T* Xa, int64_t ldo,
-                                int64_t o0, T* W_opt, int32_t* flags_opt, hipStream_t stream, int only_flagged = 0) {
+                                int64_t o0, T* W_opt, int32_t* flags_opt, hipStream_t stream, int only_flagged = 0,
+                                const mia_kernel_op_t* prog = nullptr, int n_ops = 0) {
   if (g1 < g0 || g0 < 0 || m < 1 || k < 2 || P < 0 || p_cap < 1 || p_max < 0) return MIA_ERR_SIZE;
   if (!(inf_factor > T(0))) return MIA_ERR_SIZE;
   const int64_t ng = g1 - g0;
@@ -364,6 +366,9 @@ static int analysis_packed_impl(const T* X, int64_t ldx, int m, int k, int64_t g
   if (p_max > p_cap) p_max = p_cap;
   if (P > 0 && !rec) return MIA_ERR_NULL;
   const int kp = (k + 1 + 3) & ~3;
+  if (kernel_mode == 2)   // kernel expression: runtime-order kernel only
+    return wave_analysis_launch<T>(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
+                                   kernel_mode, gamma, Xa, ldo, o0, W_opt, flags_opt, only_flagged, stream, prog, n_ops);
   const char* which = getenv("MIA_KERNEL");   // experiments: "generic" | "wave" | default (systolic, then wave)
   if constexpr (sizeof(T) == 4) {
     if (!which || which[0] == 's') {
@@ -517,6 +522,31 @@ extern "C" int mia_letkf_analysis_packed_f64(const double* X, int64_t ldx, int m
   (void)hipGetLastError();
   return analysis_packed_impl<double>(X, ldx, m, k, g0, g1, rec, P, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
                                       gamma > 0.0 ? 1 : 0, gamma, Xa, ldo, o0, W_opt, flags_opt, (hipStream_t)stream);
+}
+
+extern "C" int mia_lketkf_kernel_analysis_packed_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                                     const float* rec, int64_t P, const int32_t* nbr_cnt,
+                                                     const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
+                                                     float inf_factor, const mia_kernel_op_t* prog, int n_ops,
+                                                     float* Xa, int64_t ldo, int64_t o0, float* W_opt,
+                                                     int32_t* flags_opt, void* stream) {
+  (void)hipGetLastError();
+  const int rc = kernel_program_check(prog, n_ops);
+  if (rc != MIA_OK) return rc;
+  return analysis_packed_impl<float>(X, ldx, m, k, g0, g1, rec, P, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
+                                     2, 0.0f, Xa, ldo, o0, W_opt, flags_opt, (hipStream_t)stream, 0, prog, n_ops);
+}
+extern "C" int mia_lketkf_kernel_analysis_packed_f64(const double* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                                     const double* rec, int64_t P, const int32_t* nbr_cnt,
+                                                     const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
+                                                     double inf_factor, const mia_kernel_op_t* prog, int n_ops,
+                                                     double* Xa, int64_t ldo, int64_t o0, double* W_opt,
+                                                     int32_t* flags_opt, void* stream) {
+  (void)hipGetLastError();
+  const int rc = kernel_program_check(prog, n_ops);
+  if (rc != MIA_OK) return rc;
+  return analysis_packed_impl<double>(X, ldx, m, k, g0, g1, rec, P, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
+                                      2, 0.0, Xa, ldo, o0, W_opt, flags_opt, (hipStream_t)stream, 0, prog, n_ops);
 }
 
 extern "C" int mia_letkf_analysis_matfun_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,

@@ -33,11 +33,58 @@ struct WaveParams {
   const int32_t* cnt; const int32_t* idx; const double* w; int p_cap; int p_max;
   T reg; T* Xa; int64_t ldo, o0; T* W; int32_t* flags;
   int dual; int nmax; int lda; int rows; int pts_per_block; int max_sweeps; T rot_tol2, stop_tol2;
-  int kernel_mode; T gamma;
+  int kernel_mode; T gamma;   // 0 linear (ETKF), 1 RBF(gamma), 2 kernel expression `prog`
   int only_flagged;
+  KernelProgram<T> prog;
 };
 
 template <typename T> struct Vec4 { T x, y, z, w; };
+
+// Kernel expression in reverse Polish form (MIA_KOP_*), evaluated per matrix element from the three pair
+// statistics every reference kernel is a function of: x.y (kernels/utils.py:38-58 dot_product), |x-y|_2^2
+// (utils.py:93-110 euclidean_dist) and |x-y|_1 (utils.py:61-90 distance_matrix, norm 1).  The operand stack is six
+// named registers shifted on push/pop (no indexed private array, so no scratch memory).
+template <typename T>
+__device__ inline T kprog_eval(const KernelProgram<T>& kp, T dot, T sq, T l1, bool same) {
+  T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0), s4 = T(0), s5 = T(0);
+  for (int i = 0; i < kp.n; ++i) {
+    const int op = kp.op[i];
+    if (op <= MIA_KOP_DIAG) {      // push
+      T v;
+      switch (op) {
+        case MIA_KOP_DOT: v = dot; break;
+        case MIA_KOP_SQDIST: v = sq; break;
+        case MIA_KOP_L1DIST: v = l1; break;
+        case MIA_KOP_CONST: v = kp.val[i]; break;
+        default: v = same ? kp.val[i] : T(0); break;   // MIA_KOP_DIAG
+      }
+      s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = v;
+    } else if (op <= MIA_KOP_POW) {   // binary: (s1 op s0)
+      T v;
+      if (op == MIA_KOP_ADD) v = s1 + s0;
+      else if (op == MIA_KOP_MUL) v = s1 * s0;
+      else v = t_pow(s1, s0);
+      s0 = v; s1 = s2; s2 = s3; s3 = s4; s4 = s5;
+    } else {                         // unary
+      if (op == MIA_KOP_EXP) s0 = t_exp(s0);
+      else if (op == MIA_KOP_TANH) s0 = t_tanh(s0);
+      else s0 = t_sin(s0);
+    }
+  }
+  return s0;
+}
+
+// the three pair statistics of columns a and b of the obs-major local block (rows = local observations)
+template <typename T>
+__device__ inline T kprog_pair(const KernelProgram<T>& kp, const T* Yt, int kpad, int cnt, int a, int b, bool same) {
+  T dt = T(0), sq = T(0), l1 = T(0);
+  for (int j = 0; j < cnt; ++j) {
+    const T xa = Yt[(size_t)j * kpad + a], xb = Yt[(size_t)j * kpad + b];
+    const T df = xa - xb;
+    dt += xa * xb; sq += df * df; l1 += t_abs(df);
+  }
+  return kprog_eval(kp, dt, sq, l1, same);
+}
 
 __device__ inline int wrap_up(int v, int n1) { return v >= n1 ? v - n1 : v; }
 __device__ inline int wrap_dn(int v, int n1) { return v < 0 ? v + n1 : v; }
@@ -254,9 +301,11 @@ __global__ __launch_bounds__(NT) void letkf_wave_kernel(WaveParams<T> P) {
       } else if (b < k) {
         if (P.kernel_mode == 0) {
           for (int j = 0; j < cnt; ++j) acc += Yt[(size_t)j * kp + a] * Yt[(size_t)j * kp + b];
-        } else {   // RBF Gram exp(-gamma |y_a - y_b|^2)  (kernels/rbf.py:75-81,110-111)
+        } else if (P.kernel_mode == 1) {   // RBF Gram exp(-gamma |y_a - y_b|^2)  (kernels/rbf.py:75-81,110-111)
           for (int j = 0; j < cnt; ++j) { const T df = Yt[(size_t)j * kp + a] - Yt[(size_t)j * kp + b]; acc += df * df; }
           acc = t_exp(-P.gamma * acc);
+        } else {   // any other reference kernel or composition (kernels/*.py, base_kernels.py)
+          acc = kprog_pair(P.prog, Yt, kp, cnt, a, b, a == b);
         }
       }
       S[a * lda + b] = acc;
@@ -277,9 +326,13 @@ __global__ __launch_bounds__(NT) void letkf_wave_kernel(WaveParams<T> P) {
           T acc = T(0);
           for (int j = 0; j < k; ++j) acc += sym(S, lda, i, j);
           uv[i] = acc / T(k);
-          T ko = T(0);
-          for (int j = 0; j < cnt; ++j) { const T df = Yt[(size_t)j * kp + i] - Yt[(size_t)j * kp + k]; ko += df * df; }
-          zb[i] = t_exp(-P.gamma * ko);
+          if (P.kernel_mode == 1) {
+            T ko = T(0);
+            for (int j = 0; j < cnt; ++j) { const T df = Yt[(size_t)j * kp + i] - Yt[(size_t)j * kp + k]; ko += df * df; }
+            zb[i] = t_exp(-P.gamma * ko);
+          } else {
+            zb[i] = kprog_pair(P.prog, Yt, kp, cnt, i, k, false);   // k(Yb, d): never "the same sample" (diag.py:65-66)
+          }
         }
         __syncthreads();
         if (tid == 0) {
@@ -455,8 +508,16 @@ template <typename T>
 int wave_analysis_launch(const T* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const T* rec,
                          const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap,
                          int p_max, T inf_factor, int kernel_mode, T gamma, T* Xa, int64_t ldo, int64_t o0,
-                         T* W_opt, int32_t* flags_opt, int only_flagged, hipStream_t stream) {
+                         T* W_opt, int32_t* flags_opt, int only_flagged, hipStream_t stream,
+                         const mia_kernel_op_t* prog, int n_ops) {
   WaveParams<T> ap;
+  ap.prog.n = 0;
+  if (kernel_mode == 2) {
+    const int rc = kernel_program_check(prog, n_ops);
+    if (rc != MIA_OK) return rc;
+    ap.prog.n = n_ops;
+    for (int i = 0; i < n_ops; ++i) { ap.prog.op[i] = (unsigned char)prog[i].op; ap.prog.val[i] = T(prog[i].value); }
+  }
   ap.only_flagged = only_flagged;
   if (only_flagged && !flags_opt) return MIA_ERR_NULL;
   ap.X = X; ap.ldx = ldx; ap.m = m; ap.k = k; ap.g0 = g0; ap.ng = ng; ap.rec = rec;
@@ -505,9 +566,11 @@ int wave_analysis_launch(const T* X, int64_t ldx, int m, int k, int64_t g0, int6
 
 template int wave_analysis_launch<float>(const float*, int64_t, int, int, int64_t, int64_t, const float*,
                                          const int32_t*, const int32_t*, const double*, int, int, float, int, float,
-                                         float*, int64_t, int64_t, float*, int32_t*, int, hipStream_t);
+                                         float*, int64_t, int64_t, float*, int32_t*, int, hipStream_t,
+                                         const mia_kernel_op_t*, int);
 template int wave_analysis_launch<double>(const double*, int64_t, int, int, int64_t, int64_t, const double*,
                                           const int32_t*, const int32_t*, const double*, int, int, double, int, double,
-                                          double*, int64_t, int64_t, double*, int32_t*, int, hipStream_t);
+                                          double*, int64_t, int64_t, double*, int32_t*, int, hipStream_t,
+                                          const mia_kernel_op_t*, int);
 
 }  // namespace mia

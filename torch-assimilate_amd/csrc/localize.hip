@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void localize_kernel(LocalizeParams p) {
             d2[q.group[c]] += dx * dx;
           }
           double wgt = 1.0;
-          for (int r = 0; r < q.n_r; ++r) wgt *= gc_taper_d2(d2[r], q.inv_c[r], q.cc[r]);
+          for (int r = 0; r < q.n_r; ++r) wgt *= taper_d2(q.taper, d2[r], q.inv_c[r], q.cc[r]);
           wg[u] = pos0 + u < end ? wgt : 0.0;
         }
 #pragma unroll
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void localize_kernel(LocalizeParams p) {
 
 struct FromDistParams {
   const double* dist; const int* cand; int64_t n_pts; int p_cap; int n_r;
-  double inv_c[MIA_MAX_RADII]; double eps;
+  double inv_c[MIA_MAX_RADII]; double eps; int taper;
   int* cnt; int* idx; double* w; int* stats;
 };
 
@@ -345,8 +345,10 @@ __global__ __launch_bounds__(256) void localize_from_dist_kernel(FromDistParams 
       j = p.cand[pt * p.p_cap + s];
       if (j >= 0) {
         wgt = 1.0;
-        for (int r = 0; r < p.n_r; ++r)
-          wgt *= gc_taper<double>(p.dist[((int64_t)r * p.n_pts + pt) * p.p_cap + s] * p.inv_c[r]);
+        for (int r = 0; r < p.n_r; ++r) {
+          const double rr = p.dist[((int64_t)r * p.n_pts + pt) * p.p_cap + s] * p.inv_c[r];
+          wgt *= p.taper == MIA_TAPER_GC_INF ? gc_inf_taper<double>(rr) : gc_taper<double>(rr);
+        }
         use = wgt > p.eps;
       }
     }
@@ -365,11 +367,23 @@ __global__ __launch_bounds__(256) void localize_from_dist_kernel(FromDistParams 
   }
 }
 
-template <typename T>
+template <typename T, int TAPER>
 __global__ void gc_kernel(const T* r, int64_t n, T* w) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) w[i] = gc_taper<T>(r[i]);
+  for (; i < n; i += stride) w[i] = TAPER == MIA_TAPER_GC_INF ? gc_inf_taper<T>(r[i]) : gc_taper<T>(r[i]);
+}
+
+template <typename T, int TAPER>
+static int taper_launch(const T* r, int64_t n, T* w, hipStream_t stream) {
+  if (n < 0) return MIA_ERR_SIZE;
+  if (n == 0) return MIA_OK;
+  if (!r || !w) return MIA_ERR_NULL;
+  int64_t nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  gc_kernel<T, TAPER><<<dim3((unsigned)nb), dim3(256), 0, stream>>>(r, n, w);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
 }
 
 // builds the cell index of the observations in ws (all kernels enqueued on stream)
@@ -416,7 +430,8 @@ int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_
 
 // scan parameters over an already built index
 int make_scan_params(ScanParams* sp, const double* grid_xyz, int64_t P, int n_coord, const int32_t* coord_group,
-                     const double* gc_c, int n_r, double gc_eps, void* ws) {
+                     const double* gc_c, int n_r, double gc_eps, void* ws, int taper) {
+  if (taper != MIA_TAPER_GC && taper != MIA_TAPER_GC_INF) return MIA_ERR_SIZE;
   if (n_coord < 1 || n_coord > MIA_MAX_COORD || n_r < 1 || n_r > MIA_MAX_RADII) return MIA_ERR_SIZE;
   if (!coord_group || !gc_c || !grid_xyz || !ws) return MIA_ERR_NULL;
   const IndexLayout L = index_layout(ws, P, n_coord);
@@ -425,13 +440,14 @@ int make_scan_params(ScanParams* sp, const double* grid_xyz, int64_t P, int n_co
   for (int c = 0; c < MIA_MAX_COORD; ++c) sp->group[c] = c < n_coord ? coord_group[c] : 0;
   for (int r = 0; r < MIA_MAX_RADII; ++r) { sp->inv_c[r] = r < n_r ? 1.0 / gc_c[r] : 1.0; sp->cc[r] = r < n_r ? gc_c[r] : 1.0; }
   sp->eps = gc_eps;
+  sp->taper = taper;
   return MIA_OK;
 }
 
 int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* obs_xyz, int64_t P, int n_coord,
                   const int32_t* coord_group, const double* gc_c, int n_r, double gc_eps, int p_cap,
                   int32_t* nbr_cnt, int32_t* nbr_idx, double* nbr_w, int32_t* stats, void* ws, size_t ws_bytes,
-                  hipStream_t stream, const PackJob* pack, bool stats_zeroed, const ZeroJob* zero) {
+                  hipStream_t stream, const PackJob* pack, bool stats_zeroed, const ZeroJob* zero, int taper) {
   if (g1 < g0 || g0 < 0 || P < 0) return MIA_ERR_SIZE;
   if (n_coord < 1 || n_coord > MIA_MAX_COORD || n_r < 1 || n_r > MIA_MAX_RADII || p_cap < 1) return MIA_ERR_SIZE;
   if (!coord_group || !gc_c || !stats) return MIA_ERR_NULL;
@@ -450,7 +466,7 @@ int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* 
   int rc = index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, ws, ws_bytes, stream, pack, zero);
   if (rc != MIA_OK) return rc;
   LocalizeParams lp;
-  rc = make_scan_params(&lp.scan, grid_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, ws);
+  rc = make_scan_params(&lp.scan, grid_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, ws, taper);
   if (rc != MIA_OK) return rc;
   lp.g0 = g0; lp.ng = ng; lp.p_cap = p_cap;
   lp.cnt = nbr_cnt; lp.idx = nbr_idx; lp.w = nbr_w; lp.stats = stats;
@@ -467,26 +483,19 @@ using namespace mia;
 
 extern "C" int mia_gaspari_cohn_f64(const double* r, int64_t n, double* w, void* stream) {
   (void)hipGetLastError();  // drop stale per-thread error state left by other users of the runtime
-  if (n < 0) return MIA_ERR_SIZE;
-  if (n == 0) return MIA_OK;
-  if (!r || !w) return MIA_ERR_NULL;
-  int64_t nb = (n + 255) / 256;
-  if (nb > 4096) nb = 4096;
-  gc_kernel<double><<<dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream>>>(r, n, w);
-  MIA_LAUNCH_CHECK();
-  return MIA_OK;
+  return taper_launch<double, MIA_TAPER_GC>(r, n, w, (hipStream_t)stream);
 }
-
 extern "C" int mia_gaspari_cohn_f32(const float* r, int64_t n, float* w, void* stream) {
-  (void)hipGetLastError();  // drop stale per-thread error state left by other users of the runtime
-  if (n < 0) return MIA_ERR_SIZE;
-  if (n == 0) return MIA_OK;
-  if (!r || !w) return MIA_ERR_NULL;
-  int64_t nb = (n + 255) / 256;
-  if (nb > 4096) nb = 4096;
-  gc_kernel<float><<<dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream>>>(r, n, w);
-  MIA_LAUNCH_CHECK();
-  return MIA_OK;
+  (void)hipGetLastError();
+  return taper_launch<float, MIA_TAPER_GC>(r, n, w, (hipStream_t)stream);
+}
+extern "C" int mia_gaspari_cohn_inf_f64(const double* r, int64_t n, double* w, void* stream) {
+  (void)hipGetLastError();
+  return taper_launch<double, MIA_TAPER_GC_INF>(r, n, w, (hipStream_t)stream);
+}
+extern "C" int mia_gaspari_cohn_inf_f32(const float* r, int64_t n, float* w, void* stream) {
+  (void)hipGetLastError();
+  return taper_launch<float, MIA_TAPER_GC_INF>(r, n, w, (hipStream_t)stream);
 }
 
 extern "C" int mia_letkf_localize_workspace_bytes(int64_t P, int n_coord, size_t* bytes) {
@@ -514,12 +523,33 @@ extern "C" int mia_letkf_localize_f64(const double* grid_xyz, int64_t g0, int64_
                             nbr_idx, nbr_w, stats, ws, ws_bytes, (hipStream_t)stream, nullptr, false, nullptr);
 }
 
+extern "C" int mia_letkf_localize_taper_f64(int taper, const double* grid_xyz, int64_t g0, int64_t g1,
+                                            const double* obs_xyz, int64_t P, int n_coord,
+                                            const int32_t* coord_group, const double* gc_c, int n_r,
+                                            double gc_eps, int p_cap, int32_t* nbr_cnt, int32_t* nbr_idx,
+                                            double* nbr_w, int32_t* stats, void* ws, size_t ws_bytes,
+                                            void* stream) {
+  (void)hipGetLastError();
+  if (taper != MIA_TAPER_GC && taper != MIA_TAPER_GC_INF) return MIA_ERR_SIZE;
+  return mia::localize_impl(grid_xyz, g0, g1, obs_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, p_cap, nbr_cnt,
+                            nbr_idx, nbr_w, stats, ws, ws_bytes, (hipStream_t)stream, nullptr, false, nullptr, taper);
+}
+
 extern "C" int mia_letkf_localize_from_dist_f64(const double* dist, const int32_t* cand_idx,
                                                 int64_t n_pts, int p_cap, const double* gc_c, int n_r,
                                                 double gc_eps, int32_t* nbr_cnt, int32_t* nbr_idx,
                                                 double* nbr_w, int32_t* stats, void* stream_) {
+  return mia_letkf_localize_from_dist_taper_f64(MIA_TAPER_GC, dist, cand_idx, n_pts, p_cap, gc_c, n_r, gc_eps, nbr_cnt,
+                                                nbr_idx, nbr_w, stats, stream_);
+}
+
+extern "C" int mia_letkf_localize_from_dist_taper_f64(int taper, const double* dist, const int32_t* cand_idx,
+                                                      int64_t n_pts, int p_cap, const double* gc_c, int n_r,
+                                                      double gc_eps, int32_t* nbr_cnt, int32_t* nbr_idx,
+                                                      double* nbr_w, int32_t* stats, void* stream_) {
   (void)hipGetLastError();  // drop stale per-thread error state left by other users of the runtime
   hipStream_t stream = (hipStream_t)stream_;
+  if (taper != MIA_TAPER_GC && taper != MIA_TAPER_GC_INF) return MIA_ERR_SIZE;
   if (n_pts < 0 || p_cap < 1 || n_r < 1 || n_r > MIA_MAX_RADII) return MIA_ERR_SIZE;
   if (!gc_c || !stats) return MIA_ERR_NULL;
   for (int r = 0; r < n_r; ++r) if (!(gc_c[r] > 0.0)) return MIA_ERR_SIZE;
@@ -529,7 +559,7 @@ extern "C" int mia_letkf_localize_from_dist_f64(const double* dist, const int32_
   FromDistParams fp;
   fp.dist = dist; fp.cand = cand_idx; fp.n_pts = n_pts; fp.p_cap = p_cap; fp.n_r = n_r;
   for (int r = 0; r < MIA_MAX_RADII; ++r) fp.inv_c[r] = r < n_r ? 1.0 / gc_c[r] : 1.0;
-  fp.eps = gc_eps; fp.cnt = nbr_cnt; fp.idx = nbr_idx; fp.w = nbr_w; fp.stats = stats;
+  fp.eps = gc_eps; fp.taper = taper; fp.cnt = nbr_cnt; fp.idx = nbr_idx; fp.w = nbr_w; fp.stats = stats;
   const int64_t nb = (n_pts + 3) / 4;
   if (nb > 2147483647LL) return MIA_ERR_UNSUPPORTED;
   localize_from_dist_kernel<<<dim3((unsigned)nb), dim3(256), 0, stream>>>(fp);

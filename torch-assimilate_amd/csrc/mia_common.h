@@ -22,6 +22,26 @@ constexpr int kWave = 64;  // CDNA4 wavefront
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// device copy of a kernel expression (mia_kernel_op_t program), passed by value in the launch parameters
+template <typename T>
+struct KernelProgram { int n; unsigned char op[MIA_KERNEL_MAX_OPS]; T val[MIA_KERNEL_MAX_OPS]; };
+
+// a well-formed program: known opcodes, operand stack never below the arity of an operator, never deeper than
+// MIA_KERNEL_MAX_DEPTH, exactly one value left at the end
+static inline int kernel_program_check(const mia_kernel_op_t* prog, int n_ops) {
+  if (!prog) return MIA_ERR_NULL;
+  if (n_ops < 1 || n_ops > MIA_KERNEL_MAX_OPS) return MIA_ERR_SIZE;
+  int depth = 0;
+  for (int i = 0; i < n_ops; ++i) {
+    const int op = prog[i].op;
+    if (op < MIA_KOP_DOT || op > MIA_KOP_SIN) return MIA_ERR_SIZE;
+    if (op <= MIA_KOP_DIAG) { if (++depth > MIA_KERNEL_MAX_DEPTH) return MIA_ERR_UNSUPPORTED; }
+    else if (op <= MIA_KOP_POW) { if (depth < 2) return MIA_ERR_SIZE; --depth; }
+    else if (depth < 1) return MIA_ERR_SIZE;
+  }
+  return depth == 1 ? MIA_OK : MIA_ERR_SIZE;
+}
+
 // Gaspari-Cohn 5th-order taper, compact support r < 2 (Gaspari & Cohn 1999, eq. 4.10).
 // Branch structure of pytassim/localization/gaspari_cohn.py:127-133 (strict `<`,
 // NaN -> 0).  Horner form of _f1 (:78-84) and _f2 (:87-95).
@@ -36,6 +56,27 @@ __host__ __device__ inline T gc_taper(T r) {
   }
   return T(0);
 }
+
+// Gaspari-Cohn taper with form factor infinity, C_0(z, inf, c) (Gaspari & Cohn 1999), compact support r < 2:
+// pytassim/localization/gaspari_cohn.py:139-254 (GaspariCohnInf).  The reference assigns _f4, _f3, _f2, _f1 in this
+// order under the strict conditions r < 2, 1.5, 1, 0.5 (:244-251), i.e. the LAST matching branch wins; NaN -> 0.
+// rinv = 1 / r (only used for r >= 0.5).  Horner forms of _f1 (:176-183), _f2 (:185-193), _f3 (:195-204), _f4 (:206-215).
+template <typename T>
+__host__ __device__ inline T gc_inf_taper_rinv(T r, T rinv) {
+  if (r < T(0.5)) return (((T(-28.0 / 33.0) * r + T(8.0 / 11.0)) * r + T(20.0 / 11.0)) * r - T(80.0 / 33.0)) * r * r + T(1);
+  if (r < T(1))
+    return ((((T(20.0 / 33.0) * r - T(16.0 / 11.0)) * r * r + T(100.0 / 33.0)) * r - T(45.0 / 11.0)) * r) + T(51.0 / 22.0) -
+           T(7.0 / 44.0) * rinv;
+  if (r < T(1.5))
+    return (((((T(-4.0 / 11.0) * r + T(16.0 / 11.0)) * r - T(10.0 / 11.0)) * r - T(100.0 / 33.0)) * r + T(5)) * r) -
+           T(61.0 / 22.0) + T(115.0 / 132.0) * rinv;
+  if (r < T(2))
+    return (((((T(4.0 / 33.0) * r - T(8.0 / 11.0)) * r + T(10.0 / 11.0)) * r + T(80.0 / 33.0)) * r - T(80.0 / 11.0)) * r) +
+           T(64.0 / 11.0) - T(32.0 / 33.0) * rinv;
+  return T(0);
+}
+template <typename T>
+__host__ __device__ inline T gc_inf_taper(T r) { return gc_inf_taper_rinv<T>(r, r < T(0.5) ? T(0) : T(1) / r); }
 
 // 64-lane sum / max via DPP-friendly butterfly (result in every lane)
 template <typename T>

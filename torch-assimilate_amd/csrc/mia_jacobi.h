@@ -13,6 +13,15 @@ template <typename T> __device__ inline T t_abs(T x) { return x < T(0) ? -x : x;
 template <typename T> __device__ inline T t_exp(T x);
 template <> __device__ inline float t_exp<float>(float x) { return expf(x); }
 template <> __device__ inline double t_exp<double>(double x) { return exp(x); }
+template <typename T> __device__ inline T t_pow(T x, T y);
+template <> __device__ inline float t_pow<float>(float x, float y) { return powf(x, y); }
+template <> __device__ inline double t_pow<double>(double x, double y) { return pow(x, y); }
+template <typename T> __device__ inline T t_tanh(T x);
+template <> __device__ inline float t_tanh<float>(float x) { return tanhf(x); }
+template <> __device__ inline double t_tanh<double>(double x) { return tanh(x); }
+template <typename T> __device__ inline T t_sin(T x);
+template <> __device__ inline float t_sin<float>(float x) { return sinf(x); }
+template <> __device__ inline double t_sin<double>(double x) { return sin(x); }
 
 // Parallel cyclic Jacobi on the n x n symmetric matrix A (LDS, leading dim lda), n even.
 // V (nv rows) accumulates the rotations: A_in = V A_out V^T.  Returns true when a sweep

@@ -45,6 +45,16 @@ __device__ inline double gc_taper_d2(double d2, double inv_c, double c) {
   return r < 1.0 ? f1 : (r < 2.0 ? f2 : 0.0);
 }
 
+// the same for the form-factor-infinity taper (GaspariCohnInf, gaspari_cohn.py:139-254)
+__device__ inline double gc_inf_taper_d2(double d2, double inv_c, double c) {
+  if (!(d2 > 0.0)) return d2 == 0.0 ? 1.0 : 0.0;
+  const double y = rsqrt_f64(d2);
+  return gc_inf_taper_rinv<double>(d2 * y * inv_c, c * y);
+}
+__device__ inline double taper_d2(int taper, double d2, double inv_c, double c) {
+  return taper == MIA_TAPER_GC_INF ? gc_inf_taper_d2(d2, inv_c, c) : gc_taper_d2(d2, inv_c, c);
+}
+
 // what a wavefront needs to find the local observations of one grid point
 struct ScanParams {
   const double* grid;   // [G][nc]
@@ -57,6 +67,7 @@ struct ScanParams {
   double inv_c[MIA_MAX_RADII];
   double cc[MIA_MAX_RADII];
   double eps;
+  int taper;            // MIA_TAPER_*
 };
 
 // One wavefront scans the 3^d cells around grid point g (the innermost coordinate's three cells are one
@@ -110,7 +121,7 @@ __device__ inline int scan_neighbours(const ScanParams& p, int64_t g, int lane, 
           d2[p.group[c]] += dx * dx;
         }
         wgt = 1.0;
-        for (int r = 0; r < p.n_r; ++r) wgt *= gc_taper_d2(d2[r], p.inv_c[r], p.cc[r]);
+        for (int r = 0; r < p.n_r; ++r) wgt *= taper_d2(p.taper, d2[r], p.inv_c[r], p.cc[r]);
         use = wgt > p.eps;
       }
       const unsigned long long mask = __ballot(use);
@@ -161,8 +172,9 @@ int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_
 int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* obs_xyz, int64_t P, int n_coord,
                   const int32_t* coord_group, const double* gc_c, int n_r, double gc_eps, int p_cap,
                   int32_t* nbr_cnt, int32_t* nbr_idx, double* nbr_w, int32_t* stats, void* ws, size_t ws_bytes,
-                  hipStream_t stream, const PackJob* pack, bool stats_zeroed, const ZeroJob* zero);
+                  hipStream_t stream, const PackJob* pack, bool stats_zeroed, const ZeroJob* zero,
+                  int taper = MIA_TAPER_GC);
 int make_scan_params(ScanParams* sp, const double* grid_xyz, int64_t P, int n_coord, const int32_t* coord_group,
-                     const double* gc_c, int n_r, double gc_eps, void* ws);
+                     const double* gc_c, int n_r, double gc_eps, void* ws, int taper = MIA_TAPER_GC);
 
 }  // namespace mia

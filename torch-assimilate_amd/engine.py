@@ -85,17 +85,19 @@ class LetkfEngine:
         return t.to(device=self.device, dtype=dtype).contiguous()
 
     # ------------------------------------------------------------ localisation
-    def gaspari_cohn(self, r: torch.Tensor) -> torch.Tensor:
+    def gaspari_cohn(self, r: torch.Tensor, taper: int = 0) -> torch.Tensor:
+        """Taper of normalised distances: taper 0 = GaspariCohn, 1 = GaspariCohnInf (MIA_TAPER_*)."""
         r = r.to(self.device).contiguous()
         out = torch.empty_like(r)
-        fn = {torch.float64: self.lib.mia_gaspari_cohn_f64, torch.float32: self.lib.mia_gaspari_cohn_f32}[r.dtype]
+        name = "mia_gaspari_cohn_" + ("inf_" if taper else "") + {torch.float64: "f64", torch.float32: "f32"}[r.dtype]
+        fn = getattr(self.lib, name)
         _cabi.check(fn(_ptr(r), r.numel(), _ptr(out), self._stream()), "mia_gaspari_cohn")
         return out
 
     def localize(self, grid_xyz, obs_xyz, radii: Sequence[float], coord_group: Optional[Sequence[int]] = None,
                  eps: float = 1e-5, g0: int = 0, g1: Optional[int] = None,
                  p_cap: Optional[int] = None, assume_p_max: Optional[int] = None,
-                 stats_out: Optional[torch.Tensor] = None) -> NeighbourLists:
+                 stats_out: Optional[torch.Tensor] = None, taper: int = 0) -> NeighbourLists:
         """Neighbour lists of grid points [g0, g1).  By default the maximum list length is read back
         (one 8-byte host sync) to size the analysis launch.  With ``assume_p_max`` (e.g. the value of the
         previous cycle on the same geometry) nothing is read back here: the returned lists carry the
@@ -130,8 +132,8 @@ class LetkfEngine:
             cnt = torch.empty(n, dtype=torch.int32, device=self.device)
             idx = torch.empty((n, cap), dtype=torch.int32, device=self.device)
             w = torch.empty((n, cap), dtype=torch.float64, device=self.device)
-            _cabi.check(self.lib.mia_letkf_localize_f64(
-                _ptr(grid), g0, g1, _ptr(obs), P, nc, cg, rc, n_r, float(eps), cap,
+            _cabi.check(self.lib.mia_letkf_localize_taper_f64(
+                int(taper), _ptr(grid), g0, g1, _ptr(obs), P, nc, cg, rc, n_r, float(eps), cap,
                 _ptr(cnt), _ptr(idx), _ptr(w), _ptr(stats), _ptr(ws), ws.numel(), self._stream()),
                 "mia_letkf_localize_f64")
             return NeighbourLists(cnt, idx, w, cap, int(assume_p_max), g0, g1, stats)
@@ -139,8 +141,8 @@ class LetkfEngine:
             cnt = torch.empty(n, dtype=torch.int32, device=self.device)
             idx = torch.empty((n, cap), dtype=torch.int32, device=self.device)
             w = torch.empty((n, cap), dtype=torch.float64, device=self.device)
-            _cabi.check(self.lib.mia_letkf_localize_f64(
-                _ptr(grid), g0, g1, _ptr(obs), P, nc, cg, rc, n_r, float(eps), cap,
+            _cabi.check(self.lib.mia_letkf_localize_taper_f64(
+                int(taper), _ptr(grid), g0, g1, _ptr(obs), P, nc, cg, rc, n_r, float(eps), cap,
                 _ptr(cnt), _ptr(idx), _ptr(w), _ptr(stats), _ptr(ws), ws.numel(), self._stream()),
                 "mia_letkf_localize_f64")
             p_max, n_over = (int(v) for v in stats.tolist())   # host sync: sizes the analysis launch
@@ -213,7 +215,7 @@ class LetkfEngine:
         return out, flags, finish
 
     def localize_from_dist(self, dist, cand_idx, radii: Sequence[float], eps: float = 1e-5,
-                           g0: int = 0) -> NeighbourLists:
+                           g0: int = 0, taper: int = 0) -> NeighbourLists:
         """dist (n_r, n, p_cap) float64 caller-evaluated distances, cand_idx (n, p_cap) int32 (-1 pad)."""
         dist = self._dev(dist, torch.float64)
         if dist.dim() == 2:
@@ -228,8 +230,8 @@ class LetkfEngine:
         idx = torch.empty((n, cap), dtype=torch.int32, device=self.device)
         w = torch.empty((n, cap), dtype=torch.float64, device=self.device)
         stats = torch.empty(2, dtype=torch.int32, device=self.device)
-        _cabi.check(self.lib.mia_letkf_localize_from_dist_f64(
-            _ptr(dist), _ptr(cand), n, cap, rc, n_r, float(eps), _ptr(cnt), _ptr(idx), _ptr(w), _ptr(stats),
+        _cabi.check(self.lib.mia_letkf_localize_from_dist_taper_f64(
+            int(taper), _ptr(dist), _ptr(cand), n, cap, rc, n_r, float(eps), _ptr(cnt), _ptr(idx), _ptr(w), _ptr(stats),
             self._stream()), "mia_letkf_localize_from_dist_f64")
         p_max = int(stats[0].item())
         return NeighbourLists(cnt, idx, w, cap, p_max, g0, g0 + n)
@@ -343,7 +345,7 @@ class LetkfEngine:
                  rbf_gamma: Optional[float] = None, out: Optional[torch.Tensor] = None, out_offset: int = 0,
                  return_flags: bool = False, rec: Optional[torch.Tensor] = None, method: str = "auto",
                  defer_retry: bool = False, retry: Optional[torch.Tensor] = None,
-                 flags: Optional[torch.Tensor] = None):
+                 flags: Optional[torch.Tensor] = None, kernel_program=None):
         """X (m, k, G) prior ensemble (grid fastest), Yb (k, P), d (P,) [or their packed records
         ``rec`` from :meth:`pack_obs`]: analysis of the shard described by ``nbrs``.
         Returns Xa (m, k, n) [, W (n, k, k)] [, flags (n,)].
@@ -354,7 +356,9 @@ class LetkfEngine:
         matfun when it applies.  With ``defer_retry`` the (8-byte, synchronising) read of the decline
         counter is left to the caller: the return value gains a trailing callable that must be invoked.
         ``retry`` (1 int32, zeroed by the caller) / ``flags`` (n int32): caller-owned counter and flag
-        buffers, e.g. one counter shared by the launches of several sub-ranges."""
+        buffers, e.g. one counter shared by the launches of several sub-ranges.
+        ``rbf_gamma`` selects the RBF-kernelised core (KETKFModule with RBFKernel), ``kernel_program``
+        ([(MIA_KOP_*, value), ...], see kernels.py) the kernel-expression route for every other reference kernel."""
         if X.dim() == 2:
             X = X[None]
         X = X.to(self.device).contiguous()
@@ -386,6 +390,24 @@ class LetkfEngine:
         gamma = float(rbf_gamma) if rbf_gamma is not None else 0.0
         args = (_ptr(X), G, m, k, nbrs.g0, nbrs.g1, _ptr(rec), P, _ptr(nbrs.cnt), _ptr(nbrs.idx),
                 _ptr(nbrs.w), nbrs.p_cap, nbrs.p_max, float(inf_factor), gamma, _ptr(out), ldo, out_offset)
+        if kernel_program is not None:
+            if rbf_gamma is not None:
+                raise ValueError("give rbf_gamma or kernel_program, not both")
+            nops = len(kernel_program)
+            prog = (_cabi.KernelOp * max(nops, 1))()
+            for i, (op, val) in enumerate(kernel_program):
+                prog[i].op, prog[i].value = int(op), float(val)
+            fn = getattr(self.lib, "mia_lketkf_kernel_analysis_packed_" + sfx)
+            _cabi.check(fn(*args[:13], float(inf_factor), prog, nops, *args[15:], _ptr(W), _ptr(flags), self._stream()),
+                        "mia_lketkf_kernel_analysis_packed_" + sfx)
+            res = [out]
+            if return_weights:
+                res.append(W)
+            if return_flags:
+                res.append(flags)
+            if defer_retry:
+                res.append(lambda: 0)
+            return res[0] if len(res) == 1 else tuple(res)
         can_matfun = dtype == torch.float32 and not return_weights and n > 0
         if method == "matfun" and not can_matfun:
             raise ValueError("the matfun route needs float32 and cannot return the weights")

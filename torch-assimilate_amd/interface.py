@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from .engine import LetkfEngine
-from .kernels import LinearKernel
+from .kernels import kernel_route
 from .localization import GaspariCohn
 
 logger = logging.getLogger(__name__)
@@ -73,14 +73,9 @@ class ETKF:
             self._engine = LetkfEngine()
         return self._engine
 
-    @property
-    def _gamma(self) -> Optional[float]:
-        if self._kernel is None or isinstance(self._kernel, LinearKernel):
-            return None
-        g = getattr(self._kernel, "gamma", None)
-        if g is None:
-            raise NotImplementedError("kernel %r is not implemented on the gfx950 path" % (self._kernel,))
-        return float(g)
+    def _kernel_args(self) -> dict:
+        gamma, prog = kernel_route(self._kernel)
+        return dict(rbf_gamma=gamma, kernel_program=prog)
 
     def __str__(self):
         return "Global ETKF(inf_factor={0})".format(self.inf_factor)
@@ -95,7 +90,7 @@ class ETKF:
 
     def estimate_weights_arrays(self, yb, d, **_unused) -> torch.Tensor:
         """(k, P), (P,) -> weights (k, k) (ETKF.estimate_weights, etkf.py:99-120)."""
-        if self._gamma is not None:     # kernelised global solve: one "grid point" seeing every observation
+        if any(v is not None for v in self._kernel_args().values()):     # kernelised global solve: one "grid point" seeing every observation
             from .core import KETKFModule
             return KETKFModule(self._kernel, self.inf_factor, self.engine)(self._dev(yb), self._dev(d))
         return self.engine.etkf_weights(self._dev(yb), self._dev(d), self.inf_factor)
@@ -180,7 +175,7 @@ class LETKF(ETKF):
         nb = self._lists(grid_coords, obs_coords, g0, g1, grid_info, obs_info)
         k = yb.shape[0]
         x = torch.zeros((1, k, nb.g1), dtype=self.dtype, device=self.engine.device)
-        _, W = self.engine.analysis(x, yb, d, nb, self.inf_factor, return_weights=True, rbf_gamma=self._gamma)
+        _, W = self.engine.analysis(x, yb, d, nb, self.inf_factor, return_weights=True, **self._kernel_args())
         return W
 
     def analyse_arrays(self, state, yb, d, grid_coords=None, obs_coords=None, g0=0, g1=None,
@@ -190,7 +185,7 @@ class LETKF(ETKF):
         shp = st.shape
         nb = self._lists(grid_coords, obs_coords, g0, g1, grid_info, obs_info)
         xa, flags = self.engine.analysis(st.reshape(-1, shp[-2], shp[-1]), self._dev(yb), self._dev(d), nb,
-                                         self.inf_factor, rbf_gamma=self._gamma, return_flags=True)
+                                         self.inf_factor, return_flags=True, **self._kernel_args())
         bad = int((flags & 0xff).max().item()) if flags.numel() else 0
         if bad & 1:
             raise RuntimeError("LETKF kernel: local observation list overflow (engine bug: lists are sized from counts)")

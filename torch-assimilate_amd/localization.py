@@ -18,7 +18,7 @@ from typing import Any, Callable, Optional, Sequence, Tuple, Union
 import numpy as np
 import torch
 
-__all__ = ["GaspariCohn", "EuclideanMetric", "AbsoluteDistance"]
+__all__ = ["GaspariCohn", "GaspariCohnInf", "EuclideanMetric", "AbsoluteDistance"]
 
 
 class EuclideanMetric:
@@ -55,6 +55,8 @@ class AbsoluteDistance(EuclideanMetric):
 
 
 class GaspariCohn:
+    _taper = 0       # MIA_TAPER_GC
+
     def __init__(self, length_scale: Union[float, Tuple[float, ...]], dist_func: Callable,
                  epsilon: float = 1e-5):
         self.radius = np.atleast_1d(np.asarray(length_scale, dtype=np.float64))
@@ -78,7 +80,7 @@ class GaspariCohn:
         eng = engine or _default_engine()
         dist = np.atleast_2d(np.asarray(self.dist_func(grid_ind, obs_grid), dtype=np.float64))
         r = torch.as_tensor(dist / self.radius[:dist.shape[0], None], dtype=torch.float64)
-        w = eng.gaspari_cohn(r).cpu().numpy()
+        w = eng.gaspari_cohn(r, self._taper).cpu().numpy()
         weights = np.prod(w, axis=0)
         return weights > self.epsilon, weights
 
@@ -92,7 +94,7 @@ class GaspariCohn:
         if metric is not None:
             nc = 1 if np.ndim(grid_xyz) == 1 else np.shape(grid_xyz)[1]
             return engine.localize(grid_xyz, obs_xyz, list(self.radius), metric.groups(nc, len(self.radius)),
-                                   self.epsilon, g0, g1)
+                                   self.epsilon, g0, g1, taper=self._taper)
         # arbitrary callable: evaluate on the host (user code), in chunks of grid points
         G = len(grid_xyz)
         g1 = G if g1 is None else g1
@@ -112,5 +114,26 @@ class GaspariCohn:
                 dv = np.atleast_2d(np.asarray(self.dist_func(ginfo[gi], oinfo), dtype=np.float64))
                 dist[:, gi - c0, :P] = dv[:n_r]
             parts.append(engine.localize_from_dist(dist, cand[None].expand(c1 - c0, -1), list(self.radius),
-                                                   self.epsilon, g0=c0))
+                                                   self.epsilon, g0=c0, taper=self._taper))
         return engine.merge_neighbour_lists(parts)
+
+
+class GaspariCohnInf(GaspariCohn):
+    """Gaspari-Cohn correlation function with form factor infinity, C_0(z, inf, c): mirror of
+    pytassim.localization.GaspariCohnInf (gaspari_cohn.py:139-254).  One length scale (the reference divides the
+    distance by ``self.radius`` as a whole, :243); four polynomial pieces on [0, 0.5), [0.5, 1), [1, 1.5), [1.5, 2)
+    (:176-215, assembled :244-251), evaluated by ``mia_gaspari_cohn_inf_f64`` / the taper switch of the
+    localisation kernels."""
+    _taper = 1       # MIA_TAPER_GC_INF
+
+    def __init__(self, length_scale: float, dist_func: Callable, epsilon: float = 1e-5):
+        if np.size(length_scale) != 1:
+            raise ValueError("GaspariCohnInf takes one length scale")
+        super().__init__(float(np.asarray(length_scale).reshape(-1)[0]), dist_func, epsilon)
+        self._thres = [2, 1.5, 1, 0.5]
+
+    def __str__(self) -> str:
+        return "GaspariCohnInf(l={0})".format(str(self.radius))
+
+    def __repr__(self) -> str:
+        return "GaspariCohnInf"
