@@ -283,6 +283,35 @@ int mia_apply_weights_f32(const float* X, int64_t ldx, int m, int k, int64_t g0,
 int mia_apply_weights_f64(const double* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
                           const double* W, double* Xa, int64_t ldo, int64_t o0, void* stream);
 
+/* Ensemble transform with PER-GRID-POINT weights: _apply_weights with weights of dims (grid, ensemble, ensemble_new)
+ * (base.py:257-278; what update_state does with the result of estimate_weights, filter.py:157-164, and what the
+ * IEnKS does every iteration and at its end, variational.py:107-135).  W [g1-g0][k][k]. */
+int mia_apply_local_weights_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                const float* W, float* Xa, int64_t ldo, int64_t o0, void* stream);
+int mia_apply_local_weights_f64(const double* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                const double* W, double* Xa, int64_t ldo, int64_t o0, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Localised IEnKS: one Gauss-Newton update of the ensemble weights per grid point,
+ * IEnKSTransformModule / IEnKSBundleModule.forward (core/ienks.py:108-141, 167-173) on the localised block, as
+ * LocalizedIEnKSTransform.inner_loop / LocalizedIEnKSBundle.inner_loop run it through wrapper_localization with
+ * args_to_skip=(0,) (interface/lienks.py:75-118; the weights are not masked, wrapper.py:92-93).
+ *   W_in   [g1-g0][k][k] (w_stride = k*k), or ONE [k][k] matrix for every grid point (w_stride = 0: the prior
+ *          weights of the first iteration, base.py:244-254)
+ *   rec, nbr_*: packed observation records and local lists, as for mia_letkf_analysis_packed_*
+ *   tau in [0, 1]; epsilon <= 0: transform variant (dh/dw = Wp^-1 Yl), epsilon > 0: bundle variant (dh/dw = Yl / eps)
+ *   W_out  [g1-g0][k][k];  a grid point without local observations gets its weights back unchanged (ienks.py:135)
+ * flags_opt: MIA_FLAG_OVERFLOW / NOCONV / NONFINITE (singular Wp).
+ * ---------------------------------------------------------------------------------- */
+int mia_lienks_update_f32(const float* W_in, int64_t w_stride, int k, int64_t g0, int64_t g1,
+                          const float* rec, int64_t P,
+                          const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
+                          float tau, float epsilon, float* W_out, int32_t* flags_opt, void* stream);
+int mia_lienks_update_f64(const double* W_in, int64_t w_stride, int k, int64_t g0, int64_t g1,
+                          const double* rec, int64_t P,
+                          const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
+                          double tau, double epsilon, double* W_out, int32_t* flags_opt, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Observation-space preparation, the step immediately upstream of the analysis
  * (AssimilationInterface._get_obs_space_variables, interface/base.py:359-379): from the ensemble in observation

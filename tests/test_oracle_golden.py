@@ -166,3 +166,36 @@ def test_g8_localised(golden):
         ana, w = O.letkf_analysis(st, gx, ox, yb, d, 10.0, 1.1, core=core, taper=taper)
         assert rel_fro(w[::8], g[f"{tag}_weights"]) < 1e-10, tag
         assert rel_fro(ana, g[f"{tag}_analysis"]) < 1e-10, tag
+
+
+def test_g9_ienks_update(golden):
+    g = golden("g9_ienks.npz")
+    for bi, (k, p) in enumerate(g["blocks"]):
+        yb, d = g[f"yb_{bi}"], g[f"d_{bi}"]
+        for tau in (1.0, 0.7):
+            ttag = str(tau).replace(".", "p")
+            for vname, eps in (("transform", None), ("bundle", 1e-4)):
+                scale = 1.0 if eps is None else eps
+                w = np.eye(k)
+                for it in range(3):
+                    w = O.ienks_update(w, yb * scale, d, tau, eps).numpy()
+                    assert rel_fro(w, g[f"{vname}_{bi}_{ttag}_it{it}"]) < 1e-10, (vname, bi, tau, it)
+                got = O.ienks_update(g[f"w0_{bi}"], yb * scale, d, tau, eps).numpy()
+                assert rel_fro(got, g[f"{vname}_{bi}_{ttag}_general"]) < 1e-10
+    # no observation: weights come back unchanged (core/ienks.py:135; tests/unit_tests/core/test_ienks.py)
+    w0 = g["w0_4"]
+    np.testing.assert_array_equal(O.ienks_update(w0, np.zeros((40, 0)), np.zeros(0)).numpy(), w0)
+    # the first transform iteration from the prior weights with tau = 1 is the ETKF analysis
+    yb, d = g["yb_1"], g["d_1"]
+    assert rel_fro(O.ienks_update(np.eye(40), yb, d, 1.0).numpy(), O.etkf_weights(yb, d, 1.0).numpy()) < 1e-10
+
+
+def test_g9_localised_ienks(golden):
+    g = golden("g9_ienks.npz")
+    st, gx, ox, yb, d = g["loc_state"], g["loc_grid_x"], g["loc_obs_x"], g["loc_yb"], g["loc_d"]
+    for vname, tau, eps in (("transform", 0.8, None), ("bundle", 1.0, 1e-3)):
+        w = np.eye(40)
+        for it in range(2):
+            w = O.lienks_weights(w, gx, ox, yb * (1.0 if eps is None else eps), d, 10.0, tau, eps)
+            assert rel_fro(w[::8], g[f"loc_{vname}_it{it}_weights"]) < 1e-10, (vname, it)
+        assert rel_fro(O.apply_weights(st, w), g[f"loc_{vname}_analysis"]) < 1e-10

@@ -42,6 +42,7 @@ def import_reference():
         linear=importlib.import_module("pytassim.kernels.linear"),
         wrapper=importlib.import_module("pytassim.interface.wrapper"),
     )
+    mods["ienks"] = importlib.import_module("pytassim.core.ienks")
     for name in ("polynomial", "tanh", "periodic", "rational", "orn_uhl", "scale", "diag", "base_kernels"):
         mods[name] = importlib.import_module("pytassim.kernels." + name)
     return mods
@@ -248,6 +249,42 @@ def main():
         g8[f"{tag}_weights"] = w[::8]
         g8[f"{tag}_analysis"] = apply_weights(st, w)
     np.savez_compressed(os.path.join(OUT, "g8_kernels_gcinf.npz"), **g8)
+
+    # ---- G9: row f3, IEnKS weight update (core/ienks.py) -- chained iterations from the prior weights
+    IEnKSTransformModule, IEnKSBundleModule = R["ienks"].IEnKSTransformModule, R["ienks"].IEnKSBundleModule
+    r9 = np.random.RandomState(9)
+    g9 = {}
+    blocks9 = [(10, 6), (40, 20), (20, 40), (7, 5), (40, 0)]
+    g9["blocks"] = np.array(blocks9)
+    for bi, (k, p) in enumerate(blocks9):
+        yb = r9.normal(size=(k, p))
+        yb -= yb.mean(axis=0)
+        dd = r9.normal(size=(p,))
+        w0 = np.eye(k) + 0.1 * r9.normal(size=(k, k))          # a general, non-symmetric starting point
+        g9[f"yb_{bi}"], g9[f"d_{bi}"], g9[f"w0_{bi}"] = yb, dd, w0
+        for tau in (1.0, 0.7):
+            ttag = str(tau).replace(".", "p")
+            for vname, mod, scale in (("transform", IEnKSTransformModule(t64(tau)), 1.0),
+                                      ("bundle", IEnKSBundleModule(t64(1e-4), t64(tau)), 1e-4)):
+                w = t64(np.eye(k))
+                for it in range(3):
+                    w = mod(w, t64(yb * scale), t64(dd))
+                    g9[f"{vname}_{bi}_{ttag}_it{it}"] = w.numpy()
+                g9[f"{vname}_{bi}_{ttag}_general"] = mod(t64(w0), t64(yb * scale), t64(dd)).numpy()
+    # localised: two iterations of the per-grid-point loop of interface/lienks.py:88-113 on fixed obs-space input
+    st, gx, ox, yb, dd = synth(64, 40, 2, seed=13)
+    g9.update(loc_state=st, loc_grid_x=gx, loc_obs_x=ox, loc_yb=yb, loc_d=dd)
+    for vname, mod, scale in (("transform", IEnKSTransformModule(t64(0.8)), 1.0),
+                              ("bundle", IEnKSBundleModule(t64(1e-3), t64(1.0)), 1e-3)):
+        f_loc = wrapper_localization(wrapper_bridge(mod, torch.device("cpu"), torch.float64),
+                                     GaspariCohn(10.0, lambda g, o: np.abs(o - g[1])))
+        w = np.broadcast_to(np.eye(40), (64, 40, 40))
+        for it in range(2):
+            w = np.stack([f_loc(np.array([0.0, x]), w[gi], yb * scale, dd, obs_info=ox, args_to_skip=(0,))
+                          for gi, x in enumerate(gx)])
+            g9[f"loc_{vname}_it{it}_weights"] = w[::8]
+        g9[f"loc_{vname}_analysis"] = apply_weights(st, w)
+    np.savez_compressed(os.path.join(OUT, "g9_ienks.npz"), **g9)
 
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))

@@ -18,6 +18,8 @@ _LAZY = {
     "TanhKernel": "kernels", "PeriodicKernel": "kernels", "RationalKernel": "kernels",
     "OrnsteinUhlenbeckKernel": "kernels", "ScaleKernel": "kernels", "DiagKernel": "kernels",
     "AdditiveKernel": "kernels", "MultiplicativeKernel": "kernels", "PowerKernel": "kernels",
+    "IEnKSTransformModule": "ienks", "IEnKSBundleModule": "ienks", "IEnKSTransform": "ienks", "IEnKSBundle": "ienks",
+    "LocalizedIEnKSTransform": "ienks", "LocalizedIEnKSBundle": "ienks",
     "ShardedLetkf": "sharded", "block_partition": "sharded", "gather_blocks": "sharded",
 }
 

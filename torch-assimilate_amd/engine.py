@@ -443,6 +443,57 @@ class LetkfEngine:
             res.append(finish if finish is not None else (lambda: 0))
         return res[0] if len(res) == 1 else tuple(res)
 
+    # ------------------------------------------------------------------- IEnKS
+    def ienks_update(self, weights: torch.Tensor, Yb: Optional[torch.Tensor], d: Optional[torch.Tensor],
+                     nbrs: NeighbourLists, tau: float = 1.0, epsilon: Optional[float] = None,
+                     rec: Optional[torch.Tensor] = None, return_flags: bool = False):
+        """One IEnKS weight update per grid point of the shard ``nbrs`` (core/ienks.py:108-141 on the localised
+        block, interface/lienks.py:75-118).  ``weights``: (k, k) shared by all points (e.g. the prior weights) or
+        (n, k, k); ``epsilon`` None = transform variant, a positive value = bundle variant.  Returns (n, k, k)."""
+        weights = torch.as_tensor(weights)
+        dtype = weights.dtype if weights.dtype in (torch.float32, torch.float64) else torch.float64
+        weights = weights.to(device=self.device, dtype=dtype).contiguous()
+        k = weights.shape[-1]
+        n = nbrs.g1 - nbrs.g0
+        if weights.shape[-2] != k or weights.dim() not in (2, 3) or (weights.dim() == 3 and weights.shape[0] != n):
+            raise ValueError("weights must be (k, k) or (n, k, k) with n the number of grid points of the shard")
+        if rec is None:
+            if Yb.dim() != 2 or Yb.shape[0] != k:
+                raise ValueError("Yb must be (k, P) with the weights' ensemble size")
+            rec = self.pack_obs(Yb, d, dtype)
+        if rec.dtype != dtype or rec.shape[1] != (k + 1 + 3) // 4 * 4:
+            raise ValueError("packed records do not match the weights' dtype / ensemble size")
+        if not 0.0 <= float(tau) <= 1.0:
+            raise ValueError("tau must lie in [0, 1]")           # bound_tensor(0, 1), interface/ienks.py:82-86
+        if epsilon is not None and not float(epsilon) > 0.0:
+            raise ValueError("epsilon must be positive")
+        out = torch.empty((n, k, k), dtype=dtype, device=self.device)
+        flags = torch.empty(n, dtype=torch.int32, device=self.device)
+        sfx = "f32" if dtype == torch.float32 else "f64"
+        fn = getattr(self.lib, "mia_lienks_update_" + sfx)
+        _cabi.check(fn(_ptr(weights), k * k if weights.dim() == 3 else 0, k, nbrs.g0, nbrs.g1, _ptr(rec), rec.shape[0],
+                       _ptr(nbrs.cnt), _ptr(nbrs.idx), _ptr(nbrs.w), nbrs.p_cap, nbrs.p_max, float(tau),
+                       float(epsilon) if epsilon is not None else 0.0, _ptr(out), _ptr(flags), self._stream()),
+                    "mia_lienks_update_" + sfx)
+        return (out, flags) if return_flags else out
+
+    def apply_local_weights(self, X: torch.Tensor, W: torch.Tensor, g0: int = 0, g1: Optional[int] = None) -> torch.Tensor:
+        """_apply_weights with per-grid-point weights W (g1-g0, k, k) (interface/base.py:257-278)."""
+        if X.dim() == 2:
+            X = X[None]
+        X = X.to(self.device).contiguous()
+        m, k, G = X.shape
+        g1 = G if g1 is None else g1
+        W = W.to(device=self.device, dtype=X.dtype).contiguous()
+        if W.shape != (g1 - g0, k, k):
+            raise ValueError("weights must be (grid, ensemble, ensemble_new) = (%d, %d, %d)" % (g1 - g0, k, k))
+        out = torch.empty((m, k, g1 - g0), dtype=X.dtype, device=self.device)
+        sfx = "f32" if X.dtype == torch.float32 else "f64"
+        fn = getattr(self.lib, "mia_apply_local_weights_" + sfx)
+        _cabi.check(fn(_ptr(X), G, m, k, g0, g1, _ptr(W), _ptr(out), g1 - g0, 0, self._stream()),
+                    "mia_apply_local_weights_" + sfx)
+        return out
+
     # ------------------------------------------------------------- global ETKF
     def etkf_weights(self, Yb: torch.Tensor, d: torch.Tensor, inf_factor: float = 1.0) -> torch.Tensor:
         Yb = Yb.to(self.device).contiguous()
