@@ -153,3 +153,28 @@ def test_ienks_argument_errors_and_overflow_flag(mia, eng):
     f = flags.cpu().numpy() & 0xff
     over = nb.cnt.cpu().numpy() > 3
     assert over.any() and np.all(f[over] == 1) and torch.isnan(w[torch.tensor(over)]).all()
+
+
+def test_weight_save_path_streams_weights_through_disk(mia, golden, tmp_path):
+    """filter.py:157-164 with a weight_save_path: estimate -> store (device -> pinned -> netCDF) -> load -> apply;
+    the analysis equals the fused route's, the file holds the reference's weights."""
+    from torch_assimilate_amd import weights_io as io
+    g = golden("g7_synthetic_configs.npz")
+    st, gx, ox, yb, d = (g["c2_" + n] for n in ("state", "grid_x", "obs_x", "yb", "d"))
+    path = str(tmp_path / "w.nc")
+    loc = mia.GaspariCohn(10.0, mia.AbsoluteDistance())
+    a = mia.LETKF(localization=loc, inf_factor=1.1, dtype=torch.float64, weight_save_path=path)
+    xa = a.analyse_arrays(st, yb, d, grid_coords=gx, obs_coords=ox)
+    assert rel_fro(xa.cpu().numpy(), g["c2_1p1_analysis"]) < 1e-10
+    W, coords = io.load_weights(path)
+    assert tuple(W.shape) == (256, 40, 40) and coords["grid"].tolist() == list(range(256))
+    assert rel_fro(W.numpy()[g["c2_widx"]], g["c2_1p1_weights"]) < 1e-10
+    # several staging chunks, ragged tail, float32 weights
+    Wd = torch.randn(1000, 12, 12, device="cuda:0")
+    io.store_weights(path, Wd, chunk_points=96)
+    back, _ = io.load_weights(path, "cuda:0", torch.float32, chunk_points=130)
+    assert back.is_cuda and torch.equal(back, Wd)
+    # global ETKF: (k, k) weights through the same path
+    e = mia.ETKF(inf_factor=1.1, dtype=torch.float64, weight_save_path=path)
+    xg = e.analyse_arrays(g["c1_state"], g["c1_yb"], g["c1_d"])
+    assert rel_fro(xg.cpu().numpy(), g["c1_1p1_analysis"]) < 1e-10

@@ -126,3 +126,33 @@ def test_kernel_programs_reproduce_the_reference_kernels(golden):
     with pytest.raises(ValueError):
         K.kernel_route(deep)                            # more operations than the device evaluates
     assert str(K.PolyKernel(2.0, 1.0) + K.RBFKernel(0.5)) == "PolynomialKernel(2.0, 1.0)+RBFKernel(γ=0.5)"
+
+
+def test_weight_files_round_trip_and_layout(tmp_path):
+    """store_weights / load_weights (base.py:280-325, utilities/xarray.py:36-173) on host tensors: netCDF-3 layout
+    of xarray's scipy engine, multi-level grid index flattened with `multidim_levels`, values exact in float64."""
+    import torch
+    from scipy.io import netcdf_file
+    from torch_assimilate_amd import weights_io as io
+    rs = np.random.RandomState(0)
+    W = torch.tensor(rs.normal(size=(50, 6, 6)))
+    path = str(tmp_path / "weights.nc")
+    io.store_weights(path, W, grid_levels={"lat": rs.normal(size=50), "lon": np.arange(50)}, ensemble=np.arange(6) * 2)
+    f = netcdf_file(path, mmap=False)
+    assert f.version_byte == 2
+    var = f.variables[io.DATA_VARIABLE]
+    assert var.dimensions == ("grid", "ensemble", "ensemble_new") and var.data.dtype == np.dtype(">f8")
+    assert f.variables["grid"].multidim_levels == b"lat;lon"                  # encode_multidim, xarray.py:97-102
+    np.testing.assert_array_equal(f.variables["ensemble_new"][:], np.arange(6) * 2)
+    f.close()
+    out, coords = io.load_weights(path)
+    np.testing.assert_array_equal(out.numpy(), W.numpy())
+    assert coords["multidim_levels"] == ["lat", "lon"] and coords["lon"].tolist() == list(range(50))
+    io.store_weights(path, W[0].float())                                      # global filter: (ensemble, ensemble_new)
+    out2, coords2 = io.load_weights(path, dtype=torch.float32)
+    assert out2.dtype == torch.float32 and sorted(coords2) == ["ensemble", "ensemble_new"]
+    np.testing.assert_array_equal(out2.numpy(), W[0].float().numpy())
+    with pytest.raises(ValueError):
+        io.store_weights(path, W[:, :3])
+    with pytest.raises(ValueError):
+        io.store_weights(path, W, grid_index=np.arange(49))

@@ -117,11 +117,30 @@ class ETKF:
             off += sizes[j]
         return d, Yb
 
+    def store_weights(self, weights: torch.Tensor, grid_index=None, ensemble=None, grid_levels=None) -> None:
+        """BaseAssimilation.store_weights (base.py:280-300): the weights go to ``weight_save_path`` as netCDF."""
+        from . import weights_io
+        weights_io.store_weights(self.weight_save_path, weights, grid_index=grid_index, ensemble=ensemble,
+                                 grid_levels=grid_levels)
+
+    def load_weights(self) -> torch.Tensor:
+        """BaseAssimilation.load_weights (base.py:302-325): back onto the GPU, in the working dtype."""
+        from . import weights_io
+        return weights_io.load_weights(self.weight_save_path, self.engine.device, self.dtype)[0]
+
+    def _through_disk(self, weights: torch.Tensor, grid_index=None) -> torch.Tensor:
+        """FilterAssimilation.update_state (filter.py:160-163): with a weight_save_path the weights are stored and
+        the analysis uses what was loaded back."""
+        if self.weight_save_path is None:
+            return weights
+        self.store_weights(weights, grid_index=grid_index)
+        return self.load_weights()
+
     def analyse_arrays(self, state, yb, d, **_unused) -> torch.Tensor:
         """state (..., k, G) -> analysis of the same shape: weights + _apply_weights (base.py:257-278)."""
         st = self._dev(state)
         shp = st.shape
-        W = self.estimate_weights_arrays(yb, d)
+        W = self._through_disk(self.estimate_weights_arrays(yb, d))
         xa = self.engine.apply_weights(st.reshape(-1, shp[-2], shp[-1]), W)
         return xa.reshape(shp)
 
@@ -180,9 +199,16 @@ class LETKF(ETKF):
 
     def analyse_arrays(self, state, yb, d, grid_coords=None, obs_coords=None, g0=0, g1=None,
                        grid_info=None, obs_info=None) -> torch.Tensor:
-        """Fused path: the weights never leave the GPU's LDS."""
+        """Fused path: the weights never leave the GPU's LDS -- unless a ``weight_save_path`` asks for them: then
+        estimate_weights -> store -> load -> _apply_weights as in the reference (filter.py:157-164)."""
         st = self._dev(state)
         shp = st.shape
+        if self.weight_save_path is not None:
+            W = self.estimate_weights_arrays(yb, d, grid_coords, obs_coords, g0, g1, grid_info, obs_info)
+            gidx = np.arange(g0, g0 + W.shape[0])
+            W = self._through_disk(W, grid_index=gidx)
+            xa = self.engine.apply_local_weights(st.reshape(-1, shp[-2], shp[-1]), W, g0, g0 + W.shape[0])
+            return xa.reshape(shp[:-1] + (W.shape[0],))
         nb = self._lists(grid_coords, obs_coords, g0, g1, grid_info, obs_info)
         xa, flags = self.engine.analysis(st.reshape(-1, shp[-2], shp[-1]), self._dev(yb), self._dev(d), nb,
                                          self.inf_factor, return_flags=True, **self._kernel_args())
