@@ -388,6 +388,26 @@ int mia_letkf_sharded_step_f32(const float* X /* [m][k][G] */, int64_t G, int m,
                                float* Xa /* [m][k][G] */, int32_t* flags, int32_t* counters,
                                void* ws, size_t ws_bytes, void* stream, void* comm_stream);
 
+/* The same step with its three phases on caller-chosen streams, for software-pipelining consecutive steps:
+ *   prep_stream  (NULL: = stream)  records, observation index, neighbour lists -- a chain of small launches
+ *   stream                         the analysis kernel(s), started once prep_stream has produced the lists
+ *   comm_stream                    per-piece all-gather + placement, as above
+ * With one analysis stream shared by all steps and one prep_stream per step in flight, the preparation of step i+1
+ * runs beside the analysis of step i while the analyses themselves stay in order (two analysis kernels sharing the
+ * CUs are slower than one after the other).  step_flags: MIA_STEP_NO_JOIN = do not make `stream` wait for the
+ * exchange at the end (the next step's analysis need not wait for this step's all-gather): the result and
+ * counters[4..7] are then complete once comm_stream has drained, which the caller orders itself. */
+#define MIA_STEP_NO_JOIN 1
+int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int m, int k,
+                                       const float* Yb, const float* d, int64_t P,
+                                       const double* grid_xyz, const double* obs_xyz,
+                                       int n_coord, const int32_t* coord_group /* host */, const double* gc_c /* host */,
+                                       int n_r, double gc_eps, float inf_factor, float gamma, int method,
+                                       int p_max_assumed, mia_comm_t* comm, int n_chunks, int phase,
+                                       float* Xa, int32_t* flags, int32_t* counters,
+                                       void* ws, size_t ws_bytes, void* stream, void* comm_stream,
+                                       void* prep_stream, int step_flags);
+
 #ifdef __cplusplus
 }
 #endif

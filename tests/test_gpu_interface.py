@@ -184,7 +184,8 @@ def _emulated_peer_comm(mia, runner, rank, ref_full, G, chunks):
     calls = {"n": 0}
 
     def allgather(ctx, send, recv, nbytes, stream):
-        ws = runner._native["ws"]
+        ws = next(sl["ws"] for sl in runner._native["slots"]           # the slot (pipeline stage) this step runs in
+                  if sl.get("ws") is not None and sl["ws"].data_ptr() <= send < sl["ws"].data_ptr() + sl["ws"].numel())
         c = calls["n"] % chunks
         calls["n"] += 1
         data = m * k * nc * 4
@@ -236,7 +237,7 @@ def test_native_step_driver_two_rank_layout_on_one_gpu(mia, G, chunks, strong, r
     runner = mia.ShardedLetkf(dev, rank, 2, radii=[10.0], inf_factor=1.1, comm_chunks=chunks)
     runner._p_max_hint = plain._p_max_hint
     handle, keep, calls = _emulated_peer_comm(mia, runner, rank, ref, G, chunks)
-    runner._native = dict(comm=handle, custom=True, ws=None, stream=torch.cuda.Stream(device=dev), key=None)
+    runner._native = dict(comm=handle, custom=True, stream=torch.cuda.Stream(device=dev), slots=[{}, {}, {}])
     try:
         for _ in range(2):
             out = runner.assimilate(*args)
@@ -245,6 +246,16 @@ def test_native_step_driver_two_rank_layout_on_one_gpu(mia, G, chunks, strong, r
             assert runner.last_flags_ok()
         assert runner.native_steps == 2
         assert calls["n"] == 2 * chunks * (2 if strong else 1)
+        # the same steps software-pipelined (submit i+1 before collecting i): both slots, one exchange stream
+        if not strong:          # (the emulated peer's callback serves pieces in submission order)
+            pend = []
+            for _ in range(6):
+                pend.append(runner.submit(*args))
+                if len(pend) == 3:                          # three steps in flight
+                    assert torch.equal(pend.pop(0).result(), ref)
+            while pend:
+                assert torch.equal(pend.pop(0).result(), ref)
+            assert runner.last_flags_ok() and runner.native_steps == 8
     finally:
         from torch_assimilate_amd import _cabi
         _cabi.lib().mia_comm_destroy(handle)
@@ -276,10 +287,58 @@ def test_native_step_driver_through_real_rccl_single_rank(mia):
         torch.cuda.synchronize()
         assert r.native_steps == 3 and r._native["comm"] is not None
         assert torch.equal(out, ref) and r.last_flags_ok()
+        pend = None                                   # pipelined: two steps in flight over the real RCCL calls
+        for _ in range(6):
+            h = r.submit(*args)
+            if pend is not None:
+                assert torch.equal(pend.result(), ref)
+            pend = h
+        assert torch.equal(pend.result(), ref) and r.native_steps == 9
         r.close()
     finally:
         if own:
             dist.destroy_process_group()
+
+
+def test_pipelined_steps_match_serial_steps(mia):
+    """ShardedLetkf.submit: step i+1 is enqueued before step i is collected (two slots, two streams).  Different
+    inputs per step, a step whose strong observations make the matfun kernel decline points (phase-1 redo on the
+    slot's stream), and a step whose denser observations break the assumed list bound (all in-flight steps are
+    drained and the step is redone with exact lists): every result must equal the serial runner's, bit for bit."""
+    dev = torch.device("cuda:0")
+    G = 3000
+    case = O.synthetic_case(G, 40, 2)
+    rs = np.random.RandomState(4)
+    dense = O.synthetic_case(G, 40, 1, seed=5)           # observation at every grid point: ~39 local obs instead of 20
+
+    def inputs(i):
+        c, scale = case, 1.0
+        if i == 3:
+            scale = 12.0
+        if i == 5:
+            c = dense
+        x = torch.as_tensor(c["state"] + 0.01 * i, dtype=torch.float32, device=dev)
+        return (x, torch.as_tensor(c["grid_x"], device=dev), torch.as_tensor(c["obs_x"], device=dev),
+                torch.as_tensor(c["yb"] * scale, dtype=torch.float32, device=dev),
+                torch.as_tensor(c["d"] * scale, dtype=torch.float32, device=dev))
+
+    serial = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1)
+    refs = [serial.assimilate(*inputs(i)).clone() for i in range(8)]
+    for depth in (2, 3):
+        piped = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1, max_in_flight=depth)
+        outs, pend = [], []
+        for i in range(8):
+            pend.append(piped.submit(*inputs(i)))
+            if len(pend) == depth:
+                outs.append(pend.pop(0).result())
+        last = pend[-1]
+        while pend:
+            outs.append(pend.pop(0).result())
+        assert last.result() is outs[-1]                     # idempotent
+        for i, (a, b) in enumerate(zip(outs, refs)):
+            assert torch.equal(a, b), (depth, i)
+        assert piped.last_flags_ok() and not piped._in_flight
+        assert piped.native_steps >= 4
 
 
 # ---------------------------------------------------------------- observation-space preparation (SURVEY 8f-1)

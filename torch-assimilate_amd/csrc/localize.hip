@@ -14,6 +14,12 @@
 
 namespace mia {
 
+// The preparation kernels are short, latency-bound chains.  When consecutive steps are pipelined they share the
+// SIMDs with the previous step's analysis kernel (VALU-bound, every wave slot taken): at equal priority the
+// round-robin issue arbitration stretched localize_kernel from 35 to 200 us and made the preparation chain the
+// critical path.  Raising the waves' issue priority lets them through; alone on the GPU it changes nothing.
+#define MIA_PREP_PRIORITY() __builtin_amdgcn_s_setprio(3)
+
 struct IndexParams {
   const double* obs;  // [P][nc]
   int64_t P;
@@ -78,6 +84,7 @@ __device__ inline void index_dims(const IndexParams& p) {
 // workgroup and coordinate; the workgroup that finishes last derives the cell grid from it (a separate
 // one-thread launch cost as much as this whole kernel: ~5 us of dispatch latency each)
 __global__ __launch_bounds__(256) void index_bbox_dims_kernel(IndexParams p) {
+  MIA_PREP_PRIORITY();
   if (blockIdx.x >= p.nb_bbox) {        // independent passenger: observation records for the analysis kernel
     __shared__ float tile[32][33];
     pack_obs_tile<float>(p.pack.Yb, p.pack.d, p.pack.k, p.P, p.pack.kp, p.pack.rec, (int64_t)(blockIdx.x - p.nb_bbox), tile);
@@ -123,53 +130,47 @@ __device__ inline int obs_cell(const IndexHeader* h, const double* x, int nc) {
   return id;
 }
 
-// exclusive scan of start[0 .. ncell] by one workgroup (entry ncell receives the total).  Every thread owns a
-// contiguous run of entries; runs of up to 8 stay in registers (independent loads: one memory round trip)
+// exclusive scan of start[0 .. ncell] by one workgroup (entry ncell receives the total), in tiles of 8 entries per
+// thread: the 8 loads of a thread are independent (one memory round trip per tile), wave scan by shuffles, the
+// waves' totals and the running carry go through LDS.
 __device__ inline void index_scan_block(const IndexParams& p, int* wsum) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nt = blockDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nt = blockDim.x, nw = nt >> 6;
   const int n = p.hdr->ncell + 1;
-  const int run = (n + nt - 1) / nt;
-  const int lo = tid * run < n ? tid * run : n, hi = lo + run < n ? lo + run : n;
-  int sum = 0;
-  int vals[8];
-  // counts were accumulated by other workgroups' atomics: read them at the same scope
-  if (run <= 8) {
+  int carry = 0;
+  for (int base = 0; base < n; base += nt * 8) {
+    const int lo = base + tid * 8;
+    int vals[8];
+    int sum = 0;
+    // counts were accumulated by other workgroups' atomics: read them at the same scope
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = lo + u;
-      vals[u] = (i < hi && i < n - 1) ? __hip_atomic_load(&p.start[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      vals[u] = (i < n - 1) ? __hip_atomic_load(&p.start[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      sum += vals[u];
     }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) sum += vals[u];
-  } else {
-    for (int i = lo; i < hi; ++i)
-      sum += (i < n - 1) ? __hip_atomic_load(&p.start[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-  }
-  int x = sum;
-  for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-  if (lane == 63) wsum[wv] = x;
-  __syncthreads();
-  int off = x - sum;
-  for (int w = 0; w < wv; ++w) off += wsum[w];
-  if (run <= 8) {
+    int x = sum;
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    __syncthreads();                       // the previous tile's wsum has been consumed
+    if (lane == 63) wsum[wv] = x;
+    __syncthreads();
+    int off = carry + x - sum, total = 0;
+    for (int w = 0; w < nw; ++w) { if (w < wv) off += wsum[w]; total += wsum[w]; }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      if (lo + u < hi) p.start[lo + u] = off;
+      if (lo + u < n) p.start[lo + u] = off;
       off += vals[u];
     }
-  } else {
-    for (int i = lo; i < hi; ++i) {
-      const int v = (i < n - 1) ? __hip_atomic_load(&p.start[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-      p.start[i] = off;
-      off += v;
-    }
+    carry += total;
   }
 }
 
 // cell of every observation + per-cell counts; the workgroup that finishes last turns the counts into
-// exclusive starts (saves the dispatch of a one-workgroup scan kernel)
-__global__ __launch_bounds__(1024) void index_count_scan_kernel(IndexParams p) {
-  __shared__ int wsum[16];
+// exclusive starts (saves the dispatch of a one-workgroup scan kernel).  256-thread workgroups: when consecutive
+// steps are pipelined this kernel runs beside the previous step's analysis kernel, whose one-wave workgroups
+// fill every CU -- a 1024-thread workgroup then waits ~130 us for sixteen wave slots to fall free on ONE CU.
+__global__ __launch_bounds__(256) void index_count_scan_kernel(IndexParams p) {
+  MIA_PREP_PRIORITY();
+  __shared__ int wsum[4];
   __shared__ int is_last;
   const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (j < p.P) {
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(1024) void index_count_scan_kernel(IndexParams p) {
 }
 
 __global__ void index_scatter_kernel(IndexParams p) {
+  MIA_PREP_PRIORITY();
   int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (j >= p.P) return;
   int c = p.cell_of[j];
@@ -200,6 +202,7 @@ __global__ void index_scatter_kernel(IndexParams p) {
 // observations is ranked in registers (ids are distinct: rank = number of smaller ids) with one load and one
 // store per lane; the thread-per-cell insertion sort this replaces spent 16 us in dependent global round trips.
 __global__ __launch_bounds__(256) void index_sortcell_kernel(IndexParams p) {
+  MIA_PREP_PRIORITY();
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = (gridDim.x * blockDim.x) >> 6;
   const int ncell = p.hdr->ncell;
@@ -245,7 +248,8 @@ struct LocalizeParams {
 // round trips (header -> cell range -> index -> coordinates) of ~1.5 us each and only 32 wavefronts fit
 // a CU.  With one point per lane the same chain is amortised over 64 points and the candidate loop
 // (~30 candidates x ~50 float64 operations) runs with all lanes busy.
-__global__ __launch_bounds__(256) void localize_kernel(LocalizeParams p) {
+__global__ __launch_bounds__(64) void localize_kernel(LocalizeParams p) {
+  MIA_PREP_PRIORITY();
   const int64_t pt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int count = 0;
   if (pt < p.ng) {
@@ -418,7 +422,7 @@ int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_
   }
   index_bbox_dims_kernel<<<dim3(ip.nb_bbox + nb_pack), dim3(256), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
-  index_count_scan_kernel<<<dim3((unsigned)((P + 1023) / 1024)), dim3(1024), 0, stream>>>(ip);
+  index_count_scan_kernel<<<dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
   index_scatter_kernel<<<dim3(nbP), dim3(256), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
@@ -470,9 +474,11 @@ int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* 
   if (rc != MIA_OK) return rc;
   lp.g0 = g0; lp.ng = ng; lp.p_cap = p_cap;
   lp.cnt = nbr_cnt; lp.idx = nbr_idx; lp.w = nbr_w; lp.stats = stats;
-  const int64_t nb = (ng + 255) / 256;
+  // one-wave workgroups: beside a bulk kernel that holds every wave slot (pipelined steps) a single freed slot is
+  // enough to place one, whereas a 4-wave workgroup waited for four slots on one CU (200 us instead of 35)
+  const int64_t nb = (ng + 63) / 64;
   if (nb > 2147483647LL) return MIA_ERR_UNSUPPORTED;
-  localize_kernel<<<dim3((unsigned)nb), dim3(256), 0, stream>>>(lp);
+  localize_kernel<<<dim3((unsigned)nb), dim3(64), 0, stream>>>(lp);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

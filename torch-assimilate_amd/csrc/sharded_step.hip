@@ -12,6 +12,8 @@
 // librccl.so) so that this library keeps loading on machines without RCCL and never pulls in a second
 // HIP runtime.
 #include <dlfcn.h>
+#include <atomic>
+#include <mutex>
 #include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -253,6 +255,40 @@ extern "C" int mia_letkf_sharded_step_f32(const float* X, int64_t G, int m, int 
                                           mia_comm_t* comm, int n_chunks, int phase,
                                           float* Xa, int32_t* flags, int32_t* counters,
                                           void* ws, size_t ws_bytes, void* stream, void* comm_stream) {
+  return mia_letkf_sharded_step_streams_f32(X, G, m, k, Yb, d, P, grid_xyz, obs_xyz, n_coord, coord_group, gc_c, n_r,
+                                            gc_eps, inf_factor, gamma, method, p_max_assumed, comm, n_chunks, phase, Xa,
+                                            flags, counters, ws, ws_bytes, stream, comm_stream, nullptr, 0);
+}
+
+namespace {
+// events that order the preparation stream before the analysis stream (no communicator, hence no event storage of
+// its own, on the single-rank route): a small ring, created on first use
+hipEvent_t g_prep_ev[16];
+std::atomic<unsigned> g_prep_next{0};
+std::mutex g_prep_mutex;
+bool g_prep_init = false;
+int prep_event(hipEvent_t* ev) {
+  {
+    std::lock_guard<std::mutex> lock(g_prep_mutex);
+    if (!g_prep_init) {
+      for (int i = 0; i < 16; ++i) MIA_HIP_TRY(hipEventCreateWithFlags(&g_prep_ev[i], hipEventDisableTiming));
+      g_prep_init = true;
+    }
+  }
+  *ev = g_prep_ev[g_prep_next.fetch_add(1) & 15];
+  return MIA_OK;
+}
+}  // namespace
+
+extern "C" int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int m, int k,
+                                                  const float* Yb, const float* d, int64_t P,
+                                                  const double* grid_xyz, const double* obs_xyz, int n_coord,
+                                                  const int32_t* coord_group, const double* gc_c, int n_r, double gc_eps,
+                                                  float inf_factor, float gamma, int method, int p_max_assumed,
+                                                  mia_comm_t* comm, int n_chunks, int phase,
+                                                  float* Xa, int32_t* flags, int32_t* counters,
+                                                  void* ws, size_t ws_bytes, void* stream, void* comm_stream,
+                                                  void* prep_stream, int step_flags) {
   if (!X || !Xa || !flags || !counters || !ws || !grid_xyz || !coord_group || !gc_c) return MIA_ERR_NULL;
   if (P > 0 && (!Yb || !d || !obs_xyz)) return MIA_ERR_NULL;
   if (method < 0 || method > 2 || (phase != 0 && phase != 1)) return MIA_ERR_SIZE;
@@ -268,6 +304,7 @@ extern "C" int mia_letkf_sharded_step_f32(const float* X, int64_t G, int m, int 
   if (ws_bytes < L.total) return MIA_ERR_WORKSPACE;
   if (exch && !comm_stream) return MIA_ERR_NULL;
   hipStream_t s = (hipStream_t)stream, cs = (hipStream_t)comm_stream;
+  hipStream_t ps = prep_stream ? (hipStream_t)prep_stream : s;      // records, index, lists
   // MIA_SEGMENT_SIGNAL=0: one launch + one event per piece instead of the segmented launch (fallback / A-B runs)
   const bool signal_mode = !(getenv("MIA_SEGMENT_SIGNAL") && atoi(getenv("MIA_SEGMENT_SIGNAL")) == 0);
   char* base = (char*)ws;
@@ -298,10 +335,10 @@ extern "C" int mia_letkf_sharded_step_f32(const float* X, int64_t G, int m, int 
     const bool zero_in_kernel = P > 0 && b1 > b0;
     const size_t done_ints = (size_t)n_chunks * 64 * mia::kSlotStride;
     if (!zero_in_kernel) {
-      MIA_HIP_TRY(hipMemsetAsync(counters, 0, 8 * sizeof(int32_t), s));
+      MIA_HIP_TRY(hipMemsetAsync(counters, 0, 8 * sizeof(int32_t), ps));
       if (exch) {
-        MIA_HIP_TRY(hipMemsetAsync(ctr, 0, 4 * sizeof(int32_t), s));
-        MIA_HIP_TRY(hipMemsetAsync(done, 0, done_ints * sizeof(int32_t), s));
+        MIA_HIP_TRY(hipMemsetAsync(ctr, 0, 4 * sizeof(int32_t), ps));
+        MIA_HIP_TRY(hipMemsetAsync(done, 0, done_ints * sizeof(int32_t), ps));
       }
     }
     if (b1 > b0) {
@@ -310,12 +347,19 @@ extern "C" int mia_letkf_sharded_step_f32(const float* X, int64_t G, int m, int 
       const mia::ZeroJob zj{{counters, exch ? ctr : nullptr, exch ? done : nullptr},
                             {8, exch ? 4 : 0, exch ? (int64_t)done_ints : 0}};
       rc = mia::localize_impl(grid_xyz, b0, b1, obs_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, L.cap,
-                              cnt, idx, w, ctr, base + L.loc, L.loc_bytes, s, P > 0 ? &job : nullptr, true,
+                              cnt, idx, w, ctr, base + L.loc, L.loc_bytes, ps, P > 0 ? &job : nullptr, true,
                               zero_in_kernel ? &zj : nullptr);
       if (rc != MIA_OK) return rc;
     }
+    if (ps != s) {   // the analysis stream starts once the preparation stream has produced records and lists
+      hipEvent_t pe;
+      rc = prep_event(&pe);
+      if (rc != MIA_OK) return rc;
+      MIA_HIP_TRY(hipEventRecord(pe, ps));
+      MIA_HIP_TRY(hipStreamWaitEvent(s, pe, 0));
+    }
     if (exch) {   // the side stream starts once the lists exist (and the slots it polls have been cleared)
-      MIA_HIP_TRY(hipEventRecord(comm->ev[kMaxChunks], s));
+      MIA_HIP_TRY(hipEventRecord(comm->ev[kMaxChunks], ps));
       MIA_HIP_TRY(hipStreamWaitEvent(cs, comm->ev[kMaxChunks], 0));
     }
     // one launch over the whole block whose segments are exchanged as they complete (no kernel boundary, no
@@ -385,7 +429,7 @@ extern "C" int mia_letkf_sharded_step_f32(const float* X, int64_t G, int m, int 
   }
 
   // (without the exchange route counters[4..7] stay zero: the rank's own [0..3] are the whole story)
-  if (exch) {                              // the caller's stream continues after the exchange
+  if (exch && !(step_flags & MIA_STEP_NO_JOIN)) {   // the caller's stream continues after the exchange
     MIA_HIP_TRY(hipEventRecord(comm->ev[kMaxChunks + 1], cs));
     MIA_HIP_TRY(hipStreamWaitEvent(s, comm->ev[kMaxChunks + 1], 0));
   }

@@ -13,7 +13,7 @@ from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 
-__all__ = ["ShardedLetkf", "block_partition", "gather_blocks"]
+__all__ = ["ShardedLetkf", "PendingStep", "block_partition", "gather_blocks"]
 
 
 def block_partition(G: int, world: int) -> List[Tuple[int, int]]:
@@ -43,6 +43,19 @@ def gather_blocks(shard: torch.Tensor, G: int, world: int, group=None) -> torch.
     return gathered.view(world, m, k, n).permute(1, 2, 0, 3).reshape(m, k, world * n)[:, :, :G].contiguous()
 
 
+class PendingStep:
+    """Handle of a step enqueued by :meth:`ShardedLetkf.submit`."""
+
+    def __init__(self, runner, state, out=None):
+        self._runner, self._st, self._out = runner, state, out
+
+    def result(self) -> torch.Tensor:
+        """The (m, k, G) analysis; performs the step's host read-back the first time it is called."""
+        if self._out is None:
+            self._runner._native_finish(self)
+        return self._out
+
+
 class ShardedLetkf:
     """LETKF analysis of this rank's grid block + all-gather.
 
@@ -59,7 +72,8 @@ class ShardedLetkf:
                  inf_factor: float = 1.0, coord_group: Optional[Sequence[int]] = None, eps: float = 1e-5,
                  rbf_gamma: Optional[float] = None, compute_shard: Optional[Callable] = None, group=None,
                  method: str = "auto", fused_localization: bool = False, use_graph: bool = False,
-                 comm_chunks: int = 4, chunk_compute: Optional[Callable] = None, native_step: bool = True):
+                 comm_chunks: int = 4, chunk_compute: Optional[Callable] = None, native_step: bool = True,
+                 max_in_flight: int = 3):
         self.device, self.rank, self.world = device, rank, world
         self.radii, self.inf_factor, self.coord_group, self.eps = list(radii), inf_factor, coord_group, eps
         self.rbf_gamma = rbf_gamma
@@ -72,6 +86,9 @@ class ShardedLetkf:
         self._obuf = None
         self.native_step = native_step
         self._native = None
+        self._in_flight = []
+        self.max_in_flight = max(1, int(max_in_flight))
+        self._submitted = 0
         self._force_comm = False      # tests / tools: a one-rank RCCL communicator drives the exchange route
         self.native_steps = 0
         self._graph = None
@@ -207,7 +224,7 @@ class ShardedLetkf:
 
     def _native_state(self):
         if self._native is None:
-            st = dict(comm=None, ws=None, stream=None, key=None)
+            st = dict(comm=None, stream=None, slots=[{} for _ in range(self.max_in_flight)])
             if self.world > 1 or self._force_comm:
                 st["comm"] = self._native_comm()
             st["stream"] = torch.cuda.Stream(device=self.device)
@@ -226,18 +243,39 @@ class ShardedLetkf:
         stream, 16-byte max-reduce of the redo counters), then one 32-byte read-back decides -- identically
         on every rank -- whether anything has to be redone.  The first call on a geometry (no bound for the
         local observation count yet) takes the exact-list route through torch.distributed."""
+        return self._native_finish(self._native_submit(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, pipelined=False))
+
+    def submit(self, X, grid_xyz, obs_xyz, Yb, d) -> "PendingStep":
+        """Enqueue one assimilation step WITHOUT waiting for it: the returned handle's ``result()`` performs the
+        step's one host read-back (validation + rare redo) and hands out the analysis.  Consecutive steps
+        rotate through ``max_in_flight`` slots (own workspace, counters and HIP stream each), so the index / list
+        kernels of a later step -- a chain of small latency-bound launches -- run beside the analysis kernel of
+        an earlier one, and at N > 1 the all-gather of step i (one shared exchange stream: the collectives keep
+        one order on every rank) travels while step i+1 is computed.  A slot whose previous step was not collected
+        yet is collected first; all ranks must submit and collect in the same order."""
+        G = X.shape[-1]
+        g0, g1 = block_partition(G, self.world)[self.rank]
+        if not (self.native_step and self._compute == self._engine_shard and self._chunk_compute is None
+                and torch.is_tensor(X) and X.is_cuda and X.dtype == torch.float32 and X.dim() == 3
+                and not self.fused_localization and not self.use_graph):
+            return PendingStep(self, None, out=self.assimilate(X, grid_xyz, obs_xyz, Yb, d))
+        return self._native_submit(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, pipelined=True)
+
+    def _native_submit(self, X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, pipelined):
         import ctypes as C
         import torch.distributed as dist
         from . import _cabi
         from .engine import _ptr
         eng = self.engine
         if self._p_max_hint is None:
+            for h in list(self._in_flight):                       # drain: the exact-list route is synchronous
+                h.result()
             shard = self._engine_shard(X, grid_xyz, obs_xyz, Yb, d, g0, g1)
             if self.world > 1:
                 t = torch.tensor([self._p_max_hint], dtype=torch.int32, device=X.device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
                 self._p_max_hint = int(t.item())                  # one bound for all ranks
-            return gather_blocks(shard, G, self.world, self.group)
+            return PendingStep(self, None, out=gather_blocks(shard, G, self.world, self.group))
         st = self._native_state()
         lib = eng.lib
         X = X.contiguous()
@@ -257,37 +295,93 @@ class ShardedLetkf:
         hint = int(self._p_max_hint)
         C_chunks = self.comm_chunks if st["comm"] is not None else 1
         key = (G, m, k, P, nc, hint, C_chunks)
-        if st["key"] != key:
+        slot = st["slots"][self._submitted % len(st["slots"]) if pipelined else 0]
+        if slot.get("busy") is not None:                          # its previous step was never collected
+            slot["busy"].result()
+        if slot.get("key") != key:
             nbytes = C.c_size_t(0)
             _cabi.check(lib.mia_letkf_sharded_step_workspace_bytes(G, m, k, P, nc, self.world, C_chunks, hint,
                                                                    C.byref(nbytes)), "sharded_step_workspace_bytes")
-            if st["ws"] is None or st["ws"].numel() < nbytes.value:
-                st["ws"] = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=X.device)
+            if slot.get("ws") is None or slot["ws"].numel() < nbytes.value:
+                slot["ws"] = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=X.device)
             cg = [0] * nc if self.coord_group is None else [int(c) for c in self.coord_group]
-            st["cg"] = (C.c_int32 * nc)(*cg)
-            st["rc"] = (C.c_double * len(self.radii))(*[float(r) for r in self.radii])
-            st["counters"] = torch.zeros(8, dtype=torch.int32, device=X.device)
-            st["key"] = key
+            slot["cg"] = (C.c_int32 * nc)(*cg)
+            slot["rc"] = (C.c_double * len(self.radii))(*[float(r) for r in self.radii])
+            slot["counters"] = torch.zeros(8, dtype=torch.int32, device=X.device)
+            slot["host"] = torch.zeros(8, dtype=torch.int32).pin_memory()
+            slot["key"] = key
         out = torch.empty((m, k, G), dtype=torch.float32, device=X.device)
         flags = torch.empty(max(g1 - g0, 1), dtype=torch.int32, device=X.device)
         method = {"auto": 0, "eig": 1, "matfun": 2}[self.method]
         gamma = float(self.rbf_gamma) if self.rbf_gamma is not None else 0.0
-        comp = torch.cuda.current_stream(X.device)
+        cur = torch.cuda.current_stream(X.device)
         side = st["stream"].cuda_stream if st["stream"] is not None else None
+        exch = st["comm"] is not None and (self.world > 1 or C_chunks > 1)
+        if pipelined:
+            # three streams shared by all steps in flight: a HIGH-PRIORITY one for records / index / lists (a chain
+            # of small launches that runs beside an earlier step's analysis; the priority gives it a hardware queue
+            # of its own -- same-priority HIP streams share a small pool of queues and then serialise -- and lets its
+            # workgroups in first when the bulk kernel's drain), ONE analysis stream (two analysis kernels sharing
+            # the CUs are slower than one after the other), the exchange stream
+            if st.get("astream") is None:
+                st["astream"] = torch.cuda.Stream(device=X.device)
+                st["pstream"] = torch.cuda.Stream(device=X.device, priority=-1)
+            comp, prep = st["astream"], st["pstream"]
+            prep.wait_stream(cur)                                 # inputs (and `out`'s memory) are ready
+            last = st["stream"] if exch else comp                 # where the step's last work is enqueued
+        else:
+            comp, prep, last = cur, None, cur
 
         def call(phase):
-            _cabi.check(lib.mia_letkf_sharded_step_f32(
-                _ptr(X), G, m, k, _ptr(Yb), _ptr(d), P, _ptr(grid), _ptr(obs), nc, st["cg"], st["rc"], len(self.radii),
-                float(self.eps), float(self.inf_factor), gamma, method, hint, st["comm"], C_chunks, phase,
-                _ptr(out), _ptr(flags), _ptr(st["counters"]), _ptr(st["ws"]), st["ws"].numel(),
-                C.c_void_p(comp.cuda_stream), C.c_void_p(side) if side is not None else None),
-                "mia_letkf_sharded_step_f32")
+            _cabi.check(lib.mia_letkf_sharded_step_streams_f32(
+                _ptr(X), G, m, k, _ptr(Yb), _ptr(d), P, _ptr(grid), _ptr(obs), nc, slot["cg"], slot["rc"],
+                len(self.radii), float(self.eps), float(self.inf_factor), gamma, method, hint, st["comm"], C_chunks,
+                phase, _ptr(out), _ptr(flags), _ptr(slot["counters"]), _ptr(slot["ws"]), slot["ws"].numel(),
+                C.c_void_p(comp.cuda_stream), C.c_void_p(side) if side is not None else None,
+                C.c_void_p(prep.cuda_stream) if prep is not None else None, 1 if pipelined else 0),
+                "mia_letkf_sharded_step_streams_f32")
 
         call(0)
-        cnt = st["counters"].tolist()                         # the one host sync of the step
-        if st["comm"] is None or (self.world == 1 and C_chunks == 1):
+        ev = None
+        if pipelined:
+            if not exch:
+                # read the counters back on the (otherwise idle) exchange stream: a copy enqueued on the analysis
+                # stream sits between two analysis kernels and costs ~15 us of dispatch gaps per step
+                done = torch.cuda.Event()
+                done.record(comp)
+                last = st["stream"]
+                last.wait_event(done)
+            with torch.cuda.stream(last):
+                slot["host"].copy_(slot["counters"], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(last)
+        h = PendingStep(self, dict(slot=slot, call=call, comp=comp, cur=cur, ev=ev, out=out, flags=flags, hint=hint,
+                                   last=last,
+                                   C_chunks=C_chunks, args=(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1),
+                                   keep=(X, grid, obs, Yb, d)))
+        slot["busy"] = h
+        self._in_flight.append(h)
+        self._submitted += 1
+        return h
+
+    def _native_finish(self, h: "PendingStep"):
+        from . import _cabi
+        if h._out is not None or h._st is None:
+            return h._out
+        p = h._st
+        slot, st = p["slot"], self._native_state()
+        if p["ev"] is not None:
+            p["ev"].synchronize()                              # the one host wait of the step
+            cnt = slot["host"].tolist()
+        else:
+            cnt = slot["counters"].tolist()                    # serial route: synchronous read-back
+        slot["busy"] = None
+        self._in_flight.remove(h)
+        X, grid_xyz, obs_xyz, Yb, d, G, g0, g1 = p["args"]
+        if st["comm"] is None or (self.world == 1 and p["C_chunks"] == 1):
             cnt[4:8] = cnt[0:4]                                # no exchange route: the rank's own counters
         p_seen, n_over, n_retry = cnt[4], cnt[5], cnt[6]
+        redo = None
         if cnt[7]:
             # a segment waiter gave up (the analysis launch and the exchange stream must be able to run
             # concurrently: e.g. more HIP streams than hardware queues): all ranks switch to one launch + one
@@ -299,18 +393,39 @@ class ShardedLetkf:
             warnings.warn("segmented launch timed out waiting for a segment; falling back to per-piece launches",
                           RuntimeWarning)
             os.environ["MIA_SEGMENT_SIGNAL"] = "0"
-            return self._assimilate_native(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1)
-        if n_over or p_seen > hint:
+            redo = "same"
+        elif n_over or p_seen > p["hint"]:
             self._p_max_hint = None                            # bound broken on some rank: all ranks redo
-            return self._assimilate_native(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1)
+            redo = "exact"
+        if redo:
+            for other in list(self._in_flight):                # steps enqueued behind this one used the same bound
+                other.result()
+            p["cur"].wait_stream(p["comp"])
+            p["cur"].wait_stream(p["last"])
+            h._out = self._assimilate_native(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1)
+            h._st = None
+            return h._out
         if n_retry:
-            call(1)                                            # eigensolver redoes declined points; re-exchange
+            p["call"](1)                                       # eigensolver redoes declined points; re-exchange
+        if p["comp"] is not p["cur"]:
+            # consumers on torch's stream see the result.  Wait for THIS step's completion event only: waiting for
+            # the analysis stream as a whole would also wait for the later steps already enqueued on it, and the
+            # next submit's preparation (which waits for torch's stream) would serialise behind them
+            now = torch.cuda.current_stream(X.device)
+            if n_retry:
+                for strm in {p["comp"], p["last"]}:
+                    e2 = torch.cuda.Event()
+                    e2.record(strm)
+                    now.wait_event(e2)
+            else:
+                now.wait_event(p["ev"])
         self.native_steps += 1
         self.last_retries = cnt[2]
         self._p_max_hint = p_seen if self.world > 1 else max(p_seen, 0)
-        self.last_p_max = hint
-        self._last_flags = flags[:g1 - g0]
-        return out
+        self.last_p_max = p["hint"]
+        self._last_flags = p["flags"][:g1 - g0]
+        h._out, h._st = p["out"], None
+        return h._out
 
     # ------------------------------------------------------------------ compute / exchange overlap
     def _chunk_engine(self, X, grid_xyz, obs_xyz, Yb, d, c0, c1, state, buf):
