@@ -243,7 +243,9 @@ def main():
                                    % ("2" if world == 1 else "3-style", G, gpg, K_ENS, P, GC_RADIUS, p_max, INF),
                        "parallelism": "grid-point block shard x%d%s" % (world, " + RCCL all-gather" if world > 1 else "")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic_from_profiles(world),
+                         "frac": achieved / PEAK_FP32_TFLOPS,
+                         "traffic": (traffic_from_profiles(world) or {}).get("hbm_bytes_fetch_doubled"),
+                         "traffic_detail": traffic_from_profiles(world),
                          "kernel": runner.dominant_kernel_name, "kernel_ms": kern_ms,
                          "algorithmic_flops_per_analysis": algorithmic_flops(K_ENS, 20, 1),
                          "hbm_algorithmic_GBs": hbm_alg, "hbm_frac": hbm_alg / PEAK_HBM_GBS,

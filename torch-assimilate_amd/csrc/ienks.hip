@@ -34,6 +34,7 @@ struct IenksParams {
   T tau, inv_eps;                      // inv_eps == 0: transform variant
   T* Wout; int32_t* flags;
   int n, lda, rows, need_inv, max_sweeps; T rot_tol2, stop_tol2;
+  int nd;                              // > 0: dual route (tau == 1, p_max <= k): order of the p x p eigenproblem
 };
 
 constexpr int kIenksThreads = 256;
@@ -164,12 +165,71 @@ __global__ __launch_bounds__(kIenksThreads) void ienks_update_kernel(IenksParams
     }
   }
   __syncthreads();
-  // ---- gradient and the updated precision (canonical upper triangle of S)
+  // ---- gradient
   for (int i = tid; i < n; i += NT) {
     T acc = T(0);
     if (i < k) { for (int b = 0; b < cnt; ++b) acc += Dt[(size_t)b * kp + i] * Yt[(size_t)b * kp + k]; acc = km1 * wm[i] - acc; }
     gr[i] = acc;
   }
+  int jstat;
+  if (P.nd > 0) {
+    // ---- dual route (tau = 1): Pn = (k-1) I + D D^T has rank-p structure, so the p x p matrix D^T D = V L V^T is
+    //      decomposed instead and every function of Pn is applied as
+    //      f(Pn) = f(k-1) I + M diag((f(k-1+l) - f(k-1)) / l) M^T,  M = D V,
+    //      with the divided differences in closed, cancellation-free form (u = sqrt(k-1+l), a = sqrt(k-1)):
+    //      Pn^-1: -1 / ((k-1)(k-1+l));   sqrt(k-1) Pn^-1/2: -1 / (u (u + a))      (an eighth of the k x k Jacobi work)
+    const int nd = P.nd;
+    for (int it = tid; it < (nd - cnt) * kp; it += NT) Dt[(size_t)cnt * kp + it] = T(0);   // padding rows of D^T
+    __syncthreads();
+    for (int it = tid; it < nd * nd; it += NT) {
+      const int a = it / nd, b = it - a * nd;
+      A[a * lda + b] = (a == b) ? T(1) : T(0);
+      if (a > b) continue;
+      T acc = T(0);
+      for (int i = 0; i < k; ++i) acc += Dt[(size_t)a * kp + i] * Dt[(size_t)b * kp + i];
+      S[a * lda + b] = acc;
+    }
+    __syncthreads();
+    const bool conv = jacobi_sym<T, NT>(S, A, cs, dec, nd, nd, lda, km1, P.rot_tol2, P.stop_tol2, P.max_sweeps, jstat);
+    if (!conv) flag |= MIA_FLAG_NOCONV;
+    const T ar = t_sqrt(km1);
+    for (int r = tid; r < nd; r += NT) {
+      T l = S[r * lda + r];
+      l = l > T(0) ? l : T(0);
+      const T u = t_sqrt(km1 + l);
+      lam[r] = (r < cnt) ? T(-1) / (u * (u + ar)) : T(0);            // sqrt(k-1) Pn^-1/2 - I
+      cs[r] = (r < cnt) ? T(-1) / (km1 * (km1 + l)) : T(0);          // Pn^-1 - I / (k-1)
+    }
+    __syncthreads();
+    // M = D V  (k x nd), kept in the S buffer
+    for (int it = tid; it < k * nd; it += NT) {
+      const int i = it / nd, r = it - i * nd;
+      T acc = T(0);
+      for (int b = 0; b < cnt; ++b) acc += Dt[(size_t)b * kp + i] * A[b * lda + r];
+      S[i * lda + r] = acc;
+    }
+    __syncthreads();
+    for (int r = tid; r < nd; r += NT) {       // cs <- diag(gM) M^T grad
+      T acc = T(0);
+      for (int i = 0; i < k; ++i) acc += S[i * lda + r] * gr[i];
+      cs[r] *= acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < k; i += NT) {
+      T acc = gr[i] / km1;
+      for (int r = 0; r < nd; ++r) acc += S[i * lda + r] * cs[r];
+      cg[i] = wm[i] - P.tau * acc;              // updated w_mean
+    }
+    __syncthreads();
+    for (int it = tid; it < k * k; it += NT) {
+      const int i = it / k, j = it - i * k;
+      T acc = cg[i] + (i == j ? T(1) : T(0));
+      for (int r = 0; r < nd; ++r) acc += lam[r] * S[i * lda + r] * S[j * lda + r];
+      if (!(t_abs(acc) <= T(1e30))) flag |= MIA_FLAG_NONFINITE;
+      wout[it] = acc;
+    }
+  } else {
+  // ---- the updated precision (canonical upper triangle of S)
   {
     const T one_m_tau = T(1) - P.tau;
     for (int it = tid; it < n * n; it += NT) {
@@ -193,7 +253,6 @@ __global__ __launch_bounds__(kIenksThreads) void ienks_update_kernel(IenksParams
   // ---- eigendecomposition of Pn; V accumulates in A (Wp^-1 is no longer needed)
   for (int it = tid; it < n * n; it += NT) { const int a = it / n, b = it - a * n; A[a * lda + b] = (a == b) ? T(1) : T(0); }
   __syncthreads();
-  int jstat;
   const bool conv = jacobi_sym<T, NT>(S, A, cs, dec, n, n, lda, T(0), P.rot_tol2, P.stop_tol2, P.max_sweeps, jstat);
   if (!conv) flag |= MIA_FLAG_NOCONV;
   for (int r = tid; r < n; r += NT) {
@@ -217,6 +276,7 @@ __global__ __launch_bounds__(kIenksThreads) void ienks_update_kernel(IenksParams
     for (int r = 0; r < k; ++r) acc += lam[r] * A[i * lda + r] * A[j * lda + r];
     if (!(t_abs(acc) <= T(1e30))) flag |= MIA_FLAG_NONFINITE;
     wout[it] = acc;
+  }
   }
   if (P.flags) {
     if (tid == 0) ibuf[2] = 0;
@@ -245,7 +305,9 @@ static int ienks_update_impl(const T* W_in, int64_t w_stride, int k, int64_t g0,
   ap.cnt = nbr_cnt; ap.idx = nbr_idx; ap.w = nbr_w; ap.p_cap = p_cap; ap.p_max = p_max;
   ap.tau = tau; ap.inv_eps = epsilon > T(0) ? T(1) / epsilon : T(0);
   ap.Wout = W_out; ap.flags = flags_opt;
-  ap.n = (k + 1) & ~1; ap.lda = ap.n + 1; ap.rows = p_max > 0 ? p_max : 1;
+  ap.n = (k + 1) & ~1; ap.lda = ap.n + 1;
+  ap.nd = (tau == T(1) && p_max <= k && !getenv("MIA_IENKS_PRIMAL")) ? (((p_max > 0 ? p_max : 1) + 1) & ~1) : 0;
+  ap.rows = ap.nd > 0 ? ap.nd : (p_max > 0 ? p_max : 1);
   if (ap.n > 510) return MIA_ERR_UNSUPPORTED;
   // the inverse of Wp is needed for the transform variant's D and, when tau < 1, for w_prec
   ap.need_inv = (ap.inv_eps == T(0) || tau < T(1)) ? 1 : 0;
