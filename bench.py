@@ -135,7 +135,7 @@ def main():
                     help="steps in flight (ShardedLetkf.submit): 3 (default) = steps i+1 and i+2 are enqueued before step i "
                          "is collected; 1 = serial steps")
     ap.add_argument("--method", default="auto", choices=["auto", "eig", "matfun"],
-                    help="analysis route: auto = eigensolver-free matfun kernel for m <= 4 (default), eig = fused Jacobi")
+                    help="analysis route: auto = eigensolver-free matfun kernel (default), eig = fused Jacobi")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

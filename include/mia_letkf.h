@@ -175,7 +175,8 @@ int mia_letkf_analysis_packed_f64(const double* X, int64_t ldx, int m, int k, in
                                   double* Xa, int64_t ldo, int64_t o0, double* W_opt, int32_t* flags_opt,
                                   void* stream);
 
-/* Eigensolver-free route for few state rows (m small) when the weights are not requested: the two matrix
+/* Eigensolver-free route (whenever the weights are not requested; faster than the eigensolver kernel at every number
+ * of state rows measured, tools/time_rows.py): the two matrix
  * functions the analysis needs, (C+reg)^-1 and (C+reg)^-1/2 (core/etkf.py:67-76), are applied to the state row
  * by a Chebyshev expansion whose degree is fixed per grid point from a Gershgorin bound (SURVEY.md section 7
  * notes such evaluations are valid because W and Pa are functions of A only).  Points that would need a
@@ -354,7 +355,7 @@ int mia_obs_space_corr_f64(const double* hx, int64_t ldh, const double* y, const
  * every rank calls mia_comm_create on its device.  mia_comm_create_custom substitutes caller callbacks for
  * the two collectives (used by the tests to emulate a second rank on a one-GPU box).
  *
- * method: 0 auto (matfun for m <= 4), 1 eigensolver kernel, 2 matfun.   p_max_assumed: bound of the local
+ * method: 0 auto (= matfun, with the eigensolver redoing declined points), 1 eigensolver kernel, 2 matfun.   p_max_assumed: bound of the local
  * observation count the launch is sized for (lists capacity = round_up(., 8)).
  * counters [8] i32 (device): [0] longest list of the block, [1] lists longer than the capacity, [2] grid points
  * the matfun kernel declined, [3] error bits (bit 0: a segment waiter timed out); [4..7] the same, max- (or-)

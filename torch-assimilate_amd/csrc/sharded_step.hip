@@ -314,7 +314,7 @@ extern "C" int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int
   double* w = (double*)(base + L.w);
   const int64_t b0 = (int64_t)rank * L.n < G ? (int64_t)rank * L.n : G;
   const int64_t b1 = b0 + L.n < G ? b0 + L.n : G;
-  const bool eig_only = method == 1 || (method == 0 && m > 4);
+  const bool eig_only = method == 1;   // auto = matfun at every m (it wins at every m measured, tools/time_rows.py)
   const int rows = m * k;
   const size_t gath_stride = mia::align_up(L.send_bytes * world, 256);
   int32_t* done = (int32_t*)(base + L.done);

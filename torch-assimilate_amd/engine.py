@@ -338,7 +338,11 @@ class LetkfEngine:
             return None
         return (Yb, d, rec[:P]) if want_rec else (Yb, d)
 
-    MATFUN_MAX_ROWS = 4     # state rows per grid point up to which the eigensolver-free route is preferred
+    # state rows per grid point up to which the eigensolver-free route is preferred.  Measured on MI355X
+    # (tools/time_rows.py): it wins at every m tried (C2 m = 32: 3.3 vs 5.7 ms, C4 m = 64: 15 vs 46 ms per 2e4 points,
+    # C5 m = 64: 1.2 vs 6.3 ms), because the eigensolver kernel's per-row transform is no cheaper than one
+    # Chebyshev recurrence -- so there is no hand-over; the attribute stays for experiments
+    MATFUN_MAX_ROWS = 1 << 30
 
     def analysis(self, X: torch.Tensor, Yb: Optional[torch.Tensor], d: Optional[torch.Tensor],
                  nbrs: NeighbourLists, inf_factor: float = 1.0, return_weights: bool = False,
