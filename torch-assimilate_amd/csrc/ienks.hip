@@ -37,11 +37,11 @@ struct IenksParams {
   int nd;                              // > 0: dual route (tau == 1, p_max <= k): order of the p x p eigenproblem
 };
 
-constexpr int kIenksThreads = 256;
-
-template <typename T>
-__global__ __launch_bounds__(kIenksThreads) void ienks_update_kernel(IenksParams<T> P) {
-  constexpr int NT = kIenksThreads;
+// NT = 256 in production.  One-wave workgroups (NT = 64, MIA_IENKS_NARROW=1) were measured SLOWER for k = 40 (transform,
+// tau = 1: 19.9 vs 14.8 ms per 1e5 grid points; tau < 1: 57 vs 39 ms): the update is bound by its LDS traffic (every
+// operand of the elimination, the k x k products and the Jacobi comes from LDS), not by its barriers
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void ienks_update_kernel(IenksParams<T> P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int k = P.k, kp = P.kp, n = P.n, lda = P.lda, pm = P.p_max;
@@ -320,12 +320,19 @@ static int ienks_update_impl(const T* W_in, int64_t w_stride, int k, int64_t g0,
              (size_t)((p_max + 3) & ~1);
   size_t lds = e * sizeof(T) + (size_t)((p_max + 3) & ~1) * sizeof(int) + 4 * sizeof(int) +
                (size_t)((nbk * (nbk - 1) / 2 + 7) & ~7) * sizeof(unsigned short) + (size_t)((ap.n + 1) & ~1) * sizeof(int) +
-               (size_t)(kIenksThreads / 64 * 2) * sizeof(T);
+               (size_t)(256 / 64 * 2) * sizeof(T);
   lds = align_up(lds, 16);
   if (lds > 160 * 1024) return MIA_ERR_UNSUPPORTED;
-  auto kern = ienks_update_kernel<T>;
-  if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  kern<<<dim3((unsigned)ng), dim3(kIenksThreads), lds, stream>>>(ap);
+  const bool small = ap.n <= 44 && getenv("MIA_IENKS_NARROW");
+  if (small) {
+    auto kern = ienks_update_kernel<T, 64>;
+    if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kern<<<dim3((unsigned)ng), dim3(64), lds, stream>>>(ap);
+  } else {
+    auto kern = ienks_update_kernel<T, 256>;
+    if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kern<<<dim3((unsigned)ng), dim3(256), lds, stream>>>(ap);
+  }
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
