@@ -523,7 +523,11 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
   if (const char* e = getenv("MIA_CHEB_DMAX")) ap.dmax = atoi(e);                 // experiments only
   ap.xskip = 0;
   if (const char* e = getenv("MIA_EXPERIMENT_SKIP")) ap.xskip = atoi(e);
-  ap.log_tol = 14.5f;   // ln(1 / 5e-7): a-priori truncation bound; measured error is flat (2.5e-7..7e-7 vs the reference) for 11 <= log_tol <= 17.5
+  // a-priori truncation bound exp(-log_tol) = 6e-6 of the function scale.  Measured against the reference
+  // (tools/matfun_tol.py, C2 / C4 / C5): the total error is flat at 1.7e-7 .. 3e-7 (float32 rounding) from 17.5 down to
+  // 13, 2.5e-7 / 6.4e-7 / 1.3e-7 at 11, and only at 9 does truncation show (1e-6 / 5e-6); every unit costs ~0.85 of a
+  // degree (C2: 15.3 at 15, 11.9 at 11)
+  ap.log_tol = 12.0f;
   if (const char* e = getenv("MIA_CHEB_LOGTOL")) ap.log_tol = (float)atof(e);     // experiments only
   const size_t lds = cheb_lds_bytes(ap.kp, p_max, nmax, ap.rows);
   if (lds > 160 * 1024) return MIA_ERR_UNSUPPORTED;
