@@ -89,8 +89,13 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = P.k, kp = P.kp, pm = P.p_max;
-  float* S = reinterpret_cast<float*>(smem_raw + (size_t)wave * P.lds_per_wave);    // [NMAX][LDA] full symmetric
-  float* tv = S + NMAX * LDA;                       // [NMAX] recurrence vector (broadcast source)
+  // Orders above 32 on the dual route: S never exists as a whole in LDS -- its rows go from the MFMA accumulators to
+  // the lanes' registers one 16-row panel at a time through a 16 x LDA staging area.  At order 64 (config 4: k = 80,
+  // 64 local observations) the full matrix was 17 KB of the 42 KB a wavefront needed, which capped a CU at 3 waves.
+  constexpr bool STREAM_OK = NMAX > 32;
+  const bool stream_s = STREAM_OK && P.dual;
+  float* S = reinterpret_cast<float*>(smem_raw + (size_t)wave * P.lds_per_wave);    // [NMAX][LDA] full symmetric | [16][LDA] staging
+  float* tv = S + (stream_s ? 16 : NMAX) * LDA;     // [NMAX] recurrence vector (broadcast source)
   float* rhs = tv + NMAX;                           // [NMAX]
   float* uq = rhs + NMAX;                           // [NMAX] scratch (RBF centring)
   f2v* c2 = reinterpret_cast<f2v*>(uq + NMAX);      // [DCAP] Chebyshev coefficients (phi_j, psi_j)
@@ -190,7 +195,55 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
   const int ntrue = P.dual ? cnt : k;
   MIA_WAVE_SYNC();
   // ---- S (full symmetric storage, zero padded)
-  if (P.xskip & 2) {
+  f2v srow2[NMAX / 2];
+  float rsum = 0.0f;
+  if (stream_s) {
+    if constexpr (STREAM_OK) {
+      // S = Yl^T Yl panel by panel: the TT tiles of rows 16 tb .. 16 tb + 15 are accumulated concurrently
+      // (A operand = the panel's rows, B operands = every row panel), written to the staging area in the
+      // D layout (row 4 (lane >> 4) + q, column lane & 15) and read back as whole rows by the 16 lanes that own them.
+      const int lr = tid & 15, h = tid >> 4;
+      const int KS = (k + 3) >> 2;
+      const float* prow[TT];
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        const int row = 16 * t + lr;
+        prow[t] = Yt + (size_t)(row < cnt ? row : P.rows) * kp + KS * h;     // row P.rows = zero row
+      }
+#pragma unroll
+      for (int b2 = 0; b2 < NMAX / 2; ++b2) srow2[b2] = f2v{0.0f, 0.0f};
+      const bool kfull = (k & 3) == 0;
+#pragma unroll
+      for (int tb_ = 0; tb_ < TT; ++tb_) {
+        f32x4c acc[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) acc[t] = f32x4c{0.f, 0.f, 0.f, 0.f};
+        for (int s_ = 0; s_ < KS; ++s_) {
+          float av_[TT];
+#pragma unroll
+          for (int t = 0; t < TT; ++t) av_[t] = (kfull || KS * h + s_ < k) ? prow[t][s_] : 0.0f;
+#pragma unroll
+          for (int ta_ = 0; ta_ < TT; ++ta_)
+            acc[ta_] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[tb_], av_[ta_], acc[ta_], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ta_ = 0; ta_ < TT; ++ta_)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (16 * ta_ + lr < NMAX) S[(4 * h + q) * LDA + 16 * ta_ + lr] = acc[ta_][q];
+        MIA_WAVE_SYNC();
+        if ((tid >> 4) == tb_ && tid < NMAX) {
+#pragma unroll
+          for (int b4 = 0; b4 < N4; ++b4) {
+            const f4v v = reinterpret_cast<const f4v*>(S + lr * LDA)[b4];
+            srow2[2 * b4] = v.xy; srow2[2 * b4 + 1] = v.zw;
+            rsum += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+          }
+        }
+        MIA_WAVE_SYNC();
+      }
+    }
+  } else if (P.xskip & 2) {
     for (int it = tid; it < NMAX * LDA; it += 64) S[it] = 0.0f;
   } else if (P.dual) {
     // S = Yl^T Yl on the matrix cores (v_mfma_f32_16x16x4_f32, exact f32).  All TT row panels are loaded
@@ -279,15 +332,15 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     for (int i = tid; i < NMAX; i += 64) rhs[i] = i < k ? rhs[i] - red[1] - (uq[i] - red[0]) : 0.0f;
   }
   MIA_WAVE_SYNC();
-  // ---- row r of S into registers; Gershgorin bound L >= lambda_max
-  f2v srow2[NMAX / 2];
-  float rsum = 0.0f;
-  const int r = tid < NMAX ? tid : NMAX - 1;
+  // ---- row r of S into registers (already there when streamed); Gershgorin bound L >= lambda_max
+  if (!stream_s) {
+    const int r = tid < NMAX ? tid : NMAX - 1;
 #pragma unroll
-  for (int b4 = 0; b4 < N4; ++b4) {
-    const f4v v = reinterpret_cast<const f4v*>(S + r * LDA)[b4];
-    srow2[2 * b4] = v.xy; srow2[2 * b4 + 1] = v.zw;
-    rsum += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+    for (int b4 = 0; b4 < N4; ++b4) {
+      const f4v v = reinterpret_cast<const f4v*>(S + r * LDA)[b4];
+      srow2[2 * b4] = v.xy; srow2[2 * b4 + 1] = v.zw;
+      rsum += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+    }
   }
   const float rhs_r = tid < NMAX ? rhs[tid] : 0.0f;
   float L = wave_max_dpp(tid < NMAX ? rsum : 0.0f);
@@ -447,9 +500,10 @@ __global__ void __launch_bounds__(64) segment_wait_kernel(const int32_t* done, i
   if (lane == 0) atomicOr(err, 1);      // exit condition every wave reaches: ~seconds, then report
 }
 
-static size_t cheb_lds_bytes(int kp, int p_max, int nmax, int rows) {
+static size_t cheb_lds_bytes(int kp, int p_max, int nmax, int rows, bool dual) {
   const int lda = (nmax % 8 == 0) ? nmax + 4 : nmax;
-  size_t e = (size_t)nmax * lda + 4 * (size_t)nmax + 4 * 64 + 8 + (size_t)kp + (size_t)(rows + 1) * kp + ((p_max + 3) & ~1);
+  const int srows = (dual && nmax > 32) ? 16 : nmax;      // streamed S: staging panel only (see letkf_cheb_point)
+  size_t e = (size_t)srows * lda + 4 * (size_t)nmax + 4 * 64 + 8 + (size_t)kp + (size_t)(rows + 1) * kp + ((p_max + 3) & ~1);
   return align_up(e * sizeof(float) + (size_t)((p_max + 3) & ~1) * sizeof(int), 16);
 }
 
@@ -529,7 +583,7 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
   // degree (C2: 15.3 at 15, 11.9 at 11)
   ap.log_tol = 12.0f;
   if (const char* e = getenv("MIA_CHEB_LOGTOL")) ap.log_tol = (float)atof(e);     // experiments only
-  const size_t lds = cheb_lds_bytes(ap.kp, p_max, nmax, ap.rows);
+  const size_t lds = cheb_lds_bytes(ap.kp, p_max, nmax, ap.rows, ap.dual != 0);
   if (lds > 160 * 1024) return MIA_ERR_UNSUPPORTED;
   ap.lds_per_wave = (int)lds;
   const int64_t gx = ng < 65536 ? ng : 65536;
