@@ -374,21 +374,37 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
       f2s[tid] = f;
     }
     MIA_WAVE_SYNC();
-    if (tid < N) {
-      f2v a = {0.0f, 0.0f};
+    {
+      // The N x N cosine transform is spread over the WHOLE wavefront: lane = (coefficient j, part), every part
+      // sums a slice of the nodes and the parts are added with cross-lane moves.  (One lane per coefficient left
+      // 48 of 64 lanes idle through N quarter-rate v_cos -- the most expensive stretch of the kernel at C2.)
       // cos(j pi (i+1/2)/N) = cos(2 pi m / 4N), m = j (2i+1) mod 4N kept as an exact integer phase
       // (a float phase accumulated over i loses ~N*eps turns: 2e-5 in the analysis at degree 40)
+      const int sh = N <= 16 ? 4 : (N <= 32 ? 5 : 6);            // lanes per part = 2^sh >= N
+      const int j = tid & ((1 << sh) - 1), part = tid >> sh;
+      const int chunk = (N + (64 >> sh) - 1) >> (6 - sh);          // nodes per part
+      const int i0 = part * chunk;
+      const int i1 = i0 + chunk < N ? i0 + chunk : N;
       const int n4 = 4 * N;
       const float inv4n = 0.25f * invN;
-      int ph = tid;                       // i = 0: j * 1
-      for (int i = 0; i < N; ++i) {
-        const float c = __builtin_amdgcn_cosf(float(ph) * inv4n);
-        ph += 2 * tid;
-        ph = ph >= n4 ? ph - n4 : ph;
-        a = f2s[i] * c + a;
+      f2v a = {0.0f, 0.0f};
+      if (j < N) {
+        const int x = j * (2 * i0 + 1);                             // < 2^13: exact in float
+        int ph = x - (int)(float(x) * inv4n) * n4;                  // x mod 4N, up to one period off
+        ph = ph < 0 ? ph + n4 : (ph >= n4 ? ph - n4 : ph);
+        for (int i = i0; i < i1; ++i) {
+          const float c = __builtin_amdgcn_cosf(float(ph) * inv4n);
+          ph += 2 * j;
+          ph = ph >= n4 ? ph - n4 : ph;
+          a = f2s[i] * c + a;
+        }
       }
-      const float sc = (tid == 0 ? 1.0f : 2.0f) * invN;
-      c2[tid] = a * sc;
+      if (sh <= 5) { a.x += __shfl_xor(a.x, 32, 64); a.y += __shfl_xor(a.y, 32, 64); }
+      if (sh == 4) { a.x += __shfl_xor(a.x, 16, 64); a.y += __shfl_xor(a.y, 16, 64); }
+      if (tid < N) {
+        const float sc = (tid == 0 ? 1.0f : 2.0f) * invN;
+        c2[tid] = a * sc;
+      }
     }
     MIA_WAVE_SYNC();
   }
