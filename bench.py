@@ -183,7 +183,9 @@ def main():
         all-gather travels during step i+1; every step is still fully computed, exchanged and validated
         inside the timed region."""
         out, pend = None, collections.deque()
-        for _ in range(n_steps):
+        for it in range(n_steps):
+            if it % 4 == 0:
+                runner.time_next_step()      # HIP events around this step's analysis kernel, on its own stream
             if depth == 1:
                 out = step()
             else:
@@ -212,7 +214,10 @@ def main():
 
     depth = args.pipeline_depth
     run(args.warmup, depth)
+    runner.kernel_timings.clear()
     elapsed, out = timed(args.steps, depth)
+    loop_kernel_ms = runner.kernel_ms()      # the dominant kernel inside the timed loop (every 4th step)
+    n_timed = len(runner.kernel_timings)
     serial_ms = None
     if depth != 1:           # secondary figure: the unpipelined step (latency of one step incl. its read-back)
         n_ser = max(10, args.steps // 8)
@@ -222,7 +227,8 @@ def main():
     assert runner.last_flags_ok(), "kernel flagged grid points"
 
     # ---- dominant kernel alone, HIP events on the launch stream (torch's current stream)
-    kern_ms, stage_ms = runner.time_stages(X, grid_x, obs_x, Yb, d, reps=max(5, min(args.steps, 20)))
+    alone_ms, stage_ms = runner.time_stages(X, grid_x, obs_x, Yb, d, reps=max(5, min(args.steps, 20)))
+    kern_ms = loop_kernel_ms if loop_kernel_ms else alone_ms
     p_max = runner.last_p_max
     flops = algorithmic_flops(K_ENS, 20, 1) * gpg
     achieved = flops / (kern_ms * 1e-3) / 1e12
@@ -252,6 +258,10 @@ def main():
                          "traffic": (traffic_from_profiles(world) or {}).get("hbm_bytes_fetch_doubled"),
                          "traffic_detail": traffic_from_profiles(world),
                          "kernel": runner.dominant_kernel_name, "kernel_ms": kern_ms,
+                         "kernel_ms_source": ("HIP events recorded by the library on the analysis stream around the kernel of "
+                                              "every 4th step of the timed loop (%d launches, mia_letkf_step_timing_events)" % n_timed)
+                                             if loop_kernel_ms else "burst of 5 launches after the timed loop",
+                         "kernel_ms_alone": alone_ms,
                          "algorithmic_flops_per_analysis": algorithmic_flops(K_ENS, 20, 1),
                          "hbm_algorithmic_GBs": hbm_alg, "hbm_frac": hbm_alg / PEAK_HBM_GBS,
                          "executed_flops_per_analysis": executed_flops(K_ENS, 20, 1, deg),

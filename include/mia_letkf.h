@@ -409,6 +409,12 @@ int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int m, int k,
                                        void* ws, size_t ws_bytes, void* stream, void* comm_stream,
                                        void* prep_stream, int step_flags);
 
+/* Profiling hook (one shot, per calling thread): the NEXT step enqueued by mia_letkf_sharded_step*_f32 records
+ * `start_event` on the analysis stream immediately before its analysis kernel(s) -- after the stream has waited for
+ * the preparation -- and `stop_event` immediately after them.  Both are hipEvent_t created by the caller with timing
+ * enabled; NULL, NULL disarms.  This is how bench.py measures the dominant kernel INSIDE its timed loop. */
+int mia_letkf_step_timing_events(void* start_event, void* stop_event);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,6 +82,7 @@ _PROTOS = {
     "mia_letkf_sharded_step_workspace_bytes": ([i64, i32, i32, i64, i32, i32, i32, i32, C.POINTER(sz)], i32),
     "mia_letkf_sharded_step_f32": ([vp, i64, i32, i32, vp, vp, i64, vp, vp, i32, C.POINTER(C.c_int32), C.POINTER(f64),
                                     i32, f64, f32, f32, i32, i32, vp, i32, i32, vp, vp, vp, vp, sz, vp, vp], i32),
+    "mia_letkf_step_timing_events": ([vp, vp], i32),
     "mia_letkf_sharded_step_streams_f32": ([vp, i64, i32, i32, vp, vp, i64, vp, vp, i32, C.POINTER(C.c_int32),
                                             C.POINTER(f64), i32, f64, f32, f32, i32, i32, vp, i32, i32, vp, vp, vp, vp,
                                             sz, vp, vp, vp, i32], i32),

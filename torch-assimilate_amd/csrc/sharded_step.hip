@@ -261,6 +261,9 @@ extern "C" int mia_letkf_sharded_step_f32(const float* X, int64_t G, int m, int 
 }
 
 namespace {
+// one-shot profiling hook (mia_letkf_step_timing_events)
+thread_local hipEvent_t t_time_start = nullptr, t_time_stop = nullptr;
+
 // events that order the preparation stream before the analysis stream (no communicator, hence no event storage of
 // its own, on the single-rank route): a small ring, created on first use
 hipEvent_t g_prep_ev[16];
@@ -279,6 +282,13 @@ int prep_event(hipEvent_t* ev) {
   return MIA_OK;
 }
 }  // namespace
+
+extern "C" int mia_letkf_step_timing_events(void* start_event, void* stop_event) {
+  if ((start_event == nullptr) != (stop_event == nullptr)) return MIA_ERR_NULL;
+  t_time_start = (hipEvent_t)start_event;
+  t_time_stop = (hipEvent_t)stop_event;
+  return MIA_OK;
+}
 
 extern "C" int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int m, int k,
                                                   const float* Yb, const float* d, int64_t P,
@@ -362,6 +372,7 @@ extern "C" int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int
       MIA_HIP_TRY(hipEventRecord(comm->ev[kMaxChunks], ps));
       MIA_HIP_TRY(hipStreamWaitEvent(cs, comm->ev[kMaxChunks], 0));
     }
+    if (t_time_start) MIA_HIP_TRY(hipEventRecord(t_time_start, s));   // (after the wait for the lists: kernel time only)
     // one launch over the whole block whose segments are exchanged as they complete (no kernel boundary, no
     // event between the pieces: a 1e5-point block in 4 launches costs 292 us instead of 245 us on MI355X)
     if (exch && n_chunks > 1 && !eig_only && b1 > b0 && signal_mode) {
@@ -428,6 +439,8 @@ extern "C" int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int
     }
   }
 
+  if (phase == 0 && t_time_stop) MIA_HIP_TRY(hipEventRecord(t_time_stop, s));
+  t_time_start = t_time_stop = nullptr;
   // (without the exchange route counters[4..7] stay zero: the rank's own [0..3] are the whole story)
   if (exch && !(step_flags & MIA_STEP_NO_JOIN)) {   // the caller's stream continues after the exchange
     MIA_HIP_TRY(hipEventRecord(comm->ev[kMaxChunks + 1], cs));

@@ -87,6 +87,8 @@ class ShardedLetkf:
         self.native_step = native_step
         self._native = None
         self._in_flight = []
+        self._time_next = False        # time_next_step(): the next native step brackets its analysis kernel with events
+        self.kernel_timings = []       # [(start, stop)] torch events recorded on the analysis stream by the library
         self.max_in_flight = max(1, int(max_in_flight))
         self._submitted = 0
         self._force_comm = False      # tests / tools: a one-rank RCCL communicator drives the exchange route
@@ -341,6 +343,15 @@ class ShardedLetkf:
                 C.c_void_p(prep.cuda_stream) if prep is not None else None, 1 if pipelined else 0),
                 "mia_letkf_sharded_step_streams_f32")
 
+        timing = None
+        if self._time_next:                                        # bench: bracket this step's analysis kernel
+            self._time_next = False
+            timing = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            for e in timing:
+                e.record(cur)                                      # creates the underlying hipEvent_t
+            _cabi.check(lib.mia_letkf_step_timing_events(C.c_void_p(timing[0].cuda_event),
+                                                         C.c_void_p(timing[1].cuda_event)), "mia_letkf_step_timing_events")
+            self.kernel_timings.append(timing)
         call(0)
         ev = None
         if pipelined:
@@ -551,6 +562,18 @@ class ShardedLetkf:
             out = out[:, :, :, :n]
         out = out.reshape(m, k, world * n)
         return out if world * n == G else out[:, :, :G].contiguous()
+
+    def time_next_step(self):
+        """Arm the library's profiling hook for the next native step (mia_letkf_step_timing_events): its analysis
+        kernel is bracketed by two events on the stream it runs on; collect with :meth:`kernel_ms`."""
+        self._time_next = True
+
+    def kernel_ms(self):
+        """Mean duration (ms) of the analysis kernels timed so far inside real steps, or None."""
+        if not self.kernel_timings:
+            return None
+        torch.cuda.synchronize(self.device)
+        return sum(a.elapsed_time(b) for a, b in self.kernel_timings) / len(self.kernel_timings)
 
     def mean_degree(self):
         """Mean Chebyshev degree of the last matfun launch (flags bits 8-15), None for the eigensolver route."""
