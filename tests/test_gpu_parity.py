@@ -366,3 +366,28 @@ def test_degenerate_ensembles(eng):
             xa = eng.analysis(dev(state, torch.float32), dev(yb, torch.float32), dev(d0, torch.float32), nb, 1.2, method=method)
             assert torch.isfinite(xa).all()
             assert rel_fro(xa.cpu().numpy(), ref) < TOL32
+
+
+@pytest.mark.parametrize("m", [8, 19, 40])
+@pytest.mark.parametrize("k,stride,c", [(40, 2, 10.0), (24, 1, 6.0), (10, 3, 7.0)])
+def test_matfun_many_state_rows_on_the_matrix_cores(eng, monkeypatch, m, k, stride, c):
+    """m >= 8 state rows per grid point: the matfun kernel transforms them 16 at a time as one matrix recurrence on
+    the MFMA units (letkf_cheb_rows_kernel).  Against the oracle (<= 1e-5, north star) and against the row-by-row
+    path of the same kernel (MIA_CHEB_NO_ROWBATCH), incl. a ragged last batch, edge points with short lists and an
+    ensemble size that is not a multiple of 4."""
+    G = 300
+    case = O.synthetic_case(G, k, stride, seed=17, m=m)
+    nb = eng.localize(case["grid_x"], case["obs_x"], [c])
+    X, yb, d = dev(case["state"], torch.float32), dev(case["yb"], torch.float32), dev(case["d"], torch.float32)
+    xa, flags = eng.analysis(X, yb, d, nb, 1.1, method="matfun", return_flags=True)
+    assert int((flags & 0xff).max().item()) == 0
+    ref, _ = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], case["yb"], case["d"], c, 1.1)
+    got = xa.cpu().numpy()
+    assert rel_fro(got, ref) < TOL32
+    xm = case["state"].mean(axis=1, keepdims=True)
+    assert rel_fro(got - xm, ref - xm) < 2e-5                      # increments: the stricter measure
+    for mi in (0, m // 2, m - 1):                                  # every row on its own, not only on average
+        assert rel_fro(got[mi], ref[mi]) < TOL32
+    monkeypatch.setenv("MIA_CHEB_NO_ROWBATCH", "1")
+    xs = eng.analysis(X, yb, d, nb, 1.1, method="matfun")
+    assert rel_fro(got, xs.cpu().numpy()) < 2e-6

@@ -75,7 +75,9 @@ __device__ inline float matvec_row(const f2v (&srow2)[NMAX / 2], const float* tv
 // and the compiler may not move memory operations across (the waves of a workgroup are independent here)
 #define MIA_WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-template <int NMAX, int KL, bool FUSED, int WPB, bool SEG>
+constexpr int kRowBatch = 16;     // state rows per MFMA batch of the many-rows variant (one 16-column tile)
+
+template <int NMAX, int KL, bool FUSED, int WPB, bool SEG, bool BATCH = false>
 __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
   constexpr int LDA = (NMAX % 8 == 0) ? NMAX + 4 : NMAX;
   constexpr int N4 = NMAX / 4;
@@ -106,6 +108,10 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
   float* Yt = sw + NMAX;                            // [rows][kp]
   float* lw = Yt + (size_t)(P.rows + 1) * kp;       // [pm + 2]   (Yt has one extra, all-zero row)
   int* lidx = reinterpret_cast<int*>(lw + ((pm + 3) & ~1));   // [pm + 2]
+  // many-rows variant only: a batch of state rows, the recurrence matrix, column sums of Yl, per-row scalars
+  float* Xb = reinterpret_cast<float*>(lidx + ((pm + 3) & ~1));   // [kRowBatch][kp] raw state rows of the batch
+  float* Tl = Xb + kRowBatch * kp;                                // [NMAX (padded to 16s)][kRowBatch]
+  float* csum = Tl + ((NMAX + 15) & ~15) * kRowBatch;             // [NMAX] sum_i Yl[i][b]
 
   // XCD-aware block -> point map (letkf_sys.hip): block b's XCD group x = b % 8 owns a contiguous range of
   // point groups; the WPB waves of a block take consecutive points
@@ -409,6 +415,147 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     MIA_WAVE_SYNC();
   }
   const float alpha = 2.0f / L;            // A v = alpha S v - v
+  if constexpr (BATCH) {
+    // ---- many state rows: kRowBatch rows at a time as ONE matrix recurrence on the matrix cores.
+    //      T (n x 16) lives in the MFMA result layout (lane (lr, h) holds T[16 t + 4 h + q][lr], q = 0..3); every step
+    //      is  Y = S T  (A fragments of S stay in registers, T goes through LDS to become the B operand), then the
+    //      three-term update and the (phi, psi) accumulation on four values per lane and row tile.  z = Yl^T x' and
+    //      the final Yl s are two more small products.  (v_mfma_f32_16x16x4_f32, exact f32; lane (lr, h) feeds
+    //      A[16 t + lr][4 s + h] and B[col lr][4 s + h].)  The scalar path below costs ~0.1 ms per row per 1e5
+    //      grid points at C2 with 20 of 64 lanes busy.
+    static_assert(NMAX <= 32 && KL == 1, "the many-rows variant keeps S in LDS and one member per lane");
+    const int lr = tid & 15, h = tid >> 4;
+    float afrag[TT][N4];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int s_ = 0; s_ < N4; ++s_) afrag[t][s_] = (16 * t + lr < NMAX) ? S[(16 * t + lr) * LDA + 4 * s_ + h] : 0.0f;
+    if (tid < NMAX) {          // column sums of the local block: centring of z without centring the rows
+      float acc = 0.0f;
+      if (tid < cnt) for (int i = 0; i < k; ++i) acc += Yt[(size_t)tid * kp + i];
+      csum[tid] = acc;
+    }
+    const int kq = kp >> 2;                 // K steps over the members (pad columns of the rows are zero)
+    for (int m0 = 0; m0 < P.m; m0 += kRowBatch) {
+      const int nrow = P.m - m0 < kRowBatch ? P.m - m0 : kRowBatch;
+      MIA_WAVE_SYNC();
+      // -- the batch's state rows, raw, [row c][member i]; means by (row lr, member quarter h)
+      for (int c = 0; c < kRowBatch; ++c) {
+        float v = 0.0f;
+        if (c < nrow && tid < k) v = P.X[((int64_t)(m0 + c) * k + tid) * P.ldx + g];
+        if (tid < kp) Xb[c * kp + tid] = v;
+      }
+      MIA_WAVE_SYNC();
+      float xm;
+      {
+        float part = 0.0f;
+        for (int i = h; i < k; i += 4) part += Xb[lr * kp + i];
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        xm = part / float(k);               // mean of row lr, in every lane of column lr
+      }
+      // -- z = Yl^T x' = Yt X^T - csum xm^T
+      f32x4c tcur[TT], tprev[TT];
+      f2v aphi[TT][4];
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        const int row = 16 * t + lr;
+        const float* pa = Yt + (size_t)(row < cnt ? row : P.rows) * kp;      // rows beyond the list: the zero row
+        f32x4c acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s_ = 0; s_ < kq; ++s_)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32((4 * s_ + h < k) ? pa[4 * s_ + h] : 0.0f, Xb[lr * kp + 4 * s_ + h], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int b = 16 * t + 4 * h + q;
+          acc[q] = (b < cnt) ? acc[q] - csum[b < NMAX ? b : 0] * xm : 0.0f;
+        }
+        tprev[t] = acc;
+      }
+      // -- t1 = A t0, then the recurrence; T is published to LDS before every product
+      auto publish = [&](const f32x4c (&tt)[TT]) {
+        MIA_WAVE_SYNC();
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Tl[(16 * t + 4 * h + q) * kRowBatch + lr] = tt[t][q];
+        MIA_WAVE_SYNC();
+      };
+      auto product = [&](f32x4c (&yy)[TT]) {
+        float bf[N4];
+#pragma unroll
+        for (int s_ = 0; s_ < N4; ++s_) bf[s_] = Tl[(4 * s_ + h) * kRowBatch + lr];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          f32x4c acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s_ = 0; s_ < N4; ++s_) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[t][s_], bf[s_], acc, 0, 0, 0);
+          yy[t] = acc;
+        }
+      };
+      f32x4c y[TT];
+      publish(tprev);
+      product(y);
+      {
+        const f2v c0 = c2[0], c1 = c2[1];
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            tcur[t][q] = alpha * y[t][q] - tprev[t][q];
+            aphi[t][q] = c0 * tprev[t][q] + c1 * tcur[t][q];
+          }
+      }
+      for (int j = 2; j <= deg; ++j) {
+        publish(tcur);
+        product(y);
+        const f2v cj = c2[j];
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float tn = 2.0f * (alpha * y[t][q] - tcur[t][q]) - tprev[t][q];
+            tprev[t][q] = tcur[t][q]; tcur[t][q] = tn;
+            aphi[t][q] = cj * tn + aphi[t][q];
+          }
+      }
+      // -- x' w_mean per row (column lr): sum_b rhs_b psi_b, and s = phi(S) z published for the last product
+      float zu = 0.0f;
+      MIA_WAVE_SYNC();
+#pragma unroll
+      for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int b = 16 * t + 4 * h + q;
+          const bool live = b < ntrue;
+          zu += live ? rhs[b < NMAX ? b : 0] * aphi[t][q].y : 0.0f;
+          Tl[b * kRowBatch + lr] = live ? aphi[t][q].x : 0.0f;
+        }
+      zu += __shfl_xor(zu, 16, 64);
+      zu += __shfl_xor(zu, 32, 64);
+      MIA_WAVE_SYNC();
+      // -- out[j][c] = xm_c + zu_c + f0 (x_c[j] - xm_c) + sum_b Yl[j][b] s[b][c]
+      const float mterm = xm + zu;
+      const int KT = (k + 15) >> 4;
+      for (int tj = 0; tj < KT; ++tj) {
+        f32x4c acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s_ = 0; s_ < N4; ++s_) {
+          const int b = 4 * s_ + h, jj = 16 * tj + lr;
+          const float av = (b < cnt && jj < k) ? Yt[(size_t)b * kp + jj] : 0.0f;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Tl[b * kRowBatch + lr], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int jj = 16 * tj + 4 * h + q;
+          if (jj < k && lr < nrow) {
+            const float out = mterm + f0 * (Xb[lr * kp + jj] - xm) + acc[q];
+            if (!(fabsf(out) <= 1e30f)) flag |= MIA_FLAG_NONFINITE;
+            Xab[((int64_t)(m0 + lr) * k + jj) * P.ldo + ocol] = out;
+          }
+        }
+      }
+    }
+  } else {
   // ---- per state row: z, the shared recurrence, the output
   const int k4 = (k + 3) >> 2;
   for (int mi = 0; mi < P.m; ++mi) {
@@ -479,6 +626,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     }
     MIA_WAVE_SYNC();
   }
+  }
   if (P.flags) {
     const int any = __any(flag != 0) ? MIA_FLAG_NONFINITE : 0;
     if (tid == 0) P.flags[pt] = any | (deg << 8);     // bits 8-15: polynomial degree used (diagnostics)
@@ -488,6 +636,12 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
 template <int NMAX, int KL, bool FUSED, int WPB>
 __global__ __launch_bounds__(64 * WPB, (NMAX <= 24 ? 5 : (NMAX <= 40 ? 4 : 2))) void letkf_cheb_kernel(ChebParams P) {
   letkf_cheb_point<NMAX, KL, FUSED, WPB, false>(P);
+}
+
+// Many state rows per grid point (m >= 8, dual route, order <= 32): rows are transformed 16 at a time on the matrix cores.
+template <int NMAX>
+__global__ __launch_bounds__(64, (NMAX <= 24 ? 4 : 3)) void letkf_cheb_rows_kernel(ChebParams P) {
+  letkf_cheb_point<NMAX, 1, false, 1, false, true>(P);
 }
 
 // Segmented launch: one grid over the whole block; every workgroup (= one grid point), whatever path it left
@@ -516,11 +670,28 @@ __global__ void __launch_bounds__(64) segment_wait_kernel(const int32_t* done, i
   if (lane == 0) atomicOr(err, 1);      // exit condition every wave reaches: ~seconds, then report
 }
 
-static size_t cheb_lds_bytes(int kp, int p_max, int nmax, int rows, bool dual) {
+static size_t cheb_lds_bytes(int kp, int p_max, int nmax, int rows, bool dual, bool batch = false) {
   const int lda = (nmax % 8 == 0) ? nmax + 4 : nmax;
   const int srows = (dual && nmax > 32) ? 16 : nmax;      // streamed S: staging panel only (see letkf_cheb_point)
   size_t e = (size_t)srows * lda + 4 * (size_t)nmax + 4 * 64 + 8 + (size_t)kp + (size_t)(rows + 1) * kp + ((p_max + 3) & ~1);
+  if (batch) e += (size_t)kRowBatch * kp + (size_t)((nmax + 15) & ~15) * kRowBatch + (size_t)nmax;
   return align_up(e * sizeof(float) + (size_t)((p_max + 3) & ~1) * sizeof(int), 16);
+}
+
+template <int NMAX>
+static int cheb_launch_rows(const ChebParams& ap, size_t lds, hipStream_t stream) {
+  if constexpr (NMAX <= 32) {
+    auto kern = letkf_cheb_rows_kernel<NMAX>;
+    if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t gx = ap.ng < 65536 ? ap.ng : 65536;
+    const int64_t gy = (ap.ng + gx - 1) / gx;
+    if (gy > 65535) return MIA_ERR_UNSUPPORTED;
+    kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64), lds, stream>>>(ap);
+    MIA_LAUNCH_CHECK();
+    return MIA_OK;
+  } else {
+    return MIA_ERR_UNSUPPORTED;
+  }
 }
 
 template <int NMAX, int KL, bool FUSED, int WPB>
@@ -607,6 +778,19 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
   if (gy > 65535) return MIA_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)gx, (unsigned)gy);
   const bool two = k > 64;
+  // many state rows: batches of 16 rows on the matrix cores (dual route, order <= 32, one member per lane)
+  if (m >= 8 && ap.dual && nmax <= 32 && !two && !ap.fused && seg_len == 0 && !getenv("MIA_CHEB_NO_ROWBATCH")) {
+    ap.lds_per_wave = (int)cheb_lds_bytes(ap.kp, p_max, nmax, ap.rows, true, true);
+    switch (nmax) {
+      case 4: return cheb_launch_rows<4>(ap, ap.lds_per_wave, stream);
+      case 8: return cheb_launch_rows<8>(ap, ap.lds_per_wave, stream);
+      case 12: return cheb_launch_rows<12>(ap, ap.lds_per_wave, stream);
+      case 16: return cheb_launch_rows<16>(ap, ap.lds_per_wave, stream);
+      case 20: return cheb_launch_rows<20>(ap, ap.lds_per_wave, stream);
+      case 24: return cheb_launch_rows<24>(ap, ap.lds_per_wave, stream);
+      case 32: return cheb_launch_rows<32>(ap, ap.lds_per_wave, stream);
+    }
+  }
   if (seg_len > 0) {
 #define MIA_CHEB_SEG(N) case N: return two ? cheb_launch_seg<N, 2>(ap, lds, stream) : cheb_launch_seg<N, 1>(ap, lds, stream);
     switch (nmax) {
