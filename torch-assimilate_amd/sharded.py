@@ -211,10 +211,23 @@ class ShardedLetkf:
         from . import _cabi
         lib = self.engine.lib
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        _cabi.check(lib.mia_comm_load(path.encode() if os.path.exists(path) else None), "mia_comm_load")
+        # binding RCCL is a local step that can fail on one rank only: agree on it BEFORE anybody enters a collective
+        # (id broadcast, ncclCommInitRank) that a failed rank would never join
         buf = C.create_string_buffer(128)
-        if self.rank == 0:
-            _cabi.check(lib.mia_comm_unique_id(buf), "mia_comm_unique_id")
+        err = None
+        try:
+            _cabi.check(lib.mia_comm_load(path.encode() if os.path.exists(path) else None), "mia_comm_load")
+            if self.rank == 0:
+                _cabi.check(lib.mia_comm_unique_id(buf), "mia_comm_unique_id")
+        except (_cabi.MiaError, OSError) as e:
+            err = e
+        if dist.is_initialized() and self.world > 1:
+            t = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            if int(t.item()) == 0:
+                raise _cabi.MiaError("RCCL could not be bound on every rank (%s)" % (err if err is not None else "another rank failed"))
+        elif err is not None:
+            raise err
         box = [buf.raw]
         src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
         dist.broadcast_object_list(box, src=src, group=self.group)
@@ -229,9 +242,37 @@ class ShardedLetkf:
             st = dict(comm=None, stream=None, slots=[{} for _ in range(self.max_in_flight)])
             if self.world > 1 or self._force_comm:
                 st["comm"] = self._native_comm()
-            st["stream"] = torch.cuda.Stream(device=self.device)
+            # exchange stream at high priority: its (few, multi-wave) RCCL workgroups should be placed ahead of the
+            # bulk analysis kernel's next workgroups when wave slots fall free, not queue behind 1e5 of them
+            st["stream"] = torch.cuda.Stream(device=self.device, priority=-1)
             self._native = st
         return self._native
+
+    def _native_available(self) -> bool:
+        """Create the library-owned communicator if needed.  Should that fail on ANY rank (RCCL library not found,
+        ncclCommInitRank error), every rank falls back to the torch.distributed exchange route -- the decision is
+        all-reduced so that no rank waits in a collective the others never enter."""
+        if self._native is not None or self.world == 1:
+            return True
+        import warnings
+        import torch.distributed as dist
+        from . import _cabi
+        ok, err = 1, None
+        try:
+            self._native_state()
+        except (_cabi.MiaError, OSError, RuntimeError) as e:      # noqa: PERF203
+            ok, err = 0, e
+            self._native = None
+        t = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        if int(t.item()) == 0:
+            if self._native is not None:
+                self.close()
+            warnings.warn("library-owned RCCL communicator unavailable (%s): using the torch.distributed exchange route"
+                          % (err if err is not None else "another rank failed"), RuntimeWarning)
+            self.native_step = False
+            return False
+        return True
 
     def close(self):
         """Release the library-owned communicator (idempotent)."""
@@ -278,6 +319,8 @@ class ShardedLetkf:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
                 self._p_max_hint = int(t.item())                  # one bound for all ranks
             return PendingStep(self, None, out=gather_blocks(shard, G, self.world, self.group))
+        if not self._native_available():
+            return PendingStep(self, None, out=self.assimilate(X, grid_xyz, obs_xyz, Yb, d))
         st = self._native_state()
         lib = eng.lib
         X = X.contiguous()
