@@ -291,10 +291,11 @@ class ShardedLetkf:
     def submit(self, X, grid_xyz, obs_xyz, Yb, d) -> "PendingStep":
         """Enqueue one assimilation step WITHOUT waiting for it: the returned handle's ``result()`` performs the
         step's one host read-back (validation + rare redo) and hands out the analysis.  Consecutive steps
-        rotate through ``max_in_flight`` slots (own workspace, counters and HIP stream each), so the index / list
-        kernels of a later step -- a chain of small latency-bound launches -- run beside the analysis kernel of
-        an earlier one, and at N > 1 the all-gather of step i (one shared exchange stream: the collectives keep
-        one order on every rank) travels while step i+1 is computed.  A slot whose previous step was not collected
+        rotate through ``max_in_flight`` slots (own workspace and counters each) and share three streams -- a
+        high-priority one for the index / list kernels, one for the analysis kernels, one for the exchange -- so the
+        preparation of a later step (a chain of small latency-bound launches) runs beside the analysis kernel of
+        an earlier one, and at N > 1 the all-gather of step i (the collectives keep one order on every rank)
+        travels while step i+1 is computed.  A slot whose previous step was not collected
         yet is collected first; all ranks must submit and collect in the same order."""
         G = X.shape[-1]
         g0, g1 = block_partition(G, self.world)[self.rank]
