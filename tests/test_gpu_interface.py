@@ -395,3 +395,39 @@ def test_obs_space_reference_fixture_and_stacking(mia, golden):
     # ... and straight into the global ETKF of the fixture
     w = f.estimate_weights_arrays(yb, d).cpu().numpy()
     assert rel_fro(w, g["weights_global_1p1"]) < 1e-9
+
+
+def test_step_driver_on_a_scattered_2d_network_vs_oracle(mia):
+    """The one-call step (serial and with steps in flight) on a 2-D mesh with randomly scattered observations: list
+    lengths from 0 (grid points with no observation in reach -> prior weights) to well above the ensemble size
+    (primal route), horizontal x vertical radii.  Spot-checked against the oracle's per-grid-point loop."""
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(8)
+    k, G, P = 12, 1500, 900
+    grid = np.stack([rs.uniform(0, 1, G), rs.uniform(0, 0.2, G)], axis=1)
+    obs = np.stack([np.concatenate([rs.uniform(0, 0.45, P - 40), rs.uniform(0.9, 1.0, 40)]), rs.uniform(0, 0.2, P)], axis=1)
+    state = rs.normal(size=(2, k, G))
+    hx = rs.normal(size=(k, P))
+    yb = hx - hx.mean(axis=0)
+    d = rs.normal(size=P)
+    radii, groups = [0.05, 0.08], [0, 1]
+    args = (torch.as_tensor(state, dtype=torch.float32, device=dev), torch.as_tensor(grid, device=dev),
+            torch.as_tensor(obs, device=dev), torch.as_tensor(yb, dtype=torch.float32, device=dev),
+            torch.as_tensor(d, dtype=torch.float32, device=dev))
+    runner = mia.ShardedLetkf(dev, 0, 1, radii=radii, inf_factor=1.05, coord_group=groups)
+    outs = [runner.assimilate(*args) for _ in range(2)]               # exact-list call, then the native driver
+    pend = [runner.submit(*args) for _ in range(3)]                   # three steps in flight
+    outs += [h.result() for h in pend]
+    assert runner.native_steps == 4 and runner.last_flags_ok()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    got = outs[0].cpu().numpy()
+    counts = []
+    for gi in rs.choice(G, 60, replace=False):
+        dist = O.grouped_euclid_distance(grid[gi], obs, groups, 2)
+        use, _ = O.localize_obs(dist, radii)
+        counts.append(int(use.sum()))
+        w = O.localized_weights(dist, yb, d, radii, 1.05)
+        ref = O.apply_weights(state[:, :, [gi]], w[None])
+        assert rel_fro(got[:, :, gi], ref[:, :, 0]) < 1e-5, (gi, counts[-1])
+    assert min(counts) == 0 and max(counts) > k                        # both extremes were among the samples
