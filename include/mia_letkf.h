@@ -279,6 +279,17 @@ int mia_etkf_weights_f32(const float* Yb, const float* d, int k, int64_t P, floa
                          float* W, int32_t* flags_opt, void* ws, size_t ws_bytes, void* stream);
 int mia_etkf_weights_f64(const double* Yb, const double* d, int k, int64_t P, double inf_factor,
                          double* W, int32_t* flags_opt, void* ws, size_t ws_bytes, void* stream);
+/* Global KERNELISED ETKF for any number of observations: KETKF.estimate_weights (interface/ketkf.py:34-123) -> one
+ * KETKFModule.forward on the full (k, P) block (core/ketkf.py:65-94) with the kernel given as an expression
+ * (mia_kernel_op_t, see mia_lketkf_kernel_analysis_packed_*; RBFKernel(gamma) = SQDIST CONST(-gamma) MUL EXP).
+ * P = 0 returns the inflated prior sqrt(inf) I (core/etkf.py:91-95). */
+int mia_ketkf_workspace_bytes(int k, int64_t P, int elem_bytes, size_t* bytes);
+int mia_ketkf_weights_f32(const float* Yb, const float* d, int k, int64_t P, float inf_factor,
+                          const mia_kernel_op_t* prog /* host */, int n_ops, float* W, int32_t* flags_opt,
+                          void* ws, size_t ws_bytes, void* stream);
+int mia_ketkf_weights_f64(const double* Yb, const double* d, int k, int64_t P, double inf_factor,
+                          const mia_kernel_op_t* prog /* host */, int n_ops, double* W, int32_t* flags_opt,
+                          void* ws, size_t ws_bytes, void* stream);
 int mia_apply_weights_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
                           const float* W, float* Xa, int64_t ldo, int64_t o0, void* stream);
 int mia_apply_weights_f64(const double* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,

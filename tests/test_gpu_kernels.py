@@ -126,3 +126,31 @@ def test_expression_route_agrees_with_the_specialised_rbf_and_linear_kernels(mia
     assert rel_fro(got_lin.cpu().numpy(), ref_lin.cpu().numpy()) < 1e-9      # KETKF(linear) == ETKF
     with pytest.raises(ValueError):
         eng.analysis(X, yb, d, nb, 1.1, rbf_gamma=0.5, kernel_program=K.PolyKernel().program())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 5e-5)])
+def test_global_ketkf_with_many_observations(mia, eng, dtype, tol):
+    """KETKF.estimate_weights (interface/ketkf.py:34-123) on a block far larger than a workgroup's LDS: pair
+    statistics accumulated over observation chunks (mia_ketkf_weights_*), every kernel family, against the oracle's
+    KETKFModule restatement; a global analysis through the KETKF driver; the empty block gives the inflated prior."""
+    from torch_assimilate_amd import kernels as K
+    rs = np.random.RandomState(12)
+    k, P = 24, 5000
+    yb = rs.normal(size=(k, P)) * 0.05
+    yb -= yb.mean(axis=0)
+    d = rs.normal(size=P) * 0.05
+    ora, prod = oracle_kernels(), product_kernels()
+    for name in ("poly2", "ornuhl", "rational", "rbf_plus_diag", "tanh", "periodic"):
+        ref = O.ketkf_weights(yb, d, ora[name], 1.1).numpy()
+        got = mia.KETKFModule(prod[name], 1.1)(torch.tensor(yb, dtype=dtype), torch.tensor(d, dtype=dtype))
+        assert got.dtype == dtype and rel_fro(got.cpu().numpy(), ref) < tol, name
+    ref = O.ketkf_weights(yb, d, lambda x, y: O.rbf_kernel(x, y, 0.5), 1.0).numpy()
+    got = mia.KETKFModule(K.RBFKernel(0.5), 1.0)(torch.tensor(yb, dtype=dtype), torch.tensor(d, dtype=dtype))
+    assert rel_fro(got.cpu().numpy(), ref) < tol
+    state = rs.normal(size=(2, k, 50))
+    xa = mia.KETKF(K.RBFKernel(0.5), inf_factor=1.0, dtype=dtype).analyse_arrays(state, yb, d)
+    assert rel_fro(xa.cpu().numpy(), O.apply_weights(state, ref)) < tol
+    prior = mia.KETKFModule(K.PolyKernel(), 1.3)(torch.zeros((k, 0), dtype=dtype), torch.zeros(0, dtype=dtype))
+    np.testing.assert_allclose(prior.cpu().numpy(), np.sqrt(1.3) * np.eye(k), rtol=1e-6)
+    with pytest.raises(ValueError):
+        mia.KETKFModule(K.PolyKernel(), 1.0)(torch.ones(k, 4), torch.ones(3))

@@ -62,6 +62,9 @@ _PROTOS = {
     "mia_etkf_workspace_bytes": ([i32, i64, i32, C.POINTER(sz)], i32),
     "mia_etkf_weights_f32": ([vp, vp, i32, i64, f32, vp, vp, vp, sz, vp], i32),
     "mia_etkf_weights_f64": ([vp, vp, i32, i64, f64, vp, vp, vp, sz, vp], i32),
+    "mia_ketkf_workspace_bytes": ([i32, i64, i32, C.POINTER(sz)], i32),
+    "mia_ketkf_weights_f32": ([vp, vp, i32, i64, f32, C.POINTER(KernelOp), i32, vp, vp, vp, sz, vp], i32),
+    "mia_ketkf_weights_f64": ([vp, vp, i32, i64, f64, C.POINTER(KernelOp), i32, vp, vp, vp, sz, vp], i32),
     "mia_apply_weights_f32": ([vp, i64, i32, i32, i64, i64, vp, vp, i64, i64, vp], i32),
     "mia_apply_weights_f64": ([vp, i64, i32, i32, i64, i64, vp, vp, i64, i64, vp], i32),
     "mia_apply_local_weights_f32": ([vp, i64, i32, i32, i64, i64, vp, vp, i64, i64, vp], i32),

@@ -82,6 +82,25 @@ class KETKFModule(ETKFModule):
         super().__init__(inf_factor, engine)
         self.kernel = kernel
 
+    def __call__(self, normed_perts, normed_obs) -> torch.Tensor:
+        """One global block of any size: pair statistics over observation chunks + one k x k solve
+        (``mia_ketkf_weights_*``); a LinearKernel is the ETKF (linear.py:66-67)."""
+        gamma, prog = kernel_route(self.kernel)
+        if gamma is None and prog is None:
+            return super().__call__(normed_perts, normed_obs)
+        if prog is None:
+            prog = self.kernel.program()
+        eng = self.engine
+        perts = torch.as_tensor(normed_perts)
+        obs = torch.as_tensor(normed_obs)
+        self._test_sizes(perts, obs)
+        dtype = perts.dtype if perts.dtype in (torch.float32, torch.float64) else torch.float64
+        k = perts.shape[-2] if perts.dim() >= 2 else 1
+        perts = perts.reshape(k, perts.shape[-1]).to(device=eng.device, dtype=dtype)
+        return eng.ketkf_weights(perts, obs.reshape(-1).to(device=eng.device, dtype=dtype), prog, self.inf_factor)
+
+    forward = __call__
+
     def __str__(self):
         return "KETKFModule({0:s}, {1})".format(str(self.kernel), self.inf_factor)
 

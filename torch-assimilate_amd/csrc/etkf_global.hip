@@ -11,6 +11,7 @@
 //     weights broadcast from LDS).
 #include "mia_common.h"
 #include "mia_jacobi.h"
+#include "mia_kernel_prog.h"
 
 namespace mia {
 
@@ -40,9 +41,48 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const T* Yb, const T*
   }
 }
 
+// Global KERNELISED ETKF (KETKF.estimate_weights, interface/ketkf.py:34-123 -> KETKFModule, core/ketkf.py:65-94) for
+// any number of observations: the three pair statistics every reference kernel is a function of -- x.y, |x-y|_2^2,
+// |x-y|_1 over the P observations, for all member pairs and for every member against the observation vector -- are
+// accumulated per observation chunk into slabs [dot | sq | l1], each (k*k + k) values, summed in a fixed order.
 template <typename T>
+__global__ __launch_bounds__(256) void pairstat_partial_kernel(const T* Yb, const T* d, int k, int64_t P, int ch, T* slabs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* tile = reinterpret_cast<T*>(smem_raw);   // [k + 1][ch + 1], row k holds d
+  const int ld = ch + 1;
+  const int64_t j0 = (int64_t)blockIdx.x * ch;
+  const int nj = (int)((P - j0) < ch ? (P - j0) : ch);
+  for (int it = threadIdx.x; it < (k + 1) * ch; it += 256) {
+    const int i = it / ch, j = it - i * ch;
+    T v = T(0);
+    if (j < nj) v = (i < k) ? Yb[(int64_t)i * P + j0 + j] : d[j0 + j];
+    tile[i * ld + j] = v;
+  }
+  __syncthreads();
+  const size_t one = (size_t)k * k + k;
+  T* slab = slabs + (size_t)blockIdx.x * 3 * one;
+  for (int it = threadIdx.x; it < k * (k + 1); it += 256) {
+    const int a = it / (k + 1), b = it - a * (k + 1);   // b == k -> against the observations
+    if (b < k && b < a) continue;                        // lower triangle mirrored below
+    T dt = T(0), sq = T(0), l1 = T(0);
+    for (int j = 0; j < nj; ++j) {
+      const T xa = tile[a * ld + j], xb = tile[b * ld + j];
+      const T df = xa - xb;
+      dt += xa * xb; sq += df * df; l1 += t_abs(df);
+    }
+    if (b == k) { slab[(size_t)k * k + a] = dt; slab[one + (size_t)k * k + a] = sq; slab[2 * one + (size_t)k * k + a] = l1; }
+    else {
+      slab[a * k + b] = dt; slab[b * k + a] = dt;
+      slab[one + a * k + b] = sq; slab[one + b * k + a] = sq;
+      slab[2 * one + a * k + b] = l1; slab[2 * one + b * k + a] = l1;
+    }
+  }
+}
+
+template <typename T, bool KERN>
 __global__ __launch_bounds__(256) void etkf_solve_kernel(const T* slabs, int nslab, int k, T reg, T tol,
-                                                         int max_sweeps, T* W, int32_t* flags) {
+                                                         int max_sweeps, T* W, int32_t* flags, KernelProgram<T> prog,
+                                                         T prior_diag) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* sm = reinterpret_cast<T*>(smem_raw);
   const int tid = threadIdx.x;
@@ -55,20 +95,68 @@ __global__ __launch_bounds__(256) void etkf_solve_kernel(const T* slabs, int nsl
   T* av = gW + n;                // [n]
   T* wbar = av + n;              // [n]
   int* iflag = reinterpret_cast<int*>(wbar + n);
-  const size_t slab_sz = (size_t)k * k + k;
+  if (KERN && nslab == 0) {      // no observation at all: the inflated prior (core/etkf.py:91-95)
+    for (int it = tid; it < k * k; it += 256) W[it] = (it / k == it % k) ? prior_diag : T(0);
+    if (flags && tid == 0) flags[0] = 0;
+    return;
+  }
+  const size_t one = (size_t)k * k + k;
+  const size_t slab_sz = KERN ? 3 * one : one;
   for (int it = tid; it < n * n; it += 256) {
     const int a = it / n, b = it - a * n;
     T acc = T(0);
-    if (a < k && b < k) for (int s = 0; s < nslab; ++s) acc += slabs[s * slab_sz + a * k + b];
+    if (a < k && b < k) {
+      if (KERN) {
+        T sq = T(0), l1 = T(0);
+        for (int s = 0; s < nslab; ++s) {
+          acc += slabs[s * slab_sz + a * k + b]; sq += slabs[s * slab_sz + one + a * k + b]; l1 += slabs[s * slab_sz + 2 * one + a * k + b];
+        }
+        acc = kprog_eval(prog, acc, sq, l1, a == b);
+      } else {
+        for (int s = 0; s < nslab; ++s) acc += slabs[s * slab_sz + a * k + b];
+      }
+    }
     A[a * lda + b] = acc;
     V[a * lda + b] = (a == b) ? T(1) : T(0);
   }
   for (int a = tid; a < n; a += 256) {
     T acc = T(0);
-    if (a < k) for (int s = 0; s < nslab; ++s) acc += slabs[s * slab_sz + (size_t)k * k + a];
+    if (a < k) {
+      if (KERN) {
+        T sq = T(0), l1 = T(0);
+        for (int s = 0; s < nslab; ++s) {
+          acc += slabs[s * slab_sz + (size_t)k * k + a]; sq += slabs[s * slab_sz + one + (size_t)k * k + a];
+          l1 += slabs[s * slab_sz + 2 * one + (size_t)k * k + a];
+        }
+        acc = kprog_eval(prog, acc, sq, l1, false);     // k(Yb, d): never the same sample (diag.py:65-66)
+      } else {
+        for (int s = 0; s < nslab; ++s) acc += slabs[s * slab_sz + (size_t)k * k + a];
+      }
+    }
     rhs[a] = acc;
   }
   __syncthreads();
+  if (KERN) {      // double centring of K and centring of k(Yb, d)   (core/ketkf.py:77-89); av, gW as scratch
+    for (int a = tid; a < k; a += 256) {
+      T acc = T(0);
+      for (int b = 0; b < k; ++b) acc += A[a * lda + b];
+      av[a] = acc / T(k);                                  // row (= column) means
+    }
+    __syncthreads();
+    if (tid == 0) {
+      T gm = T(0), om = T(0);
+      for (int a = 0; a < k; ++a) { gm += av[a]; om += rhs[a]; }
+      gW[0] = gm / T(k); gW[1] = om / T(k);
+    }
+    __syncthreads();
+    const T gm = gW[0], om = gW[1];
+    for (int it = tid; it < k * k; it += 256) {
+      const int a = it / k, b = it - a * k;
+      A[a * lda + b] = A[a * lda + b] - av[b] - (av[a] - gm);
+    }
+    for (int a = tid; a < k; a += 256) rhs[a] = rhs[a] - om - (av[a] - gm);
+    __syncthreads();
+  }
   const bool conv = jacobi_lds<T, 256>(A, V, cs, iflag, n, n, lda, reg, tol, max_sweeps);
   const T km1 = T(k - 1);
   for (int r = tid; r < n; r += 256) {
@@ -120,6 +208,9 @@ __global__ __launch_bounds__(NT) void apply_weights_kernel(const T* X, int64_t l
   }
 }
 
+static inline float t_sqrt_host(float x) { return sqrtf(x); }
+static inline double t_sqrt_host(double x) { return sqrt(x); }
+
 static int gram_chunk(int k, int eb) {
   int ch = (int)(65536 / ((size_t)(k + 1) * eb)) - 1;
   ch = ch / 32 * 32;
@@ -152,10 +243,51 @@ static int etkf_weights_impl(const T* Yb, const T* d, int k, int64_t P, T inf_fa
   const int n = (k + 1) & ~1, lda = n | 1;
   const size_t lds2 = ((size_t)2 * n * lda + 5 * (size_t)n) * sizeof(T) + 16;
   if (lds2 > 160 * 1024) return MIA_ERR_UNSUPPORTED;
-  auto kern2 = etkf_solve_kernel<T>;
+  auto kern2 = etkf_solve_kernel<T, false>;
+  if (lds2 > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+  KernelProgram<T> none;
+  none.n = 0;
+  kern2<<<dim3(1), dim3(256), lds2, stream>>>(slabs, (int)nslab, k, T(k - 1) / inf_factor,
+                                               sizeof(T) == 4 ? T(2.4e-7) : T(9e-16), sizeof(T) == 4 ? 16 : 24, W, flags,
+                                               none, T(0));
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+template <typename T>
+static int ketkf_weights_impl(const T* Yb, const T* d, int k, int64_t P, T inf_factor, const mia_kernel_op_t* prog,
+                              int n_ops, T* W, int32_t* flags, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (k < 2 || P < 0 || !(inf_factor > T(0))) return MIA_ERR_SIZE;
+  int rc = kernel_program_check(prog, n_ops);
+  if (rc != MIA_OK) return rc;
+  if (!W) return MIA_ERR_NULL;
+  if (P > 0 && (!Yb || !d)) return MIA_ERR_NULL;
+  size_t need = 0;
+  rc = mia_ketkf_workspace_bytes(k, P, (int)sizeof(T), &need);
+  if (rc != MIA_OK) return rc;
+  if (ws_bytes < need || (P > 0 && !ws)) return MIA_ERR_WORKSPACE;
+  const int ch = gram_chunk(k, (int)sizeof(T));
+  const int64_t nslab = (P + ch - 1) / ch;
+  if (nslab > 1 << 20) return MIA_ERR_UNSUPPORTED;
+  T* slabs = (T*)ws;
+  if (nslab > 0) {
+    const size_t lds = (size_t)(k + 1) * (ch + 1) * sizeof(T);
+    auto kern = pairstat_partial_kernel<T>;
+    if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kern<<<dim3((unsigned)nslab), dim3(256), lds, stream>>>(Yb, d, k, P, ch, slabs);
+    MIA_LAUNCH_CHECK();
+  }
+  const int n = (k + 1) & ~1, lda = n | 1;
+  const size_t lds2 = ((size_t)2 * n * lda + 5 * (size_t)n) * sizeof(T) + 16;
+  if (lds2 > 160 * 1024) return MIA_ERR_UNSUPPORTED;
+  KernelProgram<T> kp;
+  kp.n = n_ops;
+  for (int i = 0; i < n_ops; ++i) { kp.op[i] = (unsigned char)prog[i].op; kp.val[i] = T(prog[i].value); }
+  auto kern2 = etkf_solve_kernel<T, true>;
   if (lds2 > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
   kern2<<<dim3(1), dim3(256), lds2, stream>>>(slabs, (int)nslab, k, T(k - 1) / inf_factor,
-                                               sizeof(T) == 4 ? T(2.4e-7) : T(9e-16), sizeof(T) == 4 ? 16 : 24, W, flags);
+                                               sizeof(T) == 4 ? T(2.4e-7) : T(9e-16), sizeof(T) == 4 ? 16 : 24, W, flags,
+                                               kp, t_sqrt_host(inf_factor));
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
@@ -199,6 +331,26 @@ extern "C" int mia_etkf_workspace_bytes(int k, int64_t P, int elem_bytes, size_t
   const size_t nslab = (size_t)((P + ch - 1) / ch);
   *bytes = align_up(nslab * ((size_t)k * k + k) * elem_bytes + 256, 256);
   return MIA_OK;
+}
+
+extern "C" int mia_ketkf_workspace_bytes(int k, int64_t P, int elem_bytes, size_t* bytes) {
+  size_t one = 0;
+  const int rc = mia_etkf_workspace_bytes(k, P, elem_bytes, &one);
+  if (rc != MIA_OK) return rc;
+  *bytes = align_up(3 * one, 256);
+  return MIA_OK;
+}
+extern "C" int mia_ketkf_weights_f32(const float* Yb, const float* d, int k, int64_t P, float inf_factor,
+                                     const mia_kernel_op_t* prog, int n_ops, float* W, int32_t* flags_opt, void* ws,
+                                     size_t ws_bytes, void* stream) {
+  (void)hipGetLastError();
+  return ketkf_weights_impl<float>(Yb, d, k, P, inf_factor, prog, n_ops, W, flags_opt, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int mia_ketkf_weights_f64(const double* Yb, const double* d, int k, int64_t P, double inf_factor,
+                                     const mia_kernel_op_t* prog, int n_ops, double* W, int32_t* flags_opt, void* ws,
+                                     size_t ws_bytes, void* stream) {
+  (void)hipGetLastError();
+  return ketkf_weights_impl<double>(Yb, d, k, P, inf_factor, prog, n_ops, W, flags_opt, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int mia_etkf_weights_f32(const float* Yb, const float* d, int k, int64_t P, float inf_factor, float* W,

@@ -520,6 +520,34 @@ class LetkfEngine:
                        self._stream()), "mia_etkf_weights_" + sfx)
         return W
 
+    def ketkf_weights(self, Yb: torch.Tensor, d: torch.Tensor, kernel_program, inf_factor: float = 1.0) -> torch.Tensor:
+        """Global kernelised ETKF weights (k, k) for ANY number of observations (KETKFModule on the full block,
+        core/ketkf.py:65-94): pair statistics accumulated over observation chunks, then one k x k solve."""
+        Yb = Yb.to(self.device).contiguous()
+        dtype = Yb.dtype if Yb.dtype in (torch.float32, torch.float64) else torch.float64
+        Yb = Yb.to(dtype)
+        d = d.to(device=self.device, dtype=dtype).contiguous().reshape(-1)
+        k, P = Yb.shape
+        if d.shape[0] != P:
+            raise ValueError(
+                "Observational size between ensemble ({0:d}) and observations ({1:d}) do not match!".format(
+                    P, d.shape[0]))
+        nops = len(kernel_program)
+        prog = (_cabi.KernelOp * max(nops, 1))()
+        for i, (op, val) in enumerate(kernel_program):
+            prog[i].op, prog[i].value = int(op), float(val)
+        eb = 4 if dtype == torch.float32 else 8
+        nbytes = C.c_size_t(0)
+        _cabi.check(self.lib.mia_ketkf_workspace_bytes(k, P, eb, C.byref(nbytes)), "ketkf_workspace_bytes")
+        ws = self._workspace("ketkf", nbytes.value)
+        W = torch.empty((k, k), dtype=dtype, device=self.device)
+        flags = torch.zeros(1, dtype=torch.int32, device=self.device)
+        sfx = "f32" if dtype == torch.float32 else "f64"
+        fn = getattr(self.lib, "mia_ketkf_weights_" + sfx)
+        _cabi.check(fn(_ptr(Yb), _ptr(d), k, P, float(inf_factor), prog, nops, _ptr(W), _ptr(flags), _ptr(ws), ws.numel(),
+                       self._stream()), "mia_ketkf_weights_" + sfx)
+        return W
+
     def apply_weights(self, X: torch.Tensor, W: torch.Tensor, g0: int = 0, g1: Optional[int] = None) -> torch.Tensor:
         if X.dim() == 2:
             X = X[None]
