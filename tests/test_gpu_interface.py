@@ -84,6 +84,17 @@ def test_letkf_without_localization_equals_etkf(mia, golden, dtype, tol):
     assert rel_fro(xa_e.cpu().numpy(), g["analysis_global_1p0"]) < tol
     xa_l = mia.LETKF(dtype=dtype).analyse_arrays(state, g["yb"], g["d"], **kw)
     assert rel_fro(xa_l.cpu().numpy(), g["analysis_global_1p0"]) < tol
+    W = mia.LETKF(dtype=dtype).estimate_weights_arrays(g["yb"], g["d"], **kw)          # (grid, ensemble, ensemble_new)
+    assert tuple(W.shape) == (40, 10, 10) and rel_fro(W[7].cpu().numpy(), g["weights_global_1p0"]) < 5 * tol
+    # ... and for far more observations than one workgroup could hold (the reference repeats the global solve G times)
+    rs = np.random.RandomState(2)
+    yb_big = rs.normal(size=(10, 6000)) * 0.1
+    yb_big -= yb_big.mean(axis=0)
+    d_big = rs.normal(size=6000) * 0.1
+    xa_b = mia.LETKF(dtype=dtype).analyse_arrays(state, yb_big, d_big, grid_coords=g["grid"][:, None],
+                                                obs_coords=np.zeros((6000, 1)))
+    ref_b, _ = O.etkf_analysis(state, yb_big, d_big, 1.0)
+    assert rel_fro(xa_b.cpu().numpy(), ref_b) < tol
     zero = mia.GaspariCohn((1.0, 1.0), dist_func=lambda grid, obs: np.zeros((2, obs.shape[0])))
     xa_z = mia.LETKF(localization=zero, dtype=dtype).analyse_arrays(state, g["yb"], g["d"], **kw)
     assert rel_fro(xa_z.cpu().numpy(), g["analysis_global_1p0"]) < tol

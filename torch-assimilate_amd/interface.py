@@ -190,6 +190,12 @@ class LETKF(ETKF):
     def estimate_weights_arrays(self, yb, d, grid_coords=None, obs_coords=None, g0=0, g1=None,
                                 grid_info=None, obs_info=None) -> torch.Tensor:
         """weights (G, k, k) with [g, i, j] = w_mean_i + W_ij (letkf.py:127-146)."""
+        if self.localization is None:
+            # no localisation: every grid point sees every observation with weight 1 (wrapper.py:87), i.e. the one
+            # global solve repeated G times in the reference -- done once here, for any number of observations
+            G = len(grid_coords) if g1 is None else g1
+            W = ETKF.estimate_weights_arrays(self, yb, d)
+            return W[None].expand(G - g0, -1, -1).contiguous()
         yb, d = self._dev(yb), self._dev(d)
         nb = self._lists(grid_coords, obs_coords, g0, g1, grid_info, obs_info)
         k = yb.shape[0]
@@ -203,6 +209,11 @@ class LETKF(ETKF):
         estimate_weights -> store -> load -> _apply_weights as in the reference (filter.py:157-164)."""
         st = self._dev(state)
         shp = st.shape
+        if self.localization is None and self.weight_save_path is None:
+            W = ETKF.estimate_weights_arrays(self, yb, d)          # one global solve (see estimate_weights_arrays)
+            g1_ = shp[-1] if g1 is None else g1
+            xa = self.engine.apply_weights(st.reshape(-1, shp[-2], shp[-1]), W, g0, g1_)
+            return xa.reshape(shp[:-1] + (g1_ - g0,))
         if self.weight_save_path is not None:
             W = self.estimate_weights_arrays(yb, d, grid_coords, obs_coords, g0, g1, grid_info, obs_info)
             gidx = np.arange(g0, g0 + W.shape[0])
