@@ -205,9 +205,12 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
   float rsum = 0.0f;
   if (stream_s) {
     if constexpr (STREAM_OK) {
-      // S = Yl^T Yl panel by panel: the TT tiles of rows 16 tb .. 16 tb + 15 are accumulated concurrently
-      // (A operand = the panel's rows, B operands = every row panel), written to the staging area in the
-      // D layout (row 4 (lane >> 4) + q, column lane & 15) and read back as whole rows by the 16 lanes that own them.
+      // S = Yl^T Yl: the NTILE upper 16x16 tiles are accumulated in ONE pass over the members (every K step loads the
+      // TT row panels once and feeds all tiles -- accumulating panel by panel re-read the operands TT times and left
+      // the wave waiting on LDS: 0.6 of 1.36 ms per 5e4 analyses of config 4).  Then, panel by panel, the rows
+      // 16 p .. 16 p + 15 are assembled in the staging area -- tile (p, c >= p) as it lies in the accumulators
+      // (row 4 (lane >> 4) + q, column lane & 15), tile (c < p, p) transposed, which is one 16-byte store per lane --
+      // and read back as whole rows by the 16 lanes that own them.
       const int lr = tid & 15, h = tid >> 4;
       const int KS = (k + 3) >> 2;
       const float* prow[TT];
@@ -219,26 +222,36 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
 #pragma unroll
       for (int b2 = 0; b2 < NMAX / 2; ++b2) srow2[b2] = f2v{0.0f, 0.0f};
       const bool kfull = (k & 3) == 0;
+      f32x4c acc[NTILE];
 #pragma unroll
-      for (int tb_ = 0; tb_ < TT; ++tb_) {
-        f32x4c acc[TT];
+      for (int t = 0; t < NTILE; ++t) acc[t] = f32x4c{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+      for (int s_ = 0; s_ < ((P.xskip & 2) ? 0 : KS); ++s_) {
+        float av_[TT];
 #pragma unroll
-        for (int t = 0; t < TT; ++t) acc[t] = f32x4c{0.f, 0.f, 0.f, 0.f};
-        for (int s_ = 0; s_ < KS; ++s_) {
-          float av_[TT];
+        for (int t = 0; t < TT; ++t) av_[t] = (kfull || KS * h + s_ < k) ? prow[t][s_] : 0.0f;
 #pragma unroll
-          for (int t = 0; t < TT; ++t) av_[t] = (kfull || KS * h + s_ < k) ? prow[t][s_] : 0.0f;
+        for (int tb_ = 0, tile = 0; tb_ < TT; ++tb_)
 #pragma unroll
-          for (int ta_ = 0; ta_ < TT; ++ta_)
-            acc[ta_] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[tb_], av_[ta_], acc[ta_], 0, 0, 0);
+          for (int ta_ = 0; ta_ <= tb_; ++ta_, ++tile)
+            acc[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[ta_], av_[tb_], acc[tile], 0, 0, 0);   // rows ta, columns tb
+      }
+#pragma unroll
+      for (int p_ = 0; p_ < TT; ++p_) {
+#pragma unroll
+        for (int c_ = 0; c_ < TT; ++c_) {
+          if (c_ >= p_) {            // tile (p, c): rows of the panel down the q index
+            const int tile = c_ * (c_ + 1) / 2 + p_;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (16 * c_ + lr < NMAX) S[(4 * h + q) * LDA + 16 * c_ + lr] = acc[tile][q];
+          } else {                   // tile (c, p) transposed: S[16 p + lr][16 c + 4 h + q] = D[4 h + q][lr]
+            const int tile = p_ * (p_ + 1) / 2 + c_;
+            *reinterpret_cast<f4v*>(S + lr * LDA + 16 * c_ + 4 * h) = f4v{acc[tile][0], acc[tile][1], acc[tile][2], acc[tile][3]};
+          }
         }
-#pragma unroll
-        for (int ta_ = 0; ta_ < TT; ++ta_)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (16 * ta_ + lr < NMAX) S[(4 * h + q) * LDA + 16 * ta_ + lr] = acc[ta_][q];
         MIA_WAVE_SYNC();
-        if ((tid >> 4) == tb_ && tid < NMAX) {
+        if ((tid >> 4) == p_ && tid < NMAX) {
 #pragma unroll
           for (int b4 = 0; b4 < N4; ++b4) {
             const f4v v = reinterpret_cast<const f4v*>(S + lr * LDA)[b4];
