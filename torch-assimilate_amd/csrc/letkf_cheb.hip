@@ -176,18 +176,20 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
       // quads) instead of an integer division per quad
     const int kpv = kp >> 2;
     const int total = (P.xskip & 1) ? 0 : cnt * kpv;
-    for (int base = 0; base < total; base += 256) {
-      float4 v[4];
-      int jj[4], cc[4];
+    constexpr int GQ = NMAX > 32 ? 8 : 4;       // quads in flight per lane: large blocks (config 4: 1344 quads) run at
+                                                // few waves per CU, so each trip's memory latency is exposed
+    for (int base = 0; base < total; base += 64 * GQ) {
+      float4 v[GQ];
+      int jj[GQ], cc[GQ];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < GQ; ++u) {
         const int it = base + 64 * u + tid;
         const int j = (int)(((unsigned long long)(unsigned)it * (unsigned)P.kpv_magic) >> 20);
         jj[u] = j; cc[u] = it - j * kpv;
         if (it < total) v[u] = reinterpret_cast<const float4*>(P.rec + (int64_t)lidx[j] * kp)[cc[u]];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < GQ; ++u) {
         if (base + 64 * u + tid < total) {
           const float wj = lw[jj[u]];
           float4 t = v[u];
