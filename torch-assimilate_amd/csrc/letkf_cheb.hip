@@ -364,27 +364,27 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
       rhs[i] = acc;
     }
   } else {   // double centring of K and centring of k(Yb, d)   (core/ketkf.py:77-89)
-    for (int i = tid; i < k; i += 64) {
-      float acc = 0.0f;
-      for (int j = 0; j < k; ++j) acc += S[i * LDA + j];
-      uq[i] = acc / float(k);
+    // Row means and the kernel vector by one lane per member; the two grand means by wave reductions (a single lane
+    // summing them serially cost ~5000 cycles); the centring of K itself is folded into the register load of the
+    // rows below (K is only ever read there), so the k x k read-modify-write pass over LDS is gone.
+    float um = 0.0f, ko_ = 0.0f;
+    if (tid < k) {
+#pragma unroll
+      for (int b4 = 0; b4 < N4; ++b4) {      // columns >= k are zero
+        const f4v v = reinterpret_cast<const f4v*>(S + tid * LDA)[b4];
+        um += (v.x + v.y) + (v.z + v.w);
+      }
+      um /= float(k);
       float ko = 0.0f;
-      for (int j = 0; j < cnt; ++j) { const float df = Yt[(size_t)j * kp + i] - Yt[(size_t)j * kp + k]; ko += df * df; }
-      rhs[i] = __expf(-P.gamma * ko);
+      for (int j = 0; j < cnt; ++j) { const float df = Yt[(size_t)j * kp + tid] - Yt[(size_t)j * kp + k]; ko += df * df; }
+      ko_ = __expf(-P.gamma * ko);
     }
-    MIA_WAVE_SYNC();
-    if (tid == 0) {
-      float gm = 0.0f, om = 0.0f;
-      for (int i = 0; i < k; ++i) { gm += uq[i]; om += rhs[i]; }
-      red[0] = gm / float(k); red[1] = om / float(k);
+    const float gm = wave_sum_dpp(um) / float(k), om = wave_sum_dpp(ko_) / float(k);
+    if (tid < NMAX) {
+      uq[tid] = tid < k ? um : 0.0f;
+      rhs[tid] = tid < k ? ko_ - om - (um - gm) : 0.0f;
     }
-    MIA_WAVE_SYNC();
-    for (int it = tid; it < k * k; it += 64) {
-      const int a = it / k, b = it - a * k;
-      S[a * LDA + b] = S[a * LDA + b] - uq[b] - (uq[a] - red[0]);
-    }
-    MIA_WAVE_SYNC();
-    for (int i = tid; i < NMAX; i += 64) rhs[i] = i < k ? rhs[i] - red[1] - (uq[i] - red[0]) : 0.0f;
+    if (tid == 0) red[0] = gm;
   }
   MIA_WAVE_SYNC();
   // ---- row r of S into registers (already there when streamed); Gershgorin bound L >= lambda_max
@@ -392,7 +392,15 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     const int r = tid < NMAX ? tid : NMAX - 1;
 #pragma unroll
     for (int b4 = 0; b4 < N4; ++b4) {
-      const f4v v = reinterpret_cast<const f4v*>(S + r * LDA)[b4];
+      f4v v = reinterpret_cast<const f4v*>(S + r * LDA)[b4];
+      if (!P.dual && P.kernel_mode != 0) {   // centred kernel matrix: K_rb - mean_b - (mean_r - grand mean), zero padding kept
+        const f4v u4 = reinterpret_cast<const f4v*>(uq)[b4];
+        const float cr = uq[r] - red[0];
+        v.x = (r < k && 4 * b4 + 0 < k) ? v.x - u4.x - cr : 0.0f;
+        v.y = (r < k && 4 * b4 + 1 < k) ? v.y - u4.y - cr : 0.0f;
+        v.z = (r < k && 4 * b4 + 2 < k) ? v.z - u4.z - cr : 0.0f;
+        v.w = (r < k && 4 * b4 + 3 < k) ? v.w - u4.w - cr : 0.0f;
+      }
       srow2[2 * b4] = v.xy; srow2[2 * b4 + 1] = v.zw;
       rsum += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
     }
