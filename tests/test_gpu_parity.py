@@ -267,9 +267,13 @@ def test_matfun_blocks_and_edge_cases(eng, golden):
     nb = eng.localize(np.arange(5.0), np.zeros((0, 1)), [10.0])
     xa = eng.analysis(dev(X, torch.float32), torch.zeros((10, 0)), torch.zeros(0), nb, 1.1, method="matfun")
     assert rel_fro(xa.cpu().numpy(), O.apply_weights(X, np.sqrt(1.1) * np.eye(10))) < 1e-6
+    # the weights come from the eigensolver-free route as well (mia_letkf_weights_matfun_f32); no observation: prior
+    xa, W = eng.analysis(dev(X, torch.float32), torch.zeros((10, 0)), torch.zeros(0), nb, 1.1, method="matfun",
+                         return_weights=True)
+    np.testing.assert_allclose(W.cpu().numpy()[2], np.sqrt(1.1) * np.eye(10), atol=1e-6)
+    assert rel_fro(xa.cpu().numpy(), O.apply_weights(X, np.sqrt(1.1) * np.eye(10))) < 1e-6
     with pytest.raises(ValueError):
-        eng.analysis(dev(X, torch.float32), torch.zeros((10, 0)), torch.zeros(0), nb, 1.1, method="matfun",
-                     return_weights=True)
+        eng.analysis(dev(X, torch.float64), torch.zeros((10, 0)), torch.zeros(0), nb, 1.1, method="matfun")
 
 
 def test_matfun_declines_wide_spectra_and_eigensolver_redoes_them(eng, golden, monkeypatch):
@@ -391,3 +395,30 @@ def test_matfun_many_state_rows_on_the_matrix_cores(eng, monkeypatch, m, k, stri
     monkeypatch.setenv("MIA_CHEB_NO_ROWBATCH", "1")
     xs = eng.analysis(X, yb, d, nb, 1.1, method="matfun")
     assert rel_fro(got, xs.cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("name,c", [("c2", 10.0), ("c2m3", 10.0)])
+def test_weights_without_eigensolver_vs_reference(eng, golden, monkeypatch, name, c):
+    """estimate_weights semantics (letkf.py:145-146) through mia_letkf_weights_matfun_f32: phi(S) as a matrix from the
+    Chebyshev recurrence on MFMA tiles.  Weights at the golden sample points and the analysis against the reference;
+    strong observations make the kernel decline points, which the eigensolver kernel then redoes WITH weights."""
+    g = golden("g7_synthetic_configs.npz")
+    st, gx, ox, yb, d = (g[f"{name}_{n}"] for n in ("state", "grid_x", "obs_x", "yb", "d"))
+    nb = eng.localize(gx, ox, [c])
+    for inf in (1.0, 1.1):
+        tag = f"{name}_{str(inf).replace('.', 'p')}"
+        xa, W, fl = eng.analysis(dev(st, torch.float32), dev(yb, torch.float32), dev(d, torch.float32), nb, inf,
+                                 return_weights=True, return_flags=True)
+        f = fl.cpu().numpy()
+        assert int((f & 0xff).max()) == 0 and int(((f >> 8) & 0xff).min()) >= 3       # bits 8-15: degree => matfun ran
+        assert rel_fro(W.cpu().numpy()[g[f"{name}_widx"]], g[f"{tag}_weights"]) < TOL32
+        assert rel_fro(xa.cpu().numpy(), g[f"{tag}_analysis"]) < TOL32
+    # declined points: the eigensolver redoes them, weights included
+    scale = 12.0
+    xa, W, fl = eng.analysis(dev(st, torch.float32), dev(yb * scale, torch.float32), dev(d * scale, torch.float32), nb, 1.1,
+                             return_weights=True, return_flags=True)
+    ref_xa, ref_w = O.letkf_analysis(st, gx, ox, yb * scale, d * scale, c, 1.1)
+    assert rel_fro(W.cpu().numpy(), ref_w) < 5e-5 and rel_fro(xa.cpu().numpy(), ref_xa) < TOL32
+    monkeypatch.setenv("MIA_CHEB_DMAX", "8")          # force declines on the plain case too
+    xa2, W2 = eng.analysis(dev(st, torch.float32), dev(yb, torch.float32), dev(d, torch.float32), nb, 1.1, return_weights=True)
+    assert rel_fro(W2.cpu().numpy()[g[f"{name}_widx"]], g[f"{name}_1p1_weights"]) < TOL32

@@ -49,6 +49,7 @@ struct ChebParams {
   // its own (m*k, seg_len) buffer at Xa + s * seg_stride and counts its finished points in done[s*64 + ..]
   int seg_len; int64_t seg_stride; int32_t* done;
   int kpv_magic;   // ceil(2^20 / (kp / 4))
+  float* W;        // weights-output variant: [ng][k][k]
 };
 
 using f32x4c = __attribute__((ext_vector_type(4))) float;
@@ -77,7 +78,7 @@ __device__ inline float matvec_row(const f2v (&srow2)[NMAX / 2], const float* tv
 
 constexpr int kRowBatch = 16;     // state rows per MFMA batch of the many-rows variant (one 16-column tile)
 
-template <int NMAX, int KL, bool FUSED, int WPB, bool SEG, bool BATCH = false>
+template <int NMAX, int KL, bool FUSED, int WPB, bool SEG, int MODE = 0>   // MODE 1: many state rows, 2: weights output
 __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
   constexpr int LDA = (NMAX % 8 == 0) ? NMAX + 4 : NMAX;
   constexpr int N4 = NMAX / 4;
@@ -472,7 +473,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     MIA_WAVE_SYNC();
   }
   const float alpha = 2.0f / L;            // A v = alpha S v - v
-  if constexpr (BATCH) {
+  if constexpr (MODE == 1) {
     // ---- many state rows: kRowBatch rows at a time as ONE matrix recurrence on the matrix cores.
     //      T (n x 16) lives in the MFMA result layout (lane (lr, h) holds T[16 t + 4 h + q][lr], q = 0..3); every step
     //      is  Y = S T  (A fragments of S stay in registers, T goes through LDS to become the B operand), then the
@@ -612,6 +613,179 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
         }
       }
     }
+  } else if constexpr (MODE == 2) {
+    // ---- weights output without an eigensolver (what LETKF.estimate_weights returns, letkf.py:145-146):
+    //      W = w_mean 1^T + f0 I + Yl phi(S) Yl^T,  w_mean = Yl (psi(S) d_l).
+    //      psi(S) d_l is the vector recurrence of the transform path applied to d_l; phi(S) is the SAME recurrence
+    //      run on the identity, i.e. on n x n matrices T_j = T_j(A), as MFMA products S T_j (A fragments of S in
+    //      registers, T_j through LDS into the B operand, tiles in the result layout: lane (lr, h) holds
+    //      T[16 ti + 4 h + q][16 tj + lr]).  Two more products, N = Yl Phi and W = N Yl^T, finish the job; the state rows
+    //      are then transformed with W.  ~365 MFMAs per grid point at C2 against the Jacobi route's sweeps.
+    static_assert(NMAX <= 32 && KL == 1, "the weights variant keeps S in LDS and one member per lane");
+    constexpr int NP = 16 * TT;
+    const int lr = tid & 15, h = tid >> 4;
+    const int KT = (k + 15) >> 4, KP16 = KT * 16;
+    float* Tl = reinterpret_cast<float*>(lidx + ((pm + 3) & ~1));   // [NP][NP]
+    float* Nl = Tl + NP * NP;                                       // [KP16][NP]
+    float* wbar = Nl + KP16 * NP;                                   // [k]
+    float afrag[TT][N4];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int s_ = 0; s_ < N4; ++s_) afrag[t][s_] = (16 * t + lr < NMAX) ? S[(16 * t + lr) * LDA + 4 * s_ + h] : 0.0f;
+    // -- u = psi(S) d_l, w_mean = Yl u
+    {
+      const float t0 = rhs_r;
+      if (tid < NMAX) tv[tid] = t0;
+      MIA_WAVE_SYNC();
+      float yv = matvec_row<NMAX>(srow2, tv);
+      float tprev = t0, tcur = alpha * yv - t0;
+      float apsi = c2[0].y * t0 + c2[1].y * tcur;
+      for (int j = 2; j <= deg; ++j) {
+        MIA_WAVE_SYNC();
+        if (tid < NMAX) tv[tid] = tcur;
+        MIA_WAVE_SYNC();
+        yv = matvec_row<NMAX>(srow2, tv);
+        const float tnext = 2.0f * (alpha * yv - tcur) - tprev;
+        tprev = tcur; tcur = tnext;
+        apsi = c2[j].y * tcur + apsi;
+      }
+      MIA_WAVE_SYNC();
+      if (tid < NMAX) sw[tid] = tid < ntrue ? apsi : 0.0f;
+      MIA_WAVE_SYNC();
+      if (tid < k) {
+        float acc = 0.0f;
+        for (int b = 0; b < cnt; ++b) acc += sw[b] * Yt[(size_t)b * kp + tid];
+        wbar[tid] = acc;
+      }
+    }
+    // -- Phi = phi(S): matrix recurrence from T_0 = I
+    f32x4c tp[TT][TT], tc[TT][TT], ph[TT][TT];
+    auto publish = [&](const f32x4c (&tt)[TT][TT]) {
+      MIA_WAVE_SYNC();
+#pragma unroll
+      for (int ti = 0; ti < TT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TT; ++tj)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Tl[(16 * ti + 4 * h + q) * NP + 16 * tj + lr] = tt[ti][tj][q];
+      MIA_WAVE_SYNC();
+    };
+    auto product = [&](f32x4c (&yy)[TT][TT]) {       // yy = S T  (T read from Tl)
+      float bf[TT][N4];
+#pragma unroll
+      for (int tj = 0; tj < TT; ++tj)
+#pragma unroll
+        for (int s_ = 0; s_ < N4; ++s_) bf[tj][s_] = Tl[(4 * s_ + h) * NP + 16 * tj + lr];
+#pragma unroll
+      for (int ti = 0; ti < TT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TT; ++tj) {
+          f32x4c acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s_ = 0; s_ < N4; ++s_) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ti][s_], bf[tj][s_], acc, 0, 0, 0);
+          yy[ti][tj] = acc;
+        }
+    };
+#pragma unroll
+    for (int ti = 0; ti < TT; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TT; ++tj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tp[ti][tj][q] = (16 * ti + 4 * h + q == 16 * tj + lr) ? 1.0f : 0.0f;
+    f32x4c y[TT][TT];
+    publish(tp);
+    product(y);
+    {
+      const float c0 = c2[0].x, c1 = c2[1].x;
+#pragma unroll
+      for (int ti = 0; ti < TT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TT; ++tj)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            tc[ti][tj][q] = alpha * y[ti][tj][q] - tp[ti][tj][q];
+            ph[ti][tj][q] = c0 * tp[ti][tj][q] + c1 * tc[ti][tj][q];
+          }
+    }
+    for (int j = 2; j <= deg; ++j) {
+      publish(tc);
+      product(y);
+      const float cj = c2[j].x;
+#pragma unroll
+      for (int ti = 0; ti < TT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TT; ++tj)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float tn = 2.0f * (alpha * y[ti][tj][q] - tc[ti][tj][q]) - tp[ti][tj][q];
+            tp[ti][tj][q] = tc[ti][tj][q]; tc[ti][tj][q] = tn;
+            ph[ti][tj][q] = cj * tn + ph[ti][tj][q];
+          }
+    }
+#pragma unroll
+    for (int ti = 0; ti < TT; ++ti)        // rows / columns beyond the local observations carry nothing
+#pragma unroll
+      for (int tj = 0; tj < TT; ++tj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (16 * ti + 4 * h + q >= cnt || 16 * tj + lr >= cnt) ph[ti][tj][q] = 0.0f;
+    publish(ph);
+    // -- N = Yl Phi  (k x n)
+    for (int ti = 0; ti < KT; ++ti) {
+      const int i = 16 * ti + lr;
+#pragma unroll
+      for (int tj = 0; tj < TT; ++tj) {
+        f32x4c acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s_ = 0; s_ < N4; ++s_) {
+          const int b = 4 * s_ + h;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32((b < cnt && i < k) ? Yt[(size_t)b * kp + i] : 0.0f,
+                                                     Tl[b * NP + 16 * tj + lr], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Nl[(16 * ti + 4 * h + q) * NP + 16 * tj + lr] = acc[q];
+      }
+    }
+    MIA_WAVE_SYNC();
+    // -- W = w_mean 1^T + f0 I + N Yl^T
+    float* wout = P.W + pt * (int64_t)k * k;
+    for (int ti = 0; ti < KT; ++ti)
+      for (int tj = 0; tj < KT; ++tj) {
+        const int j = 16 * tj + lr;
+        f32x4c acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s_ = 0; s_ < N4; ++s_) {
+          const int b = 4 * s_ + h;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Nl[(16 * ti + lr) * NP + b], (b < cnt && j < k) ? Yt[(size_t)b * kp + j] : 0.0f,
+                                                     acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = 16 * ti + 4 * h + q;
+          if (i < k && j < k) {
+            const float v = wbar[i] + (i == j ? f0 : 0.0f) + acc[q];
+            if (!(fabsf(v) <= 1e30f)) flag |= MIA_FLAG_NONFINITE;
+            wout[i * k + j] = v;
+          }
+        }
+      }
+    // -- the state rows: xa_j = mean + sum_i x'_i W_ij (base.py:257-278), W read back from where this wavefront just
+    //    wrote it (L2-hot, rows contiguous across lanes) -- a copy in LDS would cost 7.7 KB of occupancy at k = 40
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // this wavefront's stores of W are visible to its loads
+    __builtin_amdgcn_wave_barrier();
+    for (int mi = 0; mi < P.m; ++mi) {
+      const float xv = tid < k ? P.X[((int64_t)mi * k + tid) * P.ldx + g] : 0.0f;
+      const float xm = wave_sum_dpp(xv) / float(k);
+      if (tid < kp) xp[tid] = tid < k ? xv - xm : 0.0f;
+      MIA_WAVE_SYNC();
+      if (tid < k) {
+        float acc = 0.0f;
+        for (int i = 0; i < k; ++i) acc += xp[i] * wout[i * k + tid];
+        Xab[((int64_t)mi * k + tid) * P.ldo + ocol] = xm + acc;
+      }
+      MIA_WAVE_SYNC();
+    }
   } else {
   // ---- per state row: z, the shared recurrence, the output
   const int k4 = (k + 3) >> 2;
@@ -698,7 +872,13 @@ __global__ __launch_bounds__(64 * WPB, (NMAX <= 24 ? 5 : (NMAX <= 40 ? 4 : 2))) 
 // Many state rows per grid point (m >= 8, dual route, order <= 32): rows are transformed 16 at a time on the matrix cores.
 template <int NMAX>
 __global__ __launch_bounds__(64, (NMAX <= 24 ? 4 : 3)) void letkf_cheb_rows_kernel(ChebParams P) {
-  letkf_cheb_point<NMAX, 1, false, 1, false, true>(P);
+  letkf_cheb_point<NMAX, 1, false, 1, false, 1>(P);
+}
+
+// Weights output (dual route, order <= 32): W as a matrix function on the matrix cores, no eigensolver.
+template <int NMAX>
+__global__ __launch_bounds__(64, (NMAX <= 24 ? 4 : 3)) void letkf_cheb_weights_kernel(ChebParams P) {
+  letkf_cheb_point<NMAX, 1, false, 1, false, 2>(P);
 }
 
 // Segmented launch: one grid over the whole block; every workgroup (= one grid point), whatever path it left
@@ -727,12 +907,32 @@ __global__ void __launch_bounds__(64) segment_wait_kernel(const int32_t* done, i
   if (lane == 0) atomicOr(err, 1);      // exit condition every wave reaches: ~seconds, then report
 }
 
-static size_t cheb_lds_bytes(int kp, int p_max, int nmax, int rows, bool dual, bool batch = false) {
+static size_t cheb_lds_bytes(int kp, int p_max, int nmax, int rows, bool dual, bool batch = false, int k_weights = 0) {
   const int lda = (nmax % 8 == 0) ? nmax + 4 : nmax;
   const int srows = (dual && nmax > 32) ? 16 : nmax;      // streamed S: staging panel only (see letkf_cheb_point)
   size_t e = (size_t)srows * lda + 4 * (size_t)nmax + 4 * 64 + 8 + (size_t)kp + (size_t)(rows + 1) * kp + ((p_max + 3) & ~1);
   if (batch) e += (size_t)kRowBatch * kp + (size_t)((nmax + 15) & ~15) * kRowBatch + (size_t)nmax;
+  if (k_weights) {
+    const size_t np = (size_t)((nmax + 15) & ~15), kp16 = (size_t)((k_weights + 15) & ~15);
+    e += np * np + kp16 * np + (size_t)k_weights;
+  }
   return align_up(e * sizeof(float) + (size_t)((p_max + 3) & ~1) * sizeof(int), 16);
+}
+
+template <int NMAX>
+static int cheb_launch_weights(const ChebParams& ap, size_t lds, hipStream_t stream) {
+  if constexpr (NMAX <= 32) {
+    auto kern = letkf_cheb_weights_kernel<NMAX>;
+    if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t gx = ap.ng < 65536 ? ap.ng : 65536;
+    const int64_t gy = (ap.ng + gx - 1) / gx;
+    if (gy > 65535) return MIA_ERR_UNSUPPORTED;
+    kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64), lds, stream>>>(ap);
+    MIA_LAUNCH_CHECK();
+    return MIA_OK;
+  } else {
+    return MIA_ERR_UNSUPPORTED;
+  }
 }
 
 template <int NMAX>
@@ -796,11 +996,12 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
                          const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
                          float inf_factor, int kernel_mode, float gamma, float* Xa, int64_t ldo, int64_t o0,
                          int32_t* flags, int32_t* retry_count, const ScanParams* scan, int32_t* stats,
-                         hipStream_t stream, int seg_len, int64_t seg_stride, int32_t* done) {
+                         hipStream_t stream, int seg_len, int64_t seg_stride, int32_t* done, float* W_out) {
   if (!flags || !retry_count) return MIA_ERR_UNSUPPORTED;   // the retry protocol needs both
   if (seg_len > 0 && (scan || !done || seg_len % 8 || ng >= (int64_t)1 << 31)) return MIA_ERR_UNSUPPORTED;
   ChebParams ap;
   ap.seg_len = seg_len; ap.seg_stride = seg_stride; ap.done = done;
+  ap.W = W_out;
   ap.fused = scan != nullptr;
   if (scan) { ap.scan = *scan; ap.stats = stats; if (!stats) return MIA_ERR_NULL; } else ap.stats = nullptr;
   ap.X = X; ap.ldx = ldx; ap.m = m; ap.k = k; ap.g0 = g0; ap.ng = ng; ap.rec = rec;
@@ -835,6 +1036,21 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
   if (gy > 65535) return MIA_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)gx, (unsigned)gy);
   const bool two = k > 64;
+  if (W_out) {   // weights output: dual route, order <= 32, one member per lane; anything else is the eigensolver's
+    if (!(ap.dual && nmax <= 32 && !two && !ap.fused && seg_len == 0)) return MIA_ERR_UNSUPPORTED;
+    ap.lds_per_wave = (int)cheb_lds_bytes(ap.kp, p_max, nmax, ap.rows, true, false, k);
+    if (ap.lds_per_wave > 160 * 1024) return MIA_ERR_UNSUPPORTED;
+    switch (nmax) {
+      case 4: return cheb_launch_weights<4>(ap, ap.lds_per_wave, stream);
+      case 8: return cheb_launch_weights<8>(ap, ap.lds_per_wave, stream);
+      case 12: return cheb_launch_weights<12>(ap, ap.lds_per_wave, stream);
+      case 16: return cheb_launch_weights<16>(ap, ap.lds_per_wave, stream);
+      case 20: return cheb_launch_weights<20>(ap, ap.lds_per_wave, stream);
+      case 24: return cheb_launch_weights<24>(ap, ap.lds_per_wave, stream);
+      case 32: return cheb_launch_weights<32>(ap, ap.lds_per_wave, stream);
+    }
+    return MIA_ERR_UNSUPPORTED;
+  }
   // many state rows: batches of 16 rows on the matrix cores (dual route, order <= 32, one member per lane)
   if (m >= 8 && ap.dual && nmax <= 32 && !two && !ap.fused && seg_len == 0 && !getenv("MIA_CHEB_NO_ROWBATCH")) {
     ap.lds_per_wave = (int)cheb_lds_bytes(ap.kp, p_max, nmax, ap.rows, true, true);

@@ -17,7 +17,8 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
                          const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
                          float inf_factor, int kernel_mode, float gamma, float* Xa, int64_t ldo, int64_t o0,
                          int32_t* flags, int32_t* retry_count, const ScanParams* scan, int32_t* stats,
-                         hipStream_t stream, int seg_len = 0, int64_t seg_stride = 0, int32_t* done = nullptr);
+                         hipStream_t stream, int seg_len = 0, int64_t seg_stride = 0, int32_t* done = nullptr,
+                         float* W_out = nullptr /* weights-output variant: [ng][k][k] */);
 
 // one-wave kernel on `stream` that returns once the 64 slot counters at done64[j * kSlotStride] sum to `expected` (bounded
 // polling: after ~seconds it sets bit 0 of *err and returns, so the grid always drains)

@@ -412,6 +412,29 @@ class LetkfEngine:
             if defer_retry:
                 res.append(lambda: 0)
             return res[0] if len(res) == 1 else tuple(res)
+        if (return_weights and dtype == torch.float32 and gamma == 0.0 and method != "eig" and n > 0):
+            # weights without an eigensolver (dual route, order <= 32); -3 = shape outside that kernel
+            if retry is None:
+                retry = torch.zeros(1, dtype=torch.int32, device=self.device)
+            wargs = args[:13] + (float(inf_factor),) + args[15:]
+            rc = self.lib.mia_letkf_weights_matfun_f32(*wargs, _ptr(W), _ptr(flags), _ptr(retry), self._stream())
+            if rc != -3:
+                _cabi.check(rc, "mia_letkf_weights_matfun_f32")
+
+                def finish_w():
+                    n_retry = int(retry.item())          # host sync (8 bytes)
+                    if n_retry:
+                        _cabi.check(self.lib.mia_letkf_weights_retry_f32(*wargs, _ptr(W), _ptr(flags), self._stream()),
+                                    "mia_letkf_weights_retry_f32")
+                    return n_retry
+                if not defer_retry:
+                    finish_w()
+                res = [out, W]
+                if return_flags:
+                    res.append(flags)
+                if defer_retry:
+                    res.append(finish_w)
+                return tuple(res)
         can_matfun = dtype == torch.float32 and not return_weights and n > 0
         if method == "matfun" and not can_matfun:
             raise ValueError("the matfun route needs float32 and cannot return the weights")
