@@ -625,9 +625,10 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     constexpr int NP = 16 * TT;
     const int lr = tid & 15, h = tid >> 4;
     const int KT = (k + 15) >> 4, KP16 = KT * 16;
-    float* Tl = reinterpret_cast<float*>(lidx + ((pm + 3) & ~1));   // [NP][NP]
-    float* Nl = Tl + NP * NP;                                       // [KP16][NP]
-    float* wbar = Nl + KP16 * NP;                                   // [k]
+    constexpr int NS = NMAX + 4;                                    // row stride of N (columns < NMAX are all that is read)
+    float* Tl = reinterpret_cast<float*>(lidx + ((pm + 3) & ~1));   // [NMAX][NP]  (rows < NMAX are all that is read)
+    float* Nl = Tl + NMAX * NP;                                     // [KP16][NS]
+    float* wbar = Nl + KP16 * NS;                                   // [k]
     float afrag[TT][N4];
 #pragma unroll
     for (int t = 0; t < TT; ++t)
@@ -659,80 +660,82 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
         wbar[tid] = acc;
       }
     }
-    // -- Phi = phi(S): matrix recurrence from T_0 = I
-    f32x4c tp[TT][TT], tc[TT][TT], ph[TT][TT];
-    auto publish = [&](const f32x4c (&tt)[TT][TT]) {
+    // -- Phi = phi(S): matrix recurrence from T_0 = I.  Every T_j is a polynomial in S, hence symmetric: only the
+    //    upper tiles (ti <= tj) are computed; publishing a tile also writes its transpose (one 16-byte store per lane)
+    constexpr int NUP = TT * (TT + 1) / 2;
+    f32x4c tp[NUP], tc[NUP], ph[NUP];
+    auto publish = [&](const f32x4c (&tt)[NUP]) {
       MIA_WAVE_SYNC();
 #pragma unroll
-      for (int ti = 0; ti < TT; ++ti)
+      for (int tj = 0, tile = 0; tj < TT; ++tj)
 #pragma unroll
-        for (int tj = 0; tj < TT; ++tj)
+        for (int ti = 0; ti <= tj; ++ti, ++tile) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) Tl[(16 * ti + 4 * h + q) * NP + 16 * tj + lr] = tt[ti][tj][q];
+          for (int q = 0; q < 4; ++q)
+            if (16 * ti + 4 * h + q < NMAX) Tl[(16 * ti + 4 * h + q) * NP + 16 * tj + lr] = tt[tile][q];
+          if (ti != tj && 16 * tj + lr < NMAX)
+            *reinterpret_cast<f4v*>(Tl + (16 * tj + lr) * NP + 16 * ti + 4 * h) = f4v{tt[tile][0], tt[tile][1], tt[tile][2], tt[tile][3]};
+        }
       MIA_WAVE_SYNC();
     };
-    auto product = [&](f32x4c (&yy)[TT][TT]) {       // yy = S T  (T read from Tl)
+    auto product = [&](f32x4c (&yy)[NUP]) {       // yy = S T  (T read from Tl), upper tiles
       float bf[TT][N4];
 #pragma unroll
       for (int tj = 0; tj < TT; ++tj)
 #pragma unroll
         for (int s_ = 0; s_ < N4; ++s_) bf[tj][s_] = Tl[(4 * s_ + h) * NP + 16 * tj + lr];
 #pragma unroll
-      for (int ti = 0; ti < TT; ++ti)
+      for (int tj = 0, tile = 0; tj < TT; ++tj)
 #pragma unroll
-        for (int tj = 0; tj < TT; ++tj) {
+        for (int ti = 0; ti <= tj; ++ti, ++tile) {
           f32x4c acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int s_ = 0; s_ < N4; ++s_) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ti][s_], bf[tj][s_], acc, 0, 0, 0);
-          yy[ti][tj] = acc;
+          yy[tile] = acc;
         }
     };
 #pragma unroll
-    for (int ti = 0; ti < TT; ++ti)
+    for (int tj = 0, tile = 0; tj < TT; ++tj)
 #pragma unroll
-      for (int tj = 0; tj < TT; ++tj)
+      for (int ti = 0; ti <= tj; ++ti, ++tile)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) tp[ti][tj][q] = (16 * ti + 4 * h + q == 16 * tj + lr) ? 1.0f : 0.0f;
-    f32x4c y[TT][TT];
+        for (int q = 0; q < 4; ++q) tp[tile][q] = (16 * ti + 4 * h + q == 16 * tj + lr) ? 1.0f : 0.0f;
+    f32x4c y[NUP];
     publish(tp);
     product(y);
     {
       const float c0 = c2[0].x, c1 = c2[1].x;
 #pragma unroll
-      for (int ti = 0; ti < TT; ++ti)
+      for (int t = 0; t < NUP; ++t)
 #pragma unroll
-        for (int tj = 0; tj < TT; ++tj)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            tc[ti][tj][q] = alpha * y[ti][tj][q] - tp[ti][tj][q];
-            ph[ti][tj][q] = c0 * tp[ti][tj][q] + c1 * tc[ti][tj][q];
-          }
+        for (int q = 0; q < 4; ++q) {
+          tc[t][q] = alpha * y[t][q] - tp[t][q];
+          ph[t][q] = c0 * tp[t][q] + c1 * tc[t][q];
+        }
     }
     for (int j = 2; j <= deg; ++j) {
       publish(tc);
       product(y);
       const float cj = c2[j].x;
 #pragma unroll
-      for (int ti = 0; ti < TT; ++ti)
+      for (int t = 0; t < NUP; ++t)
 #pragma unroll
-        for (int tj = 0; tj < TT; ++tj)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float tn = 2.0f * (alpha * y[ti][tj][q] - tc[ti][tj][q]) - tp[ti][tj][q];
-            tp[ti][tj][q] = tc[ti][tj][q]; tc[ti][tj][q] = tn;
-            ph[ti][tj][q] = cj * tn + ph[ti][tj][q];
-          }
+        for (int q = 0; q < 4; ++q) {
+          const float tn = 2.0f * (alpha * y[t][q] - tc[t][q]) - tp[t][q];
+          tp[t][q] = tc[t][q]; tc[t][q] = tn;
+          ph[t][q] = cj * tn + ph[t][q];
+        }
     }
 #pragma unroll
-    for (int ti = 0; ti < TT; ++ti)        // rows / columns beyond the local observations carry nothing
+    for (int tj = 0, tile = 0; tj < TT; ++tj)        // rows / columns beyond the local observations carry nothing
 #pragma unroll
-      for (int tj = 0; tj < TT; ++tj)
+      for (int ti = 0; ti <= tj; ++ti, ++tile)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          if (16 * ti + 4 * h + q >= cnt || 16 * tj + lr >= cnt) ph[ti][tj][q] = 0.0f;
+          if (16 * ti + 4 * h + q >= cnt || 16 * tj + lr >= cnt) ph[tile][q] = 0.0f;
     publish(ph);
     // -- N = Yl Phi  (k x n)
-    for (int ti = 0; ti < KT; ++ti) {
+    for (int ti = 0; ti < ((P.xskip & 256) ? 0 : KT); ++ti) {
       const int i = 16 * ti + lr;
 #pragma unroll
       for (int tj = 0; tj < TT; ++tj) {
@@ -744,20 +747,21 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
                                                      Tl[b * NP + 16 * tj + lr], acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Nl[(16 * ti + 4 * h + q) * NP + 16 * tj + lr] = acc[q];
+        for (int q = 0; q < 4; ++q)
+          if (16 * tj + lr < NMAX) Nl[(16 * ti + 4 * h + q) * NS + 16 * tj + lr] = acc[q];
       }
     }
     MIA_WAVE_SYNC();
     // -- W = w_mean 1^T + f0 I + N Yl^T
     float* wout = P.W + pt * (int64_t)k * k;
-    for (int ti = 0; ti < KT; ++ti)
+    for (int ti = 0; ti < ((P.xskip & 512) ? 0 : KT); ++ti)
       for (int tj = 0; tj < KT; ++tj) {
         const int j = 16 * tj + lr;
         f32x4c acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s_ = 0; s_ < N4; ++s_) {
           const int b = 4 * s_ + h;
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Nl[(16 * ti + lr) * NP + b], (b < cnt && j < k) ? Yt[(size_t)b * kp + j] : 0.0f,
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Nl[(16 * ti + lr) * NS + b], (b < cnt && j < k) ? Yt[(size_t)b * kp + j] : 0.0f,
                                                      acc, 0, 0, 0);
         }
 #pragma unroll
@@ -774,7 +778,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     //    wrote it (L2-hot, rows contiguous across lanes) -- a copy in LDS would cost 7.7 KB of occupancy at k = 40
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // this wavefront's stores of W are visible to its loads
     __builtin_amdgcn_wave_barrier();
-    for (int mi = 0; mi < P.m; ++mi) {
+    for (int mi = 0; mi < ((P.xskip & 1024) ? 0 : P.m); ++mi) {
       const float xv = tid < k ? P.X[((int64_t)mi * k + tid) * P.ldx + g] : 0.0f;
       const float xm = wave_sum_dpp(xv) / float(k);
       if (tid < kp) xp[tid] = tid < k ? xv - xm : 0.0f;
@@ -914,7 +918,7 @@ static size_t cheb_lds_bytes(int kp, int p_max, int nmax, int rows, bool dual, b
   if (batch) e += (size_t)kRowBatch * kp + (size_t)((nmax + 15) & ~15) * kRowBatch + (size_t)nmax;
   if (k_weights) {
     const size_t np = (size_t)((nmax + 15) & ~15), kp16 = (size_t)((k_weights + 15) & ~15);
-    e += np * np + kp16 * np + (size_t)k_weights;
+    e += (size_t)nmax * np + kp16 * (size_t)(nmax + 4) + (size_t)k_weights;
   }
   return align_up(e * sizeof(float) + (size_t)((p_max + 3) & ~1) * sizeof(int), 16);
 }
