@@ -734,46 +734,68 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
         for (int q = 0; q < 4; ++q)
           if (16 * ti + 4 * h + q >= cnt || 16 * tj + lr >= cnt) ph[tile][q] = 0.0f;
     publish(ph);
-    // -- N = Yl Phi  (k x n)
-    for (int ti = 0; ti < ((P.xskip & 256) ? 0 : KT); ++ti) {
-      const int i = 16 * ti + lr;
+    // -- N = Yl Phi (k x n) and W = w_mean 1^T + f0 I + N Yl^T.  The fragments of Yl (member 16 t + lr, observation
+    //    4 s + h) are the A operand of the first product and the B operand of the second: loaded once.
+    constexpr int KTM = 4;                        // k <= 64
+    float yfrag[KTM][N4];
 #pragma unroll
-      for (int tj = 0; tj < TT; ++tj) {
-        f32x4c acc = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < KTM; ++t)
 #pragma unroll
-        for (int s_ = 0; s_ < N4; ++s_) {
-          const int b = 4 * s_ + h;
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32((b < cnt && i < k) ? Yt[(size_t)b * kp + i] : 0.0f,
-                                                     Tl[b * NP + 16 * tj + lr], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (16 * tj + lr < NMAX) Nl[(16 * ti + 4 * h + q) * NS + 16 * tj + lr] = acc[q];
+      for (int s_ = 0; s_ < N4; ++s_) {
+        const int b = 4 * s_ + h, i = 16 * t + lr;
+        yfrag[t][s_] = (t < KT && b < cnt && i < k) ? Yt[(size_t)b * kp + i] : 0.0f;
       }
-    }
-    MIA_WAVE_SYNC();
-    // -- W = w_mean 1^T + f0 I + N Yl^T
-    float* wout = P.W + pt * (int64_t)k * k;
-    for (int ti = 0; ti < ((P.xskip & 512) ? 0 : KT); ++ti)
-      for (int tj = 0; tj < KT; ++tj) {
-        const int j = 16 * tj + lr;
-        f32x4c acc = {0.f, 0.f, 0.f, 0.f};
+    if (!(P.xskip & 256)) {
+      float bf[TT][N4];
 #pragma unroll
-        for (int s_ = 0; s_ < N4; ++s_) {
-          const int b = 4 * s_ + h;
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Nl[(16 * ti + lr) * NS + b], (b < cnt && j < k) ? Yt[(size_t)b * kp + j] : 0.0f,
-                                                     acc, 0, 0, 0);
-        }
+      for (int tj = 0; tj < TT; ++tj)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int i = 16 * ti + 4 * h + q;
-          if (i < k && j < k) {
-            const float v = wbar[i] + (i == j ? f0 : 0.0f) + acc[q];
-            if (!(fabsf(v) <= 1e30f)) flag |= MIA_FLAG_NONFINITE;
-            wout[i * k + j] = v;
+        for (int s_ = 0; s_ < N4; ++s_) bf[tj][s_] = Tl[(4 * s_ + h) * NP + 16 * tj + lr];
+#pragma unroll
+      for (int ti = 0; ti < KTM; ++ti) {
+        if (ti < KT) {
+#pragma unroll
+          for (int tj = 0; tj < TT; ++tj) {
+            f32x4c acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s_ = 0; s_ < N4; ++s_) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(yfrag[ti][s_], bf[tj][s_], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (16 * tj + lr < NMAX) Nl[(16 * ti + 4 * h + q) * NS + 16 * tj + lr] = acc[q];
           }
         }
       }
+    }
+    MIA_WAVE_SYNC();
+    float* wout = P.W + pt * (int64_t)k * k;
+    if (!(P.xskip & 512)) {
+#pragma unroll
+      for (int ti = 0; ti < KTM; ++ti) {
+        if (ti < KT) {
+          float nfr[N4];
+#pragma unroll
+          for (int s_ = 0; s_ < N4; ++s_) nfr[s_] = Nl[(16 * ti + lr) * NS + 4 * s_ + h];
+#pragma unroll
+          for (int tj = 0; tj < KTM; ++tj) {
+            if (tj < KT) {
+              const int j = 16 * tj + lr;
+              f32x4c acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int s_ = 0; s_ < N4; ++s_) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(nfr[s_], yfrag[tj][s_], acc, 0, 0, 0);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int i = 16 * ti + 4 * h + q;
+                if (i < k && j < k) {
+                  const float v = wbar[i] + (i == j ? f0 : 0.0f) + acc[q];
+                  if (!(fabsf(v) <= 1e30f)) flag |= MIA_FLAG_NONFINITE;
+                  wout[i * k + j] = v;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
     // -- the state rows: xa_j = mean + sum_i x'_i W_ij (base.py:257-278), W read back from where this wavefront just
     //    wrote it (L2-hot, rows contiguous across lanes) -- a copy in LDS would cost 7.7 KB of occupancy at k = 40
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // this wavefront's stores of W are visible to its loads
