@@ -278,7 +278,8 @@ def main():
                                  "streams; every step is fully computed, exchanged and validated inside the timed "
                                  "region.  serial_ms_per_step: the same step run one at a time (its latency)"},
             "stages_ms": stage_ms,
-            "step_driver": ("native: mia_letkf_sharded_step_f32, %d of %d timed+warmup steps" % (runner.native_steps, args.steps + args.warmup))
+            "step_driver": ("native: one C call per step (mia_letkf_sharded_step_streams_f32); %d native steps in this process "
+                            "(warm-up, timed loop, serial comparison)" % runner.native_steps)
                            if runner.native_steps else "python (engine entries one by one)",
         }
         if cpu is not None:
