@@ -422,3 +422,33 @@ def test_weights_without_eigensolver_vs_reference(eng, golden, monkeypatch, name
     monkeypatch.setenv("MIA_CHEB_DMAX", "8")          # force declines on the plain case too
     xa2, W2 = eng.analysis(dev(st, torch.float32), dev(yb, torch.float32), dev(d, torch.float32), nb, 1.1, return_weights=True)
     assert rel_fro(W2.cpu().numpy()[g[f"{name}_widx"]], g[f"{name}_1p1_weights"]) < TOL32
+
+
+@pytest.mark.parametrize("gamma", [None, 0.5])
+def test_dense_local_networks_far_beyond_the_ensemble_size(eng, gamma):
+    """p >> k (the primal route): 1200-3000 local observations per grid point for k = 24 members.  The member Gram is
+    streamed from the packed records on the matrix cores, so no local block has to fit a workgroup's LDS (the staged
+    block capped p at a few hundred).  float32 matfun route, the eigensolver route and the float64 kernel against the
+    oracle; observation strength chosen so that the matfun kernel declines part of the points (eigensolver redo)."""
+    rs = np.random.RandomState(31)
+    k, G, P = 24, 24, 3000
+    grid, obs = rs.uniform(0.3, 0.7, size=G), rs.uniform(0, 1, size=P)
+    state = rs.normal(size=(2, k, G))
+    hx = rs.normal(size=(k, P)) * 0.35
+    yb, d = hx - hx.mean(axis=0), rs.normal(size=P) * 0.35
+    nb = eng.localize(grid, obs, [0.25])
+    assert nb.p_max > 1200
+    core = O.etkf_weights if gamma is None else (lambda a, b, inf: O.ketkf_weights(a, b, lambda x, y: O.rbf_kernel(x, y, gamma), inf))
+    ref, _ = O.letkf_analysis(state, grid, obs, yb, d, 0.25, 1.1, core=core)
+    kw = dict(rbf_gamma=gamma)
+    x64 = eng.analysis(dev(state, torch.float64), dev(yb, torch.float64), dev(d, torch.float64), nb, 1.1, **kw)
+    assert rel_fro(x64.cpu().numpy(), ref) < 1e-9
+    for method in ("auto", "eig"):
+        xa, fl = eng.analysis(dev(state, torch.float32), dev(yb, torch.float32), dev(d, torch.float32), nb, 1.1,
+                              method=method, return_flags=True, **kw)
+        assert int((fl & 0xff).max().item()) == 0
+        assert rel_fro(xa.cpu().numpy(), ref) < TOL32, method
+    if gamma is None:
+        _, W = eng.analysis(dev(state, torch.float32), dev(yb, torch.float32), dev(d, torch.float32), nb, 1.1, return_weights=True)
+        _, wref = O.letkf_analysis(state[:, :, :3], grid[:3], obs, yb, d, 0.25, 1.1)
+        assert rel_fro(W.cpu().numpy()[:3], wref) < 5e-5

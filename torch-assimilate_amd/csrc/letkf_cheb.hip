@@ -176,7 +176,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
       // (observation, column) split is a multiply-shift (P.kpv_magic = ceil(2^20 / kpv), exact below 2^20 / kpv
       // quads) instead of an integer division per quad
     const int kpv = kp >> 2;
-    const int total = (P.xskip & 1) ? 0 : cnt * kpv;
+    const int total = ((P.xskip & 1) || !P.dual) ? 0 : cnt * kpv;   // (the primal route streams the records, see below)
     constexpr int GQ = NMAX > 32 ? 8 : 4;       // quads in flight per lane: large blocks (config 4: 1344 quads) run at
                                                 // few waves per CU, so each trip's memory latency is exposed
     for (int base = 0; base < total; base += 64 * GQ) {
@@ -200,7 +200,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
       }
     }
   }
-  for (int i = tid; i < kp; i += 64) Yt[(size_t)P.rows * kp + i] = 0.0f;   // the zero row of the Gram panels
+  if (P.dual) for (int i = tid; i < kp; i += 64) Yt[(size_t)P.rows * kp + i] = 0.0f;   // the zero row of the Gram panels
   const int ntrue = P.dual ? cnt : k;
   MIA_WAVE_SYNC();
   // ---- S (full symmetric storage, zero padded)
@@ -306,64 +306,80 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
         }
   } else {
     // primal route (p > k, or the RBF-kernelised filter): the k x k matrix of member dot products over the local
-    // observations, C[a][b] = sum_j Yl[a][j] Yl[b][j], on the matrix cores (operands read down the obs-major block:
-    // A[row a][kk j] = Yt[j][a], consecutive a across lanes).  The RBF Gram exp(-gamma |y_a - y_b|^2)
-    // (kernels/rbf.py:75-81,110-111) follows from it as |y_a - y_b|^2 = C_aa + C_bb - 2 C_ab -- the form torch.cdist
-    // itself uses for more than 25 rows -- with the diagonal passed through LDS.  (The scalar loop this replaces took
-    // 0.58 of the 0.95 ms per 1e5 analyses of config 5.)
+    // observations, C[a][b] = sum_j rho_j y_aj y_bj, on the matrix cores -- STREAMED from the packed records: lane (lr, h)
+    // feeds A[row 16 t + lr][obs 4 s + h] = rec[idx][16 t + lr] * sqrt(rho), 16 consecutive floats of one record per
+    // lane group, so no local block is staged in LDS and the number of local observations is bounded by the list
+    // storage only (the LDS block capped it at ~850 for k = 40 and cost the occupancy long before).  The records carry
+    // the innovation in column k: the tiles are extended by that one row / column and deliver b = Yl d (and |d_l|^2)
+    // for free.  The RBF Gram exp(-gamma |y_a - y_b|^2) (kernels/rbf.py:75-81,110-111) follows as
+    // |y_a - y_b|^2 = C_aa + C_bb - 2 C_ab -- the form torch.cdist itself uses above 25 rows -- and the kernel vector
+    // k(Yb, d)_a from C_aa + |d|^2 - 2 b_a.
+    constexpr int TTE = (NMAX + 16) / 16, NTE = TTE * (TTE + 1) / 2;     // tiles covering rows 0 .. NMAX (>= k + 1 rows)
     const int lr = tid & 15, h = tid >> 4;
-    f32x4c acc[NTILE];
+    f32x4c acc[NTE];
 #pragma unroll
-    for (int t = 0; t < NTILE; ++t) acc[t] = f32x4c{0.f, 0.f, 0.f, 0.f};
-    const int ksteps = (cnt + 3) >> 2;
+    for (int t = 0; t < NTE; ++t) acc[t] = f32x4c{0.f, 0.f, 0.f, 0.f};
+    const int ksteps = (P.xskip & 2) ? 0 : (cnt + 3) >> 2;
     for (int s_ = 0; s_ < ksteps; ++s_) {
       const int j = 4 * s_ + h;
-      float av_[TT];
+      float av_[TTE];
+      const bool jin = j < cnt;
+      const float wj = jin ? lw[j] : 0.0f;
+      const float* rj = P.rec + (int64_t)(jin ? lidx[j] : 0) * kp;
 #pragma unroll
-      for (int t = 0; t < TT; ++t) av_[t] = (j < cnt && 16 * t + lr < k) ? Yt[(size_t)j * kp + 16 * t + lr] : 0.0f;
+      for (int t = 0; t < TTE; ++t) av_[t] = (jin && 16 * t + lr <= k) ? rj[16 * t + lr] * wj : 0.0f;
 #pragma unroll
-      for (int tb_ = 0, tile = 0; tb_ < TT; ++tb_)
+      for (int tb_ = 0, tile = 0; tb_ < TTE; ++tb_)
 #pragma unroll
         for (int ta_ = 0; ta_ <= tb_; ++ta_, ++tile)
           acc[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[ta_], av_[tb_], acc[tile], 0, 0, 0);
     }
-    if (P.kernel_mode != 0) {       // squared norms = the diagonal, through uq
+    // squared norms (the diagonal, incl. |d|^2 at index k) through uq / red, b = column k through rhs
 #pragma unroll
-      for (int t = 0, tile = 0; t < TT; tile += t + 2, ++t)      // tile index of (t, t) in the (ta <= tb) enumeration
+    for (int t = 0, tile = 0; t < TTE; tile += t + 2, ++t)      // tile index of (t, t) in the (ta <= tb) enumeration
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (h * 4 + q == lr && 16 * t + lr < NMAX) uq[16 * t + lr] = acc[tile][q];
-      MIA_WAVE_SYNC();
-    }
+      for (int q = 0; q < 4; ++q)
+        if (h * 4 + q == lr) {
+          const int a = 16 * t + lr;
+          if (a < NMAX && a < k) uq[a] = acc[tile][q];
+          if (a == k) red[2] = acc[tile][q];
+        }
 #pragma unroll
-    for (int tb_ = 0, tile = 0; tb_ < TT; ++tb_)
+    for (int tb_ = 0, tile = 0; tb_ < TTE; ++tb_)
 #pragma unroll
       for (int ta_ = 0; ta_ <= tb_; ++ta_, ++tile)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int a = 16 * ta_ + h * 4 + q, b = 16 * tb_ + lr;   // D[row = 4*(lane>>4)+q][col = lane&15]
+          const int a = 16 * ta_ + h * 4 + q, b = 16 * tb_ + lr;   // D[row = 4*(lane>>4)+q][col = lane&15], a <= b by tiles
+          if (b == k && a < k) rhs[a] = acc[tile][q];              // (a < b: the column lies in the upper tiles)
+        }
+    MIA_WAVE_SYNC();
+#pragma unroll
+    for (int tb_ = 0, tile = 0; tb_ < TTE; ++tb_)
+#pragma unroll
+      for (int ta_ = 0; ta_ <= tb_; ++ta_, ++tile)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int a = 16 * ta_ + h * 4 + q, b = 16 * tb_ + lr;
           if (a < NMAX && b < NMAX) {
-            float v = acc[tile][q];
-            if (P.kernel_mode != 0) {
-              const float sq = fmaxf(uq[a] + uq[b] - 2.0f * v, 0.0f);
-              v = (a < k && b < k) ? __expf(-P.gamma * sq) : 0.0f;
-            }
+            float v = (a < k && b < k) ? acc[tile][q] : 0.0f;
+            if (P.kernel_mode != 0 && a < k && b < k) v = __expf(-P.gamma * fmaxf(uq[a] + uq[b] - 2.0f * acc[tile][q], 0.0f));
             S[a * LDA + b] = v;
             if (ta_ != tb_) S[b * LDA + a] = v;
           }
         }
-    if (P.kernel_mode != 0) MIA_WAVE_SYNC();   // uq is reused by the centring below
+    if (tid < NMAX) {
+      if (tid >= k) rhs[tid] = 0.0f;
+      else if (P.kernel_mode != 0) rhs[tid] = __expf(-P.gamma * fmaxf(uq[tid] + red[2] - 2.0f * rhs[tid], 0.0f));   // k(Yb, d), uncentred
+    }
+    MIA_WAVE_SYNC();   // uq is reused by the centring below
   }
   MIA_WAVE_SYNC();
   // ---- right-hand side of the mean weights
   if (P.dual) {
     if (tid < NMAX) rhs[tid] = tid < cnt ? Yt[(size_t)tid * kp + k] : 0.0f;
   } else if (P.kernel_mode == 0) {
-    for (int i = tid; i < NMAX; i += 64) {
-      float acc = 0.0f;
-      if (i < k) for (int j = 0; j < cnt; ++j) acc += Yt[(size_t)j * kp + i] * Yt[(size_t)j * kp + k];
-      rhs[i] = acc;
-    }
+    // (rhs = Yl d came with the streamed Gram)
   } else {   // double centring of K and centring of k(Yb, d)   (core/ketkf.py:77-89)
     // Row means and the kernel vector by one lane per member; the two grand means by wave reductions (a single lane
     // summing them serially cost ~5000 cycles); the centring of K itself is folded into the register load of the
@@ -376,9 +392,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
         um += (v.x + v.y) + (v.z + v.w);
       }
       um /= float(k);
-      float ko = 0.0f;
-      for (int j = 0; j < cnt; ++j) { const float df = Yt[(size_t)j * kp + tid] - Yt[(size_t)j * kp + k]; ko += df * df; }
-      ko_ = __expf(-P.gamma * ko);
+      ko_ = rhs[tid];                         // exp(-gamma |y_a - d|^2), from the streamed Gram
     }
     const float gm = wave_sum_dpp(um) / float(k), om = wave_sum_dpp(ko_) / float(k);
     if (tid < NMAX) {
@@ -501,7 +515,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
       for (int c = 0; c < kRowBatch; ++c) {
         float v = 0.0f;
         if (c < nrow && tid < k) v = P.X[((int64_t)(m0 + c) * k + tid) * P.ldx + g];
-        if (tid < kp) Xb[c * kp + tid] = v;
+        for (int i = tid; i < kp; i += 64) Xb[c * kp + i] = i == tid ? v : 0.0f;   // (kp may exceed 64: zero the pad columns)
       }
       MIA_WAVE_SYNC();
       float xm;
@@ -1043,8 +1057,8 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
   int nmax = 0;
   for (int b : buckets) if (b >= ntrue) { nmax = b; break; }
   if (nmax == 0 || k > 128) return MIA_ERR_UNSUPPORTED;
-  ap.rows = ap.dual ? nmax : (p_max > 0 ? p_max : 1);
-  ap.dmax = 48;
+  ap.rows = ap.dual ? nmax : 0;      // the primal route streams the records: no local block in LDS
+  ap.dmax = 62;     // N = deg + 1 coefficient lanes <= 64; covers lambda_max / reg up to ~100 (dense local networks, p >> k)
   if (const char* e = getenv("MIA_CHEB_DMAX")) ap.dmax = atoi(e);                 // experiments only
   ap.xskip = 0;
   if (const char* e = getenv("MIA_EXPERIMENT_SKIP")) ap.xskip = atoi(e);

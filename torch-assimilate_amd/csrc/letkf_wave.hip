@@ -42,6 +42,14 @@ struct WaveParams {
 
 template <typename T> struct Vec4 { T x, y, z, w; };
 
+// 16x16x4 MFMA in the element type of the kernel (gfx950 has both; identical operand / result lane layout)
+typedef float mfma_f32x4 __attribute__((ext_vector_type(4)));
+typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
+__device__ inline mfma_f32x4 mfma16(float a, float b, mfma_f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ inline mfma_f64x4 mfma16(double a, double b, mfma_f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+template <typename T> struct MfmaAcc { using type = mfma_f32x4; };
+template <> struct MfmaAcc<double> { using type = mfma_f64x4; };
+
 // the three pair statistics of columns a and b of the obs-major local block (rows = local observations)
 template <typename T>
 __device__ inline T kprog_pair(const KernelProgram<T>& kp, const T* Yt, int kpad, int cnt, int a, int b, bool same) {
@@ -115,12 +123,16 @@ __global__ __launch_bounds__(NT) void letkf_wave_kernel(WaveParams<T> P) {
       lw[j] = T(P.w[pt * P.p_cap + j]);
     }
     __syncthreads();
+    // Primal route with a linear or RBF core: the member Gram is STREAMED from the packed records on the matrix cores
+    // (see the same construction in letkf_cheb.hip), so no local block is staged in LDS and the number of local
+    // observations is not bounded by it.  (A kernel expression may need |x - y|_1, which is no product: it keeps the block.)
+    const bool streamp = !P.dual && P.kernel_mode != 2;
     // ---- gather + sqrt(rho) scale: records are 16-byte aligned rows of kp elements
     {
       constexpr int VW = 16 / sizeof(T);
       const int kpv = kp / VW;
       using VT = typename std::conditional<sizeof(T) == 4, float4, double2>::type;
-      for (int it = tid; it < cnt * kpv; it += NT) {
+      for (int it = tid; it < (streamp ? 0 : cnt * kpv); it += NT) {
         const int j = it / kpv, c = it - j * kpv;
         VT v = reinterpret_cast<const VT*>(P.rec + (int64_t)lidx[j] * kp)[c];
         const T wj = lw[j];
@@ -138,6 +150,7 @@ __global__ __launch_bounds__(NT) void letkf_wave_kernel(WaveParams<T> P) {
       const int a = it / n, b = it - a * n;
       V[a * lda + b] = (a == b) ? T(1) : T(0);
       if (a > b) continue;
+      if (streamp) { S[a * lda + b] = T(0); continue; }     // (filled by the streamed tiles below; padding stays zero)
       T acc = T(0);
       if (P.dual) {
         const T* ya = Yt + (size_t)a * kp; const T* yb = Yt + (size_t)b * kp;
@@ -155,10 +168,57 @@ __global__ __launch_bounds__(NT) void letkf_wave_kernel(WaveParams<T> P) {
       S[a * lda + b] = acc;
     }
     __syncthreads();
+    if (streamp) {
+      // extended Gram [Yl; d_l][Yl; d_l]^T by 16x16 tiles (ta <= tb) spread over the waves: lane (lr, h) feeds
+      // rec[idx(4 s + h)][16 t + lr] * sqrt(rho); column k delivers b = Yl d, entry (k, k) |d_l|^2
+      using AccT = typename MfmaAcc<T>::type;
+      const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, h = lane >> 4;
+      const int tt = (k + 1 + 15) >> 4, ntile = tt * (tt + 1) / 2;
+      const int ksteps = (cnt + 3) >> 2;
+      for (int i = tid; i < n; i += NT) zb[i] = T(0);
+      __syncthreads();
+      for (int tile = wv; tile < ntile; tile += NT / 64) {
+        int tb_ = 0;
+        while ((tb_ + 1) * (tb_ + 2) / 2 <= tile) ++tb_;
+        const int ta_ = tile - tb_ * (tb_ + 1) / 2;
+        const int ra = 16 * ta_ + lr, rb = 16 * tb_ + lr;
+        AccT acc = {T(0), T(0), T(0), T(0)};
+        for (int s_ = 0; s_ < ksteps; ++s_) {
+          const int j = 4 * s_ + h;
+          T av = T(0), bv = T(0);
+          if (j < cnt) {
+            const T wj = lw[j];
+            const T* rj = P.rec + (int64_t)lidx[j] * kp;
+            av = ra <= k ? rj[ra] * wj : T(0);
+            bv = rb <= k ? rj[rb] * wj : T(0);
+          }
+          acc = mfma16(av, bv, acc);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // result rows: float32 tile row 4 h + q, float64 tile row 4 q + h (probed on gfx950); column lr in both
+          const int a = 16 * ta_ + (sizeof(T) == 8 ? 4 * q + h : 4 * h + q), b = 16 * tb_ + lr;
+          if (b == k && a < k) zb[a] = acc[q];
+          if (a == k && b == k) red[2] = acc[q];
+          if (a <= b && b < k) S[a * lda + b] = acc[q];
+        }
+      }
+      __syncthreads();
+      if (P.kernel_mode == 1) {   // RBF: exp(-gamma (C_aa + C_bb - 2 C_ab)); kernel vector from C_aa + |d|^2 - 2 b_a
+        for (int i = tid; i < k; i += NT) uv[i] = S[i * lda + i];
+        __syncthreads();
+        for (int it = tid; it < k * k; it += NT) {
+          const int a = it / k, b = it - a * k;
+          if (a <= b) { const T sq = uv[a] + uv[b] - T(2) * S[a * lda + b]; S[a * lda + b] = t_exp(-P.gamma * (sq > T(0) ? sq : T(0))); }
+        }
+        for (int i = tid; i < k; i += NT) { const T sq = uv[i] + red[2] - T(2) * zb[i]; zb[i] = t_exp(-P.gamma * (sq > T(0) ? sq : T(0))); }
+        __syncthreads();
+      }
+    }
     // ---- right-hand side of the mean weights (primal only; dual uses d directly)
     if (!P.dual) {
       if (P.kernel_mode == 0) {
-        for (int i = tid; i < n; i += NT) {
+        for (int i = tid; i < (streamp ? 0 : n); i += NT) {
           T acc = T(0);
           if (i < k) for (int j = 0; j < cnt; ++j) acc += Yt[(size_t)j * kp + i] * Yt[(size_t)j * kp + k];
           zb[i] = acc;
@@ -171,9 +231,7 @@ __global__ __launch_bounds__(NT) void letkf_wave_kernel(WaveParams<T> P) {
           for (int j = 0; j < k; ++j) acc += sym(S, lda, i, j);
           uv[i] = acc / T(k);
           if (P.kernel_mode == 1) {
-            T ko = T(0);
-            for (int j = 0; j < cnt; ++j) { const T df = Yt[(size_t)j * kp + i] - Yt[(size_t)j * kp + k]; ko += df * df; }
-            zb[i] = t_exp(-P.gamma * ko);
+            // (zb = k(Yb, d) came with the streamed Gram)
           } else {
             zb[i] = kprog_pair(P.prog, Yt, kp, cnt, i, k, false);   // k(Yb, d): never "the same sample" (diag.py:65-66)
           }
@@ -376,7 +434,7 @@ int wave_analysis_launch(const T* X, int64_t ldx, int m, int k, int64_t g0, int6
   if (ap.nmax < 2) ap.nmax = 2;
   if (ap.nmax > 510) return MIA_ERR_UNSUPPORTED;   // 8-bit pair ids in the block table
   ap.lda = ap.nmax + 1;
-  ap.rows = ap.dual ? ap.nmax : (p_max > 0 ? p_max : 1);
+  ap.rows = ap.dual ? ap.nmax : (kernel_mode == 2 ? (p_max > 0 ? p_max : 1) : 0);   // linear / RBF primal: streamed, no block
   ap.max_sweeps = sizeof(T) == 4 ? 16 : 24;
   // stop at sqrt(eps): the first-order correction leaves O(stop_tol^2) = O(eps).  The weights
   // output W uses the diagonal part only, so it asks for full convergence.
