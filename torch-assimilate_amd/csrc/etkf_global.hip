@@ -242,7 +242,7 @@ static int etkf_weights_impl(const T* Yb, const T* d, int k, int64_t P, T inf_fa
   }
   const int n = (k + 1) & ~1, lda = n | 1;
   const size_t lds2 = ((size_t)2 * n * lda + 5 * (size_t)n) * sizeof(T) + 16;
-  if (lds2 > 160 * 1024) return MIA_ERR_UNSUPPORTED;
+  if (lds2 > (long long)kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
   auto kern2 = etkf_solve_kernel<T, false>;
   if (lds2 > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
   KernelProgram<T> none;
@@ -279,7 +279,7 @@ static int ketkf_weights_impl(const T* Yb, const T* d, int k, int64_t P, T inf_f
   }
   const int n = (k + 1) & ~1, lda = n | 1;
   const size_t lds2 = ((size_t)2 * n * lda + 5 * (size_t)n) * sizeof(T) + 16;
-  if (lds2 > 160 * 1024) return MIA_ERR_UNSUPPORTED;
+  if (lds2 > (long long)kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
   KernelProgram<T> kp;
   kp.n = n_ops;
   for (int i = 0; i < n_ops; ++i) { kp.op[i] = (unsigned char)prog[i].op; kp.val[i] = T(prog[i].value); }
@@ -304,7 +304,7 @@ static int apply_weights_impl(const T* X, int64_t ldx, int m, int k, int64_t g0,
   const bool small = (size_t)k * 256 * sizeof(T) <= 64 * 1024;
   const int NT = small ? 256 : 64;
   const size_t lds = ((size_t)k * k + (size_t)k * NT) * sizeof(T);
-  if (lds > 160 * 1024) return MIA_ERR_UNSUPPORTED;
+  if (lds > (long long)kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
   const int64_t nb = (ng + NT - 1) / NT;
   if (nb > 2147483647LL) return MIA_ERR_UNSUPPORTED;
   if (small) {

@@ -322,7 +322,7 @@ static int ienks_update_impl(const T* W_in, int64_t w_stride, int k, int64_t g0,
                (size_t)((nbk * (nbk - 1) / 2 + 7) & ~7) * sizeof(unsigned short) + (size_t)((ap.n + 1) & ~1) * sizeof(int) +
                (size_t)(256 / 64 * 2) * sizeof(T);
   lds = align_up(lds, 16);
-  if (lds > 160 * 1024) return MIA_ERR_UNSUPPORTED;
+  if (lds > (long long)kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
   const bool small = ap.n <= 44 && getenv("MIA_IENKS_NARROW");
   if (small) {
     auto kern = ienks_update_kernel<T, 64>;

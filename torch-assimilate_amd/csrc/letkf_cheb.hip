@@ -1069,7 +1069,7 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
   ap.log_tol = 12.0f;
   if (const char* e = getenv("MIA_CHEB_LOGTOL")) ap.log_tol = (float)atof(e);     // experiments only
   const size_t lds = cheb_lds_bytes(ap.kp, p_max, nmax, ap.rows, ap.dual != 0);
-  if (lds > 160 * 1024) return MIA_ERR_UNSUPPORTED;
+  if (lds > (long long)kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
   ap.lds_per_wave = (int)lds;
   const int64_t gx = ng < 65536 ? ng : 65536;
   const int64_t gy = (ng + gx - 1) / gx;
@@ -1079,7 +1079,7 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
   if (W_out) {   // weights output: dual route, order <= 32, one member per lane; anything else is the eigensolver's
     if (!(ap.dual && nmax <= 32 && !two && !ap.fused && seg_len == 0)) return MIA_ERR_UNSUPPORTED;
     ap.lds_per_wave = (int)cheb_lds_bytes(ap.kp, p_max, nmax, ap.rows, true, false, k);
-    if (ap.lds_per_wave > 160 * 1024) return MIA_ERR_UNSUPPORTED;
+    if (ap.lds_per_wave > (long long)kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
     switch (nmax) {
       case 4: return cheb_launch_weights<4>(ap, ap.lds_per_wave, stream);
       case 8: return cheb_launch_weights<8>(ap, ap.lds_per_wave, stream);

@@ -396,7 +396,7 @@ static int analysis_packed_impl(const T* X, int64_t ldx, int m, int k, int64_t g
   ap.max_sweeps = sizeof(T) == 4 ? 16 : 24;
   ap.tol = sizeof(T) == 4 ? T(2.4e-7) : T(9e-16);
   const size_t lds = generic_lds_bytes<T>(k, p_max, ap.nmax, ap.lda, ap.ldy, W_opt != nullptr && ap.dual);
-  if (lds > 160 * 1024) return MIA_ERR_UNSUPPORTED;
+  if (lds > (long long)kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
   const bool big = ap.nmax > 32;
   // enough workgroups to fill 256 CUs several times over, but contiguous runs per workgroup
   int ppb = (int)((ng + 8191) / 8192);

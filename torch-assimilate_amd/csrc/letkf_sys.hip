@@ -651,7 +651,7 @@ int sys_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, i
   ap.rot_tol2 = rot_tol * rot_tol;
   const size_t lds = sys_lds_bytes(k, ap.kp, m, p_max, nmax, ap.rows, W_opt != nullptr, ap.dual != 0);
   if ((k > 64 && nmax <= 32) || k > 256) return MIA_ERR_UNSUPPORTED;   // one member per lane
-  if (lds > 160 * 1024) return MIA_ERR_UNSUPPORTED;
+  if (lds > (long long)kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
   // one grid point per workgroup (measured on MI355X, C2: 1-2 points per workgroup beat 4-10 by 5-12 %:
   // the dispatcher's dynamic placement balances the data-dependent sweep counts)
   ap.pts_per_block = 1;

@@ -445,7 +445,7 @@ int wave_analysis_launch(const T* X, int64_t ldx, int m, int k, int64_t g0, int6
   ap.stop_tol2 = stop_tol * stop_tol;
   ap.rot_tol2 = rot_tol * rot_tol;
   const size_t lds = wave_lds_bytes<T>(k, ap.kp, p_max, ap.nmax, ap.lda, ap.rows, W_opt != nullptr && ap.dual);
-  if (lds > 160 * 1024) return MIA_ERR_UNSUPPORTED;
+  if (lds > (long long)kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
   const bool big = ap.nmax > 44;
   int ppb = (int)((ng + 16383) / 16384);
   if (ppb < 4) ppb = 4;

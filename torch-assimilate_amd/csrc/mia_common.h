@@ -22,6 +22,10 @@ constexpr int kWave = 64;  // CDNA4 wavefront
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// largest dynamic LDS request a launch may make: 160 KB per CU on gfx950, less what the kernels declare statically
+// (a request of 159.6 KB passed a plain 160 KB check and then failed at launch with hipErrorInvalidValue)
+constexpr size_t kMaxDynamicLds = 160 * 1024 - 1024;
+
 // device copy of a kernel expression (mia_kernel_op_t program), passed by value in the launch parameters
 template <typename T>
 struct KernelProgram { int n; unsigned char op[MIA_KERNEL_MAX_OPS]; T val[MIA_KERNEL_MAX_OPS]; };
