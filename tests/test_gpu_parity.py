@@ -452,3 +452,28 @@ def test_dense_local_networks_far_beyond_the_ensemble_size(eng, gamma):
         _, W = eng.analysis(dev(state, torch.float32), dev(yb, torch.float32), dev(d, torch.float32), nb, 1.1, return_weights=True)
         _, wref = O.letkf_analysis(state[:, :, :3], grid[:3], obs, yb, d, 0.25, 1.1)
         assert rel_fro(W.cpu().numpy()[:3], wref) < 5e-5
+
+
+@pytest.mark.parametrize("k,gamma", [(80, None), (72, 0.5), (128, None)])
+def test_large_ensembles_with_more_than_64_local_observations(eng, monkeypatch, k, gamma):
+    """64 < k <= 128 with more local observations than one row per lane can hold (ensemble-space order > 64): the
+    two-rows-per-lane primal kernel (letkf_cheb_big_kernel: Gram streamed from the records, S in LDS).  Against the
+    oracle, and against the eigensolver route it replaces (MIA_CHEB_NO_BIG)."""
+    rs = np.random.RandomState(k)
+    G, P = 30, 600
+    grid, obs = rs.uniform(0.3, 0.7, size=G), rs.uniform(0, 1, size=P)
+    state = rs.normal(size=(2, k, G))
+    hx = rs.normal(size=(k, P)) * 0.5
+    yb, d = hx - hx.mean(axis=0), rs.normal(size=P) * 0.5
+    nb = eng.localize(grid, obs, [0.12])
+    assert nb.p_max > 64
+    core = O.etkf_weights if gamma is None else (lambda a, b, inf: O.ketkf_weights(a, b, lambda x, y: O.rbf_kernel(x, y, gamma), inf))
+    ref, _ = O.letkf_analysis(state, grid, obs, yb, d, 0.12, 1.1, core=core)
+    args = (dev(state, torch.float32), dev(yb, torch.float32), dev(d, torch.float32), nb, 1.1)
+    xa, fl = eng.analysis(*args, rbf_gamma=gamma, return_flags=True)
+    f = fl.cpu().numpy()
+    assert int((f & 0xff).max()) == 0 and int(((f >> 8) & 0xff).min()) >= 3       # degree recorded: the matfun kernel ran
+    assert rel_fro(xa.cpu().numpy(), ref) < TOL32
+    monkeypatch.setenv("MIA_CHEB_NO_BIG", "1")
+    xe = eng.analysis(*args, rbf_gamma=gamma)
+    assert rel_fro(xe.cpu().numpy(), ref) < TOL32

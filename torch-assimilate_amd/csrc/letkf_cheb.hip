@@ -76,6 +76,60 @@ __device__ inline float matvec_row(const f2v (&srow2)[NMAX / 2], const float* tv
 // and the compiler may not move memory operations across (the waves of a workgroup are independent here)
 #define MIA_WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 
+// Chebyshev coefficients (phi_j, psi_j), j = 0 .. deg, of the two weight functions on [0, L]: samples at the deg + 1
+// Gauss nodes, then a cosine transform spread over the wavefront.  c2 / f2s: LDS scratch of 64 pairs each.
+__device__ __forceinline__ void cheb_coefficients(int tid, int deg, float L, float reg, float km1, float ar, bool dual,
+                                                  f2v* f2s, f2v* c2) {
+  const int N = deg + 1;
+  {
+    const float invN = 1.0f / float(N);
+    if (tid < N) {
+      const float x = __builtin_amdgcn_cosf(float(2 * tid + 1) * 0.25f * invN);     // cos(pi (i+1/2)/N), argument in turns
+      const float lam = 0.5f * L * (x + 1.0f);
+      const float le = lam + reg;
+      const float u = __builtin_amdgcn_sqrtf(le);
+      f2v f;
+      f.x = dual ? -sqrtf(km1) / (u * ar * (ar + u)) : sqrtf(km1) / u;
+      f.y = 1.0f / le;
+      f2s[tid] = f;
+    }
+    MIA_WAVE_SYNC();
+    {
+      // The N x N cosine transform is spread over the WHOLE wavefront: lane = (coefficient j, part), every part
+      // sums a slice of the nodes and the parts are added with cross-lane moves.  (One lane per coefficient left
+      // 48 of 64 lanes idle through N quarter-rate v_cos -- the most expensive stretch of the kernel at C2.)
+      // cos(j pi (i+1/2)/N) = cos(2 pi m / 4N), m = j (2i+1) mod 4N kept as an exact integer phase
+      // (a float phase accumulated over i loses ~N*eps turns: 2e-5 in the analysis at degree 40)
+      const int sh = N <= 16 ? 4 : (N <= 32 ? 5 : 6);            // lanes per part = 2^sh >= N
+      const int j = tid & ((1 << sh) - 1), part = tid >> sh;
+      const int chunk = (N + (64 >> sh) - 1) >> (6 - sh);          // nodes per part
+      const int i0 = part * chunk;
+      const int i1 = i0 + chunk < N ? i0 + chunk : N;
+      const int n4 = 4 * N;
+      const float inv4n = 0.25f * invN;
+      f2v a = {0.0f, 0.0f};
+      if (j < N) {
+        const int x = j * (2 * i0 + 1);                             // < 2^13: exact in float
+        int ph = x - (int)(float(x) * inv4n) * n4;                  // x mod 4N, up to one period off
+        ph = ph < 0 ? ph + n4 : (ph >= n4 ? ph - n4 : ph);
+        for (int i = i0; i < i1; ++i) {
+          const float c = __builtin_amdgcn_cosf(float(ph) * inv4n);
+          ph += 2 * j;
+          ph = ph >= n4 ? ph - n4 : ph;
+          a = f2s[i] * c + a;
+        }
+      }
+      if (sh <= 5) { a.x += __shfl_xor(a.x, 32, 64); a.y += __shfl_xor(a.y, 32, 64); }
+      if (sh == 4) { a.x += __shfl_xor(a.x, 16, 64); a.y += __shfl_xor(a.y, 16, 64); }
+      if (tid < N) {
+        const float sc = (tid == 0 ? 1.0f : 2.0f) * invN;
+        c2[tid] = a * sc;
+      }
+    }
+    MIA_WAVE_SYNC();
+  }
+}
+
 constexpr int kRowBatch = 16;     // state rows per MFMA batch of the many-rows variant (one 16-column tile)
 
 template <int NMAX, int KL, bool FUSED, int WPB, bool SEG, int MODE = 0>   // MODE 1: many state rows, 2: weights output
@@ -437,55 +491,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     }
     return;
   }
-  // ---- Chebyshev coefficients of phi and psi on [0, L]: samples at the N = deg+1 Gauss nodes, then a DCT
-  const int N = deg + 1;
-  {
-    const float invN = 1.0f / float(N);
-    if (tid < N) {
-      const float x = __builtin_amdgcn_cosf(float(2 * tid + 1) * 0.25f * invN);     // cos(pi (i+1/2)/N), argument in turns
-      const float lam = 0.5f * L * (x + 1.0f);
-      const float le = lam + reg;
-      const float u = __builtin_amdgcn_sqrtf(le);
-      f2v f;
-      f.x = P.dual ? -sqrtf(km1) / (u * ar * (ar + u)) : sqrtf(km1) / u;
-      f.y = 1.0f / le;
-      f2s[tid] = f;
-    }
-    MIA_WAVE_SYNC();
-    {
-      // The N x N cosine transform is spread over the WHOLE wavefront: lane = (coefficient j, part), every part
-      // sums a slice of the nodes and the parts are added with cross-lane moves.  (One lane per coefficient left
-      // 48 of 64 lanes idle through N quarter-rate v_cos -- the most expensive stretch of the kernel at C2.)
-      // cos(j pi (i+1/2)/N) = cos(2 pi m / 4N), m = j (2i+1) mod 4N kept as an exact integer phase
-      // (a float phase accumulated over i loses ~N*eps turns: 2e-5 in the analysis at degree 40)
-      const int sh = N <= 16 ? 4 : (N <= 32 ? 5 : 6);            // lanes per part = 2^sh >= N
-      const int j = tid & ((1 << sh) - 1), part = tid >> sh;
-      const int chunk = (N + (64 >> sh) - 1) >> (6 - sh);          // nodes per part
-      const int i0 = part * chunk;
-      const int i1 = i0 + chunk < N ? i0 + chunk : N;
-      const int n4 = 4 * N;
-      const float inv4n = 0.25f * invN;
-      f2v a = {0.0f, 0.0f};
-      if (j < N) {
-        const int x = j * (2 * i0 + 1);                             // < 2^13: exact in float
-        int ph = x - (int)(float(x) * inv4n) * n4;                  // x mod 4N, up to one period off
-        ph = ph < 0 ? ph + n4 : (ph >= n4 ? ph - n4 : ph);
-        for (int i = i0; i < i1; ++i) {
-          const float c = __builtin_amdgcn_cosf(float(ph) * inv4n);
-          ph += 2 * j;
-          ph = ph >= n4 ? ph - n4 : ph;
-          a = f2s[i] * c + a;
-        }
-      }
-      if (sh <= 5) { a.x += __shfl_xor(a.x, 32, 64); a.y += __shfl_xor(a.y, 32, 64); }
-      if (sh == 4) { a.x += __shfl_xor(a.x, 16, 64); a.y += __shfl_xor(a.y, 16, 64); }
-      if (tid < N) {
-        const float sc = (tid == 0 ? 1.0f : 2.0f) * invN;
-        c2[tid] = a * sc;
-      }
-    }
-    MIA_WAVE_SYNC();
-  }
+  cheb_coefficients(tid, deg, L, reg, km1, ar, P.dual != 0, f2s, c2);
   const float alpha = 2.0f / L;            // A v = alpha S v - v
   if constexpr (MODE == 1) {
     // ---- many state rows: kRowBatch rows at a time as ONE matrix recurrence on the matrix cores.
@@ -947,6 +953,224 @@ __global__ void __launch_bounds__(64) segment_wait_kernel(const int32_t* done, i
   if (lane == 0) atomicOr(err, 1);      // exit condition every wave reaches: ~seconds, then report
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Large ensembles on the primal route (64 < k <= 128 with more than 64 local observations somewhere in the shard): the
+// k x k member Gram is streamed from the records as above, but one lane can no longer keep a whole row of it in
+// registers -- S stays in LDS and every lane owns the rows r = lane and r = lane + 64 of the recurrence (float4 reads of
+// its rows against the broadcast vector).  Same degree selection, coefficients, flags and retry protocol as the
+// kernels above; linear and RBF cores.  Without it these shapes fell to the k x k Jacobi kernel (k = 80, 193 local
+// observations: 2.7 ms PER 1e3 analyses).
+template <int NMAX>
+__global__ __launch_bounds__(64) void letkf_cheb_big_kernel(ChebParams P) {
+  constexpr int LDA = NMAX + 4, N4 = NMAX / 4, R = (NMAX + 63) / 64;
+  constexpr int TTE = (NMAX + 16) / 16;          // tile rows covering members 0 .. k and the innovation at index k
+  constexpr int GC = 3;                          // tile columns accumulated per pass over the local observations
+  static_assert(NMAX % 16 == 0 && NMAX > 64 && NMAX <= 128, "orders 80, 96, 112, 128");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const int k = P.k, kp = P.kp, pm = P.p_max;
+  float* S = reinterpret_cast<float*>(smem_raw);      // [NMAX][LDA]
+  float* tv = S + NMAX * LDA;                          // [NMAX]
+  float* rhs = tv + NMAX;                              // [NMAX]
+  float* uq = rhs + NMAX;                              // [NMAX + 16]  squared norms / row means
+  float* sw = uq + NMAX + 16;                          // [NMAX]
+  f2v* c2 = reinterpret_cast<f2v*>(sw + NMAX);         // [64]
+  f2v* f2s = c2 + 64;                                  // [64]
+  float* red = reinterpret_cast<float*>(f2s + 64);     // [8]
+  float* lw = red + 8;                                 // [pm + 2]
+  int* lidx = reinterpret_cast<int*>(lw + ((pm + 3) & ~1));
+
+  int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+  if (bid >= P.ng) return;
+  const int64_t q8 = P.ng >> 3, r8 = P.ng & 7, xcd = bid & 7;
+  const int64_t pt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);   // XCD-aware point map
+  const int64_t g = P.g0 + pt, ocol = P.o0 + pt;
+  int flag = 0;
+  const float km1 = float(k - 1), reg = P.reg, ar = sqrtf(reg);
+  const int nl = pm < P.p_cap ? pm : P.p_cap;
+  for (int j = tid; j < nl; j += 64) { lidx[j] = P.idx[pt * P.p_cap + j]; lw[j] = float(P.w[pt * P.p_cap + j]); }
+  const int cnt = P.cnt[pt];
+  if (cnt > pm || cnt > P.p_cap || k > NMAX) {
+    if (P.flags && tid == 0) P.flags[pt] = MIA_FLAG_OVERFLOW;
+    const float nanv = __builtin_nanf("");
+    for (int it = tid; it < P.m * k; it += 64) P.Xa[(int64_t)it * P.ldo + ocol] = nanv;
+    return;
+  }
+  MIA_WAVE_SYNC();
+  // ---- extended member Gram from the records, GC tile columns per pass
+  const int lr = tid & 15, h = tid >> 4;
+  const int ksteps = (cnt + 3) >> 2;
+  for (int it = tid; it < NMAX * LDA; it += 64) S[it] = 0.0f;
+  for (int it = tid; it < NMAX; it += 64) rhs[it] = 0.0f;
+  MIA_WAVE_SYNC();
+#pragma unroll
+  for (int c0 = 0; c0 < TTE; c0 += GC) {
+    f32x4c acc[GC][TTE];
+#pragma unroll
+    for (int c = 0; c < GC; ++c)
+#pragma unroll
+      for (int t = 0; t < TTE; ++t) acc[c][t] = f32x4c{0.f, 0.f, 0.f, 0.f};
+    for (int s_ = 0; s_ < ksteps; ++s_) {
+      const int j = 4 * s_ + h;
+      const bool jin = j < cnt;
+      const float wj = jin ? lw[j] : 0.0f;
+      const float* rj = P.rec + (int64_t)(jin ? lidx[j] : 0) * kp;
+      float av_[TTE];
+#pragma unroll
+      for (int t = 0; t < TTE; ++t) av_[t] = (jin && 16 * t + lr <= k && t <= c0 + GC - 1) ? rj[16 * t + lr] * wj : 0.0f;
+#pragma unroll
+      for (int c = 0; c < GC; ++c)
+#pragma unroll
+        for (int t = 0; t < TTE; ++t)
+          if (c0 + c < TTE && t <= c0 + c) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[t], av_[c0 + c], acc[c][t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < GC; ++c)
+#pragma unroll
+      for (int t = 0; t < TTE; ++t)
+        if (c0 + c < TTE && t <= c0 + c) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int a = 16 * t + 4 * h + q, b = 16 * (c0 + c) + lr;       // rows from tile t, columns from tile c0 + c
+            const float v = acc[c][t][q];
+            if (a < k && b < k) { S[a * LDA + b] = v; S[b * LDA + a] = v; }
+            if (a == b && a < k) uq[a] = v;
+            if (b == k && a < k) rhs[a] = v;
+            if (a == k && b == k) red[2] = v;
+          }
+        }
+  }
+  MIA_WAVE_SYNC();
+  // ---- RBF core: K_ab = exp(-gamma (C_aa + C_bb - 2 C_ab)), k(Yb, d)_a from C_aa + |d|^2 - 2 b_a, double centring
+  if (P.kernel_mode != 0) {
+    for (int it = tid; it < k * k; it += 64) {
+      const int a = it / k, b = it - a * k;
+      S[a * LDA + b] = __expf(-P.gamma * fmaxf(uq[a] + uq[b] - 2.0f * S[a * LDA + b], 0.0f));
+    }
+    for (int a = tid; a < k; a += 64) rhs[a] = __expf(-P.gamma * fmaxf(uq[a] + red[2] - 2.0f * rhs[a], 0.0f));
+    MIA_WAVE_SYNC();
+    float um_sum = 0.0f, ko_sum = 0.0f;
+    for (int a = tid; a < k; a += 64) {
+      float um = 0.0f;
+      for (int b4 = 0; b4 < N4; ++b4) { const f4v v = reinterpret_cast<const f4v*>(S + a * LDA)[b4]; um += (v.x + v.y) + (v.z + v.w); }
+      um /= float(k);
+      sw[a] = um;                                   // row means (sw is free until the state rows)
+      um_sum += um; ko_sum += rhs[a];
+    }
+    const float gm = wave_sum_dpp(um_sum) / float(k), om = wave_sum_dpp(ko_sum) / float(k);
+    MIA_WAVE_SYNC();
+    for (int it = tid; it < k * k; it += 64) {
+      const int a = it / k, b = it - a * k;
+      S[a * LDA + b] = S[a * LDA + b] - sw[b] - (sw[a] - gm);
+    }
+    for (int a = tid; a < k; a += 64) rhs[a] = rhs[a] - om - (sw[a] - gm);
+    MIA_WAVE_SYNC();
+  }
+  // ---- Gershgorin bound, degree, coefficients
+  float rsum = 0.0f;
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const int r = tid + 64 * u;
+    if (r < k) {
+      float rs_ = 0.0f;
+      for (int b4 = 0; b4 < N4; ++b4) { const f4v v = reinterpret_cast<const f4v*>(S + r * LDA)[b4]; rs_ += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w)); }
+      rsum = fmaxf(rsum, rs_);
+    }
+  }
+  float L = wave_max_dpp(rsum);
+  L = fmaxf(L, 1e-30f * reg) * 1.0001f;
+  const float sq = sqrtf(1.0f + L / reg);
+  const float rho = (sq + 1.0f) / fmaxf(sq - 1.0f, 1e-12f);
+  int deg = (int)ceilf(P.log_tol / __logf(rho)) + 2;
+  deg = deg < 3 ? 3 : deg;
+  if (!(L == L) || !(fabsf(L) < 1e30f)) { flag |= MIA_FLAG_NONFINITE; deg = 3; }
+  if (deg > P.dmax || deg > 63) {
+    if (tid == 0) { if (P.flags) P.flags[pt] = MIA_FLAG_RETRY; atomicAdd(P.retry_count, 1); }
+    return;
+  }
+  cheb_coefficients(tid, deg, L, reg, km1, ar, false, f2s, c2);
+  const float alpha = 2.0f / L;
+  float rhs_r[R];
+#pragma unroll
+  for (int u = 0; u < R; ++u) rhs_r[u] = (tid + 64 * u < k) ? rhs[tid + 64 * u] : 0.0f;
+  auto matvec = [&](float (&y)[R]) {               // y_r = sum_b S[r][b] tv[b] for this lane's rows
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const int r = tid + 64 * u < NMAX ? tid + 64 * u : NMAX - 1;
+      f2v a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f};
+      for (int b4 = 0; b4 < N4; ++b4) {
+        const f4v sv = reinterpret_cast<const f4v*>(S + r * LDA)[b4];
+        const f4v tq = reinterpret_cast<const f4v*>(tv)[b4];
+        a0 = sv.xy * tq.xy + a0; a1 = sv.zw * tq.zw + a1;
+      }
+      const f2v a = a0 + a1;
+      y[u] = a.x + a.y;
+    }
+  };
+  // ---- the state rows: z = x' (primal), shared recurrence for phi(S) z and psi(S) z, output
+  for (int mi = 0; mi < P.m; ++mi) {
+    float xv[R], xs = 0.0f;
+#pragma unroll
+    for (int u = 0; u < R; ++u) { const int i = tid + 64 * u; xv[u] = i < k ? P.X[((int64_t)mi * k + i) * P.ldx + g] : 0.0f; xs += xv[u]; }
+    const float xm = wave_sum_dpp(xs) / float(k);
+    float t0[R], tprev[R], tcur[R], y[R];
+    f2v ap[R];
+    MIA_WAVE_SYNC();
+#pragma unroll
+    for (int u = 0; u < R; ++u) { const int i = tid + 64 * u; t0[u] = i < k ? xv[u] - xm : 0.0f; if (i < NMAX) tv[i] = t0[u]; }
+    MIA_WAVE_SYNC();
+    matvec(y);
+#pragma unroll
+    for (int u = 0; u < R; ++u) { tprev[u] = t0[u]; tcur[u] = alpha * y[u] - t0[u]; ap[u] = c2[0] * t0[u] + c2[1] * tcur[u]; }
+    for (int j = 2; j <= deg; ++j) {
+      MIA_WAVE_SYNC();
+#pragma unroll
+      for (int u = 0; u < R; ++u) if (tid + 64 * u < NMAX) tv[tid + 64 * u] = tcur[u];
+      MIA_WAVE_SYNC();
+      matvec(y);
+      const f2v cj = c2[j];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const float tn = 2.0f * (alpha * y[u] - tcur[u]) - tprev[u];
+        tprev[u] = tcur[u]; tcur[u] = tn;
+        ap[u] = cj * tn + ap[u];
+      }
+    }
+    float zpart = 0.0f;
+#pragma unroll
+    for (int u = 0; u < R; ++u) if (tid + 64 * u < k) zpart += rhs_r[u] * ap[u].y;
+    const float mterm = xm + wave_sum_dpp(zpart);                    // mean + x' w_mean
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const int jm = tid + 64 * u;
+      if (jm < k) {
+        const float out = mterm + ap[u].x;                           // primal: (x' W)_j = (phi(S) x')_j
+        if (!(fabsf(out) <= 1e30f)) flag |= MIA_FLAG_NONFINITE;
+        P.Xa[((int64_t)mi * k + jm) * P.ldo + ocol] = out;
+      }
+    }
+  }
+  if (P.flags) {
+    const int any = __any(flag != 0) ? MIA_FLAG_NONFINITE : 0;
+    if (tid == 0) P.flags[pt] = any | (deg << 8);
+  }
+}
+
+template <int NMAX>
+static int cheb_launch_big(const ChebParams& ap, hipStream_t stream) {
+  const size_t e = (size_t)NMAX * (NMAX + 4) + 4 * (size_t)NMAX + 16 + 4 * 64 + 8 + (size_t)((ap.p_max + 3) & ~1);
+  const size_t lds = align_up(e * sizeof(float) + (size_t)((ap.p_max + 3) & ~1) * sizeof(int), 16);
+  if (lds > kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
+  auto kern = letkf_cheb_big_kernel<NMAX>;
+  if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int64_t gx = ap.ng < 65536 ? ap.ng : 65536;
+  const int64_t gy = (ap.ng + gx - 1) / gx;
+  if (gy > 65535) return MIA_ERR_UNSUPPORTED;
+  kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64), lds, stream>>>(ap);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
 static size_t cheb_lds_bytes(int kp, int p_max, int nmax, int rows, bool dual, bool batch = false, int k_weights = 0) {
   const int lda = (nmax % 8 == 0) ? nmax + 4 : nmax;
   const int srows = (dual && nmax > 32) ? 16 : nmax;      // streamed S: staging panel only (see letkf_cheb_point)
@@ -1053,6 +1277,21 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
   ap.kernel_mode = kernel_mode; ap.gamma = gamma;
   ap.dual = (kernel_mode == 0 && p_max <= k) ? 1 : 0;
   const int ntrue = ap.dual ? p_max : k;
+  if (ntrue > 64) {     // the eigenproblem is larger than one row per lane: primal route with two rows per lane
+    if (k <= 64 || k > 128 || scan || seg_len > 0 || W_out) return MIA_ERR_UNSUPPORTED;
+    ap.dual = 0;
+    ap.rows = 0;
+    ap.dmax = 62;
+    ap.xskip = 0;
+    ap.log_tol = 12.0f;
+    if (const char* e = getenv("MIA_CHEB_LOGTOL")) ap.log_tol = (float)atof(e);     // experiments only
+    if (const char* e = getenv("MIA_CHEB_DMAX")) ap.dmax = atoi(e);
+    if (getenv("MIA_CHEB_NO_BIG")) return MIA_ERR_UNSUPPORTED;
+    if (k <= 80) return cheb_launch_big<80>(ap, stream);
+    if (k <= 96) return cheb_launch_big<96>(ap, stream);
+    if (k <= 112) return cheb_launch_big<112>(ap, stream);
+    return cheb_launch_big<128>(ap, stream);
+  }
   static const int buckets[] = {4, 8, 12, 16, 20, 24, 32, 40, 48, 64};
   int nmax = 0;
   for (int b : buckets) if (b >= ntrue) { nmax = b; break; }
