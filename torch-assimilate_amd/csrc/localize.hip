@@ -8,6 +8,7 @@
 // scans only the 3^d neighbouring cells, evaluates distance + taper in float64 (the
 // reference's dtype, so `weight > eps` takes the reference's decision) and compacts the
 // survivors with a wave ballot.  Integer/byte work, HBM/L2-bound: no MFMA here.
+#include <cstdlib>
 #include "mia_common.h"
 #include "mia_localize_dev.h"
 #include "mia_pack_dev.h"
@@ -218,18 +219,20 @@ __global__ __launch_bounds__(256) void index_sortcell_kernel(IndexParams p) {
         for (int q = 0; q < p.nc; ++q) p.sxyz[(int64_t)(lo + rank) * p.nc + q] = p.obs[(int64_t)v * p.nc + q];
       }
     } else {
-      if (lane == 0) {
-        for (int i = lo + 1; i < hi; ++i) {
-          int v = p.sorted[i], j = i - 1;
-          while (j >= lo && p.sorted[j] > v) { p.sorted[j + 1] = p.sorted[j]; --j; }
-          p.sorted[j + 1] = v;
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      // larger cells (dense networks: hundreds of observations per cell): the same rank sort out of place -- ids copied to
+      // the cell's slice of cell_of (no longer needed once the scatter has run), every lane ranks its share of the
+      // elements against all of them.  O(n^2 / 64) per lane; the serial insertion sort this replaces took 13 ms on a
+      // network with ~500 observations per cell.
+      int* tmp = p.cell_of + lo;
+      for (int i = lane; i < n; i += 64) tmp[i] = p.sorted[lo + i];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __builtin_amdgcn_wave_barrier();
-      for (int i = lo + lane; i < hi; i += 64) {
-        const int64_t j = __hip_atomic_load(&p.sorted[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        for (int q = 0; q < p.nc; ++q) p.sxyz[(int64_t)i * p.nc + q] = p.obs[j * p.nc + q];
+      for (int i = lane; i < n; i += 64) {
+        const int v = tmp[i];
+        int rank = 0;
+        for (int l = 0; l < n; ++l) rank += tmp[l] < v ? 1 : 0;
+        p.sorted[lo + rank] = v;
+        for (int q = 0; q < p.nc; ++q) p.sxyz[(int64_t)(lo + rank) * p.nc + q] = p.obs[(int64_t)v * p.nc + q];
       }
     }
   }
@@ -323,6 +326,26 @@ __global__ __launch_bounds__(64) void localize_kernel(LocalizeParams p) {
   if ((threadIdx.x & 63) == 0) {
     if (mx > __hip_atomic_load(&p.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&p.stats[0], mx);
     if (over) atomicAdd(&p.stats[1], over);
+  }
+}
+
+// One WAVEFRONT per grid point, for long lists (dense observation networks): the thread-per-point kernel above walks a
+// list of several hundred candidates serially in every lane (p ~ 1000: 13 ms for 2e4 points, 20x the analysis itself);
+// here 64 candidates are evaluated per trip and compacted with a ballot (scan_neighbours, the routine the fused
+// analysis route uses).  Same order (cell order, ascending index inside a cell), same weights: identical lists.
+__global__ __launch_bounds__(64) void localize_wave_kernel(LocalizeParams p) {
+  MIA_PREP_PRIORITY();
+  const int lane = threadIdx.x;
+  const int64_t pt = blockIdx.x;
+  if (pt >= p.ng) return;
+  int* my_idx = p.idx + pt * p.p_cap;
+  double* my_w = p.w + pt * p.p_cap;
+  const int count = scan_neighbours<double>(p.scan, p.g0 + pt, lane, p.p_cap, my_idx, my_w);
+  for (int s_ = (count < p.p_cap ? count : p.p_cap) + lane; s_ < p.p_cap; s_ += 64) { my_idx[s_] = -1; my_w[s_] = 0.0; }
+  if (lane == 0) {
+    p.cnt[pt] = count;
+    if (count > __hip_atomic_load(&p.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&p.stats[0], count);
+    if (count > p.p_cap) atomicAdd(&p.stats[1], 1);
   }
 }
 
@@ -476,6 +499,11 @@ int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* 
   lp.cnt = nbr_cnt; lp.idx = nbr_idx; lp.w = nbr_w; lp.stats = stats;
   // one-wave workgroups: beside a bulk kernel that holds every wave slot (pipelined steps) a single freed slot is
   // enough to place one, whereas a 4-wave workgroup waited for four slots on one CU (200 us instead of 35)
+  if (p_cap >= 64 && ng <= 2147483647LL && !getenv("MIA_LOCALIZE_THREAD")) {   // long lists: one wavefront per grid point
+    localize_wave_kernel<<<dim3((unsigned)ng), dim3(64), 0, stream>>>(lp);
+    MIA_LAUNCH_CHECK();
+    return MIA_OK;
+  }
   const int64_t nb = (ng + 63) / 64;
   if (nb > 2147483647LL) return MIA_ERR_UNSUPPORTED;
   localize_kernel<<<dim3((unsigned)nb), dim3(64), 0, stream>>>(lp);
