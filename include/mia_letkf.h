@@ -335,6 +335,19 @@ int mia_lienks_update_f32(const float* W_in, int64_t w_stride, int k, int64_t g0
                           const float* rec, int64_t P,
                           const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
                           float tau, float epsilon, float* W_out, int32_t* flags_opt, void* stream);
+/* tau = 1 without an eigensolver, through the weights variant of the matfun kernel (Wp' = I + D phi(S) D^T,
+ * w_mean' = D psi(S) (d + D^T w_mean); float32, dual route, order <= 32): the bundle variant (epsilon > 0) at every
+ * iteration, the transform variant (epsilon <= 0) while Wp = I, i.e. the first iteration from the prior weights.
+ * Declined points (another Wp, spectrum too wide): MIA_FLAG_RETRY in flags, counted in *retry_count, untouched in W_out;
+ * mia_lienks_update_retry_f32 redoes exactly those with the general kernel.  MIA_ERR_UNSUPPORTED: use mia_lienks_update_f32. */
+int mia_lienks_update_matfun_f32(const float* W_in, int64_t w_stride, int k, int64_t g0, int64_t g1,
+                                 const float* rec, int64_t P,
+                                 const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
+                                 float epsilon, float* W_out, int32_t* flags, int32_t* retry_count, void* stream);
+int mia_lienks_update_retry_f32(const float* W_in, int64_t w_stride, int k, int64_t g0, int64_t g1,
+                                const float* rec, int64_t P,
+                                const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
+                                float tau, float epsilon, float* W_out, int32_t* flags, void* stream);
 int mia_lienks_update_f64(const double* W_in, int64_t w_stride, int k, int64_t g0, int64_t g1,
                           const double* rec, int64_t P,
                           const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,

@@ -75,6 +75,8 @@ _PROTOS = {
     "mia_apply_local_weights_f64": ([vp, i64, i32, i32, i64, i64, vp, vp, i64, i64, vp], i32),
     "mia_lienks_update_f32": ([vp, i64, i32, i64, i64, vp, i64, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp], i32),
     "mia_lienks_update_f64": ([vp, i64, i32, i64, i64, vp, i64, vp, vp, vp, i32, i32, f64, f64, vp, vp, vp], i32),
+    "mia_lienks_update_matfun_f32": ([vp, i64, i32, i64, i64, vp, i64, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp], i32),
+    "mia_lienks_update_retry_f32": ([vp, i64, i32, i64, i64, vp, i64, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp], i32),
     "mia_obs_space_uncorr_f32": ([vp, i64, vp, vp, i32, i64, vp, i64, vp, vp, vp], i32),
     "mia_obs_space_uncorr_f64": ([vp, i64, vp, vp, i32, i64, vp, i64, vp, vp, vp], i32),
     "mia_obs_space_corr_workspace_bytes": ([i32, i64, i32, C.POINTER(sz)], i32),

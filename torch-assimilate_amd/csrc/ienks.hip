@@ -22,6 +22,7 @@
 #include "mia_common.h"
 #include "mia_jacobi.h"
 #include "mia_jacobi_sym.h"
+#include "mia_kernels.h"
 
 namespace mia {
 
@@ -35,6 +36,7 @@ struct IenksParams {
   T* Wout; int32_t* flags;
   int n, lda, rows, need_inv, max_sweeps; T rot_tol2, stop_tol2;
   int nd;                              // > 0: dual route (tau == 1, p_max <= k): order of the p x p eigenproblem
+  int only_flagged;                    // redo only the points the matfun route declined (MIA_FLAG_RETRY in flags)
 };
 
 // NT = 256 in production.  One-wave workgroups (NT = 64, MIA_IENKS_NARROW=1) were measured SLOWER for k = 40 (transform,
@@ -70,6 +72,7 @@ __global__ __launch_bounds__(NT) void ienks_update_kernel(IenksParams<T> P) {
   }
   if (tid == 0) ibuf[1] = 0;
   const int64_t pt = blockIdx.x;
+  if (P.only_flagged && !(P.flags[pt] & MIA_FLAG_RETRY)) return;
   const T km1 = T(k - 1);
   const int cnt = P.cnt[pt];
   const T* win = P.Win + pt * P.w_stride;
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(NT) void ienks_update_kernel(IenksParams<T> P) {
 template <typename T>
 static int ienks_update_impl(const T* W_in, int64_t w_stride, int k, int64_t g0, int64_t g1, const T* rec, int64_t Pn,
                              const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
-                             T tau, T epsilon, T* W_out, int32_t* flags_opt, hipStream_t stream) {
+                             T tau, T epsilon, T* W_out, int32_t* flags_opt, hipStream_t stream, int only_flagged = 0) {
   if (g1 < g0 || g0 < 0 || k < 2 || Pn < 0 || p_cap < 1 || p_max < 0) return MIA_ERR_SIZE;
   if (!(tau >= T(0)) || !(tau <= T(1))) return MIA_ERR_SIZE;              // bound_tensor(0, 1), interface/ienks.py:84
   if (w_stride != 0 && w_stride != (int64_t)k * k) return MIA_ERR_SIZE;
@@ -301,6 +304,8 @@ static int ienks_update_impl(const T* W_in, int64_t w_stride, int k, int64_t g0,
   if (p_max > p_cap) p_max = p_cap;
   if (ng > 2147483647LL) return MIA_ERR_UNSUPPORTED;
   IenksParams<T> ap;
+  ap.only_flagged = only_flagged;
+  if (only_flagged && !flags_opt) return MIA_ERR_NULL;
   ap.Win = W_in; ap.w_stride = w_stride; ap.k = k; ap.ng = ng; ap.rec = rec; ap.kp = (k + 1 + 3) & ~3;
   ap.cnt = nbr_cnt; ap.idx = nbr_idx; ap.w = nbr_w; ap.p_cap = p_cap; ap.p_max = p_max;
   ap.tau = tau; ap.inv_eps = epsilon > T(0) ? T(1) / epsilon : T(0);
@@ -403,6 +408,33 @@ extern "C" int mia_lienks_update_f32(const float* W_in, int64_t w_stride, int k,
   return ienks_update_impl<float>(W_in, w_stride, k, g0, g1, rec, P, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, tau, epsilon,
                                   W_out, flags_opt, (hipStream_t)stream);
 }
+// tau = 1 through the eigensolver-free weights kernel (letkf_cheb.hip); the general kernel above redoes what it declines
+extern "C" int mia_lienks_update_matfun_f32(const float* W_in, int64_t w_stride, int k, int64_t g0, int64_t g1,
+                                            const float* rec, int64_t P, const int32_t* nbr_cnt, const int32_t* nbr_idx,
+                                            const double* nbr_w, int p_cap, int p_max, float epsilon, float* W_out,
+                                            int32_t* flags, int32_t* retry_count, void* stream) {
+  (void)hipGetLastError();
+  if (g1 < g0 || g0 < 0 || k < 2 || P < 0 || p_cap < 1 || p_max < 0) return MIA_ERR_SIZE;
+  if (w_stride != 0 && w_stride != (int64_t)k * k) return MIA_ERR_SIZE;
+  const int64_t ng = g1 - g0;
+  if (ng == 0) return MIA_OK;
+  if (!W_in || !W_out || !nbr_cnt || !nbr_idx || !nbr_w || !flags || !retry_count) return MIA_ERR_NULL;
+  if (P > 0 && !rec) return MIA_ERR_NULL;
+  if (p_max > p_cap) p_max = p_cap;
+  const IenksOpts opt{epsilon > 0.0f ? 2 : 1, W_in, w_stride, epsilon > 0.0f ? 1.0f / epsilon : 1.0f};
+  // (X = W_out as a harmless non-NULL placeholder: no state row is transformed, m = 0)
+  return cheb_analysis_launch(W_out, ng, 0, k, 0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, 1.0f, 0, 0.0f, W_out, ng, 0,
+                              flags, retry_count, nullptr, nullptr, (hipStream_t)stream, 0, 0, nullptr, W_out, &opt);
+}
+extern "C" int mia_lienks_update_retry_f32(const float* W_in, int64_t w_stride, int k, int64_t g0, int64_t g1,
+                                           const float* rec, int64_t P, const int32_t* nbr_cnt, const int32_t* nbr_idx,
+                                           const double* nbr_w, int p_cap, int p_max, float tau, float epsilon,
+                                           float* W_out, int32_t* flags, void* stream) {
+  (void)hipGetLastError();
+  return ienks_update_impl<float>(W_in, w_stride, k, g0, g1, rec, P, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, tau, epsilon,
+                                  W_out, flags, (hipStream_t)stream, 1);
+}
+
 extern "C" int mia_lienks_update_f64(const double* W_in, int64_t w_stride, int k, int64_t g0, int64_t g1, const double* rec,
                                      int64_t P, const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w,
                                      int p_cap, int p_max, double tau, double epsilon, double* W_out, int32_t* flags_opt,

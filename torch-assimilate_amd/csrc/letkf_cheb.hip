@@ -50,6 +50,8 @@ struct ChebParams {
   int seg_len; int64_t seg_stride; int32_t* done;
   int kpv_magic;   // ceil(2^20 / (kp / 4))
   float* W;        // weights-output variant: [ng][k][k]
+  // IEnKS update through the weights variant (tau = 1): 0 off, 1 transform (valid while Wp = I), 2 bundle (D = Yl / eps)
+  int ienks; const float* ienks_Win; int64_t ienks_wstride; float ienks_inv_eps;
 };
 
 using f32x4c = __attribute__((ext_vector_type(4))) float;
@@ -195,7 +197,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
   const float f0 = P.dual ? sqrtf(km1 / reg) : 0.0f;
   float xval[KL];
 #pragma unroll
-  for (int u = 0; u < KL; ++u) { const int i = tid + 64 * u; xval[u] = i < k ? P.X[(int64_t)i * P.ldx + g] : 0.0f; }
+  for (int u = 0; u < KL; ++u) { const int i = tid + 64 * u; xval[u] = (MODE != 2 && i < k) ? P.X[(int64_t)i * P.ldx + g] : 0.0f; }
   int cnt;
   if constexpr (FUSED) {
     // Gaspari-Cohn localisation fused in: scan the cell index, taper in float64, ballot-compact into LDS
@@ -210,7 +212,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     const int nl = pm < P.p_cap ? pm : P.p_cap;
     for (int j = tid; j < nl; j += 64) {       // (one trip for the dual route: p_max <= 64)
       lidx[j] = P.idx[pt * P.p_cap + j];
-      lw[j] = float(P.w[pt * P.p_cap + j]);
+      lw[j] = float(P.w[pt * P.p_cap + j]) * (MODE == 2 && P.ienks == 2 ? P.ienks_inv_eps : 1.0f);
     }
     cnt = P.cnt[pt];
   }
@@ -252,6 +254,13 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
           reinterpret_cast<float4*>(Yt + (size_t)jj[u] * kp)[cc[u]] = t;
         }
       }
+    }
+  }
+  if constexpr (MODE == 2) {
+    if (P.ienks == 2) {     // bundle variant: D = Yl / eps, the innovations stay as they are (core/ienks.py:167-173)
+      MIA_WAVE_SYNC();
+      const float eps = 1.0f / P.ienks_inv_eps;
+      for (int j = tid; j < cnt; j += 64) Yt[(size_t)j * kp + k] *= eps;
     }
   }
   if (P.dual) for (int i = tid; i < kp; i += 64) Yt[(size_t)P.rows * kp + i] = 0.0f;   // the zero row of the Gram panels
@@ -654,9 +663,45 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     for (int t = 0; t < TT; ++t)
 #pragma unroll
       for (int s_ = 0; s_ < N4; ++s_) afrag[t][s_] = (16 * t + lr < NMAX) ? S[(16 * t + lr) * LDA + 4 * s_ + h] : 0.0f;
+    // -- IEnKS update (tau = 1) through this kernel: with D = Wp^-1 Yl (transform) or Yl / eps (bundle) and reg = k - 1,
+    //    Wp' = sqrt(k-1) Pn^-1/2 = I + D phi(S) D^T  and  w_mean' = w_mean - Pn^-1 ((k-1) w_mean - D d) = D psi(S) (d + D^T w_mean)
+    //    (core/ienks.py:89-126; Pn = (k-1) I + D D^T, I - (k-1) Pn^-1 = D psi(S) D^T): the LETKF weights with inflation 1
+    //    and the start vector of the psi recurrence shifted by D^T w_mean.  Transform variant: only while Wp = I (the
+    //    first iteration from the prior weights) -- any other Wp needs its inverse: such points are declined (RETRY).
+    float z2 = 0.0f;
+    if (P.ienks) {
+      const float* win = P.ienks_Win + pt * P.ienks_wstride;
+      if (cnt == 0) {        // no local observation: the weights come back as they went in (core/ienks.py:135)
+        float* wo = P.W + pt * (int64_t)k * k;
+        for (int it = tid; it < k * k; it += 64) wo[it] = win[it];
+        if (P.flags && tid == 0) P.flags[pt] = 0;
+        return;
+      }
+      float wmean = 0.0f;
+      int not_identity = 0;
+      if (tid < k) {
+        float acc = 0.0f;
+        for (int j = 0; j < k; ++j) acc += win[tid * k + j];
+        wmean = (acc - 1.0f) / float(k);
+        if (P.ienks == 1)
+          for (int j = 0; j < k; ++j) not_identity |= fabsf(win[tid * k + j] - wmean - (j == tid ? 1.0f : 0.0f)) > 1e-6f ? 1 : 0;
+      }
+      if (__any(not_identity)) {
+        if (tid == 0) { if (P.flags) P.flags[pt] = MIA_FLAG_RETRY; atomicAdd(P.retry_count, 1); }
+        return;
+      }
+      MIA_WAVE_SYNC();
+      if (tid < kp) xp[tid] = tid < k ? wmean : 0.0f;
+      MIA_WAVE_SYNC();
+      if (tid < cnt) {
+        const float4* yb = reinterpret_cast<const float4*>(Yt + (size_t)tid * kp);
+        const float4* x4 = reinterpret_cast<const float4*>(xp);
+        for (int i = 0; i < ((k + 3) >> 2); ++i) { const float4 yq = yb[i], xq = x4[i]; z2 += yq.x * xq.x + yq.y * xq.y + yq.z * xq.z + yq.w * xq.w; }
+      }
+    }
     // -- u = psi(S) d_l, w_mean = Yl u
     {
-      const float t0 = rhs_r;
+      const float t0 = rhs_r + z2;
       if (tid < NMAX) tv[tid] = t0;
       MIA_WAVE_SYNC();
       float yv = matvec_row<NMAX>(srow2, tv);
@@ -1260,12 +1305,17 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
                          const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
                          float inf_factor, int kernel_mode, float gamma, float* Xa, int64_t ldo, int64_t o0,
                          int32_t* flags, int32_t* retry_count, const ScanParams* scan, int32_t* stats,
-                         hipStream_t stream, int seg_len, int64_t seg_stride, int32_t* done, float* W_out) {
+                         hipStream_t stream, int seg_len, int64_t seg_stride, int32_t* done, float* W_out, const IenksOpts* ienks) {
   if (!flags || !retry_count) return MIA_ERR_UNSUPPORTED;   // the retry protocol needs both
   if (seg_len > 0 && (scan || !done || seg_len % 8 || ng >= (int64_t)1 << 31)) return MIA_ERR_UNSUPPORTED;
   ChebParams ap;
   ap.seg_len = seg_len; ap.seg_stride = seg_stride; ap.done = done;
   ap.W = W_out;
+  ap.ienks = ienks ? ienks->variant : 0;
+  ap.ienks_Win = ienks ? ienks->W_in : nullptr;
+  ap.ienks_wstride = ienks ? ienks->w_stride : 0;
+  ap.ienks_inv_eps = ienks ? ienks->inv_eps : 1.0f;
+  if (ienks && (!W_out || !ienks->W_in || (ienks->variant != 1 && ienks->variant != 2))) return MIA_ERR_NULL;
   ap.fused = scan != nullptr;
   if (scan) { ap.scan = *scan; ap.stats = stats; if (!stats) return MIA_ERR_NULL; } else ap.stats = nullptr;
   ap.X = X; ap.ldx = ldx; ap.m = m; ap.k = k; ap.g0 = g0; ap.ng = ng; ap.rec = rec;

@@ -9,6 +9,10 @@ namespace mia {
 // are serialised by the L2 channel that owns it (25 000 on one line cost more than the whole analysis)
 constexpr int kSlotStride = 64;
 
+// IEnKS update (tau = 1) through the weights variant of the matfun kernel: variant 1 transform (points whose Wp is not the
+// identity are declined), 2 bundle (inv_eps = 1 / epsilon)
+struct IenksOpts { int variant; const float* W_in; int64_t w_stride; float inv_eps; };
+
 // letkf_cheb.hip.  MIA_ERR_UNSUPPORTED when the shape is outside the matfun route.
 // seg_len > 0: one segmented launch over the ng points (native step driver): segment s = points
 // [s*seg_len, (s+1)*seg_len) writes the (m*k, seg_len) buffer at Xa + s*seg_stride (ldo = seg_len) and counts
@@ -18,7 +22,7 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
                          float inf_factor, int kernel_mode, float gamma, float* Xa, int64_t ldo, int64_t o0,
                          int32_t* flags, int32_t* retry_count, const ScanParams* scan, int32_t* stats,
                          hipStream_t stream, int seg_len = 0, int64_t seg_stride = 0, int32_t* done = nullptr,
-                         float* W_out = nullptr /* weights-output variant: [ng][k][k] */);
+                         float* W_out = nullptr /* weights-output variant: [ng][k][k] */, const IenksOpts* ienks = nullptr);
 
 // one-wave kernel on `stream` that returns once the 64 slot counters at done64[j * kSlotStride] sum to `expected` (bounded
 // polling: after ~seconds it sets bit 0 of *err and returns, so the grid always drains)

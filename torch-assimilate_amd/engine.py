@@ -473,10 +473,12 @@ class LetkfEngine:
     # ------------------------------------------------------------------- IEnKS
     def ienks_update(self, weights: torch.Tensor, Yb: Optional[torch.Tensor], d: Optional[torch.Tensor],
                      nbrs: NeighbourLists, tau: float = 1.0, epsilon: Optional[float] = None,
-                     rec: Optional[torch.Tensor] = None, return_flags: bool = False):
+                     rec: Optional[torch.Tensor] = None, return_flags: bool = False, method: str = "auto"):
         """One IEnKS weight update per grid point of the shard ``nbrs`` (core/ienks.py:108-141 on the localised
         block, interface/lienks.py:75-118).  ``weights``: (k, k) shared by all points (e.g. the prior weights) or
-        (n, k, k); ``epsilon`` None = transform variant, a positive value = bundle variant.  Returns (n, k, k)."""
+        (n, k, k); ``epsilon`` None = transform variant, a positive value = bundle variant.  Returns (n, k, k).
+        ``method`` "auto": float32 updates with tau = 1 go through the eigensolver-free weights kernel (bundle variant
+        always, transform variant while Wp = I), the general kernel redoing what it declines; "eig": general kernel."""
         weights = torch.as_tensor(weights)
         dtype = weights.dtype if weights.dtype in (torch.float32, torch.float64) else torch.float64
         weights = weights.to(device=self.device, dtype=dtype).contiguous()
@@ -496,6 +498,22 @@ class LetkfEngine:
             raise ValueError("epsilon must be positive")
         out = torch.empty((n, k, k), dtype=dtype, device=self.device)
         flags = torch.empty(n, dtype=torch.int32, device=self.device)
+        wstride = k * k if weights.dim() == 3 else 0
+        eps_c = float(epsilon) if epsilon is not None else 0.0
+        if dtype == torch.float32 and float(tau) == 1.0 and n > 0 and method != "eig":
+            # tau = 1 through the eigensolver-free weights kernel; -3 = shape outside it (primal route, order > 32)
+            retry = torch.zeros(1, dtype=torch.int32, device=self.device)
+            rc = self.lib.mia_lienks_update_matfun_f32(
+                _ptr(weights), wstride, k, nbrs.g0, nbrs.g1, _ptr(rec), rec.shape[0], _ptr(nbrs.cnt), _ptr(nbrs.idx),
+                _ptr(nbrs.w), nbrs.p_cap, nbrs.p_max, eps_c, _ptr(out), _ptr(flags), _ptr(retry), self._stream())
+            if rc != -3:
+                _cabi.check(rc, "mia_lienks_update_matfun_f32")
+                if int(retry.item()):        # host sync (8 bytes): the general kernel redoes the declined points
+                    _cabi.check(self.lib.mia_lienks_update_retry_f32(
+                        _ptr(weights), wstride, k, nbrs.g0, nbrs.g1, _ptr(rec), rec.shape[0], _ptr(nbrs.cnt),
+                        _ptr(nbrs.idx), _ptr(nbrs.w), nbrs.p_cap, nbrs.p_max, 1.0, eps_c, _ptr(out), _ptr(flags),
+                        self._stream()), "mia_lienks_update_retry_f32")
+                return (out, flags) if return_flags else out
         sfx = "f32" if dtype == torch.float32 else "f64"
         fn = getattr(self.lib, "mia_lienks_update_" + sfx)
         _cabi.check(fn(_ptr(weights), k * k if weights.dim() == 3 else 0, k, nbrs.g0, nbrs.g1, _ptr(rec), rec.shape[0],
