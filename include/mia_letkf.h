@@ -192,19 +192,20 @@ int mia_letkf_analysis_matfun_f32(const float* X, int64_t ldx, int m, int k, int
                                   void* stream);
 /* The weights themselves without an eigensolver (what LETKF.estimate_weights returns, interface/letkf.py:145-146, next to
  * the analysis): phi(S) as an n x n matrix from the same Chebyshev recurrence run on the identity -- MFMA products
- * S T_j -- then W = w_mean 1^T + f0 I + Yl phi(S) Yl^T.  Dual route (p_max <= k), order <= 32, k <= 64; otherwise
+ * S T_j -- then W = w_mean 1^T + f0 I + Yl phi(S) Yl^T.  Dual route (p_max <= k) up to order 32, primal route (p_max > k, or
+ * gamma > 0: the RBF filter; W = w_mean 1^T + phi(S) with S the k x k member Gram / centred kernel matrix) up to k = 48; otherwise
  * MIA_ERR_UNSUPPORTED (use mia_letkf_analysis_packed_f32 with W_opt).  Declined points: MIA_FLAG_RETRY, counted in
  * *retry_count, left untouched in Xa and W; mia_letkf_weights_retry_f32 redoes them with the eigensolver kernel. */
 int mia_letkf_weights_matfun_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
                                  const float* rec, int64_t P,
                                  const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w,
-                                 int p_cap, int p_max, float inf_factor,
+                                 int p_cap, int p_max, float inf_factor, float gamma /* > 0: RBF-kernelised core */,
                                  float* Xa, int64_t ldo, int64_t o0, float* W /* [g1-g0][k][k] */,
                                  int32_t* flags, int32_t* retry_count, void* stream);
 int mia_letkf_weights_retry_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
                                 const float* rec, int64_t P,
                                 const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w,
-                                int p_cap, int p_max, float inf_factor,
+                                int p_cap, int p_max, float inf_factor, float gamma,
                                 float* Xa, int64_t ldo, int64_t o0, float* W, int32_t* flags, void* stream);
 /* matfun route with the Gaspari-Cohn localisation fused in: every wavefront scans the observation index
  * (mia_letkf_index_build_f64) for its grid point itself, so no neighbour lists are written or read.

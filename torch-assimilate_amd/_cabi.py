@@ -49,9 +49,9 @@ _PROTOS = {
                                        vp, i64, i64, vp, vp, vp], i32),
     "mia_letkf_analysis_matfun_f32": ([vp, i64, i32, i32, i64, i64, vp, i64, vp, vp, vp, i32, i32, f32, f32,
                                        vp, i64, i64, vp, vp, vp], i32),
-    "mia_letkf_weights_matfun_f32": ([vp, i64, i32, i32, i64, i64, vp, i64, vp, vp, vp, i32, i32, f32,
+    "mia_letkf_weights_matfun_f32": ([vp, i64, i32, i32, i64, i64, vp, i64, vp, vp, vp, i32, i32, f32, f32,
                                       vp, i64, i64, vp, vp, vp, vp], i32),
-    "mia_letkf_weights_retry_f32": ([vp, i64, i32, i32, i64, i64, vp, i64, vp, vp, vp, i32, i32, f32,
+    "mia_letkf_weights_retry_f32": ([vp, i64, i32, i32, i64, i64, vp, i64, vp, vp, vp, i32, i32, f32, f32,
                                      vp, i64, i64, vp, vp, vp], i32),
     "mia_letkf_index_build_f64": ([vp, i64, i32, C.POINTER(C.c_int32), C.POINTER(f64), i32, vp, sz, vp], i32),
     "mia_letkf_analysis_matfun_fused_f32": ([vp, i64, i32, i32, i64, i64, vp, i64, vp, i32, C.POINTER(C.c_int32),

@@ -650,7 +650,9 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     //      registers, T_j through LDS into the B operand, tiles in the result layout: lane (lr, h) holds
     //      T[16 ti + 4 h + q][16 tj + lr]).  Two more products, N = Yl Phi and W = N Yl^T, finish the job; the state rows
     //      are then transformed with W.  ~365 MFMAs per grid point at C2 against the Jacobi route's sweeps.
-    static_assert(NMAX <= 32 && KL == 1, "the weights variant keeps S in LDS and one member per lane");
+    //      On the primal route (p > k, and the RBF filter) S is k x k already and W = w_mean 1^T + phi(S) needs no further
+    //      product: w_mean = psi(S) (Yl d) [or the centred kernel vector], phi(S) = sqrt(k-1) (S + reg)^-1/2.
+    static_assert(NMAX <= 48 && KL == 1, "the weights variant keeps S in LDS and one member per lane");
     constexpr int NP = 16 * TT;
     const int lr = tid & 15, h = tid >> 4;
     const int KT = (k + 15) >> 4, KP16 = KT * 16;
@@ -662,7 +664,13 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
 #pragma unroll
     for (int t = 0; t < TT; ++t)
 #pragma unroll
-      for (int s_ = 0; s_ < N4; ++s_) afrag[t][s_] = (16 * t + lr < NMAX) ? S[(16 * t + lr) * LDA + 4 * s_ + h] : 0.0f;
+      for (int s_ = 0; s_ < N4; ++s_) {
+        const int r = 16 * t + lr, c = 4 * s_ + h;
+        float v = r < NMAX ? S[r * LDA + c] : 0.0f;
+        if (!P.dual && P.kernel_mode != 0)      // the centring of K lives in the register rows only: repeat it here
+          v = (r < k && c < k) ? v - uq[c] - (uq[r] - red[0]) : 0.0f;
+        afrag[t][s_] = v;
+      }
     // -- IEnKS update (tau = 1) through this kernel: with D = Wp^-1 Yl (transform) or Yl / eps (bundle) and reg = k - 1,
     //    Wp' = sqrt(k-1) Pn^-1/2 = I + D phi(S) D^T  and  w_mean' = w_mean - Pn^-1 ((k-1) w_mean - D d) = D psi(S) (d + D^T w_mean)
     //    (core/ienks.py:89-126; Pn = (k-1) I + D D^T, I - (k-1) Pn^-1 = D psi(S) D^T): the LETKF weights with inflation 1
@@ -721,7 +729,8 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
       MIA_WAVE_SYNC();
       if (tid < k) {
         float acc = 0.0f;
-        for (int b = 0; b < cnt; ++b) acc += sw[b] * Yt[(size_t)b * kp + tid];
+        if (P.dual) { for (int b = 0; b < cnt; ++b) acc += sw[b] * Yt[(size_t)b * kp + tid]; }
+        else acc = sw[tid];                   // primal: w_mean = psi(S) rhs itself
         wbar[tid] = acc;
       }
     }
@@ -797,8 +806,17 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
       for (int ti = 0; ti <= tj; ++ti, ++tile)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          if (16 * ti + 4 * h + q >= cnt || 16 * tj + lr >= cnt) ph[tile][q] = 0.0f;
+          if (16 * ti + 4 * h + q >= ntrue || 16 * tj + lr >= ntrue) ph[tile][q] = 0.0f;
     publish(ph);
+    float* wout = P.W + pt * (int64_t)k * k;
+    if (!P.dual) {       // primal: W = w_mean 1^T + Phi, written row by row (member j across the lanes)
+      if (tid < k)
+        for (int i = 0; i < k; ++i) {
+          const float v = wbar[i] + Tl[i * NP + tid];
+          if (!(fabsf(v) <= 1e30f)) flag |= MIA_FLAG_NONFINITE;
+          wout[i * k + tid] = v;
+        }
+    } else {
     // -- N = Yl Phi (k x n) and W = w_mean 1^T + f0 I + N Yl^T.  The fragments of Yl (member 16 t + lr, observation
     //    4 s + h) are the A operand of the first product and the B operand of the second: loaded once.
     constexpr int KTM = 4;                        // k <= 64
@@ -832,7 +850,6 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
       }
     }
     MIA_WAVE_SYNC();
-    float* wout = P.W + pt * (int64_t)k * k;
     if (!(P.xskip & 512)) {
 #pragma unroll
       for (int ti = 0; ti < KTM; ++ti) {
@@ -860,6 +877,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
           }
         }
       }
+    }
     }
     // -- the state rows: xa_j = mean + sum_i x'_i W_ij (base.py:257-278), W read back from where this wavefront just
     //    wrote it (L2-hot, rows contiguous across lanes) -- a copy in LDS would cost 7.7 KB of occupancy at k = 40
@@ -968,7 +986,7 @@ __global__ __launch_bounds__(64, (NMAX <= 24 ? 4 : 3)) void letkf_cheb_rows_kern
 
 // Weights output (dual route, order <= 32): W as a matrix function on the matrix cores, no eigensolver.
 template <int NMAX>
-__global__ __launch_bounds__(64, (NMAX <= 24 ? 4 : 3)) void letkf_cheb_weights_kernel(ChebParams P) {
+__global__ __launch_bounds__(64, (NMAX <= 24 ? 4 : (NMAX <= 32 ? 3 : 2))) void letkf_cheb_weights_kernel(ChebParams P) {
   letkf_cheb_point<NMAX, 1, false, 1, false, 2>(P);
 }
 
@@ -1230,7 +1248,7 @@ static size_t cheb_lds_bytes(int kp, int p_max, int nmax, int rows, bool dual, b
 
 template <int NMAX>
 static int cheb_launch_weights(const ChebParams& ap, size_t lds, hipStream_t stream) {
-  if constexpr (NMAX <= 32) {
+  if constexpr (NMAX <= 48) {
     auto kern = letkf_cheb_weights_kernel<NMAX>;
     if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t gx = ap.ng < 65536 ? ap.ng : 65536;
@@ -1365,9 +1383,11 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
   if (gy > 65535) return MIA_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)gx, (unsigned)gy);
   const bool two = k > 64;
-  if (W_out) {   // weights output: dual route, order <= 32, one member per lane; anything else is the eigensolver's
-    if (!(ap.dual && nmax <= 32 && !two && !ap.fused && seg_len == 0)) return MIA_ERR_UNSUPPORTED;
-    ap.lds_per_wave = (int)cheb_lds_bytes(ap.kp, p_max, nmax, ap.rows, true, false, k);
+  if (W_out) {   // weights output: dual route up to order 32, primal route (linear / RBF) up to k = 48, one member per lane
+    const bool ok_dual = ap.dual && nmax <= 32;
+    const bool ok_primal = !ap.dual && nmax <= 48 && !ienks;
+    if (!((ok_dual || ok_primal) && !two && !ap.fused && seg_len == 0)) return MIA_ERR_UNSUPPORTED;
+    ap.lds_per_wave = (int)cheb_lds_bytes(ap.kp, p_max, nmax, ap.rows, ap.dual != 0, false, k);
     if (ap.lds_per_wave > (long long)kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
     switch (nmax) {
       case 4: return cheb_launch_weights<4>(ap, ap.lds_per_wave, stream);
@@ -1377,6 +1397,8 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
       case 20: return cheb_launch_weights<20>(ap, ap.lds_per_wave, stream);
       case 24: return cheb_launch_weights<24>(ap, ap.lds_per_wave, stream);
       case 32: return cheb_launch_weights<32>(ap, ap.lds_per_wave, stream);
+      case 40: return cheb_launch_weights<40>(ap, ap.lds_per_wave, stream);
+      case 48: return cheb_launch_weights<48>(ap, ap.lds_per_wave, stream);
     }
     return MIA_ERR_UNSUPPORTED;
   }

@@ -570,7 +570,7 @@ extern "C" int mia_letkf_analysis_matfun_f32(const float* X, int64_t ldx, int m,
 extern "C" int mia_letkf_weights_matfun_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
                                             const float* rec, int64_t P, const int32_t* nbr_cnt,
                                             const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
-                                            float inf_factor, float* Xa, int64_t ldo, int64_t o0, float* W,
+                                            float inf_factor, float gamma, float* Xa, int64_t ldo, int64_t o0, float* W,
                                             int32_t* flags, int32_t* retry_count, void* stream) {
   (void)hipGetLastError();
   if (g1 < g0 || g0 < 0 || m < 1 || k < 2 || P < 0 || p_cap < 1 || p_max < 0) return MIA_ERR_SIZE;
@@ -581,18 +581,19 @@ extern "C" int mia_letkf_weights_matfun_f32(const float* X, int64_t ldx, int m, 
   if (ldx < g1 || ldo < o0 + ng) return MIA_ERR_SIZE;
   if (p_max > p_cap) p_max = p_cap;
   if (P > 0 && !rec) return MIA_ERR_NULL;
-  return cheb_analysis_launch(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor, 0, 0.0f,
-                              Xa, ldo, o0, flags, retry_count, nullptr, nullptr, (hipStream_t)stream, 0, 0, nullptr, W);
+  return cheb_analysis_launch(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
+                              gamma > 0.0f ? 1 : 0, gamma, Xa, ldo, o0, flags, retry_count, nullptr, nullptr,
+                              (hipStream_t)stream, 0, 0, nullptr, W);
 }
 extern "C" int mia_letkf_weights_retry_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
                                            const float* rec, int64_t P, const int32_t* nbr_cnt,
                                            const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
-                                           float inf_factor, float* Xa, int64_t ldo, int64_t o0, float* W,
+                                           float inf_factor, float gamma, float* Xa, int64_t ldo, int64_t o0, float* W,
                                            int32_t* flags, void* stream) {
   (void)hipGetLastError();
   if (!flags || !W) return MIA_ERR_NULL;
   return analysis_packed_impl<float>(X, ldx, m, k, g0, g1, rec, P, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
-                                     0, 0.0f, Xa, ldo, o0, W, flags, (hipStream_t)stream, 1);
+                                     gamma > 0.0f ? 1 : 0, gamma, Xa, ldo, o0, W, flags, (hipStream_t)stream, 1);
 }
 extern "C" int mia_letkf_analysis_retry_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
                                             const float* rec, int64_t P, const int32_t* nbr_cnt,

@@ -412,11 +412,11 @@ class LetkfEngine:
             if defer_retry:
                 res.append(lambda: 0)
             return res[0] if len(res) == 1 else tuple(res)
-        if (return_weights and dtype == torch.float32 and gamma == 0.0 and method != "eig" and n > 0):
+        if (return_weights and dtype == torch.float32 and method != "eig" and n > 0):
             # weights without an eigensolver (dual route, order <= 32); -3 = shape outside that kernel
             if retry is None:
                 retry = torch.zeros(1, dtype=torch.int32, device=self.device)
-            wargs = args[:13] + (float(inf_factor),) + args[15:]
+            wargs = args        # (..., inf_factor, gamma, Xa, ldo, o0)
             rc = self.lib.mia_letkf_weights_matfun_f32(*wargs, _ptr(W), _ptr(flags), _ptr(retry), self._stream())
             if rc != -3:
                 _cabi.check(rc, "mia_letkf_weights_matfun_f32")
