@@ -373,12 +373,12 @@ def test_degenerate_ensembles(eng):
 
 
 @pytest.mark.parametrize("m", [8, 19, 40])
-@pytest.mark.parametrize("k,stride,c", [(40, 2, 10.0), (24, 1, 6.0), (10, 3, 7.0)])
+@pytest.mark.parametrize("k,stride,c", [(40, 2, 10.0), (24, 1, 6.0), (10, 3, 7.0), (40, 1, 30.0), (12, 1, 9.0)])
 def test_matfun_many_state_rows_on_the_matrix_cores(eng, monkeypatch, m, k, stride, c):
     """m >= 8 state rows per grid point: the matfun kernel transforms them 16 at a time as one matrix recurrence on
     the MFMA units (letkf_cheb_rows_kernel).  Against the oracle (<= 1e-5, north star) and against the row-by-row
-    path of the same kernel (MIA_CHEB_NO_ROWBATCH), incl. a ragged last batch, edge points with short lists and an
-    ensemble size that is not a multiple of 4."""
+    path of the same kernel (MIA_CHEB_NO_ROWBATCH), incl. a ragged last batch, edge points with short lists, an
+    ensemble size that is not a multiple of 4, and two primal geometries (more local observations than members)."""
     G = 300
     case = O.synthetic_case(G, k, stride, seed=17, m=m)
     nb = eng.localize(case["grid_x"], case["obs_x"], [c])

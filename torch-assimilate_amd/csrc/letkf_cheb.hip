@@ -510,14 +510,22 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     //      the final Yl s are two more small products.  (v_mfma_f32_16x16x4_f32, exact f32; lane (lr, h) feeds
     //      A[16 t + lr][4 s + h] and B[col lr][4 s + h].)  The scalar path below costs ~0.1 ms per row per 1e5
     //      grid points at C2 with 20 of 64 lanes busy.
-    static_assert(NMAX <= 32 && KL == 1, "the many-rows variant keeps S in LDS and one member per lane");
+    //      Primal route (p > k, RBF filter; k <= 48): z = x' itself and (x' W) = phi(S) x', so the batch is the matrix
+    //      of centred state rows and the result leaves straight from the registers -- no product with Yl at all.
+    static_assert(NMAX <= 48 && KL == 1, "the many-rows variant keeps S in LDS and one member per lane");
     const int lr = tid & 15, h = tid >> 4;
     float afrag[TT][N4];
 #pragma unroll
     for (int t = 0; t < TT; ++t)
 #pragma unroll
-      for (int s_ = 0; s_ < N4; ++s_) afrag[t][s_] = (16 * t + lr < NMAX) ? S[(16 * t + lr) * LDA + 4 * s_ + h] : 0.0f;
-    if (tid < NMAX) {          // column sums of the local block: centring of z without centring the rows
+      for (int s_ = 0; s_ < N4; ++s_) {
+        const int r = 16 * t + lr, c = 4 * s_ + h;
+        float v = r < NMAX ? S[r * LDA + c] : 0.0f;
+        if (!P.dual && P.kernel_mode != 0)      // the centring of K lives in the register rows only: repeat it here
+          v = (r < k && c < k) ? v - uq[c] - (uq[r] - red[0]) : 0.0f;
+        afrag[t][s_] = v;
+      }
+    if (P.dual && tid < NMAX) {          // column sums of the local block: centring of z without centring the rows
       float acc = 0.0f;
       if (tid < cnt) for (int i = 0; i < k; ++i) acc += Yt[(size_t)tid * kp + i];
       csum[tid] = acc;
@@ -546,15 +554,23 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
       f2v aphi[TT][4];
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
-        const int row = 16 * t + lr;
-        const float* pa = Yt + (size_t)(row < cnt ? row : P.rows) * kp;      // rows beyond the list: the zero row
         f32x4c acc = {0.f, 0.f, 0.f, 0.f};
-        for (int s_ = 0; s_ < kq; ++s_)
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32((4 * s_ + h < k) ? pa[4 * s_ + h] : 0.0f, Xb[lr * kp + 4 * s_ + h], acc, 0, 0, 0);
+        if (P.dual) {
+          const int row = 16 * t + lr;
+          const float* pa = Yt + (size_t)(row < cnt ? row : P.rows) * kp;      // rows beyond the list: the zero row
+          for (int s_ = 0; s_ < kq; ++s_)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32((4 * s_ + h < k) ? pa[4 * s_ + h] : 0.0f, Xb[lr * kp + 4 * s_ + h], acc, 0, 0, 0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int b = 16 * t + 4 * h + q;
-          acc[q] = (b < cnt) ? acc[q] - csum[b < NMAX ? b : 0] * xm : 0.0f;
+          for (int q = 0; q < 4; ++q) {
+            const int b = 16 * t + 4 * h + q;
+            acc[q] = (b < cnt) ? acc[q] - csum[b < NMAX ? b : 0] * xm : 0.0f;
+          }
+        } else {                 // primal: z = x', member b of state row lr
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int b = 16 * t + 4 * h + q;
+            acc[q] = (b < k && lr < nrow) ? Xb[lr * kp + b] - xm : 0.0f;
+          }
         }
         tprev[t] = acc;
       }
@@ -622,7 +638,20 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
       MIA_WAVE_SYNC();
       // -- out[j][c] = xm_c + zu_c + f0 (x_c[j] - xm_c) + sum_b Yl[j][b] s[b][c]
       const float mterm = xm + zu;
-      const int KT = (k + 15) >> 4;
+      if (!P.dual) {             // primal: (x' W)_j = (phi(S) x')_j, already in this lane's registers
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int jj = 16 * t + 4 * h + q;
+            if (jj < k && lr < nrow) {
+              const float out = mterm + aphi[t][q].x;
+              if (!(fabsf(out) <= 1e30f)) flag |= MIA_FLAG_NONFINITE;
+              Xab[((int64_t)(m0 + lr) * k + jj) * P.ldo + ocol] = out;
+            }
+          }
+      }
+      const int KT = P.dual ? (k + 15) >> 4 : 0;
       for (int tj = 0; tj < KT; ++tj) {
         f32x4c acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -980,7 +1009,7 @@ __global__ __launch_bounds__(64 * WPB, (NMAX <= 24 ? 5 : (NMAX <= 40 ? 4 : 2))) 
 
 // Many state rows per grid point (m >= 8, dual route, order <= 32): rows are transformed 16 at a time on the matrix cores.
 template <int NMAX>
-__global__ __launch_bounds__(64, (NMAX <= 24 ? 4 : 3)) void letkf_cheb_rows_kernel(ChebParams P) {
+__global__ __launch_bounds__(64, (NMAX <= 24 ? 4 : (NMAX <= 32 ? 3 : 2))) void letkf_cheb_rows_kernel(ChebParams P) {
   letkf_cheb_point<NMAX, 1, false, 1, false, 1>(P);
 }
 
@@ -1264,7 +1293,7 @@ static int cheb_launch_weights(const ChebParams& ap, size_t lds, hipStream_t str
 
 template <int NMAX>
 static int cheb_launch_rows(const ChebParams& ap, size_t lds, hipStream_t stream) {
-  if constexpr (NMAX <= 32) {
+  if constexpr (NMAX <= 48) {
     auto kern = letkf_cheb_rows_kernel<NMAX>;
     if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t gx = ap.ng < 65536 ? ap.ng : 65536;
@@ -1403,8 +1432,9 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
     return MIA_ERR_UNSUPPORTED;
   }
   // many state rows: batches of 16 rows on the matrix cores (dual route, order <= 32, one member per lane)
-  if (m >= 8 && ap.dual && nmax <= 32 && !two && !ap.fused && seg_len == 0 && !getenv("MIA_CHEB_NO_ROWBATCH")) {
-    ap.lds_per_wave = (int)cheb_lds_bytes(ap.kp, p_max, nmax, ap.rows, true, true);
+  if (m >= 8 && ((ap.dual && nmax <= 32) || (!ap.dual && nmax <= 48)) && !two && !ap.fused && seg_len == 0 &&
+      !getenv("MIA_CHEB_NO_ROWBATCH")) {
+    ap.lds_per_wave = (int)cheb_lds_bytes(ap.kp, p_max, nmax, ap.rows, ap.dual != 0, true);
     switch (nmax) {
       case 4: return cheb_launch_rows<4>(ap, ap.lds_per_wave, stream);
       case 8: return cheb_launch_rows<8>(ap, ap.lds_per_wave, stream);
@@ -1413,6 +1443,8 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
       case 20: return cheb_launch_rows<20>(ap, ap.lds_per_wave, stream);
       case 24: return cheb_launch_rows<24>(ap, ap.lds_per_wave, stream);
       case 32: return cheb_launch_rows<32>(ap, ap.lds_per_wave, stream);
+      case 40: return cheb_launch_rows<40>(ap, ap.lds_per_wave, stream);
+      case 48: return cheb_launch_rows<48>(ap, ap.lds_per_wave, stream);
     }
   }
   if (seg_len > 0) {
