@@ -108,7 +108,12 @@ def cpu_baseline(n_points_total=16000):
     thread per process, one process per core) on a bounded sample of the same workload."""
     import multiprocessing as mp
     from oracle import letkf_oracle as O
-    cores = min(os.cpu_count() or 1, 32)
+    # one worker per core of this process's CPU share (a one-GPU box grants 16; affinity, not the machine's core count)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     case = O.synthetic_case(G_PER_GPU, K_ENS, OBS_STRIDE)
     pts = np.random.RandomState(0).choice(G_PER_GPU, n_points_total, replace=False)
     chunks = np.array_split(pts, cores)
