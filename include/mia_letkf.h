@@ -417,6 +417,9 @@ int mia_comm_unique_id(void* id128);
 int mia_comm_create(const void* id128, int rank, int world, mia_comm_t** comm);
 int mia_comm_create_custom(int rank, int world, mia_allgather_fn allgather, mia_allreduce_max_i32_fn allreduce_max,
                            void* ctx, mia_comm_t** comm);
+/* Optional stream for the placement of gathered pieces (NULL: the exchange stream).  Used only by steps enqueued with
+ * MIA_STEP_NO_JOIN: the result and counters[4..7] of such a step are complete once THIS stream has drained. */
+int mia_comm_set_place_stream(mia_comm_t* comm, void* stream);
 int mia_comm_destroy(mia_comm_t* comm);
 const char* mia_comm_last_error(void);
 int mia_letkf_sharded_step_workspace_bytes(int64_t G, int m, int k, int64_t P, int n_coord, int world,

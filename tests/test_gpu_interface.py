@@ -248,7 +248,11 @@ def test_native_step_driver_two_rank_layout_on_one_gpu(mia, G, chunks, strong, r
     runner = mia.ShardedLetkf(dev, rank, 2, radii=[10.0], inf_factor=1.1, comm_chunks=chunks)
     runner._p_max_hint = plain._p_max_hint
     handle, keep, calls = _emulated_peer_comm(mia, runner, rank, ref, G, chunks)
-    runner._native = dict(comm=handle, custom=True, stream=torch.cuda.Stream(device=dev), slots=[{}, {}, {}])
+    import ctypes as C
+    from torch_assimilate_amd import _cabi as cabi_
+    xstream = torch.cuda.Stream(device=dev)     # placement of the gathered pieces off the exchange stream (steps in flight)
+    cabi_.check(cabi_.lib().mia_comm_set_place_stream(handle, C.c_void_p(xstream.cuda_stream)), "mia_comm_set_place_stream")
+    runner._native = dict(comm=handle, custom=True, stream=torch.cuda.Stream(device=dev), xstream=xstream, slots=[{}, {}, {}])
     try:
         for _ in range(2):
             out = runner.assimilate(*args)

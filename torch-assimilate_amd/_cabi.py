@@ -86,6 +86,7 @@ _PROTOS = {
     "mia_comm_unique_id": ([vp], i32),
     "mia_comm_create": ([vp, i32, i32, C.POINTER(vp)], i32),
     "mia_comm_create_custom": ([i32, i32, vp, vp, vp, C.POINTER(vp)], i32),
+    "mia_comm_set_place_stream": ([vp, vp], i32),
     "mia_comm_destroy": ([vp], i32),
     "mia_comm_last_error": ([], C.c_char_p),
     "mia_letkf_sharded_step_workspace_bytes": ([i64, i32, i32, i64, i32, i32, i32, i32, C.POINTER(sz)], i32),

@@ -63,6 +63,8 @@ struct mia_comm {
   mia_allreduce_max_i32_fn ar = nullptr;
   void* ctx = nullptr;
   hipEvent_t ev[kMaxChunks + 2] = {};
+  hipEvent_t evp[kMaxChunks] = {};      // piece c gathered (exchange stream -> placement stream)
+  hipStream_t place_stream = nullptr;   // optional: mia_comm_set_place_stream
   int n_ev = 0;
 };
 
@@ -71,6 +73,7 @@ namespace {
 int comm_events(mia_comm* c) {
   if (c->n_ev) return MIA_OK;
   for (int i = 0; i < kMaxChunks + 2; ++i) MIA_HIP_TRY(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
+  for (int i = 0; i < kMaxChunks; ++i) MIA_HIP_TRY(hipEventCreateWithFlags(&c->evp[i], hipEventDisableTiming));
   c->n_ev = kMaxChunks + 2;
   return MIA_OK;
 }
@@ -226,6 +229,12 @@ extern "C" int mia_comm_create_custom(int rank, int world, mia_allgather_fn allg
   c->ar = allreduce_max;
   c->ctx = ctx;
   *out = c;
+  return MIA_OK;
+}
+
+extern "C" int mia_comm_set_place_stream(mia_comm_t* c, void* stream) {
+  if (!c) return MIA_ERR_NULL;
+  c->place_stream = (hipStream_t)stream;
   return MIA_OK;
 }
 
@@ -423,16 +432,24 @@ extern "C" int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int
       }
       rc = comm_allgather(comm, dst, gath, L.send_bytes, cs);
       if (rc != MIA_OK) return rc;
+      // With steps in flight (MIA_STEP_NO_JOIN) and a placement stream, the copy of the gathered piece into the result
+      // leaves the exchange stream: the next step's all-gather need not wait for 2 x world x piece bytes of HBM traffic
+      hipStream_t xs = cs;
+      if (comm->place_stream && (step_flags & MIA_STEP_NO_JOIN)) {
+        xs = comm->place_stream;
+        MIA_HIP_TRY(hipEventRecord(comm->evp[c], cs));
+        MIA_HIP_TRY(hipStreamWaitEvent(xs, comm->evp[c], 0));
+      }
       const int64_t off = (int64_t)c * L.nc;
       int32_t* ctr_out = (phase == 0 && c == n_chunks - 1) ? counters : nullptr;
       const bool vec = (L.nc % 4 == 0) && (G % 4 == 0) && (L.n % 4 == 0) && ((uintptr_t)Xa % 16 == 0);
       if (vec) {
         dim3 grid((unsigned)((L.nc / 4 + 255) / 256), (unsigned)rows, (unsigned)world);
-        place_chunk_kernel<4><<<grid, 256, 0, cs>>>(gath, Xa, G, L.n, off, (int)L.nc, rows, L.send_bytes / sizeof(float),
+        place_chunk_kernel<4><<<grid, 256, 0, xs>>>(gath, Xa, G, L.n, off, (int)L.nc, rows, L.send_bytes / sizeof(float),
                                                     ctr_out, rank);
       } else {
         dim3 grid((unsigned)((L.nc + 255) / 256), (unsigned)rows, (unsigned)world);
-        place_chunk_kernel<1><<<grid, 256, 0, cs>>>(gath, Xa, G, L.n, off, (int)L.nc, rows, L.send_bytes / sizeof(float),
+        place_chunk_kernel<1><<<grid, 256, 0, xs>>>(gath, Xa, G, L.n, off, (int)L.nc, rows, L.send_bytes / sizeof(float),
                                                     ctr_out, rank);
       }
       MIA_LAUNCH_CHECK();

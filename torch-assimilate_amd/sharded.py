@@ -245,6 +245,14 @@ class ShardedLetkf:
             # exchange stream at high priority: its (few, multi-wave) RCCL workgroups should be placed ahead of the
             # bulk analysis kernel's next workgroups when wave slots fall free, not queue behind 1e5 of them
             st["stream"] = torch.cuda.Stream(device=self.device, priority=-1)
+            if st["comm"] is not None:
+                # gathered pieces are copied into the result on a stream of their own, so that with steps in flight the
+                # next all-gather starts as soon as the previous one has landed
+                import ctypes as C
+                from . import _cabi
+                st["xstream"] = torch.cuda.Stream(device=self.device)
+                _cabi.check(self.engine.lib.mia_comm_set_place_stream(st["comm"], C.c_void_p(st["xstream"].cuda_stream)),
+                            "mia_comm_set_place_stream")
             self._native = st
         return self._native
 
@@ -374,7 +382,8 @@ class ShardedLetkf:
                 st["pstream"] = torch.cuda.Stream(device=X.device, priority=-1)
             comp, prep = st["astream"], st["pstream"]
             prep.wait_stream(cur)                                 # inputs (and `out`'s memory) are ready
-            last = st["stream"] if exch else comp                 # where the step's last work is enqueued
+            # where the step's last work is enqueued: the placement stream when there is one, else the exchange stream
+            last = (st.get("xstream") or st["stream"]) if exch else comp
         else:
             comp, prep, last = cur, None, cur
 
