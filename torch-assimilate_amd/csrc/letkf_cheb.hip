@@ -52,7 +52,13 @@ struct ChebParams {
   float* W;        // weights-output variant: [ng][k][k]
   // IEnKS update through the weights variant (tau = 1): 0 off, 1 transform (valid while Wp = I), 2 bundle (D = Yl / eps)
   int ienks; const float* ienks_Win; int64_t ienks_wstride; float ienks_inv_eps;
+  // launch-uniform scalars, prepared on the host (an IEEE division or square root is ~10 VALU instructions per
+  // wavefront, and the kernel is VALU-issue bound): 1/reg, sqrt(reg), sqrt((k-1)/reg), sqrt(k-1), 1/k
+  float inv_reg, sqrt_reg, f0_dual, sqrt_km1, inv_k;
 };
+
+// v_rcp_f32 (1 ulp) where a correctly rounded quotient buys nothing: degree selection, interval scale, function samples
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 using f32x4c = __attribute__((ext_vector_type(4))) float;
 
@@ -80,19 +86,19 @@ __device__ inline float matvec_row(const f2v (&srow2)[NMAX / 2], const float* tv
 
 // Chebyshev coefficients (phi_j, psi_j), j = 0 .. deg, of the two weight functions on [0, L]: samples at the deg + 1
 // Gauss nodes, then a cosine transform spread over the wavefront.  c2 / f2s: LDS scratch of 64 pairs each.
-__device__ __forceinline__ void cheb_coefficients(int tid, int deg, float L, float reg, float km1, float ar, bool dual,
+__device__ __forceinline__ void cheb_coefficients(int tid, int deg, float L, float reg, float sqrt_km1, float ar, bool dual,
                                                   f2v* f2s, f2v* c2) {
   const int N = deg + 1;
   {
-    const float invN = 1.0f / float(N);
+    const float invN = fast_rcp(float(N));
     if (tid < N) {
       const float x = __builtin_amdgcn_cosf(float(2 * tid + 1) * 0.25f * invN);     // cos(pi (i+1/2)/N), argument in turns
       const float lam = 0.5f * L * (x + 1.0f);
       const float le = lam + reg;
       const float u = __builtin_amdgcn_sqrtf(le);
       f2v f;
-      f.x = dual ? -sqrtf(km1) / (u * ar * (ar + u)) : sqrtf(km1) / u;
-      f.y = 1.0f / le;
+      f.x = dual ? -sqrt_km1 * fast_rcp(u * ar * (ar + u)) : sqrt_km1 * fast_rcp(u);
+      f.y = fast_rcp(le);
       f2s[tid] = f;
     }
     MIA_WAVE_SYNC();
@@ -132,6 +138,13 @@ __device__ __forceinline__ void cheb_coefficients(int tid, int deg, float L, flo
   }
 }
 
+// Do the coefficient tables (2 x 64 pairs) fit into the storage of S (full matrix, or the 16-row staging panel of the
+// streamed orders)?  Used by the kernel (layout) and by cheb_lds_bytes (size): keep them in step.
+__host__ __device__ constexpr bool cheb_alias_tables(int nmax) {
+  const int lda = (nmax % 8 == 0) ? nmax + 4 : nmax;
+  return nmax <= 32 && nmax * lda >= 4 * 64;      // (orders above 32 may stream S on the dual route and not on the primal)
+}
+
 constexpr int kRowBatch = 16;     // state rows per MFMA batch of the many-rows variant (one 16-column tile)
 
 template <int NMAX, int KL, bool FUSED, int WPB, bool SEG, int MODE = 0>   // MODE 1: many state rows, 2: weights output
@@ -157,9 +170,12 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
   float* tv = S + (stream_s ? 16 : NMAX) * LDA;     // [NMAX] recurrence vector (broadcast source)
   float* rhs = tv + NMAX;                           // [NMAX]
   float* uq = rhs + NMAX;                           // [NMAX] scratch (RBF centring)
-  f2v* c2 = reinterpret_cast<f2v*>(uq + NMAX);      // [DCAP] Chebyshev coefficients (phi_j, psi_j)
+  // Scalar-rows variant: the coefficient tables live where S was -- S is dead once its rows sit in the lanes'
+  // registers, before the first coefficient is computed -- which is 1 KB of the 7 KB a C2 wavefront needs
+  constexpr bool ALIAS_C = MODE == 0 && cheb_alias_tables(NMAX);
+  f2v* c2 = reinterpret_cast<f2v*>(ALIAS_C ? S : uq + NMAX);   // [DCAP] Chebyshev coefficients (phi_j, psi_j)
   f2v* f2s = c2 + DCAP;                             // [DCAP] function samples (phi, psi) at the Chebyshev nodes
-  float* red = reinterpret_cast<float*>(f2s + DCAP);   // [8]
+  float* red = ALIAS_C ? uq + NMAX : reinterpret_cast<float*>(f2s + DCAP);   // [8]
   float* xp = red + 8;                              // [kp]
   float* sw = xp + kp;                              // [NMAX] phi(S) z
   float* Yt = sw + NMAX;                            // [rows][kp]
@@ -193,8 +209,8 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
   if (P.xskip & 16) return;            // experiment: dispatch floor
   int flag = 0;
   const float km1 = float(k - 1), reg = P.reg;
-  const float ar = sqrtf(reg);
-  const float f0 = P.dual ? sqrtf(km1 / reg) : 0.0f;
+  const float ar = P.sqrt_reg;
+  const float f0 = P.dual ? P.f0_dual : 0.0f;
   float xval[KL];
 #pragma unroll
   for (int u = 0; u < KL; ++u) { const int i = tid + 64 * u; xval[u] = (MODE != 2 && i < k) ? P.X[(int64_t)i * P.ldx + g] : 0.0f; }
@@ -231,27 +247,35 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
       // consumed (one memory round trip for the usual <= 256 quads instead of one per 64), and the quad ->
       // (observation, column) split is a multiply-shift (P.kpv_magic = ceil(2^20 / kpv), exact below 2^20 / kpv
       // quads) instead of an integer division per quad
-    const int kpv = kp >> 2;
-    const int total = ((P.xskip & 1) || !P.dual) ? 0 : cnt * kpv;   // (the primal route streams the records, see below)
+    const unsigned kpv = (unsigned)kp >> 2;
+    const int total = ((P.xskip & 1) || !P.dual) ? 0 : cnt * (int)kpv;   // (the primal route streams the records, see below)
     constexpr int GQ = NMAX > 32 ? 8 : 4;       // quads in flight per lane: large blocks (config 4: 1344 quads) run at
                                                 // few waves per CU, so each trip's memory latency is exposed
+    // Quad `it` of the block IS quad `it` of Yt (row j, column c <-> j kpv + c), so the store needs no index at all; the
+    // load address is one 32 x 32 -> 64 bit multiply-add on the (non-negative) list entry.  it * magic < 2^27 here
+    // (it < 64 kpv on the dual route): the split stays in 32-bit arithmetic.
+    const float4* rec4 = reinterpret_cast<const float4*>(P.rec);
+    float4* Yt4 = reinterpret_cast<float4*>(Yt);
     for (int base = 0; base < total; base += 64 * GQ) {
       float4 v[GQ];
-      int jj[GQ], cc[GQ];
+      unsigned jj[GQ];
 #pragma unroll
       for (int u = 0; u < GQ; ++u) {
-        const int it = base + 64 * u + tid;
-        const int j = (int)(((unsigned long long)(unsigned)it * (unsigned)P.kpv_magic) >> 20);
-        jj[u] = j; cc[u] = it - j * kpv;
-        if (it < total) v[u] = reinterpret_cast<const float4*>(P.rec + (int64_t)lidx[j] * kp)[cc[u]];
+        // (lanes beyond the block re-read quad 0: an unconditional load -- a predicated one made hipcc wait for
+        //  vmcnt(0) before each of the GQ requests, i.e. GQ memory round trips instead of one)
+        const unsigned it = base + 64 * u + tid < total ? (unsigned)(base + 64 * u + tid) : 0u;
+        const unsigned j = (it * (unsigned)P.kpv_magic) >> 20;
+        jj[u] = j;
+        v[u] = rec4[(uint64_t)(unsigned)lidx[j] * kpv + (it - j * kpv)];
       }
 #pragma unroll
       for (int u = 0; u < GQ; ++u) {
-        if (base + 64 * u + tid < total) {
+        const int it = base + 64 * u + tid;
+        if (it < total) {
           const float wj = lw[jj[u]];
           float4 t = v[u];
           t.x *= wj; t.y *= wj; t.z *= wj; t.w *= wj;
-          reinterpret_cast<float4*>(Yt + (size_t)jj[u] * kp)[cc[u]] = t;
+          Yt4[it] = t;
         }
       }
     }
@@ -347,6 +371,24 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) acc[t] = f32x4c{0.f, 0.f, 0.f, 0.f};
     const bool kfull = (k & 3) == 0;
+    if ((k & 7) == 0) {
+      // k a multiple of 8: a lane's KS members are an even number of floats at an 8-byte aligned address -- two K steps
+      // per 64-bit LDS read, no per-step predicate (the general loop below spends ~10 VALU and two exec-mask
+      // round trips per K step on a kernel that is VALU-issue bound)
+#pragma unroll 5
+      for (int s_ = 0; s_ < KS; s_ += 2) {
+        f2v av_[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) av_[t] = *reinterpret_cast<const f2v*>(prow[t] + s_);
+#pragma unroll
+        for (int tb_ = 0, tile = 0; tb_ < TT; ++tb_)
+#pragma unroll
+          for (int ta_ = 0; ta_ <= tb_; ++ta_, ++tile) {
+            acc[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[ta_].x, av_[tb_].x, acc[tile], 0, 0, 0);
+            acc[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[ta_].y, av_[tb_].y, acc[tile], 0, 0, 0);
+          }
+      }
+    } else {
 #pragma unroll 5
     for (int s_ = 0; s_ < KS; ++s_) {
       float av_[TT];
@@ -357,6 +399,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
 #pragma unroll
         for (int ta_ = 0; ta_ <= tb_; ++ta_, ++tile)
           acc[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[ta_], av_[tb_], acc[tile], 0, 0, 0);
+    }
     }
 #pragma unroll
     for (int tb_ = 0, tile = 0; tb_ < TT; ++tb_)
@@ -487,9 +530,9 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
   float L = wave_max_dpp(tid < NMAX ? rsum : 0.0f);
   L = fmaxf(L, 1e-30f * reg) * 1.0001f;
   // ---- degree from the Bernstein-ellipse parameter of the singularity at -reg
-  const float sq = sqrtf(1.0f + L / reg);
-  const float rho = (sq + 1.0f) / fmaxf(sq - 1.0f, 1e-12f);
-  int deg = (int)ceilf(P.log_tol / __logf(rho)) + 2;
+  const float sq = __builtin_amdgcn_sqrtf(fmaf(L, P.inv_reg, 1.0f));
+  const float rho = (sq + 1.0f) * fast_rcp(fmaxf(sq - 1.0f, 1e-12f));
+  int deg = (int)ceilf(P.log_tol * fast_rcp(__logf(rho))) + 2;
   deg = deg < 3 ? 3 : deg;
   if (P.xskip & 4) deg = 3;
   if (!(L == L) || !(fabsf(L) < 1e30f)) { flag |= MIA_FLAG_NONFINITE; deg = 3; }
@@ -500,8 +543,9 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     }
     return;
   }
-  cheb_coefficients(tid, deg, L, reg, km1, ar, P.dual != 0, f2s, c2);
-  const float alpha = 2.0f / L;            // A v = alpha S v - v
+  if constexpr (ALIAS_C) MIA_WAVE_SYNC();     // the rows of S have been read: its storage becomes the coefficient tables
+  cheb_coefficients(tid, deg, L, reg, P.sqrt_km1, ar, P.dual != 0, f2s, c2);
+  const float alpha = 2.0f * fast_rcp(L);  // A v = alpha S v - v
   if constexpr (MODE == 1) {
     // ---- many state rows: kRowBatch rows at a time as ONE matrix recurrence on the matrix cores.
     //      T (n x 16) lives in the MFMA result layout (lane (lr, h) holds T[16 t + 4 h + q][lr], q = 0..3); every step
@@ -935,7 +979,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     float xs = 0.0f;
 #pragma unroll
     for (int u = 0; u < KL; ++u) xs += xval[u];
-    const float xm = wave_sum_dpp(xs) / float(k);
+    const float xm = wave_sum_dpp(xs) * P.inv_k;
 #pragma unroll
     for (int u = 0; u <= KL; ++u) {         // one pass more than members per lane: zero the d / pad slots
       const int i = tid + 64 * u;
@@ -946,9 +990,12 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     if (tid < NMAX) {
       if (P.dual) {
         if (tid < cnt) {
-          const float4* yb = reinterpret_cast<const float4*>(Yt + (size_t)tid * kp);
-          const float4* x4 = reinterpret_cast<const float4*>(xp);
-          for (int i = 0; i < k4; ++i) { const float4 y = yb[i], x = x4[i]; t0 += y.x * x.x + y.y * x.y + y.z * x.z + y.w * x.w; }
+          const f4v* yb = reinterpret_cast<const f4v*>(Yt + (size_t)tid * kp);
+          const f4v* x4 = reinterpret_cast<const f4v*>(xp);
+          f2v a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f};          // (pad columns of xp are zero)
+          for (int i = 0; i < k4; ++i) { const f4v y = yb[i], x = x4[i]; a0 = y.xy * x.xy + a0; a1 = y.zw * x.zw + a1; }
+          const f2v a = a0 + a1;
+          t0 = a.x + a.y;
         }
       } else t0 = tid < k ? xp[tid] : 0.0f;
       tv[tid] = t0;
@@ -1003,7 +1050,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
 }
 
 template <int NMAX, int KL, bool FUSED, int WPB>
-__global__ __launch_bounds__(64 * WPB, (NMAX <= 24 ? 5 : (NMAX <= 40 ? 4 : 2))) void letkf_cheb_kernel(ChebParams P) {
+__global__ __launch_bounds__(64 * WPB, (NMAX <= 24 ? (FUSED || KL > 1 ? 5 : 6) : (NMAX <= 40 ? 4 : 2))) void letkf_cheb_kernel(ChebParams P) {
   letkf_cheb_point<NMAX, KL, FUSED, WPB, false>(P);
 }
 
@@ -1078,7 +1125,7 @@ __global__ __launch_bounds__(64) void letkf_cheb_big_kernel(ChebParams P) {
   const int64_t pt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);   // XCD-aware point map
   const int64_t g = P.g0 + pt, ocol = P.o0 + pt;
   int flag = 0;
-  const float km1 = float(k - 1), reg = P.reg, ar = sqrtf(reg);
+  const float km1 = float(k - 1), reg = P.reg, ar = P.sqrt_reg;
   const int nl = pm < P.p_cap ? pm : P.p_cap;
   for (int j = tid; j < nl; j += 64) { lidx[j] = P.idx[pt * P.p_cap + j]; lw[j] = float(P.w[pt * P.p_cap + j]); }
   const int cnt = P.cnt[pt];
@@ -1180,7 +1227,7 @@ __global__ __launch_bounds__(64) void letkf_cheb_big_kernel(ChebParams P) {
     if (tid == 0) { if (P.flags) P.flags[pt] = MIA_FLAG_RETRY; atomicAdd(P.retry_count, 1); }
     return;
   }
-  cheb_coefficients(tid, deg, L, reg, km1, ar, false, f2s, c2);
+  cheb_coefficients(tid, deg, L, reg, P.sqrt_km1, ar, false, f2s, c2);
   const float alpha = 2.0f / L;
   float rhs_r[R];
 #pragma unroll
@@ -1266,7 +1313,8 @@ static int cheb_launch_big(const ChebParams& ap, hipStream_t stream) {
 static size_t cheb_lds_bytes(int kp, int p_max, int nmax, int rows, bool dual, bool batch = false, int k_weights = 0) {
   const int lda = (nmax % 8 == 0) ? nmax + 4 : nmax;
   const int srows = (dual && nmax > 32) ? 16 : nmax;      // streamed S: staging panel only (see letkf_cheb_point)
-  size_t e = (size_t)srows * lda + 4 * (size_t)nmax + 4 * 64 + 8 + (size_t)kp + (size_t)(rows + 1) * kp + ((p_max + 3) & ~1);
+  const bool alias = !batch && !k_weights && cheb_alias_tables(nmax);   // scalar-rows variant: tables inside S
+  size_t e = (size_t)srows * lda + 4 * (size_t)nmax + (alias ? 0 : 4 * 64) + 8 + (size_t)kp + (size_t)(rows + 1) * kp + ((p_max + 3) & ~1);
   if (batch) e += (size_t)kRowBatch * kp + (size_t)((nmax + 15) & ~15) * kRowBatch + (size_t)nmax;
   if (k_weights) {
     const size_t np = (size_t)((nmax + 15) & ~15), kp16 = (size_t)((k_weights + 15) & ~15);
@@ -1370,6 +1418,11 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
   ap.kpv_magic = ((1 << 20) + (ap.kp >> 2) - 1) / (ap.kp >> 2);
   ap.cnt = nbr_cnt; ap.idx = nbr_idx; ap.w = nbr_w; ap.p_cap = p_cap; ap.p_max = p_max;
   ap.reg = float(k - 1) / inf_factor;
+  ap.inv_reg = (float)(1.0 / (double)ap.reg);
+  ap.sqrt_reg = (float)sqrt((double)ap.reg);
+  ap.f0_dual = (float)sqrt((double)(k - 1) / (double)ap.reg);
+  ap.sqrt_km1 = (float)sqrt((double)(k - 1));
+  ap.inv_k = (float)(1.0 / (double)k);
   ap.Xa = Xa; ap.ldo = ldo; ap.o0 = o0; ap.flags = flags; ap.retry_count = retry_count;
   ap.kernel_mode = kernel_mode; ap.gamma = gamma;
   ap.dual = (kernel_mode == 0 && p_max <= k) ? 1 : 0;
