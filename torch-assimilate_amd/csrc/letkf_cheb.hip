@@ -84,6 +84,21 @@ __device__ inline float matvec_row(const f2v (&srow2)[NMAX / 2], const float* tv
 // and the compiler may not move memory operations across (the waves of a workgroup are independent here)
 #define MIA_WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 
+// v + (v of lane ^ 32) and v + (v of lane ^ 16) through gfx950's row-swap instructions (v_permlane32_swap exchanges
+// the upper half of its first operand with the lower half of the second, v_permlane16_swap the odd rows of the first
+// with the even rows of the second: with both operands equal the two results are the two halves / row pairs, each
+// spread over the wave).  A ds_bpermute-based __shfl_xor is ~10 instructions, this is 2.
+__device__ __forceinline__ float add_xor32(float v) {
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  const u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float add_xor16(float v) {
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  const u2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
 // Chebyshev coefficients (phi_j, psi_j), j = 0 .. deg, of the two weight functions on [0, L]: samples at the deg + 1
 // Gauss nodes, then a cosine transform spread over the wavefront.  c2 / f2s: LDS scratch of 64 pairs each.
 __device__ __forceinline__ void cheb_coefficients(int tid, int deg, float L, float reg, float sqrt_km1, float ar, bool dual,
@@ -127,8 +142,8 @@ __device__ __forceinline__ void cheb_coefficients(int tid, int deg, float L, flo
           a = f2s[i] * c + a;
         }
       }
-      if (sh <= 5) { a.x += __shfl_xor(a.x, 32, 64); a.y += __shfl_xor(a.y, 32, 64); }
-      if (sh == 4) { a.x += __shfl_xor(a.x, 16, 64); a.y += __shfl_xor(a.y, 16, 64); }
+      if (sh <= 5) { a.x = add_xor32(a.x); a.y = add_xor32(a.y); }
+      if (sh == 4) { a.x = add_xor16(a.x); a.y = add_xor16(a.y); }
       if (tid < N) {
         const float sc = (tid == 0 ? 1.0f : 2.0f) * invN;
         c2[tid] = a * sc;
@@ -225,12 +240,12 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
   } else {
     // count, list entries and the state row are all requested before anything is waited for: one memory
     // round trip instead of a count -> entries chain (entries beyond the count are loaded and ignored)
+    cnt = P.cnt[pt];                           // (first in program order: hipcc issued it after the loop's own wait)
     const int nl = pm < P.p_cap ? pm : P.p_cap;
     for (int j = tid; j < nl; j += 64) {       // (one trip for the dual route: p_max <= 64)
       lidx[j] = P.idx[pt * P.p_cap + j];
       lw[j] = float(P.w[pt * P.p_cap + j]) * (MODE == 2 && P.ienks == 2 ? P.ienks_inv_eps : 1.0f);
     }
-    cnt = P.cnt[pt];
   }
   if (cnt > pm || (!FUSED && cnt > P.p_cap) || (P.dual ? cnt : k) > NMAX) {   // loud failure, never truncate
     if (P.flags && tid == 0) P.flags[pt] = MIA_FLAG_OVERFLOW;
@@ -375,11 +390,12 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
       // k a multiple of 8: a lane's KS members are an even number of floats at an 8-byte aligned address -- two K steps
       // per 64-bit LDS read, no per-step predicate (the general loop below spends ~10 VALU and two exec-mask
       // round trips per K step on a kernel that is VALU-issue bound)
+      const int KS2 = KS >> 1;
 #pragma unroll 5
-      for (int s_ = 0; s_ < KS; s_ += 2) {
+      for (int s2 = 0; s2 < KS2; ++s2) {
         f2v av_[TT];
 #pragma unroll
-        for (int t = 0; t < TT; ++t) av_[t] = *reinterpret_cast<const f2v*>(prow[t] + s_);
+        for (int t = 0; t < TT; ++t) av_[t] = reinterpret_cast<const f2v*>(prow[t])[s2];
 #pragma unroll
         for (int tb_ = 0, tile = 0; tb_ < TT; ++tb_)
 #pragma unroll
@@ -527,12 +543,12 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     }
   }
   const float rhs_r = tid < NMAX ? rhs[tid] : 0.0f;
-  float L = wave_max_dpp(tid < NMAX ? rsum : 0.0f);
+  float L = wave_max_nonneg_dpp(tid < NMAX ? rsum : 0.0f);     // (a NaN row sum survives as the maximum)
   L = fmaxf(L, 1e-30f * reg) * 1.0001f;
   // ---- degree from the Bernstein-ellipse parameter of the singularity at -reg
   const float sq = __builtin_amdgcn_sqrtf(fmaf(L, P.inv_reg, 1.0f));
-  const float rho = (sq + 1.0f) * fast_rcp(fmaxf(sq - 1.0f, 1e-12f));
-  int deg = (int)ceilf(P.log_tol * fast_rcp(__logf(rho))) + 2;
+  const float rho = (sq + 1.0f) * fast_rcp(fmaxf(sq - 1.0f, 1e-12f));     // in (1, 2e12]: v_log_f32 needs no range fix
+  int deg = (int)ceilf(P.log_tol * fast_rcp(0.6931471806f * __builtin_amdgcn_logf(rho))) + 2;
   deg = deg < 3 ? 3 : deg;
   if (P.xskip & 4) deg = 3;
   if (!(L == L) || !(fabsf(L) < 1e30f)) { flag |= MIA_FLAG_NONFINITE; deg = 3; }
@@ -1070,7 +1086,7 @@ __global__ __launch_bounds__(64, (NMAX <= 24 ? 4 : (NMAX <= 32 ? 3 : 2))) void l
 // the analysis on, has its output written through to memory and then counts itself in its segment's slot counters.
 // A waiter on another stream (segment_wait_kernel) sees a segment complete while later segments still run.
 template <int NMAX, int KL>
-__global__ __launch_bounds__(64, (NMAX <= 24 ? 5 : (NMAX <= 40 ? 4 : 2))) void letkf_cheb_seg_kernel(ChebParams P) {
+__global__ __launch_bounds__(64, (NMAX <= 24 ? (KL > 1 ? 5 : 6) : (NMAX <= 40 ? 4 : 2))) void letkf_cheb_seg_kernel(ChebParams P) {
   letkf_cheb_point<NMAX, KL, false, 1, true>(P);
   const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
   if (bid >= P.ng) return;

@@ -110,5 +110,19 @@ __device__ inline float wave_max_dpp(float v) {
   v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false)));
   return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
 }
+// maximum over the wave of values that are >= +0 or NaN: their bit patterns order like the values (NaN above all), so
+// the integer maximum folds into the DPP instruction (fmaxf adds a canonicalising v_max per step)
+__device__ inline float wave_max_nonneg_dpp(float v) {
+  unsigned u = __float_as_uint(v);
+  unsigned t;
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0xB1, 0xf, 0xf, false); u = u > t ? u : t;
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x4E, 0xf, 0xf, false); u = u > t ? u : t;
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x124, 0xf, 0xf, false); u = u > t ? u : t;
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x128, 0xf, 0xf, false); u = u > t ? u : t;
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)u, 0), b = (unsigned)__builtin_amdgcn_readlane((int)u, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)u, 32), d = (unsigned)__builtin_amdgcn_readlane((int)u, 48);
+  const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+  return __uint_as_float(ab > cd ? ab : cd);
+}
 
 }  // namespace mia
