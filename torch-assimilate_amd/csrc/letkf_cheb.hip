@@ -1009,6 +1009,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
           const f4v* yb = reinterpret_cast<const f4v*>(Yt + (size_t)tid * kp);
           const f4v* x4 = reinterpret_cast<const f4v*>(xp);
           f2v a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f};          // (pad columns of xp are zero)
+#pragma unroll 2
           for (int i = 0; i < k4; ++i) { const f4v y = yb[i], x = x4[i]; a0 = y.xy * x.xy + a0; a1 = y.zw * x.zw + a1; }
           const f2v a = a0 + a1;
           t0 = a.x + a.y;
@@ -1043,7 +1044,8 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
       if (j < k) {
         float acc;
         if (P.dual) {   // Yl s from the LDS block (still resident on this route; member j contiguous across lanes)
-          acc = f0 * (xval[u] - xm);
+          acc = f0 * xp[j];                        // x' of member j (kept in LDS, not in a register across the recurrence)
+#pragma unroll 4
           for (int b = 0; b < ((P.xskip & 8) ? 0 : cnt); ++b) acc += sw[b] * Yt[(size_t)b * kp + j];
         } else acc = sw[j];
         const float out = mterm + acc;

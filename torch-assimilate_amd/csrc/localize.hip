@@ -131,61 +131,51 @@ __device__ inline int obs_cell(const IndexHeader* h, const double* x, int nc) {
   return id;
 }
 
-// exclusive scan of start[0 .. ncell] by one workgroup (entry ncell receives the total), in tiles of 8 entries per
-// thread: the 8 loads of a thread are independent (one memory round trip per tile), wave scan by shuffles, the
-// waves' totals and the running carry go through LDS.
-__device__ inline void index_scan_block(const IndexParams& p, int* wsum) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nt = blockDim.x, nw = nt >> 6;
+// exclusive scan of start[0 .. ncell] (entry ncell receives the total) by ONE wavefront, in tiles of 16 entries per
+// lane: the 16 loads of a lane are independent (one memory round trip per tile), the wave scan runs on shuffles and the
+// carry stays in a register.  A launch of its own with a single-wave workgroup, not the tail of the counting kernel's
+// last 256-thread workgroup as it used to be: when consecutive steps are pipelined these kernels run beside the
+// previous step's analysis kernel, which keeps 6 waves x 80 VGPRs on every SIMD.  That leaves 32 VGPRs per SIMD, so
+// a 4-wave workgroup that needs more (the fused kernel took 61) finds no CU until the analysis grid has drained
+// (160 us instead of 22), while a single wave gets the slot of the next analysis wave that retires.
+__global__ __launch_bounds__(64) void index_scan_kernel(IndexParams p) {
+  MIA_PREP_PRIORITY();
+  constexpr int T = 16;
+  const int lane = threadIdx.x;
   const int n = p.hdr->ncell + 1;
   int carry = 0;
-  for (int base = 0; base < n; base += nt * 8) {
-    const int lo = base + tid * 8;
-    int vals[8];
+  for (int base = 0; base < n; base += 64 * T) {
+    const int lo = base + lane * T;
+    int vals[T];
     int sum = 0;
-    // counts were accumulated by other workgroups' atomics: read them at the same scope
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < T; ++u) {
       const int i = lo + u;
-      vals[u] = (i < n - 1) ? __hip_atomic_load(&p.start[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      vals[u] = (i < n - 1) ? p.start[i] : 0;      // (counts of the previous kernel: visible at its end)
       sum += vals[u];
     }
     int x = sum;
     for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-    __syncthreads();                       // the previous tile's wsum has been consumed
-    if (lane == 63) wsum[wv] = x;
-    __syncthreads();
-    int off = carry + x - sum, total = 0;
-    for (int w = 0; w < nw; ++w) { if (w < wv) off += wsum[w]; total += wsum[w]; }
+    int off = carry + x - sum;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < T; ++u) {
       if (lo + u < n) p.start[lo + u] = off;
       off += vals[u];
     }
-    carry += total;
+    carry += __shfl(x, 63, 64);
   }
 }
 
-// cell of every observation + per-cell counts; the workgroup that finishes last turns the counts into
-// exclusive starts (saves the dispatch of a one-workgroup scan kernel).  256-thread workgroups: when consecutive
-// steps are pipelined this kernel runs beside the previous step's analysis kernel, whose one-wave workgroups
-// fill every CU -- a 1024-thread workgroup then waits ~130 us for sixteen wave slots to fall free on ONE CU.
-__global__ __launch_bounds__(256) void index_count_scan_kernel(IndexParams p) {
+// cell of every observation + per-cell counts.  256-thread workgroups of 15 VGPRs: they fit beside the analysis
+// kernel's waves (see index_scan_kernel).
+__global__ __launch_bounds__(256) void index_count_kernel(IndexParams p) {
   MIA_PREP_PRIORITY();
-  __shared__ int wsum[4];
-  __shared__ int is_last;
   const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (j < p.P) {
     const int c = obs_cell(p.hdr, p.obs + j * p.nc, p.nc);
     p.cell_of[j] = c;
     atomicAdd(&p.start[c], 1);
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned done = __hip_atomic_fetch_add(&p.hdr->done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = done == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (is_last) index_scan_block(p, wsum);
 }
 
 __global__ void index_scatter_kernel(IndexParams p) {
@@ -445,7 +435,9 @@ int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_
   }
   index_bbox_dims_kernel<<<dim3(ip.nb_bbox + nb_pack), dim3(256), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
-  index_count_scan_kernel<<<dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream>>>(ip);
+  index_count_kernel<<<dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream>>>(ip);
+  MIA_LAUNCH_CHECK();
+  index_scan_kernel<<<dim3(1), dim3(64), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
   index_scatter_kernel<<<dim3(nbP), dim3(256), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
