@@ -26,6 +26,9 @@
 // against the broadcast vector (LDS float4 reads of one address = broadcast), one LDS write of the new
 // vector.  The Gram matrix comes from the matrix cores (v_mfma_f32_16x16x4_f32) as in letkf_sys.hip.
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
 #include "mia_common.h"
 #include "mia_localize_dev.h"
 #include "mia_kernels.h"
@@ -55,7 +58,87 @@ struct ChebParams {
   // launch-uniform scalars, prepared on the host (an IEEE division or square root is ~10 VALU instructions per
   // wavefront, and the kernel is VALU-issue bound): 1/reg, sqrt(reg), sqrt((k-1)/reg), sqrt(k-1), 1/k
   float inv_reg, sqrt_reg, f0_dual, sqrt_km1, inv_k;
+  // coefficient table (see CoefTable below); tab_hdr == nullptr: coefficients are computed in the kernel
+  const int2* tab_hdr; const float2* tab_c; float cs_phi, cs_psi;
 };
+
+// ---- Chebyshev coefficients from a table ------------------------------------------------------------------------
+// In the scaled variable t = lambda / reg both weight functions are universal up to a factor,
+//     dual    phi = sqrt(k-1) reg^-3/2 * [ -1 / (sqrt(t+1) (1 + sqrt(t+1))) ],    psi = reg^-1 * [ 1 / (t+1) ]
+//     primal  phi = sqrt(k-1) reg^-1/2 * [  1 / sqrt(t+1) ],
+// so their Chebyshev coefficients on [0, T] depend on T alone.  The spectral bound T = L / reg of a grid point is rounded
+// UP to the next point of a geometric grid (32 per octave, 2^-24 .. 2^8: an expansion on a larger interval stays valid
+// and costs < 2.2 % of interval, i.e. ~1 % of degree) and the coefficients of that grid point are read from a table built
+// once per device, route and truncation target -- in float64, by the same Gauss-node cosine transform.  In the kernel
+// the degree selection (sqrt, two reciprocals, log) and the transform (N samples, N x N cosines spread over the wave)
+// were ~160 of the ~840 VALU instructions of a C2 analysis; the lookup is a v_log, one 8-byte and one 512-byte read.
+constexpr int kTabPerOctave = 32, kTabIdx0 = 24 * kTabPerOctave, kTabN = 32 * kTabPerOctave, kTabDeg = 64;
+
+__global__ __launch_bounds__(64) void cheb_table_kernel(int2* hdr, float2* c, int dual, double log_tol) {
+  __shared__ double fs[kTabDeg][2];
+  const int idx = blockIdx.x, tid = threadIdx.x;
+  const double T = exp2(double(idx - kTabIdx0) / double(kTabPerOctave));
+  const double sq = sqrt(1.0 + T);
+  const double rho = (sq + 1.0) / fmax(sq - 1.0, 1e-12);
+  double dd = ceil(log_tol / log(rho)) + 2.0;
+  dd = dd < 3.0 ? 3.0 : (dd > 32767.0 ? 32767.0 : dd);
+  const int deg = (int)dd;
+  if (tid == 0) hdr[idx] = make_int2(deg, __float_as_int((float)(2.0 / T)));
+  c[(size_t)idx * kTabDeg + tid] = make_float2(0.0f, 0.0f);
+  if (deg > kTabDeg - 1) return;                      // the kernel declines such points (eigensolver route)
+  const int N = deg + 1;
+  if (tid < N) {
+    const double x = cospi((tid + 0.5) / double(N));
+    const double u = sqrt(0.5 * T * (x + 1.0) + 1.0);   // sqrt(t + 1)
+    fs[tid][0] = dual ? -1.0 / (u * (1.0 + u)) : 1.0 / u;
+    fs[tid][1] = 1.0 / (u * u);
+  }
+  __syncthreads();
+  if (tid < N) {
+    double a0 = 0.0, a1 = 0.0;
+    for (int i = 0; i < N; ++i) {
+      const double cs = cospi(double((long long)tid * (2 * i + 1) % (4LL * N)) / double(2 * N));
+      a0 += fs[i][0] * cs; a1 += fs[i][1] * cs;
+    }
+    const double sc = (tid == 0 ? 1.0 : 2.0) / double(N);
+    c[(size_t)idx * kTabDeg + tid] = make_float2((float)(a0 * sc), (float)(a1 * sc));
+  }
+}
+
+struct CoefTable { int device; int dual; float log_tol; int2* hdr; float2* c; };
+// nullptr pair when the table cannot be had (allocation failure, stream being captured): the kernel then computes
+// its coefficients itself.  Built synchronously on first use (one 1024-workgroup launch, ~0.1 ms, then a wait for
+// that stream): afterwards the table is immutable and visible to every stream of the device.
+static const CoefTable* cheb_coef_table(int dual, float log_tol, hipStream_t stream) {
+  static std::mutex mu;
+  static std::vector<CoefTable*> tabs;
+  if (getenv("MIA_CHEB_NO_TABLE")) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> lock(mu);
+  for (const CoefTable* t : tabs)
+    if (t->device == dev && t->dual == dual && t->log_tol == log_tol) return t;
+  if (tabs.size() >= 64) return nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+  CoefTable* t = new CoefTable{dev, dual, log_tol, nullptr, nullptr};
+  if (hipMalloc((void**)&t->hdr, sizeof(int2) * kTabN) != hipSuccess ||
+      hipMalloc((void**)&t->c, sizeof(float2) * kTabN * kTabDeg) != hipSuccess) {
+    (void)hipGetLastError();
+    if (t->hdr) (void)hipFree(t->hdr);
+    delete t;
+    return nullptr;
+  }
+  cheb_table_kernel<<<dim3(kTabN), dim3(64), 0, stream>>>(t->hdr, t->c, dual, (double)log_tol);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(t->hdr); (void)hipFree(t->c);
+    delete t;
+    return nullptr;
+  }
+  tabs.push_back(t);
+  return t;
+}
 
 // v_rcp_f32 (1 ulp) where a correctly rounded quotient buys nothing: degree selection, interval scale, function samples
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -160,6 +243,20 @@ __host__ __device__ constexpr bool cheb_alias_tables(int nmax) {
   return nmax <= 32 && nmax * lda >= 4 * 64;      // (orders above 32 may stream S on the dual route and not on the primal)
 }
 
+// Compact LDS layout of the scalar-rows variant on the dual route (orders 20 .. 32): everything but the local block Yt
+// takes its turn in the storage of S --
+//   until the Gram product:  neighbour list (weights, indices) and the all-zero panel row,
+//   Gram product -> rows:    S,
+//   afterwards:              coefficient tables (2 x 64 pairs), recurrence vector, phi(S) z, 8 scalars, x'
+// and the right-hand side is read from Yt's innovation column where it is needed.  C2 (order 20, k = 40): 5120 B per
+// wavefront instead of 6000 -- four LDS allocation granules of 1280 B instead of five, i.e. 32 instead of 25 wavefronts
+// per CU as far as LDS goes (the 70 VGPRs allow 28).  Used by the kernel (layout) and cheb_lds_bytes (size).
+__host__ __device__ constexpr bool cheb_compact_layout(int nmax, int kp, int p_max, bool dual, bool fused) {
+  const int lda = (nmax % 8 == 0) ? nmax + 4 : nmax;
+  const int pmr = (p_max + 3) & ~1;
+  return dual && !fused && nmax >= 20 && nmax <= 32 && 4 * 64 + 2 * nmax + 8 + kp <= nmax * lda && 2 * pmr + kp <= nmax * lda;
+}
+
 constexpr int kRowBatch = 16;     // state rows per MFMA batch of the many-rows variant (one 16-column tile)
 
 template <int NMAX, int KL, bool FUSED, int WPB, bool SEG, int MODE = 0>   // MODE 1: many state rows, 2: weights output
@@ -182,20 +279,23 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
   constexpr bool STREAM_OK = NMAX > 32;
   const bool stream_s = STREAM_OK && P.dual;
   float* S = reinterpret_cast<float*>(smem_raw + (size_t)wave * P.lds_per_wave);    // [NMAX][LDA] full symmetric | [16][LDA] staging
-  float* tv = S + (stream_s ? 16 : NMAX) * LDA;     // [NMAX] recurrence vector (broadcast source)
-  float* rhs = tv + NMAX;                           // [NMAX]
-  float* uq = rhs + NMAX;                           // [NMAX] scratch (RBF centring)
+  const bool compact = MODE == 0 && cheb_compact_layout(NMAX, kp, pm, P.dual != 0, FUSED);   // (see cheb_compact_layout)
+  const int pmr = (pm + 3) & ~1;
+  float* tv = compact ? S + 4 * DCAP : S + (stream_s ? 16 : NMAX) * LDA;     // [NMAX] recurrence vector (broadcast source)
+  float* rhs = tv + NMAX;                           // [NMAX]   (compact: not there -- Yt's innovation column is read instead)
+  float* uq = rhs + NMAX;                           // [NMAX] scratch (RBF centring; primal route only)
   // Scalar-rows variant: the coefficient tables live where S was -- S is dead once its rows sit in the lanes'
   // registers, before the first coefficient is computed -- which is 1 KB of the 7 KB a C2 wavefront needs
   constexpr bool ALIAS_C = MODE == 0 && cheb_alias_tables(NMAX);
   f2v* c2 = reinterpret_cast<f2v*>(ALIAS_C ? S : uq + NMAX);   // [DCAP] Chebyshev coefficients (phi_j, psi_j)
   f2v* f2s = c2 + DCAP;                             // [DCAP] function samples (phi, psi) at the Chebyshev nodes
-  float* red = ALIAS_C ? uq + NMAX : reinterpret_cast<float*>(f2s + DCAP);   // [8]
+  float* red = compact ? tv + 2 * NMAX : (ALIAS_C ? uq + NMAX : reinterpret_cast<float*>(f2s + DCAP));   // [8]
   float* xp = red + 8;                              // [kp]
-  float* sw = xp + kp;                              // [NMAX] phi(S) z
-  float* Yt = sw + NMAX;                            // [rows][kp]
-  float* lw = Yt + (size_t)(P.rows + 1) * kp;       // [pm + 2]   (Yt has one extra, all-zero row)
-  int* lidx = reinterpret_cast<int*>(lw + ((pm + 3) & ~1));   // [pm + 2]
+  float* sw = compact ? tv + NMAX : xp + kp;        // [NMAX] phi(S) z
+  float* Yt = compact ? S + NMAX * LDA : sw + NMAX; // [rows][kp]
+  float* lw = compact ? S : Yt + (size_t)(P.rows + 1) * kp;       // [pm + 2]   (Yt has one extra, all-zero row)
+  int* lidx = reinterpret_cast<int*>(lw + pmr);     // [pm + 2]
+  float* zrow = compact ? S + 2 * pmr : Yt + (size_t)P.rows * kp;   // [kp] all-zero row of the Gram panels
   // many-rows variant only: a batch of state rows, the recurrence matrix, column sums of Yl, per-row scalars
   float* Xb = reinterpret_cast<float*>(lidx + ((pm + 3) & ~1));   // [kRowBatch][kp] raw state rows of the batch
   float* Tl = Xb + kRowBatch * kp;                                // [NMAX (padded to 16s)][kRowBatch]
@@ -302,7 +402,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
       for (int j = tid; j < cnt; j += 64) Yt[(size_t)j * kp + k] *= eps;
     }
   }
-  if (P.dual) for (int i = tid; i < kp; i += 64) Yt[(size_t)P.rows * kp + i] = 0.0f;   // the zero row of the Gram panels
+  if (P.dual) for (int i = tid; i < kp; i += 64) zrow[i] = 0.0f;   // the zero row of the Gram panels
   const int ntrue = P.dual ? cnt : k;
   MIA_WAVE_SYNC();
   // ---- S (full symmetric storage, zero padded)
@@ -322,7 +422,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
         const int row = 16 * t + lr;
-        prow[t] = Yt + (size_t)(row < cnt ? row : P.rows) * kp + KS * h;     // row P.rows = zero row
+        prow[t] = (row < cnt ? Yt + (size_t)row * kp : zrow) + KS * h;
       }
 #pragma unroll
       for (int b2 = 0; b2 < NMAX / 2; ++b2) srow2[b2] = f2v{0.0f, 0.0f};
@@ -380,7 +480,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
       const int row = 16 * t + lr;
-      prow[t] = Yt + (size_t)(row < cnt ? row : P.rows) * kp + KS * h;     // row P.rows = zero row
+      prow[t] = (row < cnt ? Yt + (size_t)row * kp : zrow) + KS * h;
     }
     f32x4c acc[NTILE];
 #pragma unroll
@@ -499,7 +599,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
   MIA_WAVE_SYNC();
   // ---- right-hand side of the mean weights
   if (P.dual) {
-    if (tid < NMAX) rhs[tid] = tid < cnt ? Yt[(size_t)tid * kp + k] : 0.0f;
+    if (tid < NMAX && !compact) rhs[tid] = tid < cnt ? Yt[(size_t)tid * kp + k] : 0.0f;
   } else if (P.kernel_mode == 0) {
     // (rhs = Yl d came with the streamed Gram)
   } else {   // double centring of K and centring of k(Yb, d)   (core/ketkf.py:77-89)
@@ -542,16 +642,30 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
       rsum += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
     }
   }
-  const float rhs_r = tid < NMAX ? rhs[tid] : 0.0f;
+  const float rhs_r = compact ? (tid < cnt ? Yt[(size_t)tid * kp + k] : 0.0f) : (tid < NMAX ? rhs[tid] : 0.0f);
   float L = wave_max_nonneg_dpp(tid < NMAX ? rsum : 0.0f);     // (a NaN row sum survives as the maximum)
   L = fmaxf(L, 1e-30f * reg) * 1.0001f;
+  const bool use_tab = P.tab_hdr != nullptr;
+  int deg, tab_idx = 0;
+  float alpha;                             // A v = alpha S v - v
+  if (use_tab) {
+    // ---- degree and coefficients of the next tabulated interval [0, Tq reg] that contains [0, L]
+    if (!(L == L) || !(fabsf(L) < 1e30f)) { flag |= MIA_FLAG_NONFINITE; L = reg; }
+    tab_idx = (int)ceilf(float(kTabPerOctave) * __builtin_amdgcn_logf(L * P.inv_reg)) + kTabIdx0;
+    tab_idx = tab_idx < 0 ? 0 : (tab_idx > kTabN - 1 ? kTabN - 1 : tab_idx);      // (the last entries decline: T = 2^8)
+    const int2 h = P.tab_hdr[tab_idx];
+    deg = h.x;
+    alpha = __int_as_float(h.y) * P.inv_reg;
+  } else {
   // ---- degree from the Bernstein-ellipse parameter of the singularity at -reg
   const float sq = __builtin_amdgcn_sqrtf(fmaf(L, P.inv_reg, 1.0f));
   const float rho = (sq + 1.0f) * fast_rcp(fmaxf(sq - 1.0f, 1e-12f));     // in (1, 2e12]: v_log_f32 needs no range fix
-  int deg = (int)ceilf(P.log_tol * fast_rcp(0.6931471806f * __builtin_amdgcn_logf(rho))) + 2;
+  deg = (int)ceilf(P.log_tol * fast_rcp(0.6931471806f * __builtin_amdgcn_logf(rho))) + 2;
   deg = deg < 3 ? 3 : deg;
   if (P.xskip & 4) deg = 3;
   if (!(L == L) || !(fabsf(L) < 1e30f)) { flag |= MIA_FLAG_NONFINITE; deg = 3; }
+  alpha = 2.0f * fast_rcp(L);
+  }
   if (deg > P.dmax || deg > DCAP - 1) {   // spectrum too wide for the polynomial route: eigensolver redoes this point
     if (tid == 0) {
       if (P.flags) P.flags[pt] = MIA_FLAG_RETRY;
@@ -560,8 +674,13 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     return;
   }
   if constexpr (ALIAS_C) MIA_WAVE_SYNC();     // the rows of S have been read: its storage becomes the coefficient tables
-  cheb_coefficients(tid, deg, L, reg, P.sqrt_km1, ar, P.dual != 0, f2s, c2);
-  const float alpha = 2.0f * fast_rcp(L);  // A v = alpha S v - v
+  if (use_tab) {
+    const float2 cj = P.tab_c[(size_t)tab_idx * kTabDeg + tid];      // (entries beyond the degree are zero)
+    c2[tid] = f2v{cj.x * P.cs_phi, cj.y * P.cs_psi};
+    MIA_WAVE_SYNC();
+  } else {
+    cheb_coefficients(tid, deg, L, reg, P.sqrt_km1, ar, P.dual != 0, f2s, c2);
+  }
   if constexpr (MODE == 1) {
     // ---- many state rows: kRowBatch rows at a time as ONE matrix recurrence on the matrix cores.
     //      T (n x 16) lives in the MFMA result layout (lane (lr, h) holds T[16 t + 4 h + q][lr], q = 0..3); every step
@@ -1328,8 +1447,11 @@ static int cheb_launch_big(const ChebParams& ap, hipStream_t stream) {
   return MIA_OK;
 }
 
-static size_t cheb_lds_bytes(int kp, int p_max, int nmax, int rows, bool dual, bool batch = false, int k_weights = 0) {
+static size_t cheb_lds_bytes(int kp, int p_max, int nmax, int rows, bool dual, bool batch = false, int k_weights = 0,
+                             bool fused = false) {
   const int lda = (nmax % 8 == 0) ? nmax + 4 : nmax;
+  if (!batch && !k_weights && cheb_compact_layout(nmax, kp, p_max, dual, fused))
+    return align_up(((size_t)nmax * lda + (size_t)nmax * kp) * sizeof(float), 16);
   const int srows = (dual && nmax > 32) ? 16 : nmax;      // streamed S: staging panel only (see letkf_cheb_point)
   const bool alias = !batch && !k_weights && cheb_alias_tables(nmax);   // scalar-rows variant: tables inside S
   size_t e = (size_t)srows * lda + 4 * (size_t)nmax + (alias ? 0 : 4 * 64) + 8 + (size_t)kp + (size_t)(rows + 1) * kp + ((p_max + 3) & ~1);
@@ -1441,6 +1563,7 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
   ap.f0_dual = (float)sqrt((double)(k - 1) / (double)ap.reg);
   ap.sqrt_km1 = (float)sqrt((double)(k - 1));
   ap.inv_k = (float)(1.0 / (double)k);
+  ap.tab_hdr = nullptr; ap.tab_c = nullptr; ap.cs_phi = ap.cs_psi = 1.0f;
   ap.Xa = Xa; ap.ldo = ldo; ap.o0 = o0; ap.flags = flags; ap.retry_count = retry_count;
   ap.kernel_mode = kernel_mode; ap.gamma = gamma;
   ap.dual = (kernel_mode == 0 && p_max <= k) ? 1 : 0;
@@ -1475,7 +1598,15 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
   // degree (C2: 15.3 at 15, 11.9 at 11)
   ap.log_tol = 12.0f;
   if (const char* e = getenv("MIA_CHEB_LOGTOL")) ap.log_tol = (float)atof(e);     // experiments only
-  const size_t lds = cheb_lds_bytes(ap.kp, p_max, nmax, ap.rows, ap.dual != 0);
+  if (!ap.xskip) {
+    if (const CoefTable* t = cheb_coef_table(ap.dual, ap.log_tol, stream)) {
+      ap.tab_hdr = t->hdr; ap.tab_c = t->c;
+      const double rg = (double)ap.reg, km = (double)(k - 1);
+      ap.cs_phi = (float)(ap.dual ? sqrt(km) / (rg * sqrt(rg)) : sqrt(km) / sqrt(rg));
+      ap.cs_psi = (float)(1.0 / rg);
+    }
+  }
+  const size_t lds = cheb_lds_bytes(ap.kp, p_max, nmax, ap.rows, ap.dual != 0, false, 0, ap.fused != 0);
   if (lds > (long long)kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
   ap.lds_per_wave = (int)lds;
   const int64_t gx = ng < 65536 ? ng : 65536;
