@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void index_bbox_dims_kernel(IndexParams p) {
     return;
   }
   __shared__ unsigned long long sx[4], sn[4];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int64_t stride = (int64_t)p.nb_bbox * blockDim.x;
   for (int q = 0; q < 3; ++q)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < p.zero.n[q]; i += stride) p.zero.ptr[q][i] = 0;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void index_bbox_dims_kernel(IndexParams p) {
     if (lane == 0) { sx[wv] = kx; sn[wv] = kn; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      for (int w = 1; w < 4; ++w) { kx = sx[w] > kx ? sx[w] : kx; kn = sn[w] > kn ? sn[w] : kn; }
+      for (int w = 1; w < nw; ++w) { kx = sx[w] > kx ? sx[w] : kx; kn = sn[w] > kn ? sn[w] : kn; }
       if (kx != 0ull) { atomicMax(&p.hdr->kmax[c], kx); atomicMax(&p.hdr->kmin_inv[c], kn); }
     }
     __syncthreads();
@@ -164,6 +164,12 @@ __global__ __launch_bounds__(64) void index_scan_kernel(IndexParams p) {
     }
     carry += __shfl(x, 63, 64);
   }
+}
+
+__global__ __launch_bounds__(64) void index_clear_kernel(uint32_t* p, size_t n) {
+  MIA_PREP_PRIORITY();
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0u;
 }
 
 // cell of every observation + per-cell counts.  256-thread workgroups of 15 VGPRs: they fit beside the analysis
@@ -241,6 +247,8 @@ struct LocalizeParams {
 // round trips (header -> cell range -> index -> coordinates) of ~1.5 us each and only 32 wavefronts fit
 // a CU.  With one point per lane the same chain is amortised over 64 points and the candidate loop
 // (~30 candidates x ~50 float64 operations) runs with all lanes busy.
+// (106 VGPRs.  Capping it at 80, so that ONE retiring wave of a co-running analysis kernel -- 7 x 72 registers per
+//  SIMD -- makes room, cost 24 spilled registers and gained nothing: 68 us beside the analysis kernel either way)
 __global__ __launch_bounds__(64) void localize_kernel(LocalizeParams p) {
   MIA_PREP_PRIORITY();
   const int64_t pt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -421,10 +429,21 @@ int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_
   ip.obs = obs_xyz; ip.P = P; ip.nc = n_coord; ip.cell_cap = (int)L.cap;
   for (int c = 0; c < MIA_MAX_COORD; ++c) ip.cutoff[c] = c < n_coord ? 2.0 * gc_c[coord_group[c]] : 1.0;
   ip.hdr = L.hdr; ip.start = L.start; ip.cursor = L.cursor; ip.sorted = L.sorted; ip.cell_of = L.cell_of; ip.sxyz = L.sxyz;
-  // header, start and cursor are adjacent: one fill clears all three
-  MIA_HIP_TRY(hipMemsetAsync(ip.hdr, 0, (char*)ip.sorted - (char*)ip.hdr, stream));
-  const unsigned nbP = (unsigned)((P + 255) / 256);
-  ip.nb_bbox = nbP < 64 ? nbP : 64;
+  // SINGLE-WAVE workgroups throughout the chain: when steps are pipelined these kernels run beside the previous step's
+  // analysis kernel, which fills every SIMD's register file (7 waves x 72 VGPRs at C2).  A lone wave takes the slot of
+  // the next analysis wave that retires; a 4-wave workgroup needs one to retire on each SIMD of one CU at the same
+  // moment and waited for the analysis grid to drain (160 us instead of 25, measured).
+  constexpr unsigned kPrepThreads = 64;
+  const unsigned nbP = (unsigned)((P + kPrepThreads - 1) / kPrepThreads);
+  ip.nb_bbox = nbP < 256 ? nbP : 256;
+  {   // header, start and cursor are adjacent: one fill clears all three (a kernel of single-wave workgroups, not
+      // hipMemsetAsync: the runtime's fill kernel has 256-thread workgroups and waited 30-60 us for a CU, see above)
+    const size_t words = ((char*)ip.sorted - (char*)ip.hdr) / sizeof(uint32_t);
+    const unsigned nb = (unsigned)((words + kPrepThreads * 16 - 1) / (kPrepThreads * 16));
+    index_clear_kernel<<<dim3(nb < 1024 ? (nb ? nb : 1) : 1024), dim3(kPrepThreads), 0, stream>>>(
+        reinterpret_cast<uint32_t*>(ip.hdr), words);
+    MIA_LAUNCH_CHECK();
+  }
   ip.pack = PackJob{nullptr, nullptr, nullptr, 0, 0};
   ip.zero = zero ? *zero : ZeroJob{{nullptr, nullptr, nullptr}, {0, 0, 0}};
   unsigned nb_pack = 0;
@@ -433,16 +452,16 @@ int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_
     ip.pack = *pack;
     nb_pack = (unsigned)((P + 31) / 32);
   }
-  index_bbox_dims_kernel<<<dim3(ip.nb_bbox + nb_pack), dim3(256), 0, stream>>>(ip);
+  index_bbox_dims_kernel<<<dim3(ip.nb_bbox + nb_pack), dim3(kPrepThreads), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
-  index_count_kernel<<<dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream>>>(ip);
+  index_count_kernel<<<dim3(nbP), dim3(kPrepThreads), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
   index_scan_kernel<<<dim3(1), dim3(64), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
-  index_scatter_kernel<<<dim3(nbP), dim3(256), 0, stream>>>(ip);
+  index_scatter_kernel<<<dim3(nbP), dim3(kPrepThreads), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
-  const size_t sort_blocks = (L.cap + 3) / 4 < 2048 ? (L.cap + 3) / 4 : 2048;      // 4 waves (cells) per workgroup
-  index_sortcell_kernel<<<dim3((unsigned)sort_blocks), dim3(256), 0, stream>>>(ip);
+  const size_t sort_blocks = L.cap < 8192 ? (L.cap ? L.cap : 1) : 8192;      // one wave (cell) per workgroup
+  index_sortcell_kernel<<<dim3((unsigned)sort_blocks), dim3(kPrepThreads), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

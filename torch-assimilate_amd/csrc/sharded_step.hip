@@ -97,8 +97,12 @@ int comm_allreduce_max(mia_comm* c, int32_t* buf, int n, hipStream_t s) {
 // Every rank's piece carries a 16-byte trailer {longest list, truncated lists, declined points, error bits};
 // with ctr_out the first thread also folds the trailers: ctr_out[0..3] = this rank's, [4..7] = max over ranks
 // (the all-reduce of the redo decision rides on the last piece's all-gather instead of being a collective).
+// Single-wave workgroups, four column groups per lane: with steps in flight this kernel runs beside a later step's
+// analysis kernel, which fills every SIMD's register file -- a lone wave takes the slot of the next analysis wave that
+// retires, a 4-wave workgroup waits for one to retire on every SIMD of a CU at once (see localize.hip).
+constexpr int kPlaceThreads = 64, kPlaceUnroll = 4;
 template <int VEC>
-__global__ void __launch_bounds__(256) place_chunk_kernel(const float* __restrict__ gath, float* __restrict__ out,
+__global__ void __launch_bounds__(kPlaceThreads) place_chunk_kernel(const float* __restrict__ gath, float* __restrict__ out,
                                                           int64_t G, int64_t n, int64_t off, int nc, int rows,
                                                           size_t rank_stride /* floats */, int32_t* ctr_out, int rank) {
   const int r = blockIdx.z, row = blockIdx.y;
@@ -112,7 +116,9 @@ __global__ void __launch_bounds__(256) place_chunk_kernel(const float* __restric
     ctr_out[threadIdx.x] = own;
     ctr_out[4 + threadIdx.x] = mx;
   }
-  const int i = (blockIdx.x * 256 + threadIdx.x) * VEC;
+#pragma unroll
+  for (int u = 0; u < kPlaceUnroll; ++u) {
+  const int i = ((blockIdx.x * kPlaceUnroll + u) * kPlaceThreads + threadIdx.x) * VEC;
   if (i >= nc) return;
   const int64_t in_block = off + i;
   const int64_t col = (int64_t)r * n + in_block;
@@ -121,12 +127,13 @@ __global__ void __launch_bounds__(256) place_chunk_kernel(const float* __restric
   if (VEC == 4) {
     if (in_block + 3 < n && col + 3 < G) {
       *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
-      return;
+      continue;
     }
   }
 #pragma unroll
   for (int v = 0; v < VEC; ++v)
     if (i + v < nc && in_block + v < n && col + v < G) dst[v] = src[v];
+  }
 }
 
 struct StepLayout {
@@ -444,12 +451,14 @@ extern "C" int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int
       int32_t* ctr_out = (phase == 0 && c == n_chunks - 1) ? counters : nullptr;
       const bool vec = (L.nc % 4 == 0) && (G % 4 == 0) && (L.n % 4 == 0) && ((uintptr_t)Xa % 16 == 0);
       if (vec) {
-        dim3 grid((unsigned)((L.nc / 4 + 255) / 256), (unsigned)rows, (unsigned)world);
-        place_chunk_kernel<4><<<grid, 256, 0, xs>>>(gath, Xa, G, L.n, off, (int)L.nc, rows, L.send_bytes / sizeof(float),
+        const int per = kPlaceThreads * kPlaceUnroll;
+        dim3 grid((unsigned)((L.nc / 4 + per - 1) / per), (unsigned)rows, (unsigned)world);
+        place_chunk_kernel<4><<<grid, kPlaceThreads, 0, xs>>>(gath, Xa, G, L.n, off, (int)L.nc, rows, L.send_bytes / sizeof(float),
                                                     ctr_out, rank);
       } else {
-        dim3 grid((unsigned)((L.nc + 255) / 256), (unsigned)rows, (unsigned)world);
-        place_chunk_kernel<1><<<grid, 256, 0, xs>>>(gath, Xa, G, L.n, off, (int)L.nc, rows, L.send_bytes / sizeof(float),
+        const int per = kPlaceThreads * kPlaceUnroll;
+        dim3 grid((unsigned)((L.nc + per - 1) / per), (unsigned)rows, (unsigned)world);
+        place_chunk_kernel<1><<<grid, kPlaceThreads, 0, xs>>>(gath, Xa, G, L.n, off, (int)L.nc, rows, L.send_bytes / sizeof(float),
                                                     ctr_out, rank);
       }
       MIA_LAUNCH_CHECK();
