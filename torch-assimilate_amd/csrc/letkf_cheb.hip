@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(64 * WPB, (NMAX <= 24 ? (FUSED || KL > 1 ? 5 : 6) :
 
 // Many state rows per grid point (m >= 8, dual route, order <= 32): rows are transformed 16 at a time on the matrix cores.
 template <int NMAX>
-__global__ __launch_bounds__(64, (NMAX <= 24 ? 4 : (NMAX <= 32 ? 3 : 2))) void letkf_cheb_rows_kernel(ChebParams P) {
+__global__ __launch_bounds__(64, (NMAX <= 32 ? 3 : 2)) void letkf_cheb_rows_kernel(ChebParams P) {
   letkf_cheb_point<NMAX, 1, false, 1, false, 1>(P);
 }
 
