@@ -220,7 +220,9 @@ def main():
         return el, out
 
     depth = args.pipeline_depth
-    run(args.warmup, depth)
+    # (at least one pass over every slot of the pipeline, whatever --warmup says: the first use of a slot allocates its
+    #  workspace and the first launch builds the coefficient table -- ~50 ms that belong to no step)
+    run(max(args.warmup, 2 * depth + 2), depth)
     # the interpreter's heap as it stands (torch, numpy: ~1e6 objects) out of the collector's way: a full collection
     # scanning it takes 30-40 ms, i.e. ~150 steps' worth of GPU idle time; what the loop itself allocates is still collected
     import gc
