@@ -477,3 +477,28 @@ def test_large_ensembles_with_more_than_64_local_observations(eng, monkeypatch, 
     monkeypatch.setenv("MIA_CHEB_NO_BIG", "1")
     xe = eng.analysis(*args, rbf_gamma=gamma)
     assert rel_fro(xe.cpu().numpy(), ref) < TOL32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale,gamma", [(1.0, None), (4.0, None), (1.0, 0.5)])
+def test_coefficient_table_equals_the_in_kernel_transform(eng, monkeypatch, scale, gamma):
+    """The Chebyshev coefficients come from a per-device table over the scaled spectral bound (letkf_cheb.hip,
+    cheb_coef_table); MIA_CHEB_NO_TABLE=1 computes them in the analysis kernel as before.  Same analysis to float32
+    rounding on the dual route, with stronger observations (higher degrees), and on the RBF (primal) route; both within
+    the north-star tolerance of the oracle."""
+    case = O.synthetic_case(400, 40, 2, seed=7)
+    yb, d = case["yb"] * scale, case["d"] * scale
+    nb = eng.localize(case["grid_x"], case["obs_x"], [10.0])
+    args = (dev(case["state"], torch.float32), dev(yb, torch.float32), dev(d, torch.float32), nb, 1.1)
+    xa_tab, fl_tab = eng.analysis(*args, return_flags=True, method="matfun", rbf_gamma=gamma)
+    monkeypatch.setenv("MIA_CHEB_NO_TABLE", "1")
+    xa_ker, fl_ker = eng.analysis(*args, return_flags=True, method="matfun", rbf_gamma=gamma)
+    monkeypatch.delenv("MIA_CHEB_NO_TABLE")
+    assert int((fl_tab.cpu() & 0xff).max()) == 0 and int((fl_ker.cpu() & 0xff).max()) == 0
+    assert rel_fro(xa_tab.cpu().numpy(), xa_ker.cpu().numpy()) < 2e-6
+    # the table's interval is the next grid point above the bound: at most one degree more than the exact interval
+    dt, dk = (fl_tab.cpu().numpy() >> 8) & 0xff, (fl_ker.cpu().numpy() >> 8) & 0xff
+    assert int((dt - dk).min()) >= 0 and int((dt - dk).max()) <= 1
+    if gamma is None:
+        ref, _ = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], yb, d, 10.0, 1.1)
+        assert rel_fro(xa_tab.cpu().numpy(), ref) < TOL32
