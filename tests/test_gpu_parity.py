@@ -502,3 +502,22 @@ def test_coefficient_table_equals_the_in_kernel_transform(eng, monkeypatch, scal
     if gamma is None:
         ref, _ = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], yb, d, 10.0, 1.1)
         assert rel_fro(xa_tab.cpu().numpy(), ref) < TOL32
+
+
+@pytest.mark.parametrize("k,stride,c", [(40, 2, 10.0), (36, 2, 11.5), (44, 1, 7.5), (50, 2, 15.5), (72, 2, 9.0),
+                                        (96, 3, 16.0), (128, 2, 12.0), (24, 2, 9.5)])
+def test_dual_route_orders_20_to_32_in_the_compact_lds_layout(eng, k, stride, c):
+    """Scalar-rows matfun kernel on the dual route with 17 .. 32 local observations (order buckets 20 / 24 / 32): list,
+    zero row, S, coefficient tables, recurrence vector and x' share the storage of S (cheb_compact_layout), the Gram
+    loop reads member pairs when k % 8 == 0 and single members otherwise, k > 64 keeps two members per lane (where the
+    compact layout no longer fits and the plain one is used).  Three state rows; against the oracle."""
+    case = O.synthetic_case(96, k, stride, seed=k, m=3)
+    nb = eng.localize(case["grid_x"], case["obs_x"], [c])
+    assert 16 < nb.p_max <= min(32, k)
+    xa, fl = eng.analysis(dev(case["state"], torch.float32), dev(case["yb"], torch.float32), dev(case["d"], torch.float32),
+                          nb, 1.2, return_flags=True, method="matfun")
+    f = fl.cpu().numpy()
+    assert int((f & 0xff).max()) == 0 and int(((f >> 8) & 0xff).min()) >= 3
+    ref, _ = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], case["yb"], case["d"], c, 1.2)
+    assert rel_fro(xa.cpu().numpy(), ref) < TOL32
+    assert rel_fro(xa.cpu().numpy() - case["state"].mean(axis=1, keepdims=True), ref - case["state"].mean(axis=1, keepdims=True)) < 5e-5
