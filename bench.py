@@ -220,14 +220,15 @@ def main():
         return el, out
 
     depth = args.pipeline_depth
-    # (at least one pass over every slot of the pipeline, whatever --warmup says: the first use of a slot allocates its
-    #  workspace and the first launch builds the coefficient table -- ~50 ms that belong to no step)
-    run(max(args.warmup, 2 * depth + 2), depth)
+    run(2 * depth + 2, depth)     # one pass over every pipeline slot: workspaces, coefficient table (~50 ms, no step's)
     # the interpreter's heap as it stands (torch, numpy: ~1e6 objects) out of the collector's way: a full collection
     # scanning it takes 30-40 ms, i.e. ~150 steps' worth of GPU idle time; what the loop itself allocates is still collected
     import gc
     gc.collect()
     gc.freeze()
+    # warm-up LAST, straight into the timed loop: the collection above leaves the GPU idle for ~0.1 s and the clocks
+    # take a few milliseconds of work to come back (20 timed steps right after it ran 25 % slower than steady state)
+    run(max(args.warmup, 50), depth)
     runner.kernel_timings.clear()
     elapsed, out = timed(args.steps, depth)
     loop_kernel_ms = runner.kernel_ms()      # the dominant kernel inside the timed loop (every 4th step)
