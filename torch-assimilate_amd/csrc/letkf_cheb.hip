@@ -657,14 +657,14 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     deg = h.x;
     alpha = __int_as_float(h.y) * P.inv_reg;
   } else {
-  // ---- degree from the Bernstein-ellipse parameter of the singularity at -reg
-  const float sq = __builtin_amdgcn_sqrtf(fmaf(L, P.inv_reg, 1.0f));
-  const float rho = (sq + 1.0f) * fast_rcp(fmaxf(sq - 1.0f, 1e-12f));     // in (1, 2e12]: v_log_f32 needs no range fix
-  deg = (int)ceilf(P.log_tol * fast_rcp(0.6931471806f * __builtin_amdgcn_logf(rho))) + 2;
-  deg = deg < 3 ? 3 : deg;
-  if (P.xskip & 4) deg = 3;
-  if (!(L == L) || !(fabsf(L) < 1e30f)) { flag |= MIA_FLAG_NONFINITE; deg = 3; }
-  alpha = 2.0f * fast_rcp(L);
+    // ---- degree from the Bernstein-ellipse parameter of the singularity at -reg
+    const float sq = __builtin_amdgcn_sqrtf(fmaf(L, P.inv_reg, 1.0f));
+    const float rho = (sq + 1.0f) * fast_rcp(fmaxf(sq - 1.0f, 1e-12f));     // in (1, 2e12]: v_log_f32 needs no range fix
+    deg = (int)ceilf(P.log_tol * fast_rcp(0.6931471806f * __builtin_amdgcn_logf(rho))) + 2;
+    deg = deg < 3 ? 3 : deg;
+    if (P.xskip & 4) deg = 3;
+    if (!(L == L) || !(fabsf(L) < 1e30f)) { flag |= MIA_FLAG_NONFINITE; deg = 3; }
+    alpha = 2.0f * fast_rcp(L);
   }
   if (deg > P.dmax || deg > DCAP - 1) {   // spectrum too wide for the polynomial route: eigensolver redoes this point
     if (tid == 0) {
