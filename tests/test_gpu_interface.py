@@ -446,3 +446,38 @@ def test_step_driver_on_a_scattered_2d_network_vs_oracle(mia):
         ref = O.apply_weights(state[:, :, [gi]], w[None])
         assert rel_fro(got[:, :, gi], ref[:, :, 0]) < 1e-5, (gi, counts[-1])
     assert min(counts) == 0 and max(counts) > k                        # both extremes were among the samples
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 1e-5)])
+def test_assimilate_filter_and_smoother_mode_on_the_reference_fixture(mia, golden, dtype, tol):
+    """``LETKF.assimilate`` end to end on the reference's fixture with ALL THREE times of state and observations
+    (interface/base.py:419-512, filter.py:39-165): filter mode cuts everything to the analysis time (P = 40), smoother
+    mode stacks 3 x 40 observations; the obs-space normalisation (correlated R), localisation, weights and transform
+    all run on the GPU.  The localisation's dist_func is the reference test's own (test_letkf.py:107-110): it indexes
+    the observation table BY COLUMN NAME, so obs_info must be a DataFrame (mixin_local.py:44-47)."""
+    g = golden("g6_reference_fixture_letkf.npz")
+    F = mia.ModelState, mia.ObsSubset
+
+    def operator(sub, pseudo):                       # testing/dummy.py:39-66
+        return np.asarray(pseudo.values)[0].transpose(1, 0, 2)
+
+    def dist_func(x, y):
+        diff = x - y
+        return diff["obs_grid_1"].abs().values,
+
+    state = mia.ModelState(g["state"], g["state_time"], g["grid"])
+    obs = mia.ObsSubset(g["obs"], g["cov"], g["obs_time"], g["obs_grid"], operator)
+    mute = mia.ObsSubset(g["obs"], g["cov"], g["obs_time"], g["obs_grid"])            # no operator: dropped
+    for df in (dist_func, mia.AbsoluteDistance()):
+        algo = mia.LETKF(localization=mia.GaspariCohn((10.0,), df), inf_factor=1.1, dtype=dtype)
+        ana = algo.assimilate(state, (mute, obs), analysis_time=g["state_time"][0])
+        assert tuple(ana.values.shape) == (2, 1, 10, 40) and ana.values.is_cuda
+        assert rel_fro(ana.values.cpu().numpy(), g["analysis_1p1"]) < tol
+    algo.smoother = True
+    ana = algo.assimilate(state, obs)
+    assert tuple(ana.values.shape) == (2, 3, 10, 40)
+    assert rel_fro(ana.values.cpu().numpy(), g["analysis_smoother_1p1"]) < tol
+    # global ETKF through the same entry point; nearest-time fallback warns and lands on time 0
+    with pytest.warns(UserWarning, match="is not within state"):
+        ana = mia.ETKF(inf_factor=1.1, dtype=dtype).assimilate(state, obs, analysis_time=g["state_time"][0] + 60.0)
+    assert rel_fro(ana.values.cpu().numpy(), g["analysis_global_1p1"]) < tol

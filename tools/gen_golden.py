@@ -162,6 +162,22 @@ def main():
         wg = f_glob(np.array([0.0, 0.0]), yb, dd, obs_info=obs_grid)
         g6[f"weights_global_{tag}"] = wg
         g6[f"analysis_global_{tag}"] = apply_weights(state[:, [ti]], np.broadcast_to(wg, (40,) + wg.shape))
+    # the fixtures' time axes (hours since 1992-12-25 in both files) as unix seconds, and the SMOOTHER-mode case of the
+    # same fixture: nothing is sliced (filter.py:150-153 is skipped), all 3 x 40 observations are stacked time-major
+    # (base.py:223-241) against the three-time state; weights through the reference's localised core, analysis over
+    # every time of the state (base.py:257-278)
+    t_unix = (np.datetime64("1992-12-25T00:00:00") - np.datetime64("1970-01-01T00:00:00")) / np.timedelta64(1, "s")
+    g6["state_time"] = t_unix + 3600.0 * np.arange(3.0)
+    g6["obs_time"] = t_unix + 3600.0 * np.arange(3.0)
+    hx_s = state[0].transpose(1, 0, 2)                                  # (ensemble, time, grid)
+    mean_s = hx_s.mean(axis=0)
+    yb_s = ((hx_s - mean_s) @ chol_inv).reshape(10, 120)
+    d_s = ((obs - mean_s) @ chol_inv).reshape(120)
+    f_loc = wrapper_localization(
+        wrapper_bridge(ETKFModule(t64(1.1)), torch.device("cpu"), torch.float64),
+        GaspariCohn(10.0, lambda g, o: np.abs(o - g[1])))
+    w_s = np.stack([f_loc(np.array([0.0, x]), yb_s, d_s, obs_info=np.tile(obs_grid, 3)) for x in grid])
+    g6.update(yb_smoother=yb_s, d_smoother=d_s, weights_smoother_1p1=w_s, analysis_smoother_1p1=apply_weights(state, w_s))
     np.savez(os.path.join(OUT, "g6_reference_fixture_letkf.npz"), **g6)
 
     # ---- G7: scaled-down synthetic configs (SURVEY.md §8d generator), G = 256

@@ -20,6 +20,8 @@ _LAZY = {
     "AdditiveKernel": "kernels", "MultiplicativeKernel": "kernels", "PowerKernel": "kernels",
     "IEnKSTransformModule": "ienks", "IEnKSBundleModule": "ienks", "IEnKSTransform": "ienks", "IEnKSBundle": "ienks",
     "LocalizedIEnKSTransform": "ienks", "LocalizedIEnKSBundle": "ienks",
+    "ModelState": "assim_flow", "ObsSubset": "assim_flow", "StateError": "assim_flow", "ObservationError": "assim_flow",
+    "assimilate_arrays": "assim_flow",
     "ShardedLetkf": "sharded", "block_partition": "sharded", "gather_blocks": "sharded",
 }
 

@@ -144,8 +144,13 @@ class ETKF:
         xa = self.engine.apply_weights(st.reshape(-1, shp[-2], shp[-1]), W)
         return xa.reshape(shp)
 
-    # ---- xarray level ---------------------------------------------------------------------
+    # ---- assimilate(): the reference's entry point (interface/base.py:419-512) ------------------------
     def assimilate(self, state, observations, pseudo_state=None, analysis_time=None):
+        """xarray in / xarray out as in the reference; with the array-level data model of ``assim_flow``
+        (``ModelState`` / ``ObsSubset``) in, the same flow runs without xarray and returns a ``ModelState``."""
+        from . import assim_flow
+        if isinstance(state, assim_flow.ModelState):
+            return assim_flow.assimilate_arrays(self, state, observations, pseudo_state, analysis_time)
         from . import xr_adapter
         return xr_adapter.assimilate(self, state, observations, pseudo_state, analysis_time)
 

@@ -1,109 +1,93 @@
-"""xarray-in / xarray-out adapter: pytassim's ``assimilate()`` flow around the gfx950 engine.
-
-Follows BaseAssimilation.assimilate (pytassim/interface/base.py:419-512) and
-FilterAssimilation.update_state (interface/filter.py:96-165); what stays xarray in the reference
-stays xarray here, only estimate_weights + _apply_weights are replaced by the fused GPU call.
-xarray (and pandas) are imported lazily: they are absent from the build and GPU images.
+"""xarray-in / xarray-out shim over :mod:`assim_flow`: converts pytassim's state ``DataArray`` and observation
+``Dataset`` objects to the array-level data model, runs ``assimilate_arrays`` (which carries ALL the semantics of
+interface/base.py:419-512 and interface/filter.py:39-165) and wraps the analysis back.  xarray is imported lazily:
+it is absent from the build and GPU images, so everything with behaviour lives in ``assim_flow`` where it is tested.
 """
 from __future__ import annotations
 
-import logging
-import time
-import warnings
-
 import numpy as np
 
-logger = logging.getLogger(__name__)
+from . import assim_flow as flow
 
 
-def _total_seconds(index):
-    """pytassim.utilities.pandas.dtindex_to_total_seconds: seconds since 1970-01-01."""
-    import pandas as pd
-    return np.asarray((pd.DatetimeIndex(index) - pd.Timestamp(1970, 1, 1)).total_seconds(), dtype=np.float64)
-
-
-def _index_to_array(index):
-    """pytassim.utilities.pandas.index_to_array (pandas.py:70-102): MultiIndex -> (n, levels)."""
-    import pandas as pd
-    if isinstance(index, pd.MultiIndex):
-        return np.array(index.tolist(), dtype=np.float64)
+def _grid_table(index):
+    """utilities/pandas.py:70-102 ``index_to_array``: (Multi)Index -> float (n, levels)."""
     vals = np.asarray(index)
     if vals.dtype == object:
         vals = np.array([np.atleast_1d(v) for v in vals], dtype=np.float64)
-    vals = vals.astype(np.float64)
-    return vals.reshape(len(vals), -1)
+    return vals.astype(np.float64).reshape(len(vals), -1)
 
 
-def _rcinv_normalise(ds, value):
-    """Observation.mul_rcinv (observation.py:241-295) for one value array with an obs_grid_1 axis."""
+def _state(da):
+    """DataArray -> ModelState (dims are carried as they are: validity is judged by the flow, base.py:129-137)."""
+    if da is None:
+        return None
+    return flow.ModelState(np.asarray(da.values), da.indexes["time"].values, _grid_table(da.indexes["grid"]),
+                           dims=tuple(da.dims), source=da,
+                           ensemble=da.indexes["ensemble"].values if "ensemble" in da.dims else None)
+
+
+def _xr_of(st):
+    """The xarray view of a (possibly time-sliced) ModelState that came through :func:`_state`."""
+    return st.source.isel(time=list(st.time_index))
+
+
+def _subset(ds):
+    names = list(getattr(ds.indexes["obs_grid_1"], "names", None) or ["obs_grid_1"])
     cov = ds["covariance"]
-    if "obs_grid_2" in cov.dims:                          # correlated: right-multiply by inv(chol(R).T)
-        import xarray as xr
-        if "time" in cov.dims:
-            parts = []
-            for t in range(cov.sizes["time"]):
-                ci = np.linalg.inv(np.linalg.cholesky(cov.isel(time=t).values).T)
-                parts.append(cov.isel(time=t).copy(data=ci))
-            cinv = xr.concat(parts, dim="time")
-        else:
-            cinv = cov.copy(data=np.linalg.inv(np.linalg.cholesky(cov.values).T))
-        out = xr.dot(value, cinv, dims="obs_grid_1").rename({"obs_grid_2": "obs_grid_1"})
-        return out.assign_coords(obs_grid_1=value["obs_grid_1"])
-    return value / np.sqrt(cov)                            # uncorrelated: 1 / sqrt(var)
+    op = getattr(getattr(ds, "obs", None), "operator", None)        # pytassim's accessor, when registered
+
+    def operator(sub, pseudo):            # the reference calls obs.obs.operator(sliced obs, sliced pseudo state)
+        if op is None:
+            raise NotImplementedError("No observation operator is set!")
+        hx = op(ds.isel(time=list(sub.time_index)), _xr_of(pseudo))
+        return np.asarray(hx.transpose("ensemble", "time", "obs_grid_1").values)
+
+    return flow.ObsSubset(ds["observations"].values, cov.values, ds.indexes["time"].values,
+                          _grid_table(ds.indexes["obs_grid_1"]), operator, correlated="obs_grid_2" in cov.dims,
+                          cov_has_time="time" in cov.dims, grid_names=[n or "obs_grid_1" for n in names])
 
 
-def obs_space_variables(ens_obs, observations):
-    """_get_obs_space_variables + _stack_obs (base.py:359-379, 223-241) -> Yb (k, P), d (P,),
-    obs coordinate table (P, 1 + n_coord) with column 0 = time in seconds."""
-    ybs, ds_, coords = [], [], []
-    for ens, obs in zip(ens_obs, observations):
-        mean = ens.mean("ensemble")
-        perts = ens - mean
-        innov = _rcinv_normalise(obs, obs["observations"] - mean).transpose("time", "obs_grid_1")
-        perts = _rcinv_normalise(obs, perts).transpose("ensemble", "time", "obs_grid_1")
-        k = perts.sizes["ensemble"]
-        ybs.append(np.asarray(perts.values, dtype=np.float64).reshape(k, -1))
-        ds_.append(np.asarray(innov.values, dtype=np.float64).reshape(-1))
-        t = _total_seconds(innov.indexes["time"])
-        g = _index_to_array(innov.indexes["obs_grid_1"])
-        coords.append(np.hstack([np.repeat(t, len(g))[:, None], np.tile(g, (len(t), 1))]))
-    return np.concatenate(ybs, axis=1), np.concatenate(ds_), np.concatenate(coords, axis=0)
+class _XrAlgo:
+    """The algorithm as the flow sees it: user callables (forward model, transforms) keep receiving xarray objects."""
+
+    def __init__(self, algo):
+        self._algo = algo
+        self.pre_transform = self.post_transform = None      # applied by assimilate() below, on xarray objects
+
+    def __getattr__(self, name):
+        return getattr(self._algo, name)
+
+    @property
+    def forward_model(self):
+        fm = self._algo.forward_model
+        if fm is None:
+            return None
+        return lambda state, iter_num: (None, _state(fm(_xr_of(state), iter_num)[1]))
 
 
 def assimilate(algo, state, observations, pseudo_state=None, analysis_time=None):
     import xarray as xr
-    start = time.time()
-    if not isinstance(state, xr.DataArray):
-        raise TypeError("*** Given state is not a valid {0} ***\n{1:s}".format(type(xr.DataArray), str(state)))
-    if isinstance(observations, xr.Dataset):
+    if not observations:                                     # base.py:478-481 (before any validation)
+        return flow.assimilate_arrays(algo, state, ())
+    if not isinstance(observations, (list, set, tuple)):
         observations = (observations,)
-    if not observations:
-        warnings.warn("No observation is given, I will return the background state!", UserWarning)
-        return state
-    for p in (algo.pre_transform or ()):
-        state, observations, pseudo_state = p.pre(state, observations, pseudo_state)
-    if analysis_time is None:
-        analysis_time = state.time[-1].values              # base.py:154-179 (latest state time)
-    pseudo = state if pseudo_state is None else pseudo_state
-    back = state if algo.smoother else state.sel(time=[analysis_time])
-    pseudo = pseudo if algo.smoother else pseudo  # the obs operator sees the full pseudo state (filter.py:140-150)
-    ens_obs, used = [], []
-    for obs in observations:                               # base.py:181-220
-        try:
-            ens_obs.append(obs.obs.operator(obs, pseudo))
-            used.append(obs)
-        except (AttributeError, NotImplementedError) as err:
-            raise NotImplementedError("observation subset without a usable `.obs.operator`") from err
-    yb, d, obs_tab = obs_space_variables(ens_obs, used)
-    grid = _index_to_array(back.indexes["grid"])
-    t0 = _total_seconds(back.indexes["time"][:1])[0]
-    grid_info = np.hstack([np.full((len(grid), 1), t0), grid])     # mixin_local.py:55-58
-    st = np.asarray(back.transpose("var_name", "time", "ensemble", "grid").values)
-    xa = algo.analyse_arrays(st, yb, d, grid_coords=grid, obs_coords=obs_tab[:, 1:],
-                             grid_info=grid_info, obs_info=obs_tab)
-    analysis = back.transpose("var_name", "time", "ensemble", "grid").copy(
-        data=xa.cpu().numpy().astype(st.dtype)).transpose(*back.dims)
-    for p in (algo.post_transform or ()):
-        analysis = p.post(analysis, state, observations, pseudo_state)
-    logger.info("Finished assimilation after {0:.2f} s".format(time.time() - start))
+    if not isinstance(state, xr.DataArray):
+        raise TypeError("*** Given state is not a valid ``xarray.DataArray`` ***\n{0}".format(type(state)))
+    for obs in observations:
+        if not isinstance(obs, xr.Dataset):
+            raise TypeError("*** Given observation is not a valid ``xarray.Dataset`` ***\n{0}".format(obs))
+    st, subs = _state(state), [_subset(o) for o in observations]
+    flow.validate_state(st)
+    flow.validate_observations(subs)
+    t_ana = flow.get_analysis_time(st, analysis_time)
+    for trans in (algo.pre_transform or ()):                 # base.py:493-497: after validation and analysis time
+        state, observations, pseudo_state = trans.pre(state, observations, pseudo_state)
+        st, subs = _state(state), [_subset(o) for o in observations]
+    ana = flow.update_state(_XrAlgo(algo), st, subs, _state(pseudo_state), t_ana)
+    vals = ana.values.cpu().numpy() if hasattr(ana.values, "cpu") else np.asarray(ana.values)
+    analysis = _xr_of(ana).copy(data=vals.astype(state.dtype))
+    for trans in (algo.post_transform or ()):
+        analysis = trans.post(analysis, state, observations, pseudo_state)
+    flow.validate_state(_state(analysis))
     return analysis
