@@ -129,6 +129,96 @@ def cpu_baseline(n_points_total=16000):
                       "1 thread/process" % n_points_total}
 
 
+def launch_workers(n, argv):
+    """One worker process per GPU (rank r on device r), rendezvous on 127.0.0.1; returns the exit status.
+    Rank 0's stdout (the JSON line) is relayed, the other ranks' stdout goes to stderr.  If any worker fails the rest
+    are terminated (by PID) and the status is non-zero."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    import threading
+    box = []
+    reader = threading.Thread(target=lambda: box.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    status, deadline = 0, time.time() + float(os.environ.get("MIA_BENCH_TIMEOUT", "1500"))
+    while any(p.poll() is None for p in procs):
+        failed = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if failed or time.time() > deadline:       # a rank died (or the run hangs): the others wait in a collective
+            for q in procs:
+                if q.poll() is None:
+                    q.terminate()
+            time.sleep(2.0)
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+            break
+        time.sleep(0.05)
+    for r, p in enumerate(procs):
+        rc = p.wait()
+        if rc != 0:
+            status = status or (rc if rc > 0 else 1)
+            sys.stderr.write("bench.py: worker rank %d exited with status %s\n" % (r, rc))
+    reader.join(timeout=5.0)
+    sys.stdout.write(box[0] if box else "")
+    sys.stdout.flush()
+    return status
+
+
+def dryrun(args, rank, world):
+    """MIA_BENCH_DRYRUN=1: the launcher / rendezvous / max-over-ranks timing / JSON plumbing of the N-rank run on a
+    box without GPUs -- gloo backend, a small grid, the CPU oracle as the per-shard compute (the stand-in of
+    tests/test_sharded_gloo.py).  Measures nothing: the line is marked ``dryrun``."""
+    import torch.distributed as dist
+    import torch_assimilate_amd as mia
+    from oracle import letkf_oracle as O
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if os.environ.get("MIA_BENCH_DRYRUN_FAIL_RANK") == str(rank):     # launcher test: one rank dies before the rendezvous
+        raise SystemExit(3)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    gpg, k = 24, 12
+    G = gpg * world
+    case = O.synthetic_case(G, k, OBS_STRIDE)
+
+    def shard(X, grid_x, obs_x, Yb, d, g0, g1):
+        ana, _ = O.letkf_analysis(X.numpy()[:, :, g0:g1], grid_x.numpy()[g0:g1], obs_x.numpy(), Yb.numpy(), d.numpy(),
+                                  GC_RADIUS, INF)
+        return torch.from_numpy(ana)
+
+    runner = mia.ShardedLetkf("cpu", rank, world, radii=[GC_RADIUS], inf_factor=INF, compute_shard=shard, comm_chunks=1)
+    a = [torch.from_numpy(case[n]) for n in ("state", "grid_x", "obs_x", "yb", "d")]
+    for _ in range(args.warmup):
+        runner.assimilate(*a)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = runner.assimilate(*a)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ranks = dist.get_world_size()
+    if rank == 0:
+        print(json.dumps({"metric": "local analyses/sec (LETKF, 40-member)", "value": G * args.steps / float(t.item()),
+                          "unit": "analyses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * float(t.item()) / args.steps, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f64", "data": "synthetic", "dryrun": True,
+                          "config": {"workload": "DRY RUN (no GPU): G=%d, k=%d, CPU oracle per shard, gloo" % (G, k),
+                                     "parallelism": "grid-point block shard x%d + all-gather (%d ranks joined)" % (world, ranks)},
+                          "shape_ok": list(out.shape) == [1, k, G]}))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,12 +235,17 @@ def main():
                     help="analysis route: auto = eigensolver-free matfun kernel (default), eig = fused Jacobi")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: become the launcher.  This parent never touches the GPU
+        # (no HIP call, no torch.cuda call): it starts one fresh worker process per GPU and relays rank 0's line.
+        raise SystemExit(launch_workers(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("MIA_BENCH_DRYRUN"):
+        return dryrun(args, rank, world)
     # the CPU baseline forks worker processes: run it BEFORE this process touches the GPU
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -156,3 +156,25 @@ def test_weight_files_round_trip_and_layout(tmp_path):
         io.store_weights(path, W[:, :3])
     with pytest.raises(ValueError):
         io.store_weights(path, W, grid_index=np.arange(49))
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` without WORLD_SIZE (how the driver calls it) starts N worker processes itself,
+    relays rank 0's JSON line and fails when a worker fails.  MIA_BENCH_DRYRUN swaps the GPU workload for the gloo /
+    oracle stand-in: launcher, rendezvous, max-over-ranks timing and the line's fields are what is under test."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MIA_BENCH_DRYRUN"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["dryrun"] and line["shape_ok"]
+    assert line["value"] > 0 and line["ms_per_step"] > 0 and "2 ranks joined" in line["config"]["parallelism"]
+    # a worker that dies (rank 1, before the rendezvous rank 0 then waits in) fails the launcher instead of hanging it
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
+                         env=dict(env, MIA_BENCH_DRYRUN_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "rank 1 exited with status 3" in bad.stderr
