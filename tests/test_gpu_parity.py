@@ -304,9 +304,11 @@ def test_matfun_declines_wide_spectra_and_eigensolver_redoes_them(eng, golden, m
     assert rel_fro(xa2.cpu().numpy(), ref2) < TOL32
 
 
-def test_fused_localisation_equals_list_route_bitwise(eng, golden):
-    """The kernel that scans the observation index itself must reproduce the explicit-list route bit for bit
-    (same scan code, same order), in 1-D and with two radii in 3-D; an under-estimated list bound is reported."""
+def test_fused_localisation_equals_list_route_bitwise(eng, golden, monkeypatch):
+    """The kernel that scans the observation index itself must reproduce the explicit-list route of the SAME per-point
+    kernel bit for bit (same scan code, same order; MIA_NO_TILE keeps the list route off the sixteen-point kernel, whose
+    summation order differs), in 1-D and with two radii in 3-D; an under-estimated list bound is reported."""
+    monkeypatch.setenv("MIA_NO_TILE", "1")
     rs = np.random.RandomState(11)
     cases = [(np.arange(3000.0)[:, None], np.arange(0, 3000, 2.0)[:, None], [10.0], [0]),
              (rs.uniform(0, 1, size=(1500, 3)), rs.uniform(0, 1, size=(4000, 3)), [0.12, 0.25], [0, 0, 1])]

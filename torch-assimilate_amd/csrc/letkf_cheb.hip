@@ -72,7 +72,7 @@ struct ChebParams {
 // once per device, route and truncation target -- in float64, by the same Gauss-node cosine transform.  In the kernel
 // the degree selection (sqrt, two reciprocals, log) and the transform (N samples, N x N cosines spread over the wave)
 // were ~160 of the ~840 VALU instructions of a C2 analysis; the lookup is a v_log, one 8-byte and one 512-byte read.
-constexpr int kTabPerOctave = 32, kTabIdx0 = 24 * kTabPerOctave, kTabN = 32 * kTabPerOctave, kTabDeg = 64;
+// (kTabPerOctave, kTabIdx0, kTabN, kTabDeg: mia_kernels.h -- the tile kernel reads the same tables)
 
 __global__ __launch_bounds__(64) void cheb_table_kernel(int2* hdr, float2* c, int dual, double log_tol) {
   __shared__ double fs[kTabDeg][2];
@@ -1606,6 +1606,10 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
       ap.cs_psi = (float)(1.0 / rg);
     }
   }
+  // sixteen grid points per wavefront (letkf_tile.hip): dual route, few state rows, no weights output
+  if (ap.dual && ap.tab_hdr && !W_out && !ienks && !ap.fused && tile_route_covers(m, k, p_max) && !getenv("MIA_NO_TILE"))
+    return tile_analysis_launch(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, 0, p_cap, p_max, inf_factor, Xa, ldo, o0,
+                                flags, retry_count, ap.dmax, ap.tab_hdr, ap.tab_c, stream, seg_len, seg_stride, done);
   const size_t lds = cheb_lds_bytes(ap.kp, p_max, nmax, ap.rows, ap.dual != 0, false, 0, ap.fused != 0);
   if (lds > (long long)kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
   ap.lds_per_wave = (int)lds;

@@ -1,0 +1,544 @@
+// Fused LETKF analysis, SIXTEEN grid points per wavefront, every contraction on the matrix cores.
+//
+// Same mathematics as letkf_cheb.hip (matrix functions of the local matrix applied by a Chebyshev recurrence, dual
+// route: S_g = Yl^T Yl is p x p, reference: core/etkf.py:57-103 + interface/wrapper.py:86-98 + base.py:257-278), but
+// the unit of work is a TILE of 16 consecutive grid points instead of one.  Neighbouring grid points see almost the
+// same observations (config 2: 19 of 20 shared), and in the union index space of a tile
+//
+//     S_g = D_g G D_g,      G = Yw Yw^T  (U x U, U = |union of the tile's lists|),   D_g = diag(sqrt(rho_g)) (0 = not local)
+//
+// so ONE Gram product serves 16 points, and everything a point needs is a product with a 16-column right-hand side:
+//
+//     Z   = Yw X'                     (U x k)(k x 16)     z_g = D_g Z[:, g]
+//     R   = |G| D                     Gershgorin bounds -> degree and interval of every point
+//     T'  = 2 (alpha D o (G (D o T)) - T) - T''            the three-term recurrence, 16 points at a time
+//     Xa' = Yw^T (D o Phi)            (k x U)(U x 16)
+//
+// Lane roles follow v_mfma_f32_16x16x4_f32: lane (lr, h) = (lane & 15, lane >> 4) owns COLUMN lr (= grid point lr of
+// the tile) and, of every 16-row tile, rows 4h .. 4h+3.  A result tile therefore sits in the registers exactly where
+// the next product wants its B operand, PROVIDED the summation index of that product is enumerated as
+// slot(step (t, q), lane group h) = 16 t + 4 h + q -- any enumeration sums the same product, so none of the vectors of
+// the recurrence ever leaves the registers (no LDS round trip, no cross-lane move); the Gram tiles themselves are,
+// by symmetry, the A fragments of G in that enumeration.  Members are enumerated the same way in Z and Xa', which puts
+// x' in the registers where the output tile needs it.
+//
+// Summation order is canonical: union slots are assigned by RANK of the observation index (hash-dedupe, then a counting
+// rank), permuted so that the enumeration above visits them in ascending rank.  A grid point's own observations are thus
+// always summed in ascending index order with exact zeros in between, whatever else is in the tile: results do not
+// depend on tile composition, shard boundaries or launch geometry, bit for bit.
+//
+// A tile whose union exceeds the 16 UT slots the instantiation has is processed in halves (quarters, ...) -- one point
+// always fits (p_max <= 16 UT is checked on the host); degree cap / non-finite / overflow / retry protocol are those
+// of letkf_cheb.hip (MIA_FLAG_RETRY points are redone by the eigensolver kernel).
+#include "mia_common.h"
+#include "mia_kernels.h"
+
+namespace mia {
+
+using f4t = __attribute__((ext_vector_type(4))) float;
+
+#define MIA_TILE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+struct TileParams {
+  const float* X; int64_t ldx; int m; int k; int kp;
+  int64_t g0, ng;
+  const float* rec;
+  const int32_t* cnt; const int32_t* idx; const void* w; int w_f32; int p_cap; int p_max;
+  float reg, inv_reg, f0, inv_k;
+  float* Xa; int64_t ldo, o0; int32_t* flags; int32_t* retry_count;
+  int dmax;
+  const int2* tab_hdr; const float2* tab_c; float cs_phi, cs_psi;
+  int kpv_magic;       // ceil(2^20 / (kp / 4))
+  // segmented launch (native step driver, see letkf_cheb_seg_kernel): the ng points are seg_len-sized segments, segment s
+  // writes its own (m k, seg_len) buffer at Xa + s * seg_stride with write-through stores and counts its finished POINTS
+  // in done[(s * 64 + j) * kSlotStride]; tiles never straddle a segment
+  int seg_len; int64_t seg_stride; int32_t* done;
+};
+
+__device__ __forceinline__ float tile_add_h(float v) {       // sum over the four lanes (lr, h = 0..3), in every one of them
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r.x) + __uint_as_float(r.y);
+  r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float tile_max_h(float v) {       // maximum over the same four lanes (NaN-propagating by bits
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));   //  for values >= +0: integer compare, see mia_common.h)
+  unsigned u = __float_as_uint(v);
+  u2v r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  u = r.x > r.y ? r.x : r.y;
+  r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u = r.x > r.y ? r.x : r.y;
+  return __uint_as_float(u);
+}
+
+template <int UT, int KT, bool SEG>
+__global__ __launch_bounds__(64, (UT <= 2 ? 3 : (UT == 3 ? 2 : 1))) void letkf_tile_kernel(TileParams P) {
+  constexpr int UMAX = 16 * UT, NU = 4 * UT;
+  constexpr int LOGHS = UT <= 1 ? 6 : (UT <= 2 ? 7 : 8), HS = 1 << LOGHS, HR = HS / 64;
+  constexpr int DS = UMAX + 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane0 = threadIdx.x;
+  const int k = P.k, kp = P.kp, pm = P.p_max;
+  float* Yw = reinterpret_cast<float*>(smem_raw);            // [UMAX][kp] union records (+ 16 zero floats)
+  float* Dl = Yw + UMAX * kp + 16;                           // [16][DS]   sqrt(rho) of (point, slot), 0 = not local
+  int* H = reinterpret_cast<int*>(Dl + 16 * DS);             // [HS]       hash table of observation indices
+  int* Hs = H + HS;                                          // [HS]       slot of a table position
+  int* ukey = Hs + HS;                                       // [UMAX]     observation index of a slot, -1 = unused
+  int* comp = ukey + UMAX;                                   // [64]       compacted keys
+  int* cpos = comp + 64;                                     // [64]       their table positions
+
+  // XCD-aware block -> tile map: blocks b, b + 8, ... share an XCD (and its L2) and take consecutive tiles, whose
+  // records overlap
+  const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+  int64_t p0;            // first point of the tile (index into the launch's ng points)
+  int npts;
+  int64_t oc0;           // output column of the tile's first point
+  float* Xab = P.Xa;
+  int sg = 0;
+  if constexpr (SEG) {
+    const int64_t tps = ((int64_t)P.seg_len + 15) >> 4;               // tiles per segment
+    const int64_t nseg = (P.ng + P.seg_len - 1) / P.seg_len;
+    if (bid >= tps * nseg) return;
+    sg = (int)(bid / tps);
+    const int64_t lt = bid - (int64_t)sg * tps;
+    const int64_t s0 = (int64_t)sg * P.seg_len;
+    const int64_t slen = P.ng - s0 < P.seg_len ? P.ng - s0 : P.seg_len;
+    p0 = s0 + (lt << 4);
+    npts = slen - (lt << 4) < 16 ? (int)(slen - (lt << 4)) : 16;
+    if (npts <= 0) return;
+    oc0 = lt << 4;
+    Xab += (int64_t)sg * P.seg_stride;
+  } else {
+    const int64_t ntile = (P.ng + 15) >> 4;
+    if (bid >= ntile) return;
+    const int64_t q8 = ntile >> 3, r8 = ntile & 7, xcd = bid & 7;
+    const int64_t tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    p0 = tile << 4;
+    npts = P.ng - p0 < 16 ? (int)(P.ng - p0) : 16;
+    oc0 = P.o0 + p0;
+  }
+
+  // ---- the tile's neighbour lists: lane (lp, sub) = (lane >> 2, lane & 3) holds entries sub, sub + 4, ... of point lp
+  int lcnt;
+  unsigned long long badmask;
+  const int nl = pm < P.p_cap ? pm : P.p_cap;
+  {
+    const int lp = lane0 >> 2, sub = lane0 & 3;
+    const int64_t lpt = p0 + (lp < npts ? lp : 0);
+    lcnt = P.cnt[lpt];
+    const bool pbad = lp < npts && (lcnt > pm || lcnt > P.p_cap || lcnt > UMAX);   // loud failure, never truncate
+    if (pbad) {
+      if (sub == 0) P.flags[p0 + lp] = MIA_FLAG_OVERFLOW;
+      const float nanv = __builtin_nanf("");
+      for (int it = sub; it < P.m * k; it += 4) {
+        if constexpr (SEG) __hip_atomic_store(&Xab[(int64_t)it * P.ldo + oc0 + lp], nanv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else Xab[(int64_t)it * P.ldo + oc0 + lp] = nanv;
+      }
+    }
+    if (lp >= npts || pbad) lcnt = 0;
+    badmask = __ballot(pbad);
+  }
+
+  int lo = 0;
+#pragma clang loop unroll(disable)
+  while (lo < npts) {
+    // The loop body runs once per tile unless the tile had to be split.  Everything addressed through the tile origin
+    // goes through an opaque copy of it, so that the compiler does not hoist ~40 address registers out of a loop that
+    // does not loop (they were live across the whole body and pushed the matrix phases into scratch).
+    int64_t p0v = p0, oc0v = oc0;
+    int lane = lane0;
+    asm volatile("" : "+s"(p0v), "+s"(oc0v), "+v"(lane));
+    const int lr = lane & 15, h = lane >> 4, lp = lane >> 2, sub = lane & 3;
+    const int64_t lptv = p0v + (lp < npts ? lp : 0);
+    const bool colok = lr < npts && !((badmask >> (4 * lr)) & 1ull);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // (the entries are (re)loaded per pass: they are dead once D is built, and a second pass happens only when a tile
+    //  had to be split)
+    int eidx[NU];
+    float ew[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {            // (unconditional loads inside the row's storage; masked below)
+      const int pos = sub + 4 * u, posc = pos < nl ? pos : 0;
+      eidx[u] = P.idx[lptv * P.p_cap + posc];
+      ew[u] = P.w_f32 ? reinterpret_cast<const float*>(P.w)[lptv * P.p_cap + posc]
+                      : float(reinterpret_cast<const double*>(P.w)[lptv * P.p_cap + posc]);
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      if (sub + 4 * u >= lcnt) { eidx[u] = -1; ew[u] = 0.0f; }
+    // ---- union of the lists of points [lo, hi): dedupe in a hash table, shrink the range until it fits
+    int n = 16, hi, U;
+    int epos[NU];
+    bool act;
+    for (;;) {
+      hi = lo + n < npts ? lo + n : npts;
+#pragma unroll
+      for (int r = 0; r < HR; ++r) H[lane + 64 * r] = -1;
+      if (lane < UMAX) ukey[lane] = -1;
+      MIA_TILE_SYNC();
+      act = lp >= lo && lp < hi;
+      int full = 0;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        epos[u] = 0;
+        if (act && eidx[u] >= 0) {
+          unsigned hh = ((unsigned)eidx[u] * 2654435761u) >> (32 - LOGHS);
+          int it = 0;
+#pragma clang loop unroll(disable)
+          for (; it < HS; ++it) {           // bounded: a table that fills up means the union cannot fit anyway
+            const int old = atomicCAS(&H[hh], -1, eidx[u]);
+            if (old == -1 || old == eidx[u]) break;
+            hh = (hh + 1) & (HS - 1);
+          }
+          if (it == HS) full = 1;
+          epos[u] = (int)hh;
+        }
+      }
+      MIA_TILE_SYNC();
+      int mykey[HR], myci[HR], tot = 0;
+#pragma unroll
+      for (int r = 0; r < HR; ++r) {
+        mykey[r] = H[lane * HR + r];
+        const bool occ = mykey[r] != -1;
+        const unsigned long long mask = __ballot(occ);
+        myci[r] = occ ? tot + __popcll(mask & lt_mask) : -1;
+        tot += __popcll(mask);
+      }
+      U = __any(full) ? (1 << 20) : tot;
+      if (U > UMAX) { n >>= 1; continue; }      // (n = 1 always fits: a single list has at most UMAX entries)
+#pragma unroll
+      for (int r = 0; r < HR; ++r)
+        if (myci[r] >= 0) { comp[myci[r]] = mykey[r]; cpos[myci[r]] = lane * HR + r; }
+      MIA_TILE_SYNC();
+      // ---- slots by rank of the observation index; enumeration order of the products = ascending rank
+      if (lane < U) {
+        const int key = comp[lane];
+        int rk = 0;
+        for (int j = 0; j < U; ++j) rk += comp[j] < key ? 1 : 0;
+        const int slot = 16 * (rk >> 4) + 4 * (rk & 3) + ((rk >> 2) & 3);
+        ukey[slot] = key;
+        Hs[cpos[lane]] = slot;
+      }
+      MIA_TILE_SYNC();
+      // ---- the union's records, unscaled (the sqrt(rho) factors differ per point: they live in D)
+      float fin = 0.0f;       // stays 0 while every value is finite (inf * 0 = NaN)
+      {
+        const unsigned kpv = (unsigned)kp >> 2;
+        const int total = UMAX * (int)kpv;
+        const float4* rec4 = reinterpret_cast<const float4*>(P.rec);
+        float4* Yw4 = reinterpret_cast<float4*>(Yw);
+        constexpr int GQ = 4;
+        for (int base = 0; base < total; base += 64 * GQ) {
+          float4 v[GQ];
+          int kk[GQ];
+#pragma unroll
+          for (int u = 0; u < GQ; ++u) {
+            const unsigned it = base + 64 * u + lane < total ? (unsigned)(base + 64 * u + lane) : 0u;
+            const unsigned j = (it * (unsigned)P.kpv_magic) >> 20;
+            kk[u] = ukey[j];
+            // (unconditional load -- a predicated one serialises the GQ requests -- from an address that is valid also for
+            //  unused slots and for P = 0, where there is no record array at all: the coefficient table)
+            const float4* src = kk[u] < 0 ? reinterpret_cast<const float4*>(P.tab_c)
+                                          : rec4 + ((uint64_t)(unsigned)kk[u] * kpv + (it - j * kpv));
+            v[u] = *src;
+          }
+#pragma unroll
+          for (int u = 0; u < GQ; ++u) {
+            const int it = base + 64 * u + lane;
+            if (it < total) {
+              const float4 t = kk[u] < 0 ? float4{0.f, 0.f, 0.f, 0.f} : v[u];
+              fin = fmaf(t.x, 0.0f, fmaf(t.y, 0.0f, fmaf(t.z, 0.0f, fmaf(t.w, 0.0f, fin))));
+              Yw4[it] = t;
+            }
+          }
+        }
+        if (lane < 4) Yw4[total + lane] = float4{0.f, 0.f, 0.f, 0.f};
+      }
+      // A non-finite record would reach EVERY column of the tile through the shared Gram matrix (NaN * 0 = NaN), also
+      // the points that do not see that observation.  Such a tile is analysed point by point: the union is then the
+      // point's own list and the damage stays where the reference has it (the points that use the observation).
+      if (__any(fin != fin) && hi - lo > 1) { n = 1; continue; }
+      break;
+    }
+    for (int i = lane; i < 4 * DS; i += 64) reinterpret_cast<f4t*>(Dl)[i] = f4t{0.f, 0.f, 0.f, 0.f};
+    MIA_TILE_SYNC();
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      if (act && eidx[u] >= 0) Dl[lp * DS + Hs[epos[u]]] = ew[u];
+    MIA_TILE_SYNC();
+    const bool colact = colok && lr >= lo && lr < hi;
+    const unsigned xoff = (unsigned)(4 * h) * (unsigned)P.ldx + (unsigned)lr;      // (4 h ldx + lr < 2^30: checked on the host)
+    const unsigned ooff = (unsigned)(4 * h) * (unsigned)P.ldo + (unsigned)lr;
+    f4t dreg[UT];
+#pragma unroll
+    for (int t = 0; t < UT; ++t) dreg[t] = *reinterpret_cast<const f4t*>(Dl + lr * DS + 16 * t + 4 * h);
+
+    f4t G[UT][UT];          // G[t1][t2][q] = Gram[16 t1 + 4 h + q][16 t2 + lr]
+    float alpha = 0.0f;
+    int deg = 0, tab_idx = 0, degmax = 0, pflag = 0;
+    bool decl = false;
+    for (int mi = 0; mi < P.m; ++mi) {
+      // ---- the tile's state row: member (tm, q) of lane group h = 16 tm + 4 h + q, column lr
+      f4t xb[KT];
+      float xs = 0.0f;
+#pragma unroll
+      for (int tm = 0; tm < KT; ++tm)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int mem = 16 * tm + 4 * h + q;
+          // (wave-uniform row base in scalar registers + ONE lane offset shared by every row: per-element 64-bit addresses
+          //  were strength-reduced into 8 KT address registers that lived across the whole recurrence)
+          const float* xrow = P.X + ((int64_t)mi * k + 16 * tm + q) * P.ldx + P.g0 + p0v;
+          const float v = (mem < k && colact) ? xrow[xoff] : 0.0f;
+          xb[tm][q] = v;
+          xs += v;
+        }
+      const float xm = tile_add_h(xs) * P.inv_k;
+#pragma unroll
+      for (int tm = 0; tm < KT; ++tm)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xb[tm][q] = (16 * tm + 4 * h + q < k && colact) ? xb[tm][q] - xm : 0.0f;
+      // ---- G = Yw Yw^T (first row only) and Z = Yw X'
+      f4t Z[UT];
+#pragma unroll
+      for (int t = 0; t < UT; ++t) Z[t] = f4t{0.f, 0.f, 0.f, 0.f};
+      if (mi == 0) {
+#pragma unroll
+        for (int t1 = 0; t1 < UT; ++t1)
+#pragma unroll
+          for (int t2 = 0; t2 < UT; ++t2) G[t1][t2] = f4t{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int tm = 0; tm < KT; ++tm) {
+        f4t av[UT];
+#pragma unroll
+        for (int t = 0; t < UT; ++t) {
+          av[t] = *reinterpret_cast<const f4t*>(Yw + (16 * t + lr) * kp + 16 * tm + 4 * h);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (16 * tm + 4 * h + q >= k) av[t][q] = 0.0f;        // innovation / pad columns, next row's start
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (mi == 0) {
+#pragma unroll
+            for (int t2 = 0; t2 < UT; ++t2)
+#pragma unroll
+              for (int t1 = 0; t1 < UT; ++t1)
+                G[t1][t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t1][q], av[t2][q], G[t1][t2], 0, 0, 0);
+          }
+#pragma unroll
+          for (int t = 0; t < UT; ++t) Z[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][q], xb[tm][q], Z[t], 0, 0, 0);
+        }
+      }
+      if (mi == 0) {
+        // ---- Gershgorin bound of every point: L_g = max_a w_a sum_b |G_ab| w_b, then degree / interval from the table
+        f4t R[UT];
+#pragma unroll
+        for (int t = 0; t < UT; ++t) R[t] = f4t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tk = 0; tk < UT; ++tk)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < UT; ++t)
+              R[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fabsf(G[tk][t][q]), dreg[tk][q], R[t], 0, 0, 0);
+        float L = 0.0f;
+#pragma unroll
+        for (int t = 0; t < UT; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float v = dreg[t][q] * R[t][q];
+            L = (v > L || v != v) ? v : L;
+          }
+        L = tile_max_h(L);
+        L = fmaxf(L, 1e-30f * P.reg) * 1.0001f;
+        if (!(L == L) || !(fabsf(L) < 1e30f)) { pflag |= MIA_FLAG_NONFINITE; L = P.reg; }
+        tab_idx = (int)ceilf(float(kTabPerOctave) * __builtin_amdgcn_logf(L * P.inv_reg)) + kTabIdx0;
+        tab_idx = tab_idx < 0 ? 0 : (tab_idx > kTabN - 1 ? kTabN - 1 : tab_idx);
+        const int2 hd = P.tab_hdr[tab_idx];
+        deg = hd.x;
+        alpha = __int_as_float(hd.y) * P.inv_reg;
+        decl = colact && (deg > P.dmax || deg > kTabDeg - 1);
+        if (decl && h == 0) {
+          P.flags[p0v + lr] = MIA_FLAG_RETRY;
+          atomicAdd(P.retry_count, 1);
+        }
+        degmax = (int)wave_max_nonneg_dpp((colact && !decl) ? float(deg) : 0.0f);
+      }
+      // ---- the recurrence on the 16 columns at once; vectors stay in the result layout
+      const float2* crow = P.tab_c + (size_t)tab_idx * kTabDeg;
+      f4t tp[UT], tc[UT], aphi[UT], apsi[UT], y[UT];
+      auto product = [&](const f4t (&tv)[UT]) {
+#pragma unroll
+        for (int t = 0; t < UT; ++t) y[t] = f4t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tk = 0; tk < UT; ++tk)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float b = dreg[tk][q] * tv[tk][q];
+#pragma unroll
+            for (int t = 0; t < UT; ++t) y[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(G[tk][t][q], b, y[t], 0, 0, 0);
+          }
+      };
+      float2 c0 = crow[0], c1 = crow[1];
+#pragma unroll
+      for (int t = 0; t < UT; ++t) tp[t] = dreg[t] * Z[t];
+      product(tp);
+#pragma unroll
+      for (int t = 0; t < UT; ++t) {
+        tc[t] = alpha * (dreg[t] * y[t]) - tp[t];
+        aphi[t] = (c0.x * P.cs_phi) * tp[t] + (c1.x * P.cs_phi) * tc[t];
+        apsi[t] = (c0.y * P.cs_psi) * tp[t] + (c1.y * P.cs_psi) * tc[t];
+      }
+      for (int j = 2; j <= degmax; ++j) {
+        const float2 cj = crow[j < kTabDeg ? j : kTabDeg - 1];      // (zero beyond a point's own degree)
+        product(tc);
+        const float cphi = cj.x * P.cs_phi, cpsi = cj.y * P.cs_psi;
+#pragma unroll
+        for (int t = 0; t < UT; ++t) {
+          const f4t tn = 2.0f * (alpha * (dreg[t] * y[t]) - tc[t]) - tp[t];
+          tp[t] = tc[t]; tc[t] = tn;
+          aphi[t] = cphi * tn + aphi[t];
+          apsi[t] = cpsi * tn + apsi[t];
+        }
+      }
+      // ---- x' w_mean = sum_b d_b (w_b psi_b): one more product, row vector of the innovations (column k of the records)
+      //      times D o Psi -- on the matrix cores like everything else, because their enumeration IS the canonical
+      //      summation order (a lane-local partial sum would group the observations by rank mod 4, i.e. by tile
+      //      composition).  Row 0 of the result tile = lanes (lr, h = 0), register 0; handed to the column's other lanes.
+      f4t zacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tk = 0; tk < UT; ++tk)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float a = lr == 0 ? Yw[(16 * tk + 4 * h + q) * kp + k] : 0.0f;
+          zacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, dreg[tk][q] * apsi[tk][q], zacc, 0, 0, 0);
+        }
+      const float zu = __shfl(zacc[0], lr, 64);
+#pragma unroll
+      for (int t = 0; t < UT; ++t) aphi[t] *= dreg[t];        // s = D o phi: right-hand side of the last product
+      const float mterm = xm + zu;
+#pragma unroll
+      for (int tj = 0; tj < KT; ++tj) {
+        f4t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tk = 0; tk < UT; ++tk)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Yw[(16 * tk + 4 * h + q) * kp + 16 * tj + lr], aphi[tk][q], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int mem = 16 * tj + 4 * h + q;
+          if (mem < k && colact && !decl) {
+            // (x is read again here, L2-hot, instead of being held in 4 KT registers across the recurrence)
+            const float* xrow = P.X + ((int64_t)mi * k + 16 * tj + q) * P.ldx + P.g0 + p0v;
+            float* orow = Xab + ((int64_t)mi * k + 16 * tj + q) * P.ldo + oc0v;
+            const float xv = xrow[xoff];
+            const float out = mterm + P.f0 * (xv - xm) + acc[q];
+            if (!(fabsf(out) <= 1e30f)) pflag |= MIA_FLAG_NONFINITE;
+            // segmented launch: write-through (agent-scope) stores, published by the counter below
+            if constexpr (SEG) __hip_atomic_store(&orow[ooff], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else orow[ooff] = out;
+          }
+        }
+      }
+    }
+    {
+      const unsigned long long fb = __ballot(pflag != 0);
+      const bool anyf = ((fb >> lr) & 0x0001000100010001ull) != 0ull;
+      if (h == 0 && colact && !decl) P.flags[p0v + lr] = (anyf ? MIA_FLAG_NONFINITE : 0) | (deg << 8);
+    }
+    lo = hi;
+    MIA_TILE_SYNC();
+  }
+  if constexpr (SEG) {
+    // all output stores of this wavefront have been acknowledged before it counts its points
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane0 == 0)
+      __hip_atomic_fetch_add(P.done + ((size_t)sg * 64 + (unsigned)(bid & 63)) * kSlotStride, npts, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+static size_t tile_lds_bytes(int ut, int kp) {
+  const int umax = 16 * ut, hs = ut <= 1 ? 64 : (ut <= 2 ? 128 : 256);
+  return align_up(((size_t)umax * kp + 16 + 16 * (size_t)(umax + 4)) * sizeof(float) + ((size_t)2 * hs + umax + 128) * sizeof(int), 16);
+}
+
+template <int UT, int KT, bool SEG>
+static int tile_launch_s(const TileParams& tp, hipStream_t stream) {
+  const size_t lds = tile_lds_bytes(UT, tp.kp);
+  if (lds > kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
+  auto kern = letkf_tile_kernel<UT, KT, SEG>;
+  if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int64_t ntile = SEG ? (((int64_t)tp.seg_len + 15) >> 4) * ((tp.ng + tp.seg_len - 1) / tp.seg_len) : (tp.ng + 15) >> 4;
+  const int64_t gx = ntile < 65536 ? ntile : 65536;
+  const int64_t gy = (ntile + gx - 1) / gx;
+  if (gy > 65535) return MIA_ERR_UNSUPPORTED;
+  kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64), lds, stream>>>(tp);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+template <int UT, int KT>
+static int tile_launch_t(const TileParams& tp, hipStream_t stream) {
+  return tp.seg_len > 0 ? tile_launch_s<UT, KT, true>(tp, stream) : tile_launch_s<UT, KT, false>(tp, stream);
+}
+
+template <int UT>
+static int tile_launch_u(const TileParams& tp, int kt, hipStream_t stream) {
+  switch (kt) {
+    case 1: return tile_launch_t<UT, 1>(tp, stream);
+    case 2: return tile_launch_t<UT, 2>(tp, stream);
+    case 3: return tile_launch_t<UT, 3>(tp, stream);
+    case 4: return tile_launch_t<UT, 4>(tp, stream);
+  }
+  return MIA_ERR_UNSUPPORTED;
+}
+
+// Slots an instantiation offers a tile beyond the longest single list.  Sixteen consecutive points of a regular
+// network add ~one observation per second point (config 2: 20 -> 28); below this slack most tiles would be split.
+constexpr int kTileSlack = 8;
+
+bool tile_route_covers(int m, int k, int p_max) {
+  return m < 8 && k >= 2 && k <= 64 && p_max <= k && p_max + kTileSlack <= 64;
+}
+
+int tile_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
+                         const int32_t* nbr_cnt, const int32_t* nbr_idx, const void* nbr_w, int w_f32, int p_cap,
+                         int p_max, float inf_factor, float* Xa, int64_t ldo, int64_t o0, int32_t* flags,
+                         int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c, hipStream_t stream,
+                         int seg_len, int64_t seg_stride, int32_t* done) {
+  if (seg_len > 0 && (!done || ng >= (int64_t)1 << 31)) return MIA_ERR_UNSUPPORTED;
+  if (!tile_route_covers(m, k, p_max) || !flags || !retry_count || !tab_hdr || !tab_c) return MIA_ERR_UNSUPPORTED;
+  if (ldx > (1 << 26) || ldo > (1 << 26)) return MIA_ERR_UNSUPPORTED;     // 32-bit lane offsets (12 ld + 15 elements)
+  TileParams tp;
+  tp.X = X; tp.ldx = ldx; tp.m = m; tp.k = k; tp.kp = (k + 1 + 3) & ~3;
+  tp.g0 = g0; tp.ng = ng; tp.rec = rec;
+  tp.cnt = nbr_cnt; tp.idx = nbr_idx; tp.w = nbr_w; tp.w_f32 = w_f32; tp.p_cap = p_cap; tp.p_max = p_max;
+  const double rg = (double)(k - 1) / (double)inf_factor, km = (double)(k - 1);
+  tp.reg = (float)rg;
+  tp.inv_reg = (float)(1.0 / rg);
+  tp.f0 = (float)sqrt(km / rg);
+  tp.inv_k = (float)(1.0 / (double)k);
+  tp.Xa = Xa; tp.ldo = ldo; tp.o0 = o0; tp.flags = flags; tp.retry_count = retry_count;
+  tp.dmax = dmax;
+  tp.tab_hdr = tab_hdr; tp.tab_c = tab_c;
+  tp.cs_phi = (float)(sqrt(km) / (rg * sqrt(rg)));
+  tp.cs_psi = (float)(1.0 / rg);
+  tp.kpv_magic = ((1 << 20) + (tp.kp >> 2) - 1) / (tp.kp >> 2);
+  tp.seg_len = seg_len; tp.seg_stride = seg_stride; tp.done = done;
+  const int kt = (k + 15) >> 4;
+  const int ut = (p_max + kTileSlack + 15) >> 4;
+  switch (ut < 1 ? 1 : ut) {
+    case 1: return tile_launch_u<1>(tp, kt, stream);
+    case 2: return tile_launch_u<2>(tp, kt, stream);
+    case 3: return tile_launch_u<3>(tp, kt, stream);
+    case 4: return tile_launch_u<4>(tp, kt, stream);
+  }
+  return MIA_ERR_UNSUPPORTED;
+}
+
+}  // namespace mia

@@ -24,6 +24,21 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
                          hipStream_t stream, int seg_len = 0, int64_t seg_stride = 0, int32_t* done = nullptr,
                          float* W_out = nullptr /* weights-output variant: [ng][k][k] */, const IenksOpts* ienks = nullptr);
 
+// Chebyshev coefficient tables of the matfun kernels (letkf_cheb.hip, cheb_coef_table): geometric grid of scaled
+// spectral bounds T = L / reg, 32 per octave over 2^-24 .. 2^8; entry i holds {degree, bits of 2 / T} and 64 (phi, psi)
+// coefficient pairs, zero beyond the degree.
+constexpr int kTabPerOctave = 32, kTabIdx0 = 24 * kTabPerOctave, kTabN = 32 * kTabPerOctave, kTabDeg = 64;
+
+// letkf_tile.hip: the same analysis with sixteen grid points per wavefront (dual route, k <= 64, few state rows).
+// tile_route_covers: shape test; tile_analysis_launch: MIA_ERR_UNSUPPORTED outside it.  nbr_w is float64 or (w_f32)
+// float32 lists.
+bool tile_route_covers(int m, int k, int p_max);
+int tile_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
+                         const int32_t* nbr_cnt, const int32_t* nbr_idx, const void* nbr_w, int w_f32, int p_cap,
+                         int p_max, float inf_factor, float* Xa, int64_t ldo, int64_t o0, int32_t* flags,
+                         int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c, hipStream_t stream,
+                         int seg_len = 0, int64_t seg_stride = 0, int32_t* done = nullptr);
+
 // one-wave kernel on `stream` that returns once the 64 slot counters at done64[j * kSlotStride] sum to `expected` (bounded
 // polling: after ~seconds it sets bit 0 of *err and returns, so the grid always drains)
 int segment_wait_launch(const int32_t* done64, int expected, int32_t* err, hipStream_t stream);
