@@ -12,6 +12,7 @@ ap.add_argument("--methods", default="matfun,eig")
 ap.add_argument("--batches", type=int, default=7)
 ap.add_argument("--grid", type=int, default=100000)
 a = ap.parse_args()
+mia.build()
 dev = torch.device("cuda:0")
 eng = mia.LetkfEngine(dev)
 cfgs = {"c2": (40, 2, 10.0, None), "c4": (80, 1, 16.5, None), "c5": (40, 2, 10.0, 0.5)}

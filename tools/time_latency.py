@@ -6,10 +6,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import torch_assimilate_amd as mia
+mia.build()
 dev = torch.device("cuda:0")
 eng = mia.LetkfEngine(dev)
 K = 40
-for G in (256, 1024, 2048, 4096, 8192, 16384, 32768, 100000):
+for G in (256, 1024, 4096, 16384, 32768, 49152, 65536, 100000):
     X, gx, ox, Yb, d = bench.make_case(G, K, 2, dev)
     nb = eng.localize(gx, ox, [10.0])
     rec = eng.pack_obs(Yb, d, torch.float32)
@@ -26,4 +27,4 @@ for G in (256, 1024, 2048, 4096, 8192, 16384, 32768, 100000):
             fn()
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 10)
-    print("G = %6d   %8.1f us per launch   %6.2f ns per point   (%.2f waves per SIMD)" % (G, best * 1e3, best * 1e6 / G, G / 1024.0), flush=True)
+    print("G = %6d   %8.1f us per launch   %6.2f ns per point   (%.2f waves, %.2f 16-point tiles per SIMD)" % (G, best * 1e3, best * 1e6 / G, G / 1024.0, G / 16384.0), flush=True)

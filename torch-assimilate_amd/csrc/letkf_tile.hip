@@ -72,21 +72,57 @@ __device__ __forceinline__ float tile_max_h(float v) {       // maximum over the
   return __uint_as_float(u);
 }
 
+__device__ __forceinline__ unsigned tile_wave_max_u32(unsigned u) {     // wave-uniform maximum (DPP, see mia_common.h)
+  unsigned t;
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0xB1, 0xf, 0xf, false); u = u > t ? u : t;
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x4E, 0xf, 0xf, false); u = u > t ? u : t;
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x124, 0xf, 0xf, false); u = u > t ? u : t;
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x128, 0xf, 0xf, false); u = u > t ? u : t;
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)u, 0), b = (unsigned)__builtin_amdgcn_readlane((int)u, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)u, 32), d = (unsigned)__builtin_amdgcn_readlane((int)u, 48);
+  const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
+}
+
+// Every global access of the kernel is `wave-uniform base + 32-bit lane offset in bytes` (the saddr + voffset form of
+// global_load / global_store): the host checks that the offsets fit, and no 64-bit address ever lives in vector registers.
+template <typename T>
+__device__ __forceinline__ T ld_off(const void* base, unsigned byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// In-kernel phase stamps (diagnostic builds only, tools/tile_stamps.py): -DMIA_TILE_STAMPS compiles them in; the stamp
+// values go to a buffer of their own that nothing else reads.
+#ifdef MIA_TILE_STAMPS
+constexpr int kStampN = 12, kStampTiles = 8192;
+__device__ long long g_tile_stamps[kStampTiles * kStampN];
+#define MIA_STAMP(i) do { if (lane0 == 0 && bid < kStampTiles) g_tile_stamps[bid * kStampN + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MIA_STAMP(i) do { } while (0)
+#endif
+
+#ifndef MIA_TILE_WAVES_UT2
+#define MIA_TILE_WAVES_UT2 3
+#endif
+
 template <int UT, int KT, bool SEG>
-__global__ __launch_bounds__(64, (UT <= 2 ? 3 : (UT == 3 ? 2 : 1))) void letkf_tile_kernel(TileParams P) {
+__global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 1))) void letkf_tile_kernel(TileParams P) {
   constexpr int UMAX = 16 * UT, NU = 4 * UT;
   constexpr int LOGHS = UT <= 1 ? 6 : (UT <= 2 ? 7 : 8), HS = 1 << LOGHS, HR = HS / 64;
   constexpr int DS = UMAX + 4;
+  constexpr int CL = (16 * DS + 2 * HS + UMAX + 128) / 32;   // degrees whose coefficients fit the union scratch (31 at UT = 2)
+  constexpr int CQ = (CL + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane0 = threadIdx.x;
   const int k = P.k, kp = P.kp, pm = P.p_max;
   float* Yw = reinterpret_cast<float*>(smem_raw);            // [UMAX][kp] union records (+ 16 zero floats)
   float* Dl = Yw + UMAX * kp + 16;                           // [16][DS]   sqrt(rho) of (point, slot), 0 = not local
-  int* H = reinterpret_cast<int*>(Dl + 16 * DS);             // [HS]       hash table of observation indices
+  int* H = reinterpret_cast<int*>(Dl + 16 * DS);             // [HS]       hash table of observation indices / index bitmap
   int* Hs = H + HS;                                          // [HS]       slot of a table position
   int* ukey = Hs + HS;                                       // [UMAX]     observation index of a slot, -1 = unused
   int* comp = ukey + UMAX;                                   // [64]       compacted keys
   int* cpos = comp + 64;                                     // [64]       their table positions
+  float2* Cl = reinterpret_cast<float2*>(Dl);                // [CL][16]   scaled Chebyshev coefficients (reuses Dl .. cpos)
 
   // XCD-aware block -> tile map: blocks b, b + 8, ... share an XCD (and its L2) and take consecutive tiles, whose
   // records overlap
@@ -118,15 +154,36 @@ __global__ __launch_bounds__(64, (UT <= 2 ? 3 : (UT == 3 ? 2 : 1))) void letkf_t
     npts = P.ng - p0 < 16 ? (int)(P.ng - p0) : 16;
     oc0 = P.o0 + p0;
   }
+  MIA_STAMP(0);
 
-  // ---- the tile's neighbour lists: lane (lp, sub) = (lane >> 2, lane & 3) holds entries sub, sub + 4, ... of point lp
+  // ---- the tile's neighbour lists: lane (lp, sub) = (lane >> 2, lane & 3) holds entries sub, sub + 4, ... of point lp.
+  //      Count and entries are requested before anything is waited for.  The entries are loop-carried: loaded here for
+  //      the first pass and, at the bottom of the loop, for the next one (only a split tile has one) -- dead in between.
+  const int nl = pm < P.p_cap ? pm : P.p_cap;
+  const int nu = (nl + 3) >> 2;                  // entries a lane can hold a valid one in (wave-uniform): 5 of 8 at config 2
+  int eidx[NU];
+  float ew[NU];
+  auto load_lists = [&](int64_t pt0, int lp, int sub) {
+    const unsigned rowb = (unsigned)(lp < npts ? lp : 0) * (unsigned)P.p_cap;
+    const int32_t* ib = P.idx + pt0 * P.p_cap;
+    const char* wb = reinterpret_cast<const char*>(P.w) + pt0 * P.p_cap * (P.w_f32 ? 4 : 8);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      eidx[u] = -1; ew[u] = 0.0f;
+      if (u < nu) {                          // (unconditional loads inside the row's storage; masked when consumed)
+        const int pos = sub + 4 * u;
+        const unsigned e = rowb + (unsigned)(pos < nl ? pos : 0);
+        eidx[u] = ld_off<int32_t>(ib, e * 4u);
+        ew[u] = P.w_f32 ? ld_off<float>(wb, e * 4u) : float(ld_off<double>(wb, e * 8u));
+      }
+    }
+  };
   int lcnt;
   unsigned long long badmask;
-  const int nl = pm < P.p_cap ? pm : P.p_cap;
   {
     const int lp = lane0 >> 2, sub = lane0 & 3;
-    const int64_t lpt = p0 + (lp < npts ? lp : 0);
-    lcnt = P.cnt[lpt];
+    lcnt = ld_off<int32_t>(P.cnt + p0, (unsigned)(lp < npts ? lp : 0) * 4u);
+    load_lists(p0, lp, sub);
     const bool pbad = lp < npts && (lcnt > pm || lcnt > P.p_cap || lcnt > UMAX);   // loud failure, never truncate
     if (pbad) {
       if (sub == 0) P.flags[p0 + lp] = MIA_FLAG_OVERFLOW;
@@ -143,90 +200,149 @@ __global__ __launch_bounds__(64, (UT <= 2 ? 3 : (UT == 3 ? 2 : 1))) void letkf_t
   int lo = 0;
 #pragma clang loop unroll(disable)
   while (lo < npts) {
-    // The loop body runs once per tile unless the tile had to be split.  Everything addressed through the tile origin
-    // goes through an opaque copy of it, so that the compiler does not hoist ~40 address registers out of a loop that
-    // does not loop (they were live across the whole body and pushed the matrix phases into scratch).
+    // The loop body runs once per tile unless the tile had to be split.  Tile origin and lane id go through opaque
+    // copies, so that the compiler does not hoist dozens of address / predicate registers out of a loop that does not
+    // loop (they lived across the whole body and pushed the matrix phases into scratch).
     int64_t p0v = p0, oc0v = oc0;
     int lane = lane0;
     asm volatile("" : "+s"(p0v), "+s"(oc0v), "+v"(lane));
     const int lr = lane & 15, h = lane >> 4, lp = lane >> 2, sub = lane & 3;
-    const int64_t lptv = p0v + (lp < npts ? lp : 0);
     const bool colok = lr < npts && !((badmask >> (4 * lr)) & 1ull);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    // (the entries are (re)loaded per pass: they are dead once D is built, and a second pass happens only when a tile
-    //  had to be split)
-    int eidx[NU];
-    float ew[NU];
+    const int lrc = lr < npts ? lr : npts - 1;                      // a column that exists (clamped, unconditional loads)
+    const unsigned ldxb = (unsigned)P.ldx * 4u, ldob = (unsigned)P.ldo * 4u;       // (k ld 4 < 2^31: checked on the host)
+    const unsigned xlane = (unsigned)(4 * h) * ldxb + (unsigned)lrc * 4u;
+    // ---- a state row of the tile: member (tm, q) of lane group h = 16 tm + 4 h + q, column lr.  Unconditional loads
+    //      (clamped to the last member / an existing column), requested now and consumed after the union is built
+    auto load_x = [&](int mi, f4t (&xr)[KT]) {
+      const float* xbase = P.X + (int64_t)mi * k * P.ldx + P.g0 + p0v;
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {            // (unconditional loads inside the row's storage; masked below)
-      const int pos = sub + 4 * u, posc = pos < nl ? pos : 0;
-      eidx[u] = P.idx[lptv * P.p_cap + posc];
-      ew[u] = P.w_f32 ? reinterpret_cast<const float*>(P.w)[lptv * P.p_cap + posc]
-                      : float(reinterpret_cast<const double*>(P.w)[lptv * P.p_cap + posc]);
-    }
+      for (int tm = 0; tm < KT; ++tm)
 #pragma unroll
-    for (int u = 0; u < NU; ++u)
-      if (sub + 4 * u >= lcnt) { eidx[u] = -1; ew[u] = 0.0f; }
-    // ---- union of the lists of points [lo, hi): dedupe in a hash table, shrink the range until it fits
+        for (int q = 0; q < 4; ++q) {
+          unsigned off = xlane + (unsigned)(16 * tm + q) * ldxb;
+          if (tm == KT - 1) {
+            const int mem = 16 * tm + 4 * h + q;
+            off = (unsigned)(mem < k ? mem : k - 1) * ldxb + (unsigned)lrc * 4u;
+          }
+          xr[tm][q] = ld_off<float>(xbase, off);
+        }
+    };
+    f4t xb[KT];
+    load_x(0, xb);
+    MIA_STAMP(1);
+
+    // ---- union of the lists of points [lo, hi), slots by RANK of the observation index (the enumeration order of the
+    //      products = ascending rank); shrink the range until the union fits
     int n = 16, hi, U;
-    int epos[NU];
-    bool act;
+    int es[NU];            // slot of this lane's entries
     for (;;) {
       hi = lo + n < npts ? lo + n : npts;
-#pragma unroll
-      for (int r = 0; r < HR; ++r) H[lane + 64 * r] = -1;
+      const bool act = lp >= lo && lp < hi;
       if (lane < UMAX) ukey[lane] = -1;
-      MIA_TILE_SYNC();
-      act = lp >= lo && lp < hi;
-      int full = 0;
+      unsigned mx1 = 0u, mninv = 0u;             // range of the observation indices (wave-uniform after the reductions)
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
-        epos[u] = 0;
-        if (act && eidx[u] >= 0) {
-          unsigned hh = ((unsigned)eidx[u] * 2654435761u) >> (32 - LOGHS);
-          int it = 0;
-#pragma clang loop unroll(disable)
-          for (; it < HS; ++it) {           // bounded: a table that fills up means the union cannot fit anyway
-            const int old = atomicCAS(&H[hh], -1, eidx[u]);
-            if (old == -1 || old == eidx[u]) break;
-            hh = (hh + 1) & (HS - 1);
-          }
-          if (it == HS) full = 1;
-          epos[u] = (int)hh;
+        es[u] = -1;
+        if (u < nu) {
+          const bool v = act && sub + 4 * u < lcnt;
+          const unsigned key = (unsigned)eidx[u];
+          mx1 = (v && key + 1u > mx1) ? key + 1u : mx1;
+          mninv = (v && ~key > mninv) ? ~key : mninv;
         }
       }
-      MIA_TILE_SYNC();
-      int mykey[HR], myci[HR], tot = 0;
+      mx1 = tile_wave_max_u32(mx1);
+      mninv = tile_wave_max_u32(mninv);
+      const int ibase = (int)~mninv;
+      if (mx1 == 0u) {
+        U = 0;                                       // no local observation anywhere in the range
+        MIA_TILE_SYNC();
+      } else if ((int)mx1 - 1 - ibase < 256) {
+        // -- fast path (1-D / index-sorted networks): the indices span < 256 values.  A 256-bit map in LDS (atomic OR, no
+        //    return value) that every lane reads back whole: rank = set bits below, no dedupe, no sort
+        unsigned long long* bm = reinterpret_cast<unsigned long long*>(H);
+        if (lane < 4) bm[lane] = 0ull;
+        MIA_TILE_SYNC();
 #pragma unroll
-      for (int r = 0; r < HR; ++r) {
-        mykey[r] = H[lane * HR + r];
-        const bool occ = mykey[r] != -1;
-        const unsigned long long mask = __ballot(occ);
-        myci[r] = occ ? tot + __popcll(mask & lt_mask) : -1;
-        tot += __popcll(mask);
-      }
-      U = __any(full) ? (1 << 20) : tot;
-      if (U > UMAX) { n >>= 1; continue; }      // (n = 1 always fits: a single list has at most UMAX entries)
+        for (int u = 0; u < NU; ++u)
+          if (u < nu && act && sub + 4 * u < lcnt) {
+            const unsigned off = (unsigned)(eidx[u] - ibase);
+            atomicOr(reinterpret_cast<unsigned*>(H) + (off >> 5), 1u << (off & 31u));
+          }
+        MIA_TILE_SYNC();
+        const unsigned long long m0 = bm[0], m1 = bm[1], m2 = bm[2], m3 = bm[3];
+        const int c0 = __popcll(m0), c1 = c0 + __popcll(m1), c2 = c1 + __popcll(m2);
+        U = c2 + __popcll(m3);
+        if (U > UMAX) { n >>= 1; continue; }      // (n = 1 always fits: a single list has at most UMAX entries)
 #pragma unroll
-      for (int r = 0; r < HR; ++r)
-        if (myci[r] >= 0) { comp[myci[r]] = mykey[r]; cpos[myci[r]] = lane * HR + r; }
-      MIA_TILE_SYNC();
-      // ---- slots by rank of the observation index; enumeration order of the products = ascending rank
-      if (lane < U) {
-        const int key = comp[lane];
-        int rk = 0;
-        for (int j = 0; j < U; ++j) rk += comp[j] < key ? 1 : 0;
-        const int slot = 16 * (rk >> 4) + 4 * (rk & 3) + ((rk >> 2) & 3);
-        ukey[slot] = key;
-        Hs[cpos[lane]] = slot;
+        for (int u = 0; u < NU; ++u)
+          if (u < nu && act && sub + 4 * u < lcnt) {
+            const unsigned off = (unsigned)(eidx[u] - ibase), wsel = off >> 6;
+            const unsigned long long mw = wsel == 0 ? m0 : (wsel == 1 ? m1 : (wsel == 2 ? m2 : m3));
+            const int pre = wsel == 0 ? 0 : (wsel == 1 ? c0 : (wsel == 2 ? c1 : c2));
+            const int rk = pre + __popcll(mw & ((1ull << (off & 63u)) - 1ull));
+            es[u] = 16 * (rk >> 4) + 4 * (rk & 3) + ((rk >> 2) & 3);
+            ukey[es[u]] = eidx[u];                   // (lanes that share an observation write the same value)
+          }
+        MIA_TILE_SYNC();
+      } else {
+        // -- general path: dedupe in a hash table, rank by counting
+#pragma unroll
+        for (int r = 0; r < HR; ++r) H[lane + 64 * r] = -1;
+        MIA_TILE_SYNC();
+        int full = 0;
+        int epos[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          epos[u] = 0;
+          if (u < nu && act && sub + 4 * u < lcnt) {
+            unsigned hh = ((unsigned)eidx[u] * 2654435761u) >> (32 - LOGHS);
+            int it = 0;
+#pragma clang loop unroll(disable)
+            for (; it < HS; ++it) {           // bounded: a table that fills up means the union cannot fit anyway
+              const int old = atomicCAS(&H[hh], -1, eidx[u]);
+              if (old == -1 || old == eidx[u]) break;
+              hh = (hh + 1) & (HS - 1);
+            }
+            if (it == HS) full = 1;
+            epos[u] = (int)hh;
+          }
+        }
+        MIA_TILE_SYNC();
+        int mykey[HR], myci[HR], tot = 0;
+#pragma unroll
+        for (int r = 0; r < HR; ++r) {
+          mykey[r] = H[lane * HR + r];
+          const bool occ = mykey[r] != -1;
+          const unsigned long long mask = __ballot(occ);
+          myci[r] = occ ? tot + __popcll(mask & lt_mask) : -1;
+          tot += __popcll(mask);
+        }
+        U = __any(full) ? (1 << 20) : tot;
+        if (U > UMAX) { n >>= 1; continue; }
+#pragma unroll
+        for (int r = 0; r < HR; ++r)
+          if (myci[r] >= 0) { comp[myci[r]] = mykey[r]; cpos[myci[r]] = lane * HR + r; }
+        MIA_TILE_SYNC();
+        if (lane < U) {
+          const int key = comp[lane];
+          int rk = 0;
+          for (int j = 0; j < U; ++j) rk += comp[j] < key ? 1 : 0;
+          const int slot = 16 * (rk >> 4) + 4 * (rk & 3) + ((rk >> 2) & 3);
+          ukey[slot] = key;
+          Hs[cpos[lane]] = slot;
+        }
+        MIA_TILE_SYNC();
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+          if (u < nu && act && sub + 4 * u < lcnt) es[u] = Hs[epos[u]];
       }
-      MIA_TILE_SYNC();
+      MIA_STAMP(2);
       // ---- the union's records, unscaled (the sqrt(rho) factors differ per point: they live in D)
       float fin = 0.0f;       // stays 0 while every value is finite (inf * 0 = NaN)
       {
         const unsigned kpv = (unsigned)kp >> 2;
         const int total = UMAX * (int)kpv;
-        const float4* rec4 = reinterpret_cast<const float4*>(P.rec);
         float4* Yw4 = reinterpret_cast<float4*>(Yw);
         constexpr int GQ = 4;
         for (int base = 0; base < total; base += 64 * GQ) {
@@ -239,8 +355,9 @@ __global__ __launch_bounds__(64, (UT <= 2 ? 3 : (UT == 3 ? 2 : 1))) void letkf_t
             kk[u] = ukey[j];
             // (unconditional load -- a predicated one serialises the GQ requests -- from an address that is valid also for
             //  unused slots and for P = 0, where there is no record array at all: the coefficient table)
+            // (the one 64-bit lane address of the kernel: the record array may exceed 4 GB)
             const float4* src = kk[u] < 0 ? reinterpret_cast<const float4*>(P.tab_c)
-                                          : rec4 + ((uint64_t)(unsigned)kk[u] * kpv + (it - j * kpv));
+                                          : reinterpret_cast<const float4*>(P.rec) + ((uint64_t)(unsigned)kk[u] * kpv + (it - j * kpv));
             v[u] = *src;
           }
 #pragma unroll
@@ -261,44 +378,46 @@ __global__ __launch_bounds__(64, (UT <= 2 ? 3 : (UT == 3 ? 2 : 1))) void letkf_t
       if (__any(fin != fin) && hi - lo > 1) { n = 1; continue; }
       break;
     }
+    MIA_STAMP(3);
     for (int i = lane; i < 4 * DS; i += 64) reinterpret_cast<f4t*>(Dl)[i] = f4t{0.f, 0.f, 0.f, 0.f};
     MIA_TILE_SYNC();
 #pragma unroll
     for (int u = 0; u < NU; ++u)
-      if (act && eidx[u] >= 0) Dl[lp * DS + Hs[epos[u]]] = ew[u];
+      if (es[u] >= 0) Dl[lp * DS + es[u]] = ew[u];
     MIA_TILE_SYNC();
     const bool colact = colok && lr >= lo && lr < hi;
-    const unsigned xoff = (unsigned)(4 * h) * (unsigned)P.ldx + (unsigned)lr;      // (4 h ldx + lr < 2^30: checked on the host)
-    const unsigned ooff = (unsigned)(4 * h) * (unsigned)P.ldo + (unsigned)lr;
     f4t dreg[UT];
 #pragma unroll
     for (int t = 0; t < UT; ++t) dreg[t] = *reinterpret_cast<const f4t*>(Dl + lr * DS + 16 * t + 4 * h);
+    MIA_STAMP(4);
 
     f4t G[UT][UT];          // G[t1][t2][q] = Gram[16 t1 + 4 h + q][16 t2 + lr]
     float alpha = 0.0f;
     int deg = 0, tab_idx = 0, degmax = 0, pflag = 0;
     bool decl = false;
     for (int mi = 0; mi < P.m; ++mi) {
-      // ---- the tile's state row: member (tm, q) of lane group h = 16 tm + 4 h + q, column lr
-      f4t xb[KT];
+      // (lane roles through opaque copies once more: what is invariant in this loop -- addresses, predicates of the
+      //  first-row-only phases -- would otherwise be hoisted in front of it and spilled there)
+      int hv = h, lrv = lr;
+      asm volatile("" : "+v"(hv), "+v"(lrv));
+      if (mi > 0) load_x(mi, xb);
       float xs = 0.0f;
 #pragma unroll
       for (int tm = 0; tm < KT; ++tm)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int mem = 16 * tm + 4 * h + q;
-          // (wave-uniform row base in scalar registers + ONE lane offset shared by every row: per-element 64-bit addresses
-          //  were strength-reduced into 8 KT address registers that lived across the whole recurrence)
-          const float* xrow = P.X + ((int64_t)mi * k + 16 * tm + q) * P.ldx + P.g0 + p0v;
-          const float v = (mem < k && colact) ? xrow[xoff] : 0.0f;
-          xb[tm][q] = v;
-          xs += v;
+          const bool live = colact && (tm < KT - 1 || 16 * tm + 4 * hv + q < k);       // (only the last member block is ragged)
+          xb[tm][q] = live ? xb[tm][q] : 0.0f;
+          xs += xb[tm][q];
         }
       const float xm = tile_add_h(xs) * P.inv_k;
 #pragma unroll
       for (int tm = 0; tm < KT; ++tm)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xb[tm][q] = (16 * tm + 4 * h + q < k && colact) ? xb[tm][q] - xm : 0.0f;
+        for (int q = 0; q < 4; ++q) {
+          const bool live = colact && (tm < KT - 1 || 16 * tm + 4 * hv + q < k);
+          xb[tm][q] = live ? xb[tm][q] - xm : 0.0f;
+        }
       // ---- G = Yw Yw^T (first row only) and Z = Yw X'
       f4t Z[UT];
 #pragma unroll
@@ -314,10 +433,12 @@ __global__ __launch_bounds__(64, (UT <= 2 ? 3 : (UT == 3 ? 2 : 1))) void letkf_t
         f4t av[UT];
 #pragma unroll
         for (int t = 0; t < UT; ++t) {
-          av[t] = *reinterpret_cast<const f4t*>(Yw + (16 * t + lr) * kp + 16 * tm + 4 * h);
+          av[t] = *reinterpret_cast<const f4t*>(Yw + (16 * t + lrv) * kp + 16 * tm + 4 * hv);
+          if (tm == KT - 1) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (16 * tm + 4 * h + q >= k) av[t][q] = 0.0f;        // innovation / pad columns, next row's start
+            for (int q = 0; q < 4; ++q)
+              if (16 * tm + 4 * hv + q >= k) av[t][q] = 0.0f;        // innovation / pad columns, next row's start
+          }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -332,8 +453,11 @@ __global__ __launch_bounds__(64, (UT <= 2 ? 3 : (UT == 3 ? 2 : 1))) void letkf_t
           for (int t = 0; t < UT; ++t) Z[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][q], xb[tm][q], Z[t], 0, 0, 0);
         }
       }
+      MIA_STAMP(5);
       if (mi == 0) {
         // ---- Gershgorin bound of every point: L_g = max_a w_a sum_b |G_ab| w_b, then degree / interval from the table
+        //      (step (tk, q) of a product over the union covers ranks 16 tk + 4 q .. + 3: steps beyond the union are
+        //       skipped -- config 2: 28 observations, 7 of 8 steps)
         f4t R[UT];
 #pragma unroll
         for (int t = 0; t < UT; ++t) R[t] = f4t{0.f, 0.f, 0.f, 0.f};
@@ -341,9 +465,11 @@ __global__ __launch_bounds__(64, (UT <= 2 ? 3 : (UT == 3 ? 2 : 1))) void letkf_t
         for (int tk = 0; tk < UT; ++tk)
 #pragma unroll
           for (int q = 0; q < 4; ++q)
+            if (16 * tk + 4 * q < U) {
 #pragma unroll
-            for (int t = 0; t < UT; ++t)
-              R[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fabsf(G[tk][t][q]), dreg[tk][q], R[t], 0, 0, 0);
+              for (int t = 0; t < UT; ++t)
+                R[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fabsf(G[tk][t][q]), dreg[tk][q], R[t], 0, 0, 0);
+            }
         float L = 0.0f;
 #pragma unroll
         for (int t = 0; t < UT; ++t)
@@ -357,18 +483,32 @@ __global__ __launch_bounds__(64, (UT <= 2 ? 3 : (UT == 3 ? 2 : 1))) void letkf_t
         if (!(L == L) || !(fabsf(L) < 1e30f)) { pflag |= MIA_FLAG_NONFINITE; L = P.reg; }
         tab_idx = (int)ceilf(float(kTabPerOctave) * __builtin_amdgcn_logf(L * P.inv_reg)) + kTabIdx0;
         tab_idx = tab_idx < 0 ? 0 : (tab_idx > kTabN - 1 ? kTabN - 1 : tab_idx);
-        const int2 hd = P.tab_hdr[tab_idx];
+        // header and coefficients are requested together: the coefficients of the 16 points go, scaled, to LDS --
+        // [degree][point] pairs in the storage of the union scratch (D, hash table, slot tables: dead until the next
+        // pass) -- for every degree that storage holds (the table is zero beyond an entry's degree): one memory round trip
+        // in all, none per recurrence step
+        const int2 hd = ld_off<int2>(P.tab_hdr, (unsigned)tab_idx * 8u);
+        {
+          const unsigned cb = (unsigned)tab_idx * (unsigned)(kTabDeg * 8);
+          float2 cst[CQ];
+#pragma unroll
+          for (int u = 0; u < CQ; ++u) cst[u] = ld_off<float2>(P.tab_c, cb + (unsigned)(hv + 4 * u < kTabDeg ? hv + 4 * u : kTabDeg - 1) * 8u);
+#pragma unroll
+          for (int u = 0; u < CQ; ++u)
+            if (hv + 4 * u < CL) Cl[(hv + 4 * u) * 16 + lrv] = float2{cst[u].x * P.cs_phi, cst[u].y * P.cs_psi};
+        }
         deg = hd.x;
         alpha = __int_as_float(hd.y) * P.inv_reg;
         decl = colact && (deg > P.dmax || deg > kTabDeg - 1);
-        if (decl && h == 0) {
-          P.flags[p0v + lr] = MIA_FLAG_RETRY;
+        if (decl && hv == 0) {
+          P.flags[p0v + lrv] = MIA_FLAG_RETRY;
           atomicAdd(P.retry_count, 1);
         }
         degmax = (int)wave_max_nonneg_dpp((colact && !decl) ? float(deg) : 0.0f);
+        MIA_TILE_SYNC();
       }
+      MIA_STAMP(6);
       // ---- the recurrence on the 16 columns at once; vectors stay in the result layout
-      const float2* crow = P.tab_c + (size_t)tab_idx * kTabDeg;
       f4t tp[UT], tc[UT], aphi[UT], apsi[UT], y[UT];
       auto product = [&](const f4t (&tv)[UT]) {
 #pragma unroll
@@ -376,75 +516,95 @@ __global__ __launch_bounds__(64, (UT <= 2 ? 3 : (UT == 3 ? 2 : 1))) void letkf_t
 #pragma unroll
         for (int tk = 0; tk < UT; ++tk)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float b = dreg[tk][q] * tv[tk][q];
+          for (int q = 0; q < 4; ++q)
+            if (16 * tk + 4 * q < U) {
+              const float b = dreg[tk][q] * tv[tk][q];
 #pragma unroll
-            for (int t = 0; t < UT; ++t) y[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(G[tk][t][q], b, y[t], 0, 0, 0);
-          }
+              for (int t = 0; t < UT; ++t) y[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(G[tk][t][q], b, y[t], 0, 0, 0);
+            }
       };
-      float2 c0 = crow[0], c1 = crow[1];
+      auto coef = [&](int j) -> float2 {                              // (zero beyond a point's own degree)
+        if (j < CL) return Cl[j * 16 + lrv];
+        const float2 c = ld_off<float2>(P.tab_c, ((unsigned)tab_idx * (unsigned)kTabDeg + (unsigned)(j < kTabDeg ? j : kTabDeg - 1)) * 8u);
+        return float2{c.x * P.cs_phi, c.y * P.cs_psi};
+      };
+      const float2 c0 = coef(0), c1 = coef(1);
 #pragma unroll
       for (int t = 0; t < UT; ++t) tp[t] = dreg[t] * Z[t];
       product(tp);
 #pragma unroll
       for (int t = 0; t < UT; ++t) {
         tc[t] = alpha * (dreg[t] * y[t]) - tp[t];
-        aphi[t] = (c0.x * P.cs_phi) * tp[t] + (c1.x * P.cs_phi) * tc[t];
-        apsi[t] = (c0.y * P.cs_psi) * tp[t] + (c1.y * P.cs_psi) * tc[t];
+        aphi[t] = c0.x * tp[t] + c1.x * tc[t];
+        apsi[t] = c0.y * tp[t] + c1.y * tc[t];
       }
       for (int j = 2; j <= degmax; ++j) {
-        const float2 cj = crow[j < kTabDeg ? j : kTabDeg - 1];      // (zero beyond a point's own degree)
+        const float2 cj = coef(j);
         product(tc);
-        const float cphi = cj.x * P.cs_phi, cpsi = cj.y * P.cs_psi;
 #pragma unroll
         for (int t = 0; t < UT; ++t) {
           const f4t tn = 2.0f * (alpha * (dreg[t] * y[t]) - tc[t]) - tp[t];
           tp[t] = tc[t]; tc[t] = tn;
-          aphi[t] = cphi * tn + aphi[t];
-          apsi[t] = cpsi * tn + apsi[t];
+          aphi[t] = cj.x * tn + aphi[t];
+          apsi[t] = cj.y * tn + apsi[t];
         }
       }
+      MIA_STAMP(7);
       // ---- x' w_mean = sum_b d_b (w_b psi_b): one more product, row vector of the innovations (column k of the records)
       //      times D o Psi -- on the matrix cores like everything else, because their enumeration IS the canonical
       //      summation order (a lane-local partial sum would group the observations by rank mod 4, i.e. by tile
-      //      composition).  Row 0 of the result tile = lanes (lr, h = 0), register 0; handed to the column's other lanes.
+      //      composition).  Row 0 of the result tile = lanes (lrv, hv = 0), register 0; handed to the column's other lanes.
+      // (x of this row is needed once more, for f0 x': read again, L2-hot, instead of being held in 4 KT registers across
+      //  the recurrence; requested before the last two products, which cover its latency)
+      f4t xre[KT];
+      load_x(mi, xre);
       f4t zacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int tk = 0; tk < UT; ++tk)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float a = lr == 0 ? Yw[(16 * tk + 4 * h + q) * kp + k] : 0.0f;
-          zacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, dreg[tk][q] * apsi[tk][q], zacc, 0, 0, 0);
-        }
-      const float zu = __shfl(zacc[0], lr, 64);
+        for (int q = 0; q < 4; ++q)
+          if (16 * tk + 4 * q < U) {
+            const float a = lrv == 0 ? Yw[(16 * tk + 4 * hv + q) * kp + k] : 0.0f;
+            zacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, dreg[tk][q] * apsi[tk][q], zacc, 0, 0, 0);
+          }
+      const float zu = __shfl(zacc[0], lrv, 64);
 #pragma unroll
       for (int t = 0; t < UT; ++t) aphi[t] *= dreg[t];        // s = D o phi: right-hand side of the last product
       const float mterm = xm + zu;
+      f4t acc[KT];
 #pragma unroll
       for (int tj = 0; tj < KT; ++tj) {
-        f4t acc = {0.f, 0.f, 0.f, 0.f};
+        acc[tj] = f4t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tk = 0; tk < UT; ++tk)
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Yw[(16 * tk + 4 * h + q) * kp + 16 * tj + lr], aphi[tk][q], acc, 0, 0, 0);
+            if (16 * tk + 4 * q < U)
+              acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(Yw[(16 * tk + 4 * hv + q) * kp + 16 * tj + lrv], aphi[tk][q], acc[tj], 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int mem = 16 * tj + 4 * h + q;
-          if (mem < k && colact && !decl) {
-            // (x is read again here, L2-hot, instead of being held in 4 KT registers across the recurrence)
-            const float* xrow = P.X + ((int64_t)mi * k + 16 * tj + q) * P.ldx + P.g0 + p0v;
-            float* orow = Xab + ((int64_t)mi * k + 16 * tj + q) * P.ldo + oc0v;
-            const float xv = xrow[xoff];
-            const float out = mterm + P.f0 * (xv - xm) + acc[q];
-            if (!(fabsf(out) <= 1e30f)) pflag |= MIA_FLAG_NONFINITE;
-            // segmented launch: write-through (agent-scope) stores, published by the counter below
-            if constexpr (SEG) __hip_atomic_store(&orow[ooff], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else orow[ooff] = out;
-          }
+          acc[tj][q] += mterm + P.f0 * (xre[tj][q] - xm);
+          if (!(fabsf(acc[tj][q]) <= 1e30f) && (tj < KT - 1 || 16 * tj + 4 * hv + q < k)) pflag |= MIA_FLAG_NONFINITE;
         }
       }
+      if (colact && !decl) {
+        float* obase = Xab + (int64_t)mi * k * P.ldo + oc0v;
+        const unsigned olane = (unsigned)(4 * hv) * ldob + (unsigned)lrv * 4u;
+#pragma unroll
+        for (int tj = 0; tj < KT; ++tj)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (tj < KT - 1 || 16 * tj + 4 * hv + q < k) {
+              float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(obase) + (olane + (unsigned)(16 * tj + q) * ldob));
+              // segmented launch: write-through (agent-scope) stores, published by the counter below
+              if constexpr (SEG) __hip_atomic_store(dst, acc[tj][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              else *dst = acc[tj][q];
+            }
+      } else {
+        pflag = 0;          // (columns that are not written do not report)
+      }
     }
+    MIA_STAMP(8);
     {
       const unsigned long long fb = __ballot(pflag != 0);
       const bool anyf = ((fb >> lr) & 0x0001000100010001ull) != 0ull;
@@ -452,6 +612,7 @@ __global__ __launch_bounds__(64, (UT <= 2 ? 3 : (UT == 3 ? 2 : 1))) void letkf_t
     }
     lo = hi;
     MIA_TILE_SYNC();
+    if (lo < npts) load_lists(p0v, lp, sub);       // a split tile: the entries of the next pass
   }
   if constexpr (SEG) {
     // all output stores of this wavefront have been acknowledged before it counts its points
@@ -461,6 +622,13 @@ __global__ __launch_bounds__(64, (UT <= 2 ? 3 : (UT == 3 ? 2 : 1))) void letkf_t
                              __HIP_MEMORY_SCOPE_AGENT);
   }
 }
+
+#ifdef MIA_TILE_STAMPS
+extern "C" int mia_debug_tile_stamps(long long* host, int n_tiles) {
+  if (n_tiles > kStampTiles) n_tiles = kStampTiles;
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tile_stamps), sizeof(long long) * kStampN * (size_t)n_tiles);
+}
+#endif
 
 static size_t tile_lds_bytes(int ut, int kp) {
   const int umax = 16 * ut, hs = ut <= 1 ? 64 : (ut <= 2 ? 128 : 256);
@@ -513,7 +681,11 @@ int tile_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
                          int seg_len, int64_t seg_stride, int32_t* done) {
   if (seg_len > 0 && (!done || ng >= (int64_t)1 << 31)) return MIA_ERR_UNSUPPORTED;
   if (!tile_route_covers(m, k, p_max) || !flags || !retry_count || !tab_hdr || !tab_c) return MIA_ERR_UNSUPPORTED;
-  if (ldx > (1 << 26) || ldo > (1 << 26)) return MIA_ERR_UNSUPPORTED;     // 32-bit lane offsets (12 ld + 15 elements)
+  // every global access is base + 32-bit byte offset: the largest offsets are a column of one state row block (k ld
+  // floats), the record array, one tile's list rows
+  if ((int64_t)k * ldx * 4 >= ((int64_t)1 << 31) || (int64_t)k * ldo * 4 >= ((int64_t)1 << 31) ||
+      (int64_t)p_cap * 16 * 8 >= ((int64_t)1 << 31))
+    return MIA_ERR_UNSUPPORTED;
   TileParams tp;
   tp.X = X; tp.ldx = ldx; tp.m = m; tp.k = k; tp.kp = (k + 1 + 3) & ~3;
   tp.g0 = g0; tp.ng = ng; tp.rec = rec;
