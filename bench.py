@@ -44,16 +44,34 @@ def algorithmic_flops(k, p, m):
     return k * k * p + 2 * k * p + 9 * k ** 3 + k ** 3 + 5 * k * k + 2 * k * k * m + 25 * p
 
 
-def executed_flops(k, p, m, deg):
-    """What the matfun kernel really executes per analysis (dual route): Gram on 16x16x4 MFMA tiles over
-    the padded order (upper tiles), z and output products, Chebyshev coefficients and recurrence."""
+def executed_flops(k, p, m, deg, kernel="tile"):
+    """What the dominant kernel really executes per analysis (dual route), padding included.
+    tile (letkf_tile_kernel, 16 grid points per wavefront, csrc/letkf_tile.hip): v_mfma_f32_16x16x4_f32 instructions per
+    tile -- Gram UT^2 4KT + Z UT 4KT, Gershgorin UT nks, recurrence deg UT nks, x'w_mean nks, output KT nks, with UT row
+    blocks of 16 union slots, KT member blocks, nks = ceil(U / 4) steps over the tile's union U ~ p + 8 -- times 2048 flop,
+    plus the three-term update on the vector unit (10 flop per union slot, step and point); per point = / 16.
+    point (letkf_cheb_kernel): Gram on 16x16x4 tiles over the padded order, z / output products, recurrence."""
     if not deg:
         return None
+    if kernel == "tile":
+        ut, kt, u = (p + 8 + 15) // 16, (k + 15) // 16, p + 8
+        nks = (u + 3) // 4
+        dmax = int(deg + 0.999)                      # a tile runs to the largest degree of its 16 points
+        mfma = ut * ut * 4 * kt + m * (ut * 4 * kt + dmax * ut * nks + nks + kt * nks) + ut * nks
+        return (mfma * 2048 + m * dmax * 16 * ut * 16 * 10) / 16.0
     tt = (max(p, 1) + 15) // 16
     ks = (k + 3) // 4
     gram = tt * (tt + 1) // 2 * ks * 2048
     n = (p + 3) // 4 * 4
     return gram + m * (2 * k * n * 2 + deg * 2 * n * n) + 4 * (deg + 1) ** 2 + 25 * p
+
+
+def useful_flops(k, p, m, deg):
+    """The same analysis without padding or sharing: symmetric Gram 2 k p(p+1)/2, per state row z and output 4 k p and a
+    degree-deg recurrence 2 deg p^2, Gaspari-Cohn 25 p ('useful work')."""
+    if not deg:
+        return None
+    return k * p * (p + 1) + m * (4 * k * p + 2 * deg * p * p) + 25 * p
 
 
 def algorithmic_bytes(k, m, P_over_G, n_coord=1):
@@ -90,11 +108,14 @@ def make_case(G, k, stride, device, seed=42):
     return X, grid_x, obs_x, Yb, d
 
 
-def _cpu_worker(args):
+_CPU_CASE = None      # the workload of the CPU baseline: set in the parent before the pool forks (tasks carry indices only)
+
+
+def _cpu_worker(pts):
     import torch as _t
     _t.set_num_threads(1)
     from oracle import letkf_oracle as O
-    state, grid_x, obs_x, yb, d, pts = args
+    state, grid_x, obs_x, yb, d = (_CPU_CASE[n] for n in ("state", "grid_x", "obs_x", "yb", "d"))
     t0 = time.perf_counter()
     for g in pts:
         dist = O.abs_distance_1d(grid_x[g], obs_x)
@@ -103,9 +124,43 @@ def _cpu_worker(args):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(n_points_total=16000):
-    """The oracle (CPU restatement of the reference's per-grid-point path, torch float64, one
-    thread per process, one process per core) on a bounded sample of the same workload."""
+def _cpu_batched(case, pts, p_cap=24):
+    """Best-effort CPU figure (last bullet): the same analyses as ONE batched computation per chunk --
+    window gather, batched Gram, torch.linalg.eigh on (n, k, k), batched weights and transform, float64, all the
+    process's threads."""
+    import torch as _t
+    st = _t.from_numpy(case["state"][0])                 # (k, G)
+    yb, d = _t.from_numpy(case["yb"]), _t.from_numpy(case["d"])
+    ox = _t.from_numpy(case["obs_x"])
+    k = st.shape[0]
+    g = _t.from_numpy(case["grid_x"][pts])
+    first = _t.clamp(_t.ceil((g - 2 * GC_RADIUS) / OBS_STRIDE).long(), 0, ox.shape[0] - 1)
+    raw = first[:, None] + _t.arange(p_cap)[None]                                        # (n, p_cap) window of candidates
+    idx = _t.clamp(raw, 0, ox.shape[0] - 1)
+    r = (ox[idx] - g[:, None]).abs() / GC_RADIUS
+    r = _t.where(raw == idx, r, _t.full_like(r, 3.0))                                   # (beyond the last observation)
+    f1 = (((-0.25 * r + 0.5) * r + 0.625) * r - 5.0 / 3.0) * r * r + 1.0
+    f2 = ((((r / 12.0 - 0.5) * r + 0.625) * r + 5.0 / 3.0) * r - 5.0) * r + 4.0 - (2.0 / 3.0) / r.clamp_min(1e-300)
+    w = _t.where(r < 1, f1, _t.where(r < 2, f2, _t.zeros_like(r)))
+    w = _t.where(w > 1e-5, w, _t.zeros_like(w)).sqrt()
+    Yl = yb[:, idx].permute(1, 0, 2) * w[:, None, :]                                   # (n, k, p)
+    dl = d[idx] * w
+    reg = (k - 1) / INF
+    C = Yl @ Yl.transpose(1, 2)
+    ev, V = _t.linalg.eigh(C)
+    ev = ev.clamp_min(0) + reg
+    wm = (V * (1.0 / ev)[:, None, :]) @ (V.transpose(1, 2) @ (Yl @ dl[:, :, None]))
+    W = (V * ((k - 1) ** 0.5 / ev.sqrt())[:, None, :]) @ V.transpose(1, 2) + wm
+    x = st[:, pts].T                                                                    # (n, k)
+    xm = x.mean(dim=1, keepdim=True)
+    return xm + ((x - xm)[:, None, :] @ W)[:, 0]
+
+
+def cpu_baseline(n_points_total=12000):
+    """The oracle (CPU restatement of the reference's per-grid-point path, torch float64, one thread per process, one
+    process per core) on a bounded sample of the same workload -- the grid split into tasks of `chunksize` points as the
+    reference's dask graph does (default 10, interface/letkf.py:80; 1000 next to it) -- plus the batched best-effort
+    figure of SURVEY 8(d)."""
     import multiprocessing as mp
     from oracle import letkf_oracle as O
     # one worker per core of this process's CPU share (a one-GPU box grants 16; affinity, not the machine's core count)
@@ -116,17 +171,36 @@ def cpu_baseline(n_points_total=16000):
     cores = max(1, min(avail, 16))
     case = O.synthetic_case(G_PER_GPU, K_ENS, OBS_STRIDE)
     pts = np.random.RandomState(0).choice(G_PER_GPU, n_points_total, replace=False)
-    chunks = np.array_split(pts, cores)
+    global _CPU_CASE
+    _CPU_CASE = case
     ctx = mp.get_context("fork")
-    t0 = time.perf_counter()
+    rates = {}
     with ctx.Pool(cores) as pool:
-        pool.map(_cpu_worker, [(case["state"], case["grid_x"], case["obs_x"], case["yb"], case["d"], c)
-                               for c in chunks])
-    wall = time.perf_counter() - t0
-    return {"value": n_points_total / wall, "unit": "analyses/s", "cores": cores, "kind": "port",
+        for chunksize, n in ((10, n_points_total), (1000, n_points_total)):
+            sub = pts[:n]
+            tasks = [sub[i:i + chunksize] for i in range(0, n, chunksize)]
+            t0 = time.perf_counter()
+            pool.map(_cpu_worker, tasks, chunksize=1)
+            rates[chunksize] = n / (time.perf_counter() - t0)
+    torch.set_num_threads(cores)
+    nb = 100000
+    bp = np.random.RandomState(1).choice(G_PER_GPU, nb, replace=True)
+    t0 = time.perf_counter()
+    for i in range(0, nb, 20000):
+        _cpu_batched(case, bp[i:i + 20000])
+    batched = nb / (time.perf_counter() - t0)
+    chk = _cpu_batched(case, pts[:64]).numpy()
+    ref = np.stack([O.apply_weights(case["state"][:, :, [g]], O.localized_weights(
+        O.abs_distance_1d(case["grid_x"][g], case["obs_x"]), case["yb"], case["d"], [GC_RADIUS], INF)[None])[0, :, 0] for g in pts[:64]])
+    return {"value": rates[10], "unit": "analyses/s", "cores": cores, "kind": "port",
             "sample": "%d random grid points of the same G=1e5/P=5e4 problem, per-point python loop "
                       "(localize over all P obs -> mask/scale -> torch fp64 eigh weights -> transform), "
-                      "1 thread/process" % n_points_total}
+                      "1 thread/process, tasks of 10 grid points (the reference's default chunksize)" % n_points_total,
+            "variants": {"chunksize_10": rates[10], "chunksize_1000": rates[1000],
+                         "batched_eigh_best_effort": batched,
+                         "batched_note": "%d analyses as batched torch float64 (window gather, Gram, linalg.eigh on (n, 40, 40), "
+                                         "weights, transform), %d threads; max |diff| to the per-point port on 64 points %.1e"
+                                         % (nb, cores, float(np.abs(chk - ref).max()))}}
 
 
 def launch_workers(n, argv):
@@ -227,6 +301,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config-4 / config-5 kernel timings")
     ap.add_argument("--grid-per-gpu", type=int, default=G_PER_GPU)
     ap.add_argument("--pipeline-depth", type=int, default=int(os.environ.get("MIA_PIPELINE_DEPTH", "3")), choices=[1, 2, 3, 4],
                     help="steps in flight (ShardedLetkf.submit): 3 (default) = steps i+1 and i+2 are enqueued before step i "
@@ -323,7 +398,8 @@ def main():
     gc.freeze()
     # warm-up LAST, straight into the timed loop: the collection above leaves the GPU idle for ~0.1 s and the clocks
     # take a few milliseconds of work to come back (20 timed steps right after it ran 25 % slower than steady state)
-    run(max(args.warmup, 50), depth)
+    warm = max(args.warmup, 50)
+    run(warm, depth)
     runner.kernel_timings.clear()
     elapsed, out = timed(args.steps, depth)
     loop_kernel_ms = runner.kernel_ms()      # the dominant kernel inside the timed loop (every 4th step)
@@ -340,8 +416,17 @@ def main():
     alone_ms, stage_ms = runner.time_stages(X, grid_x, obs_x, Yb, d, reps=max(5, min(args.steps, 20)))
     kern_ms = loop_kernel_ms if loop_kernel_ms else alone_ms
     p_max = runner.last_p_max
-    flops = algorithmic_flops(K_ENS, 20, 1) * gpg
-    achieved = flops / (kern_ms * 1e-3) / 1e12
+    deg = runner.mean_degree()
+    kname = runner.dominant_kernel_name
+    kkind = "tile" if "tile" in kname else "point"
+
+    def rates(k, p, m, dg, n_pts, ms, kind):
+        """executed / useful / reference-credit flop rates of one launch of n_pts analyses in `ms`"""
+        ex, us = executed_flops(k, p, m, dg, kind), useful_flops(k, p, m, dg)
+        tf = lambda f: None if f is None else f * n_pts / (ms * 1e-3) / 1e12
+        return ex, us, tf(ex), tf(us), tf(algorithmic_flops(k, p, m))
+
+    ex_f, us_f, ex_tf, us_tf, credit_tf = rates(K_ENS, 20, 1, deg, gpg, kern_ms, kkind)
     hbm_alg = algorithmic_bytes(K_ENS, 1, P / G) * gpg / (kern_ms * 1e-3) / 1e9
 
     # secondary figure: the fused Jacobi-eigensolver route on the same shard (kernel only)
@@ -350,50 +435,117 @@ def main():
         r2 = ShardedLetkf(device, rank, world, radii=[GC_RADIUS], inf_factor=INF, method="eig")
         r2._engine = runner.engine
         eig_ms, _ = r2.time_stages(X, grid_x, obs_x, Yb, d, reps=5)
-    deg = runner.mean_degree()
+
+    # ---- one step END TO END from pinned host buffers: H2D of state / obs-space inputs / coordinates,
+    #      the step, D2H of the analysis ensemble (never part of `value`)
+    e2e_ms = None
+    if world == 1 and rank == 0:
+        host = [t.cpu().pin_memory() for t in (X, grid_x, obs_x, Yb, d)]
+        out_h = torch.empty((1, K_ENS, G), dtype=torch.float32).pin_memory()
+        dev_in = [torch.empty_like(t) for t in (X, grid_x, obs_x, Yb, d)]
+        ts = []
+        for _ in range(8):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for a, h in zip(dev_in, host):
+                a.copy_(h, non_blocking=True)
+            o = runner.assimilate(*dev_in)
+            out_h.copy_(o, non_blocking=True)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        e2e_ms = 1e3 * float(np.median(ts[2:]))
+
+    # ---- the other single-GPU configurations of BASELINE.json, timed in this same process: kernel only (burst of five
+    #      launches, HIP events), 64 sampled grid points checked against the oracle
+    secondary = {}
+    if world == 1 and rank == 0 and not args.no_secondary:
+        from oracle import letkf_oracle as O
+        for name, (k2, stride2, c2, gamma2) in (("c4", (80, 1, 16.5, None)), ("c5", (40, 2, 10.0, 0.5))):
+            X2, gx2, ox2, Yb2, d2 = make_case(gpg, k2, stride2, device, seed=43)
+            r3 = ShardedLetkf(device, 0, 1, radii=[c2], inf_factor=INF, rbf_gamma=gamma2, method=args.method, native_step=False)
+            r3._engine = runner.engine
+            xa2 = r3.assimilate(X2, gx2, ox2, Yb2, d2)
+            ms2, _ = r3.time_stages(X2, gx2, ox2, Yb2, d2, reps=5)
+            pm2, deg2 = r3.last_p_max, r3.mean_degree()
+            pts = np.random.RandomState(2).choice(gpg, 64, replace=False)
+            st, yb_h, d_h = X2.double().cpu().numpy(), Yb2.double().cpu().numpy(), d2.double().cpu().numpy()
+            gxh, oxh = gx2.cpu().numpy(), ox2.cpu().numpy()
+            core = O.etkf_weights if gamma2 is None else (
+                lambda a, b, inf, g_=gamma2: O.ketkf_weights(a, b, lambda x, y: O.rbf_kernel(x, y, g_), inf))
+            ref = np.stack([O.apply_weights(st[:, :, [g]], O.localized_weights(O.abs_distance_1d(gxh[g], oxh), yb_h, d_h,
+                                                                              [c2], INF, core=core)[None])[:, :, 0] for g in pts], axis=-1)
+            got = xa2[:, :, torch.as_tensor(pts, device=device)].double().cpu().numpy()
+            rec = {"workload": "G=%d, k=%d, obs every %d, Gaspari-Cohn radius %g (<=%d local obs)%s, m=1"
+                               % (gpg, k2, stride2, c2, pm2, ", RBF kernel gamma %.1f" % gamma2 if gamma2 else ""),
+                   "kernel_ms": ms2, "analyses_per_s": gpg / (ms2 * 1e-3), "mean_chebyshev_degree": deg2,
+                   "rel_frobenius_error_64_points_vs_oracle": float(np.linalg.norm(got - ref) / np.linalg.norm(ref)),
+                   "reference_algorithm_credit_TFLOPs": algorithmic_flops(k2, pm2, 1) * gpg / (ms2 * 1e-3) / 1e12}
+            if gamma2 is None and deg2:
+                kk = "tile" if (k2 <= 64 and pm2 + 8 <= 64) else "point"
+                exf = executed_flops(k2, pm2, 1, deg2, kk)
+                rec.update(executed_flops_per_analysis=exf, executed_frac=exf * gpg / (ms2 * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                           kernel="letkf_tile_kernel" if kk == "tile" else "letkf_cheb_kernel (one grid point per wavefront)")
+            secondary[name] = rec
 
     if rank == 0:
         value = G * args.steps / elapsed
+        traffic = traffic_from_profiles(world)
         line = {
             "metric": "local analyses/sec (LETKF, 40-member)", "value": value, "unit": "analyses/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": warm,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "LETKF config %s: G=%d grid points (%d per GPU), k=%d members, P=%d obs, "
                                    "Gaspari-Cohn radius %g (<=%d local obs), inf %.1f, m=1"
                                    % ("2" if world == 1 else "3-style", G, gpg, K_ENS, P, GC_RADIUS, p_max, INF),
-                       "parallelism": "grid-point block shard x%d%s" % (world, " + RCCL all-gather" if world > 1 else "")},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS,
-                         "traffic": (traffic_from_profiles(world) or {}).get("hbm_bytes_fetch_doubled"),
-                         "traffic_detail": traffic_from_profiles(world),
-                         "kernel": runner.dominant_kernel_name, "kernel_ms": kern_ms,
+                       "parallelism": "grid-point block shard x%d%s" % (world, " + all-gather of the analysis ensemble over xGMI "
+                                                                        "(%s)" % runner.exchange_route if world > 1 else ""),
+                       "ranks": world},
+            # frac <= 1 by construction: flops the kernel EXECUTES (MFMA tiles incl. padding + the vector-unit update),
+            # per launch, over the measured launch duration, against the fp32 peak (vector = f32-MFMA = 157.3 TFLOP/s)
+            "roofline": {"bound": "mfma" if kkind == "tile" else "valu_issue",
+                         "achieved": ex_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": None if ex_tf is None else ex_tf / PEAK_FP32_TFLOPS,
+                         "executed_flops_per_analysis": ex_f,
+                         "useful_flops_per_analysis": us_f, "useful_TFLOPs": us_tf,
+                         "useful_frac": None if us_tf is None else us_tf / PEAK_FP32_TFLOPS,
+                         "reference_algorithm_credit": {"flops_per_analysis": algorithmic_flops(K_ENS, 20, 1), "TFLOPs": credit_tf,
+                                                        "ratio_to_peak": credit_tf / PEAK_FP32_TFLOPS,
+                                                        "note": "SURVEY 8(d) count of the reference's algorithm (9k^3 symmetric-QR "
+                                                                "eigensolve) per analysis: NOT executed by the matrix-function "
+                                                                "route, not a utilisation"},
+                         "traffic": (traffic or {}).get("hbm_bytes_fetch_doubled"),
+                         "traffic_source": "offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_kernel.py on this "
+                                           "workload, committed as profiles/latest_traffic.json (bench.py cannot profile itself)",
+                         "traffic_detail": traffic,
+                         "kernel": kname, "kernel_ms": kern_ms,
                          "kernel_ms_source": ("HIP events recorded by the library on the analysis stream around the kernel of "
                                               "every 4th step of the timed loop (%d launches, mia_letkf_step_timing_events)" % n_timed)
                                              if loop_kernel_ms else "burst of 5 launches after the timed loop",
                          "kernel_ms_alone": alone_ms,
-                         "algorithmic_flops_per_analysis": algorithmic_flops(K_ENS, 20, 1),
                          "hbm_algorithmic_GBs": hbm_alg, "hbm_frac": hbm_alg / PEAK_HBM_GBS,
-                         "executed_flops_per_analysis": executed_flops(K_ENS, 20, 1, deg),
-                         "executed_frac": executed_flops(K_ENS, 20, 1, deg) * gpg / (kern_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
-                         "note": "fp32 peak: vector = f32-MFMA = 157.3 TFLOP/s; `achieved`/`frac` credit the SURVEY 8(d) "
-                                 "flop count of the reference algorithm (9k^3 symmetric-QR eigensolve) whatever the method; "
-                                 "the matfun route executes far fewer flops (executed_*: 16x16x4 MFMA Gram tiles incl. "
-                                 "padding + Chebyshev recurrence of the measured mean degree), so frac can exceed 1"},
+                         "note": "the matrix cores do every contraction (16 grid points per wavefront share one Gram matrix); "
+                                 "profiles/r02_*_pmc.json: MFMA pipe ~32 % busy, VALU ~29 %: the kernel is latency-bound between "
+                                 "them at 3 wavefronts per SIMD, MFMA pipe time is its floor"},
             "route": {"method": args.method, "mean_chebyshev_degree": deg, "declined_points_last_step": runner.last_retries,
                       "eigensolver_route_kernel_ms": eig_ms,
                       "eigensolver_route_kernel_analyses_per_s": (gpg / (eig_ms * 1e-3)) if eig_ms else None},
             "pipeline": {"depth": depth, "serial_ms_per_step": serial_ms,
+                         "serial_analyses_per_s": (G / (serial_ms * 1e-3)) if serial_ms else None,
                          "note": "depth d > 1: consecutive (independent) steps are software-pipelined over d slots / HIP "
                                  "streams; every step is fully computed, exchanged and validated inside the timed "
-                                 "region.  serial_ms_per_step: the same step run one at a time (its latency)"},
+                                 "region.  serial_*: the same step run one at a time (what a cycled filter, whose step i+1 "
+                                 "depends on step i, gets)"},
+            "e2e_ms_incl_h2d_d2h": e2e_ms,
             "stages_ms": stage_ms,
+            "secondary": secondary,
             "step_driver": ("native: one C call per step (mia_letkf_sharded_step_streams_f32); %d native steps in this process "
                             "(warm-up, timed loop, serial comparison)" % runner.native_steps)
                            if runner.native_steps else "python (engine entries one by one)",
         }
         if cpu is not None:
             line["cpu_baseline"] = cpu
+            line["vs_cpu_baseline"] = value / cpu["value"]
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -66,7 +66,14 @@ class ShardedLetkf:
 
     @property
     def dominant_kernel_name(self):
-        return "letkf_sys_kernel<20, 64>" if self.method == "eig" else "letkf_cheb_kernel<20, 1, false>"
+        if self.method == "eig":
+            return "letkf_sys_kernel<20, 64>"
+        import os
+        return "letkf_cheb_kernel<20, 1, false>" if os.environ.get("MIA_NO_TILE") else "letkf_tile_kernel<2, 3, false>"
+
+    @property
+    def exchange_route(self):
+        return "RCCL all-gather + placement kernel"
 
     def __init__(self, device, rank: int = 0, world: int = 1, radii: Sequence[float] = (10.0,),
                  inf_factor: float = 1.0, coord_group: Optional[Sequence[int]] = None, eps: float = 1e-5,
