@@ -61,6 +61,21 @@ int mia_version(void);
 const char* mia_status_string(int status);
 
 /* ------------------------------------------------------------------------------------
+ * Route options: explicit, process-wide switches for the kernel routes a caller (or a test) may want to steer.  No
+ * counterpart in the reference (whose only knob on this path is `chunksize`, interface/letkf.py:80); they replace the
+ * MIA_* environment variables that round 1 read inside launch code.  value < 0 restores the default.
+ *   "cheb_dmax"       62  largest Chebyshev degree the matrix-function kernels accept before they decline a grid point
+ *                         (MIA_FLAG_RETRY -> eigensolver); 3 .. 62
+ *   "cheb_table"       1  Chebyshev coefficients from the per-device table / 0: computed inside the kernel
+ *   "cheb_rowbatch"    1  m >= 8 state rows in 16-row MFMA batches / 0: row by row
+ *   "cheb_big"         1  64 < k <= 128 with more than 64 local observations: matrix-function kernel / 0: eigensolver
+ *   "tile"             1  sixteen grid points per wavefront where the shape allows (csrc/letkf_tile.hip) / 0: one
+ *   "segment_signal"   1  step driver with several pieces: one segmented launch / 0: one launch + event per piece
+ * Returns MIA_ERR_UNSUPPORTED for an unknown name, MIA_ERR_SIZE for a value out of range. */
+int mia_set_option(const char* name, int value);
+int mia_get_option(const char* name, int* value);
+
+/* ------------------------------------------------------------------------------------
  * Gaspari-Cohn taper of normalised distances r = dist / c (unit-testable stage).
  * Replaces GaspariCohn._f1/_f2 and the piecewise assembly in
  * pytassim/localization/gaspari_cohn.py:78-95,127-133 (strict `<` at r = 1 and r = 2).

@@ -25,3 +25,22 @@ def rel_fro(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def set_option(name, value):
+    """mia_set_option for the duration of one test: the autouse fixture below restores what the test changed."""
+    from torch_assimilate_amd import _cabi
+    _PENDING.append((name, _cabi.set_option(name, value)))
+
+
+_PENDING = []
+
+
+@pytest.fixture(autouse=True)
+def _restore_options():
+    yield
+    if _PENDING:
+        from torch_assimilate_amd import _cabi
+        while _PENDING:
+            name, old = _PENDING.pop()
+            _cabi.set_option(name, old)

@@ -95,3 +95,19 @@ def test_engine_refuses_to_run_without_gpu():
     import torch_assimilate_amd as mia
     with pytest.raises(mia.MiaError):
         mia.LetkfEngine()
+
+
+def test_route_options(lib):
+    """mia_set_option / mia_get_option: names, defaults, ranges (no device work)."""
+    v = C.c_int(-5)
+    for name, default in ((b"cheb_dmax", 62), (b"cheb_table", 1), (b"cheb_rowbatch", 1), (b"cheb_big", 1), (b"tile", 1),
+                          (b"segment_signal", 1)):
+        assert lib.mia_get_option(name, C.byref(v)) == 0 and v.value == default
+    assert lib.mia_set_option(b"cheb_dmax", 14) == 0 and lib.mia_get_option(b"cheb_dmax", C.byref(v)) == 0 and v.value == 14
+    assert lib.mia_set_option(b"cheb_dmax", 2) == -2 and lib.mia_set_option(b"cheb_dmax", 63) == -2
+    assert lib.mia_set_option(b"cheb_dmax", -1) == 0 and lib.mia_get_option(b"cheb_dmax", C.byref(v)) == 0 and v.value == 62
+    assert lib.mia_set_option(b"tile", 7) == 0 and lib.mia_get_option(b"tile", C.byref(v)) == 0 and v.value == 1
+    assert lib.mia_set_option(b"tile", 0) == 0 and lib.mia_get_option(b"tile", C.byref(v)) == 0 and v.value == 0
+    assert lib.mia_set_option(b"tile", -1) == 0 and lib.mia_get_option(b"tile", C.byref(v)) == 0 and v.value == 1
+    assert lib.mia_set_option(b"no_such_option", 1) == -3 and lib.mia_get_option(b"no_such_option", C.byref(v)) == -3
+    assert lib.mia_set_option(None, 1) == -1 and lib.mia_get_option(b"tile", None) == -1

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_fro
+from conftest import rel_fro, set_option
 from oracle import letkf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -228,7 +228,7 @@ def test_native_step_driver_two_rank_layout_on_one_gpu(mia, G, chunks, strong, r
     """mia_letkf_sharded_step_f32 as rank 0 and as rank 1 of a 2-rank world (peer emulated, see above): block /
     chunk partition, per-chunk exchange on the side stream, placement into (m, k, G) incl. ragged tails and the
     unaligned scalar path, and the phase-1 redo after declined points.  Must reproduce the single-rank result."""
-    monkeypatch.setenv("MIA_SEGMENT_SIGNAL", signal)   # "1": one segmented launch + device-side segment counters
+    set_option("segment_signal", int(signal))   # "1": one segmented launch + device-side segment counters
     dev = torch.device("cuda:0")
     case = O.synthetic_case(G, 40, 2)
     scale = 12.0 if strong else 1.0

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_fro
+from conftest import rel_fro, set_option
 from oracle import letkf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -294,7 +294,7 @@ def test_matfun_declines_wide_spectra_and_eigensolver_redoes_them(eng, golden, m
     xm = case["state"].mean(axis=1, keepdims=True)
     assert rel_fro(xa.cpu().numpy() - xm, ref - xm) < 10 * TOL32
     # a moderate case mixes both kernels inside one shard
-    monkeypatch.setenv("MIA_CHEB_DMAX", "14")
+    set_option("cheb_dmax", 14)
     yb2, d2 = case["yb"], case["d"]
     xa2, fl2, fin2 = eng.analysis(dev(case["state"], torch.float32), dev(yb2, torch.float32), dev(d2, torch.float32),
                                   nb, 1.1, return_flags=True, method="matfun", defer_retry=True)
@@ -306,9 +306,9 @@ def test_matfun_declines_wide_spectra_and_eigensolver_redoes_them(eng, golden, m
 
 def test_fused_localisation_equals_list_route_bitwise(eng, golden, monkeypatch):
     """The kernel that scans the observation index itself must reproduce the explicit-list route of the SAME per-point
-    kernel bit for bit (same scan code, same order; MIA_NO_TILE keeps the list route off the sixteen-point kernel, whose
+    kernel bit for bit (same scan code, same order; option tile = 0 keeps the list route off the sixteen-point kernel, whose
     summation order differs), in 1-D and with two radii in 3-D; an under-estimated list bound is reported."""
-    monkeypatch.setenv("MIA_NO_TILE", "1")
+    set_option("tile", 0)
     rs = np.random.RandomState(11)
     cases = [(np.arange(3000.0)[:, None], np.arange(0, 3000, 2.0)[:, None], [10.0], [0]),
              (rs.uniform(0, 1, size=(1500, 3)), rs.uniform(0, 1, size=(4000, 3)), [0.12, 0.25], [0, 0, 1])]
@@ -379,7 +379,7 @@ def test_degenerate_ensembles(eng):
 def test_matfun_many_state_rows_on_the_matrix_cores(eng, monkeypatch, m, k, stride, c):
     """m >= 8 state rows per grid point: the matfun kernel transforms them 16 at a time as one matrix recurrence on
     the MFMA units (letkf_cheb_rows_kernel).  Against the oracle (<= 1e-5, north star) and against the row-by-row
-    path of the same kernel (MIA_CHEB_NO_ROWBATCH), incl. a ragged last batch, edge points with short lists, an
+    path of the same kernel (option cheb_rowbatch = 0), incl. a ragged last batch, edge points with short lists, an
     ensemble size that is not a multiple of 4, and two primal geometries (more local observations than members)."""
     G = 300
     case = O.synthetic_case(G, k, stride, seed=17, m=m)
@@ -394,7 +394,7 @@ def test_matfun_many_state_rows_on_the_matrix_cores(eng, monkeypatch, m, k, stri
     assert rel_fro(got - xm, ref - xm) < 2e-5                      # increments: the stricter measure
     for mi in (0, m // 2, m - 1):                                  # every row on its own, not only on average
         assert rel_fro(got[mi], ref[mi]) < TOL32
-    monkeypatch.setenv("MIA_CHEB_NO_ROWBATCH", "1")
+    set_option("cheb_rowbatch", 0)
     xs = eng.analysis(X, yb, d, nb, 1.1, method="matfun")
     assert rel_fro(got, xs.cpu().numpy()) < 2e-6
 
@@ -421,7 +421,7 @@ def test_weights_without_eigensolver_vs_reference(eng, golden, monkeypatch, name
                              return_weights=True, return_flags=True)
     ref_xa, ref_w = O.letkf_analysis(st, gx, ox, yb * scale, d * scale, c, 1.1)
     assert rel_fro(W.cpu().numpy(), ref_w) < 5e-5 and rel_fro(xa.cpu().numpy(), ref_xa) < TOL32
-    monkeypatch.setenv("MIA_CHEB_DMAX", "8")          # force declines on the plain case too
+    set_option("cheb_dmax", 8)          # force declines on the plain case too
     xa2, W2 = eng.analysis(dev(st, torch.float32), dev(yb, torch.float32), dev(d, torch.float32), nb, 1.1, return_weights=True)
     assert rel_fro(W2.cpu().numpy()[g[f"{name}_widx"]], g[f"{name}_1p1_weights"]) < TOL32
 
@@ -460,7 +460,7 @@ def test_dense_local_networks_far_beyond_the_ensemble_size(eng, gamma):
 def test_large_ensembles_with_more_than_64_local_observations(eng, monkeypatch, k, gamma):
     """64 < k <= 128 with more local observations than one row per lane can hold (ensemble-space order > 64): the
     two-rows-per-lane primal kernel (letkf_cheb_big_kernel: Gram streamed from the records, S in LDS).  Against the
-    oracle, and against the eigensolver route it replaces (MIA_CHEB_NO_BIG)."""
+    oracle, and against the eigensolver route it replaces (option cheb_big = 0)."""
     rs = np.random.RandomState(k)
     G, P = 30, 600
     grid, obs = rs.uniform(0.3, 0.7, size=G), rs.uniform(0, 1, size=P)
@@ -476,7 +476,7 @@ def test_large_ensembles_with_more_than_64_local_observations(eng, monkeypatch, 
     f = fl.cpu().numpy()
     assert int((f & 0xff).max()) == 0 and int(((f >> 8) & 0xff).min()) >= 3       # degree recorded: the matfun kernel ran
     assert rel_fro(xa.cpu().numpy(), ref) < TOL32
-    monkeypatch.setenv("MIA_CHEB_NO_BIG", "1")
+    set_option("cheb_big", 0)
     xe = eng.analysis(*args, rbf_gamma=gamma)
     assert rel_fro(xe.cpu().numpy(), ref) < TOL32
 
@@ -485,7 +485,7 @@ def test_large_ensembles_with_more_than_64_local_observations(eng, monkeypatch, 
 @pytest.mark.parametrize("scale,gamma", [(1.0, None), (4.0, None), (1.0, 0.5)])
 def test_coefficient_table_equals_the_in_kernel_transform(eng, monkeypatch, scale, gamma):
     """The Chebyshev coefficients come from a per-device table over the scaled spectral bound (letkf_cheb.hip,
-    cheb_coef_table); MIA_CHEB_NO_TABLE=1 computes them in the analysis kernel as before.  Same analysis to float32
+    cheb_coef_table); option cheb_table = 0 computes them in the analysis kernel as before.  Same analysis to float32
     rounding on the dual route, with stronger observations (higher degrees), and on the RBF (primal) route; both within
     the north-star tolerance of the oracle."""
     case = O.synthetic_case(400, 40, 2, seed=7)
@@ -493,9 +493,9 @@ def test_coefficient_table_equals_the_in_kernel_transform(eng, monkeypatch, scal
     nb = eng.localize(case["grid_x"], case["obs_x"], [10.0])
     args = (dev(case["state"], torch.float32), dev(yb, torch.float32), dev(d, torch.float32), nb, 1.1)
     xa_tab, fl_tab = eng.analysis(*args, return_flags=True, method="matfun", rbf_gamma=gamma)
-    monkeypatch.setenv("MIA_CHEB_NO_TABLE", "1")
+    set_option("cheb_table", 0)
     xa_ker, fl_ker = eng.analysis(*args, return_flags=True, method="matfun", rbf_gamma=gamma)
-    monkeypatch.delenv("MIA_CHEB_NO_TABLE")
+    set_option("cheb_table", 1)
     assert int((fl_tab.cpu() & 0xff).max()) == 0 and int((fl_ker.cpu() & 0xff).max()) == 0
     assert rel_fro(xa_tab.cpu().numpy(), xa_ker.cpu().numpy()) < 2e-6
     # the table's interval is the next grid point above the bound: at most one degree more than the exact interval

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_fro
+from conftest import rel_fro, set_option
 from oracle import letkf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -35,7 +35,7 @@ def run(eng, case, nb, inf=1.1, **kw):
 def test_tile_kernel_vs_oracle_and_per_point_kernel(eng, monkeypatch, k, stride, c, m):
     """Union tiles of 1 .. 4 sixteen-row blocks (p_max 4 .. 52), 1 .. 4 member blocks, ragged last tile (G = 203),
     several state rows.  Against the oracle (north-star tolerance, also on the increments) and against the per-point
-    kernel on the same lists (MIA_NO_TILE): same mathematics, different summation order."""
+    kernel on the same lists (option tile = 0): same mathematics, different summation order."""
     case = O.synthetic_case(203, k, stride, seed=k + m, m=m)
     nb = eng.localize(case["grid_x"], case["obs_x"], [c])
     assert nb.p_max <= min(k, 56)
@@ -46,7 +46,7 @@ def test_tile_kernel_vs_oracle_and_per_point_kernel(eng, monkeypatch, k, stride,
         assert rel_fro(xa, ref) < TOL32
         mean = case["state"].mean(axis=1, keepdims=True)
         assert rel_fro(xa - mean, ref - mean) < 5e-5
-    monkeypatch.setenv("MIA_NO_TILE", "1")
+    set_option("tile", 0)
     xo, fo = run(eng, case, nb, 1.1)
     assert rel_fro(xa, xo) < 3e-6
     np.testing.assert_array_equal((fl >> 8) & 0xff, (fo >> 8) & 0xff)         # same bound, same table entry, same degree

@@ -3,6 +3,8 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import torch_assimilate_amd as mia
+os.environ.setdefault("MIA_BUILD_FLAGS", "-DMIA_EXPERIMENTS")   # the hooks this script drives exist in experiment builds only
+mia.build()
 dev = torch.device("cuda:0")
 eng = mia.LetkfEngine(dev)
 X, gx, ox, Yb, d = bench.make_case(100000, 40, 2, dev)

@@ -6,6 +6,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import torch_assimilate_amd as mia
+os.environ.setdefault("MIA_BUILD_FLAGS", "-DMIA_EXPERIMENTS")   # the hooks this script drives exist in experiment builds only
+mia.build()
 dev = torch.device("cuda:0")
 eng = mia.LetkfEngine(dev)
 g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "g7_synthetic_configs.npz"))

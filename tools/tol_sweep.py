@@ -10,6 +10,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 import torch_assimilate_amd as mia  # noqa: E402
+os.environ.setdefault("MIA_BUILD_FLAGS", "-DMIA_EXPERIMENTS")   # the hooks this script drives exist in experiment builds only
+mia.build()
 
 dev = torch.device("cuda:0")
 eng = mia.LetkfEngine(dev)

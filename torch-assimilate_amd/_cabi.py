@@ -20,6 +20,8 @@ class KernelOp(C.Structure):
 _PROTOS = {
     "mia_version": ([], i32),
     "mia_status_string": ([i32], C.c_char_p),
+    "mia_set_option": ([C.c_char_p, i32], i32),
+    "mia_get_option": ([C.c_char_p, C.POINTER(C.c_int)], i32),
     "mia_gaspari_cohn_f64": ([vp, i64, vp, vp], i32),
     "mia_gaspari_cohn_f32": ([vp, i64, vp, vp], i32),
     "mia_gaspari_cohn_inf_f64": ([vp, i64, vp, vp], i32),
@@ -125,6 +127,14 @@ def lib():
             fn.argtypes, fn.restype = args, res
         _lib = h
     return _lib
+
+
+def set_option(name: str, value: int) -> int:
+    """mia_set_option: returns the previous value (so that a caller / test can restore it)."""
+    old = C.c_int(0)
+    check(lib().mia_get_option(name.encode(), C.byref(old)), "mia_get_option(%s)" % name)
+    check(lib().mia_set_option(name.encode(), int(value)), "mia_set_option(%s)" % name)
+    return old.value
 
 
 def check(status, what):

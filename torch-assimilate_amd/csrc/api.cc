@@ -15,3 +15,38 @@ extern "C" const char* mia_status_string(int status) {
     default: return status > 0 ? "HIP runtime error (value is the hipError_t)" : "unknown status";
   }
 }
+
+// ---- route options (include/mia_letkf.h, mia_set_option): explicit, process-wide switches for the routes a caller or a test
+//      may legitimately want to steer.  They replace the MIA_* environment variables round 1 read inside launch code;
+//      what remains environment-driven is compiled in only with -DMIA_EXPERIMENTS (tools/ builds).
+#include <atomic>
+#include <cstring>
+#include "mia_options.h"
+
+namespace mia {
+static std::atomic<int> g_opt[MIA_OPT_COUNT_] = {62, 1, 1, 1, 1, 1};
+int option(int id) { return (id >= 0 && id < MIA_OPT_COUNT_) ? g_opt[id].load(std::memory_order_relaxed) : 0; }
+}  // namespace mia
+
+static const char* const kOptNames[MIA_OPT_COUNT_] = {"cheb_dmax", "cheb_table", "cheb_rowbatch", "cheb_big", "tile",
+                                                      "segment_signal"};
+static const int kOptDefault[MIA_OPT_COUNT_] = {62, 1, 1, 1, 1, 1};
+
+extern "C" int mia_set_option(const char* name, int value) {
+  if (!name) return MIA_ERR_NULL;
+  for (int i = 0; i < MIA_OPT_COUNT_; ++i)
+    if (!strcmp(name, kOptNames[i])) {
+      if (i == MIA_OPT_CHEB_DMAX) { if (value < 0) value = kOptDefault[i]; if (value < 3 || value > 62) return MIA_ERR_SIZE; }
+      else value = value < 0 ? kOptDefault[i] : (value != 0);
+      mia::g_opt[i].store(value, std::memory_order_relaxed);
+      return MIA_OK;
+    }
+  return MIA_ERR_UNSUPPORTED;
+}
+
+extern "C" int mia_get_option(const char* name, int* value) {
+  if (!name || !value) return MIA_ERR_NULL;
+  for (int i = 0; i < MIA_OPT_COUNT_; ++i)
+    if (!strcmp(name, kOptNames[i])) { *value = mia::option(i); return MIA_OK; }
+  return MIA_ERR_UNSUPPORTED;
+}

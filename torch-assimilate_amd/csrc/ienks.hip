@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "mia_common.h"
+#include "mia_options.h"
 #include "mia_jacobi.h"
 #include "mia_jacobi_sym.h"
 #include "mia_kernels.h"
@@ -311,7 +312,7 @@ static int ienks_update_impl(const T* W_in, int64_t w_stride, int k, int64_t g0,
   ap.tau = tau; ap.inv_eps = epsilon > T(0) ? T(1) / epsilon : T(0);
   ap.Wout = W_out; ap.flags = flags_opt;
   ap.n = (k + 1) & ~1; ap.lda = ap.n + 1;
-  ap.nd = (tau == T(1) && p_max <= k && !getenv("MIA_IENKS_PRIMAL")) ? (((p_max > 0 ? p_max : 1) + 1) & ~1) : 0;
+  ap.nd = (tau == T(1) && p_max <= k && !MIA_EXP_FLAG("MIA_IENKS_PRIMAL")) ? (((p_max > 0 ? p_max : 1) + 1) & ~1) : 0;
   ap.rows = ap.nd > 0 ? ap.nd : (p_max > 0 ? p_max : 1);
   if (ap.n > 510) return MIA_ERR_UNSUPPORTED;
   // the inverse of Wp is needed for the transform variant's D and, when tau < 1, for w_prec
@@ -328,7 +329,7 @@ static int ienks_update_impl(const T* W_in, int64_t w_stride, int k, int64_t g0,
                (size_t)(256 / 64 * 2) * sizeof(T);
   lds = align_up(lds, 16);
   if (lds > (long long)kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
-  const bool small = ap.n <= 44 && getenv("MIA_IENKS_NARROW");
+  const bool small = ap.n <= 44 && MIA_EXP_FLAG("MIA_IENKS_NARROW");
   if (small) {
     auto kern = ienks_update_kernel<T, 64>;
     if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -8,7 +8,7 @@
 // analysis of a state row x only needs their action on ONE vector:
 //     xa = mean + x' w_mean + x' W .
 // SURVEY.md section 7 ("Hard parts") notes that W and Pa being functions of A alone makes
-// eigensolver-free evaluations valid.  On the dual route (p <= k, see letkf_generic.hip) with
+// eigensolver-free evaluations valid.  On the dual route (p <= k, see letkf_entry.hip) with
 // S = Yl^T Yl, z = Yl^T x' :
 //     x' W      = f0 x' + Yl (phi(S) z),        phi(l) = -sqrt(k-1) / (u a (a + u)),  u = sqrt(l+reg), a = sqrt(reg)
 //     x' w_mean = d_l . (psi(S) z),             psi(l) = 1 / (l + reg)
@@ -32,8 +32,16 @@
 #include "mia_common.h"
 #include "mia_localize_dev.h"
 #include "mia_kernels.h"
+#include "mia_options.h"
 
 namespace mia {
+
+// phase-skipping hooks of the timing experiments: compiled out of the production kernels (they cost SALU and registers)
+#ifdef MIA_EXPERIMENTS
+#define MIA_XSKIP(P) ((P).xskip)
+#else
+#define MIA_XSKIP(P) 0
+#endif
 
 struct ChebParams {
   const float* X; int64_t ldx; int m; int k;
@@ -46,7 +54,7 @@ struct ChebParams {
   int32_t* retry_count;
   // fused localisation: the wavefront scans the observation index itself instead of reading lists
   int fused; ScanParams scan; int32_t* stats;
-  int xskip;   // timing experiments only (MIA_EXPERIMENT_SKIP), 0 in production
+  int xskip;   // timing experiments only (MIA_EXPERIMENT_SKIP, -DMIA_EXPERIMENTS builds); the production kernels read 0
   int lds_per_wave;
   // segmented launch (native step driver): the ng points are seg_len-sized segments; segment s writes
   // its own (m*k, seg_len) buffer at Xa + s * seg_stride and counts its finished points in done[s*64 + ..]
@@ -112,7 +120,7 @@ struct CoefTable { int device; int dual; float log_tol; int2* hdr; float2* c; };
 static const CoefTable* cheb_coef_table(int dual, float log_tol, hipStream_t stream) {
   static std::mutex mu;
   static std::vector<CoefTable*> tabs;
-  if (getenv("MIA_CHEB_NO_TABLE")) return nullptr;
+  if (!option(MIA_OPT_CHEB_TABLE)) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   std::lock_guard<std::mutex> lock(mu);
@@ -321,7 +329,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
   const int64_t ocol = SEG ? grp : P.o0 + pt;          // output column of this point
   if (pt >= P.ng) return;
   const int64_t g = P.g0 + pt;
-  if (P.xskip & 16) return;            // experiment: dispatch floor
+  if (MIA_XSKIP(P) & 16) return;            // experiment: dispatch floor
   int flag = 0;
   const float km1 = float(k - 1), reg = P.reg;
   const float ar = P.sqrt_reg;
@@ -356,14 +364,14 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     }
     return;
   }
-  if (P.xskip & 32) return;            // experiment: after the list / state loads
+  if (MIA_XSKIP(P) & 32) return;            // experiment: after the list / state loads
   MIA_WAVE_SYNC();
   {   // gather + sqrt(rho) scale (wrapper.py:91-97).  Four record quads per lane are requested before any is
       // consumed (one memory round trip for the usual <= 256 quads instead of one per 64), and the quad ->
       // (observation, column) split is a multiply-shift (P.kpv_magic = ceil(2^20 / kpv), exact below 2^20 / kpv
       // quads) instead of an integer division per quad
     const unsigned kpv = (unsigned)kp >> 2;
-    const int total = ((P.xskip & 1) || !P.dual) ? 0 : cnt * (int)kpv;   // (the primal route streams the records, see below)
+    const int total = ((MIA_XSKIP(P) & 1) || !P.dual) ? 0 : cnt * (int)kpv;   // (the primal route streams the records, see below)
     constexpr int GQ = NMAX > 32 ? 8 : 4;       // quads in flight per lane: large blocks (config 4: 1344 quads) run at
                                                 // few waves per CU, so each trip's memory latency is exposed
     // Quad `it` of the block IS quad `it` of Yt (row j, column c <-> j kpv + c), so the store needs no index at all; the
@@ -431,7 +439,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
 #pragma unroll
       for (int t = 0; t < NTILE; ++t) acc[t] = f32x4c{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
-      for (int s_ = 0; s_ < ((P.xskip & 2) ? 0 : KS); ++s_) {
+      for (int s_ = 0; s_ < ((MIA_XSKIP(P) & 2) ? 0 : KS); ++s_) {
         float av_[TT];
 #pragma unroll
         for (int t = 0; t < TT; ++t) av_[t] = (kfull || KS * h + s_ < k) ? prow[t][s_] : 0.0f;
@@ -467,7 +475,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
         MIA_WAVE_SYNC();
       }
     }
-  } else if (P.xskip & 2) {
+  } else if (MIA_XSKIP(P) & 2) {
     for (int it = tid; it < NMAX * LDA; it += 64) S[it] = 0.0f;
   } else if (P.dual) {
     // S = Yl^T Yl on the matrix cores (v_mfma_f32_16x16x4_f32, exact f32).  All TT row panels are loaded
@@ -541,7 +549,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     f32x4c acc[NTE];
 #pragma unroll
     for (int t = 0; t < NTE; ++t) acc[t] = f32x4c{0.f, 0.f, 0.f, 0.f};
-    const int ksteps = (P.xskip & 2) ? 0 : (cnt + 3) >> 2;
+    const int ksteps = (MIA_XSKIP(P) & 2) ? 0 : (cnt + 3) >> 2;
     for (int s_ = 0; s_ < ksteps; ++s_) {
       const int j = 4 * s_ + h;
       float av_[TTE];
@@ -662,7 +670,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     const float rho = (sq + 1.0f) * fast_rcp(fmaxf(sq - 1.0f, 1e-12f));     // in (1, 2e12]: v_log_f32 needs no range fix
     deg = (int)ceilf(P.log_tol * fast_rcp(0.6931471806f * __builtin_amdgcn_logf(rho))) + 2;
     deg = deg < 3 ? 3 : deg;
-    if (P.xskip & 4) deg = 3;
+    if (MIA_XSKIP(P) & 4) deg = 3;
     if (!(L == L) || !(fabsf(L) < 1e30f)) { flag |= MIA_FLAG_NONFINITE; deg = 3; }
     alpha = 2.0f * fast_rcp(L);
   }
@@ -1036,7 +1044,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
         const int b = 4 * s_ + h, i = 16 * t + lr;
         yfrag[t][s_] = (t < KT && b < cnt && i < k) ? Yt[(size_t)b * kp + i] : 0.0f;
       }
-    if (!(P.xskip & 256)) {
+    if (!(MIA_XSKIP(P) & 256)) {
       float bf[TT][N4];
 #pragma unroll
       for (int tj = 0; tj < TT; ++tj)
@@ -1058,7 +1066,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
       }
     }
     MIA_WAVE_SYNC();
-    if (!(P.xskip & 512)) {
+    if (!(MIA_XSKIP(P) & 512)) {
 #pragma unroll
       for (int ti = 0; ti < KTM; ++ti) {
         if (ti < KT) {
@@ -1091,7 +1099,7 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
     //    wrote it (L2-hot, rows contiguous across lanes) -- a copy in LDS would cost 7.7 KB of occupancy at k = 40
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // this wavefront's stores of W are visible to its loads
     __builtin_amdgcn_wave_barrier();
-    for (int mi = 0; mi < ((P.xskip & 1024) ? 0 : P.m); ++mi) {
+    for (int mi = 0; mi < ((MIA_XSKIP(P) & 1024) ? 0 : P.m); ++mi) {
       const float xv = tid < k ? P.X[((int64_t)mi * k + tid) * P.ldx + g] : 0.0f;
       const float xm = wave_sum_dpp(xv) / float(k);
       if (tid < kp) xp[tid] = tid < k ? xv - xm : 0.0f;
@@ -1165,14 +1173,14 @@ __device__ __forceinline__ void letkf_cheb_point(const ChebParams& P) {
         if (P.dual) {   // Yl s from the LDS block (still resident on this route; member j contiguous across lanes)
           acc = f0 * xp[j];                        // x' of member j (kept in LDS, not in a register across the recurrence)
 #pragma unroll 4
-          for (int b = 0; b < ((P.xskip & 8) ? 0 : cnt); ++b) acc += sw[b] * Yt[(size_t)b * kp + j];
+          for (int b = 0; b < ((MIA_XSKIP(P) & 8) ? 0 : cnt); ++b) acc += sw[b] * Yt[(size_t)b * kp + j];
         } else acc = sw[j];
         const float out = mterm + acc;
         if (!(fabsf(out) <= 1e30f)) flag |= MIA_FLAG_NONFINITE;
         // segmented launch: write-through (agent-scope) stores, so that the segment counter below can
         // publish them without a cache-wide release (a __threadfence per point costs 18x the kernel)
         if constexpr (SEG) {
-          if (P.xskip & 128) orow[(int64_t)j * P.ldo] = out;    // experiment
+          if (MIA_XSKIP(P) & 128) orow[(int64_t)j * P.ldo] = out;    // experiment
           else __hip_atomic_store(&orow[(int64_t)j * P.ldo], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else orow[(int64_t)j * P.ldo] = out;
       }
@@ -1212,7 +1220,7 @@ __global__ __launch_bounds__(64, (NMAX <= 24 ? (KL > 1 ? 5 : 6) : (NMAX <= 40 ? 
   const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
   if (bid >= P.ng) return;
   // all output stores of this wavefront (write-through, see above) have been acknowledged before it counts
-  if (!(P.xskip & 64)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!(MIA_XSKIP(P) & 64)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if ((threadIdx.x & 63) == 0) {
     const unsigned sg = (unsigned)bid / (unsigned)P.seg_len;
     __hip_atomic_fetch_add(P.done + ((size_t)sg * 64 + (unsigned)(bid & 63)) * kSlotStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1512,7 +1520,7 @@ static int cheb_launch_w(const ChebParams& ap, size_t lds, hipStream_t stream) {
 template <int NMAX, int KL, bool FUSED>
 static int cheb_launch(const ChebParams& ap, size_t lds, dim3, hipStream_t stream) {
   // four independent points per workgroup when their LDS slices fit comfortably
-  if (getenv("MIA_CHEB_WPB4") && lds * 4 <= 40 * 1024) return cheb_launch_w<NMAX, KL, FUSED, 4>(ap, lds, stream);   // experiment
+  if (MIA_EXP_FLAG("MIA_CHEB_WPB4") && lds * 4 <= 40 * 1024) return cheb_launch_w<NMAX, KL, FUSED, 4>(ap, lds, stream);
   return cheb_launch_w<NMAX, KL, FUSED, 1>(ap, lds, stream);
 }
 
@@ -1572,12 +1580,11 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
     if (k <= 64 || k > 128 || scan || seg_len > 0 || W_out) return MIA_ERR_UNSUPPORTED;
     ap.dual = 0;
     ap.rows = 0;
-    ap.dmax = 62;
+    ap.dmax = option(MIA_OPT_CHEB_DMAX);
     ap.xskip = 0;
     ap.log_tol = 12.0f;
-    if (const char* e = getenv("MIA_CHEB_LOGTOL")) ap.log_tol = (float)atof(e);     // experiments only
-    if (const char* e = getenv("MIA_CHEB_DMAX")) ap.dmax = atoi(e);
-    if (getenv("MIA_CHEB_NO_BIG")) return MIA_ERR_UNSUPPORTED;
+    MIA_EXP_SET(ap.log_tol, "MIA_CHEB_LOGTOL", (float)atof);
+    if (!option(MIA_OPT_CHEB_BIG)) return MIA_ERR_UNSUPPORTED;
     if (k <= 80) return cheb_launch_big<80>(ap, stream);
     if (k <= 96) return cheb_launch_big<96>(ap, stream);
     if (k <= 112) return cheb_launch_big<112>(ap, stream);
@@ -1588,16 +1595,16 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
   for (int b : buckets) if (b >= ntrue) { nmax = b; break; }
   if (nmax == 0 || k > 128) return MIA_ERR_UNSUPPORTED;
   ap.rows = ap.dual ? nmax : 0;      // the primal route streams the records: no local block in LDS
-  ap.dmax = 62;     // N = deg + 1 coefficient lanes <= 64; covers lambda_max / reg up to ~100 (dense local networks, p >> k)
-  if (const char* e = getenv("MIA_CHEB_DMAX")) ap.dmax = atoi(e);                 // experiments only
+  // N = deg + 1 coefficient lanes <= 64; 62 covers lambda_max / reg up to ~100 (dense local networks, p >> k)
+  ap.dmax = option(MIA_OPT_CHEB_DMAX);
   ap.xskip = 0;
-  if (const char* e = getenv("MIA_EXPERIMENT_SKIP")) ap.xskip = atoi(e);
+  MIA_EXP_SET(ap.xskip, "MIA_EXPERIMENT_SKIP", atoi);
   // a-priori truncation bound exp(-log_tol) = 6e-6 of the function scale.  Measured against the reference
   // (tools/matfun_tol.py, C2 / C4 / C5): the total error is flat at 1.7e-7 .. 3e-7 (float32 rounding) from 17.5 down to
   // 13, 2.5e-7 / 6.4e-7 / 1.3e-7 at 11, and only at 9 does truncation show (1e-6 / 5e-6); every unit costs ~0.85 of a
   // degree (C2: 15.3 at 15, 11.9 at 11)
   ap.log_tol = 12.0f;
-  if (const char* e = getenv("MIA_CHEB_LOGTOL")) ap.log_tol = (float)atof(e);     // experiments only
+  MIA_EXP_SET(ap.log_tol, "MIA_CHEB_LOGTOL", (float)atof);
   if (!ap.xskip) {
     if (const CoefTable* t = cheb_coef_table(ap.dual, ap.log_tol, stream)) {
       ap.tab_hdr = t->hdr; ap.tab_c = t->c;
@@ -1607,7 +1614,7 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
     }
   }
   // sixteen grid points per wavefront (letkf_tile.hip): dual route, few state rows, no weights output
-  if (ap.dual && ap.tab_hdr && !W_out && !ienks && !ap.fused && tile_route_covers(m, k, p_max) && !getenv("MIA_NO_TILE"))
+  if (ap.dual && ap.tab_hdr && !W_out && !ienks && !ap.fused && tile_route_covers(m, k, p_max) && option(MIA_OPT_TILE))
     return tile_analysis_launch(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, 0, p_cap, p_max, inf_factor, Xa, ldo, o0,
                                 flags, retry_count, ap.dmax, ap.tab_hdr, ap.tab_c, stream, seg_len, seg_stride, done);
   const size_t lds = cheb_lds_bytes(ap.kp, p_max, nmax, ap.rows, ap.dual != 0, false, 0, ap.fused != 0);
@@ -1639,7 +1646,7 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
   }
   // many state rows: batches of 16 rows on the matrix cores (dual route, order <= 32, one member per lane)
   if (m >= 8 && ((ap.dual && nmax <= 32) || (!ap.dual && nmax <= 48)) && !two && !ap.fused && seg_len == 0 &&
-      !getenv("MIA_CHEB_NO_ROWBATCH")) {
+      option(MIA_OPT_CHEB_ROWBATCH)) {
     ap.lds_per_wave = (int)cheb_lds_bytes(ap.kp, p_max, nmax, ap.rows, ap.dual != 0, true);
     switch (nmax) {
       case 4: return cheb_launch_rows<4>(ap, ap.lds_per_wave, stream);

@@ -1,25 +1,18 @@
-// Generic LDS-resident local analysis for gfx950 (any k / p_max that fits the 160 KB LDS,
-// float32 and float64).  One workgroup walks a contiguous run of grid points; for each
-// point the whole local block lives in LDS:
+// C entry points of the per-grid-point analysis and their dispatch to the eigensolver kernels (letkf_sys.hip: float32,
+// order <= 64, systolic Jacobi; letkf_wave.hip: runtime order, float32 / float64) and the matrix-function kernels
+// (letkf_cheb.hip, letkf_tile.hip); observation-record packing.  (The first-generation LDS-resident kernel that used to
+// live here -- 11.8 ms per 1e5 analyses at C2, kept for A/B runs through round 1 -- is gone.)
 //
+// What every route computes per grid point:
 //   gather + sqrt(rho)-scale of the local obs columns      interface/wrapper.py:91-97
 //   Gram matrix                                            core/utils.py:172 via etkf.py:68
 //   symmetric eigensolve, clamp >= 0, +(k-1)/inf           core/utils.py:57-60, etkf.py:67
 //   w_mean = Pa (Yb d^T), W = V diag(sqrt((k-1)/l)) V^T    core/etkf.py:70-76
 //   xa = mean + X' (w_mean 1^T + W)                        interface/base.py:257-278
-//
-// Two algebraically identical routes, chosen per launch:
-//  * primal (p_max > k): eigensolve of the k x k matrix C = Yl Yl^T, exactly the
-//    reference's operation sequence;
-//  * dual (p_max <= k): C has rank <= p, so the p x p matrix S = Yl^T Yl is decomposed
-//    instead (S = V L V^T) and every function of A = C + reg*I is applied through
-//       f(A) = f(reg) I + Yl V diag((f(l+reg) - f(reg)) / l) V^T Yl^T,
-//    with the divided differences written in their cancellation-free closed forms.
-//    For p == 0 this collapses to the reference's prior branch sqrt(inf)*I (etkf.py:91-95).
-//
-// The eigensolver is a parallel-order (round-robin tournament) cyclic Jacobi with the
-// rotation threshold scaled by (|a_pp| + reg): what enters the result is f(l + reg), so
-// off-diagonal mass below eps*(l + reg) is already below rounding of the reference result.
+// primal route (p_max > k): the k x k matrix C = Yl Yl^T, the reference's operation sequence; dual route (p_max <= k): the
+// p x p matrix S = Yl^T Yl, every function of A = C + reg I applied through
+//   f(A) = f(reg) I + Yl V diag((f(l+reg) - f(reg)) / l) V^T Yl^T
+// with cancellation-free divided differences; p == 0 collapses to the reference's prior branch sqrt(inf) I (etkf.py:91-95).
 #include "mia_common.h"
 #include "mia_jacobi.h"
 #include "mia_localize_dev.h"
@@ -42,300 +35,12 @@ int sys_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, i
                         float inf_factor, int kernel_mode, float gamma, float* Xa, int64_t ldo, int64_t o0,
                         float* W_opt, int32_t* flags_opt, int only_flagged, hipStream_t stream);
 
-template <typename T>
-struct AnaParams {
-  const T* X; int64_t ldx; int m; int k;
-  int64_t g0, ng;
-  const T* rec; int kp;              // packed obs records [P][kp]: yb[0..k), d, pad
-  const int32_t* cnt; const int32_t* idx; const double* w; int p_cap; int p_max;
-  T reg;                             // (k-1)/inf
-  T* Xa; int64_t ldo, o0;
-  T* W; int32_t* flags;
-  int dual; int nmax; int lda; int ldy; int pts_per_block;
-  int max_sweeps; T tol;
-  int kernel_mode;                   // 0 = linear (ETKF), 1 = RBF (KETKF, primal only)
-  T gamma;
-};
-
-template <typename T, int NT>
-__global__ __launch_bounds__(NT) void letkf_generic_kernel(AnaParams<T> P) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* sm = reinterpret_cast<T*>(smem_raw);
-  const int tid = threadIdx.x;
-  const int k = P.k, pm = P.p_max, nmax = P.nmax, lda = P.lda, ldy = P.ldy;
-  T* Yl = sm;                        // [k][ldy]   local, sqrt(rho)-scaled obs perturbations
-  T* dl = Yl + (size_t)k * ldy;      // [pm + 2]   local scaled innovations
-  T* A = dl + (pm + 2);              // [nmax][lda]
-  T* V = A + (size_t)nmax * lda;     // [nmax][lda]
-  T* cs = V + (size_t)nmax * lda;    // [nmax]
-  T* gW = cs + nmax;                 // [nmax] per-mode factor of the square-root term
-  T* gM = gW + nmax;                 // [nmax] per-mode factor of the mean term
-  T* av = gM + nmax;                 // [nmax]
-  T* uv = av + nmax;                 // [nmax]
-  T* wbar = uv + nmax;               // [k]
-  T* xp = wbar + k;                  // [k]
-  T* zb = xp + k;                    // [nmax]
-  T* qb = zb + nmax;                 // [nmax]
-  T* sb = qb + nmax;                 // [nmax]
-  T* red = sb + nmax;                // [4]
-  int* iflag = reinterpret_cast<int*>(red + 4);  // [4]
-  T* Mq = reinterpret_cast<T*>(iflag + 4);       // [k][lda] only for W output on the dual route (primal: M = V)
-  int* lidx = reinterpret_cast<int*>(Mq + ((P.W && P.dual) ? (size_t)k * lda : 0));  // [pm + 1]
-  T* lw = reinterpret_cast<T*>(lidx + ((pm + 2) & ~1));                  // [pm + 1]
-
-  const T km1 = T(k - 1);
-  const T reg = P.reg;
-  const T f0 = P.dual ? t_sqrt(km1 / reg) : T(0);
-
-  const int64_t pt_begin = (int64_t)blockIdx.x * P.pts_per_block;
-  int64_t pt_end = pt_begin + P.pts_per_block;
-  if (pt_end > P.ng) pt_end = P.ng;
-
-  for (int64_t pt = pt_begin; pt < pt_end; ++pt) {
-    const int64_t g = P.g0 + pt;
-    int cnt = P.cnt[pt];
-    int flag = 0;
-    __syncthreads();  // previous point's LDS no longer in use
-    if (cnt > pm || cnt > P.p_cap) {
-      // loud failure: never analyse with a truncated list
-      if (P.flags && tid == 0) P.flags[pt] = MIA_FLAG_OVERFLOW;
-      const T nanv = T(__builtin_nanf(""));
-      for (int it = tid; it < P.m * k; it += NT) P.Xa[(int64_t)it * P.ldo + P.o0 + pt] = nanv;
-      if (P.W) for (int it = tid; it < k * k; it += NT) P.W[pt * (int64_t)k * k + it] = nanv;
-      continue;
-    }
-    // ---- neighbour list -> LDS
-    for (int j = tid; j < cnt; j += NT) {
-      lidx[j] = P.idx[pt * P.p_cap + j];
-      lw[j] = T(P.w[pt * P.p_cap + j]);
-    }
-    __syncthreads();
-    // ---- gather + scale (wrapper.py:91-97); records are contiguous in the member index
-    for (int it = tid; it < cnt * (k + 1); it += NT) {
-      const int j = it / (k + 1), i = it - j * (k + 1);
-      const T v = P.rec[(int64_t)lidx[j] * P.kp + i] * lw[j];
-      if (i < k) Yl[i * ldy + j] = v; else dl[j] = v;
-    }
-    const int ntrue = P.dual ? cnt : k;          // modes that can carry signal
-    const int n = (ntrue + 1) & ~1;              // even order for the tournament
-    if (P.dual) {
-      // zero pad column when cnt is odd
-      if (n > cnt) { for (int i = tid; i < k; i += NT) Yl[i * ldy + cnt] = T(0); if (tid == 0) dl[cnt] = T(0); }
-    }
-    __syncthreads();
-    // ---- Gram matrix + identity
-    if (P.dual) {
-      for (int it = tid; it < n * n; it += NT) {
-        const int a = it / n, b = it - a * n;
-        if (a <= b) {
-          T acc = T(0);
-          for (int i = 0; i < k; ++i) acc += Yl[i * ldy + a] * Yl[i * ldy + b];
-          A[a * lda + b] = acc; A[b * lda + a] = acc;
-        }
-        V[a * lda + b] = (a == b) ? T(1) : T(0);
-      }
-    } else if (P.kernel_mode == 0) {
-      for (int it = tid; it < n * n; it += NT) {
-        const int a = it / n, b = it - a * n;
-        if (a <= b) {
-          T acc = T(0);
-          if (b < k) for (int j = 0; j < cnt; ++j) acc += Yl[a * ldy + j] * Yl[b * ldy + j];
-          A[a * lda + b] = acc; A[b * lda + a] = acc;
-        }
-        V[a * lda + b] = (a == b) ? T(1) : T(0);
-      }
-    } else {
-      // RBF Gram matrix exp(-gamma*|y_a - y_b|^2) (kernels/rbf.py:75-81,110-111)
-      for (int it = tid; it < n * n; it += NT) {
-        const int a = it / n, b = it - a * n;
-        if (a <= b) {
-          T acc = T(0);
-          if (b < k) {
-            for (int j = 0; j < cnt; ++j) { const T df = Yl[a * ldy + j] - Yl[b * ldy + j]; acc += df * df; }
-            acc = t_exp(-P.gamma * acc);
-          }
-          A[a * lda + b] = acc; A[b * lda + a] = acc;
-        }
-        V[a * lda + b] = (a == b) ? T(1) : T(0);
-      }
-    }
-    __syncthreads();
-    // ---- right-hand side of the mean weights
-    //   dual  : b = dl (p)           primal linear : b = Yl dl (k)
-    //   primal RBF : b = centred k(Yl, dl)   (core/ketkf.py:86-89)
-    if (!P.dual) {
-      if (P.kernel_mode == 0) {
-        for (int i = tid; i < k; i += NT) {
-          T acc = T(0);
-          for (int j = 0; j < cnt; ++j) acc += Yl[i * ldy + j] * dl[j];
-          zb[i] = acc;
-        }
-        if (n > k && tid == 0) zb[k] = T(0);
-        __syncthreads();
-      } else {
-        // row means of K (k_partial_mean before its own centring), core/ketkf.py:77
-        for (int i = tid; i < k; i += NT) {
-          T acc = T(0);
-          for (int j = 0; j < k; ++j) acc += A[i * lda + j];
-          uv[i] = acc / T(k);
-          T ko = T(0);
-          for (int j = 0; j < cnt; ++j) { const T df = Yl[i * ldy + j] - dl[j]; ko += df * df; }
-          zb[i] = t_exp(-P.gamma * ko);
-        }
-        __syncthreads();
-        if (tid == 0) {
-          T gm = T(0), om = T(0);
-          for (int i = 0; i < k; ++i) { gm += uv[i]; om += zb[i]; }
-          red[0] = gm / T(k); red[1] = om / T(k);
-        }
-        __syncthreads();
-        // K_c[a][b] = K[a][b] - colmean[b] - (rowmean[a] - grand)   (ketkf.py:78-81);
-        // K symmetric -> colmean == rowmean
-        for (int it = tid; it < k * k; it += NT) {
-          const int a = it / k, b = it - a * k;
-          A[a * lda + b] = A[a * lda + b] - uv[b] - (uv[a] - red[0]);
-        }
-        // k_obs centred (ketkf.py:87-88)
-        for (int i = tid; i < k; i += NT) zb[i] = zb[i] - red[1] - (uv[i] - red[0]);
-        if (n > k && tid == 0) zb[k] = T(0);
-        __syncthreads();
-      }
-    }
-    // ---- symmetric eigensolve
-    const bool conv = jacobi_lds<T, NT>(A, V, cs, iflag, n, n, lda, reg, P.tol, P.max_sweeps);
-    if (!conv) flag |= MIA_FLAG_NOCONV;
-    // ---- per-mode factors (clamp >= 0 then + reg: core/utils.py:58-59)
-    for (int r = tid; r < n; r += NT) {
-      T lam = A[r * lda + r];
-      lam = lam > T(0) ? lam : T(0);
-      const T le = lam + reg;
-      T acc = T(0);
-      if (P.dual) {
-        const T sl = t_sqrt(le), sr = t_sqrt(reg);
-        gW[r] = (r < ntrue) ? -t_sqrt(km1) / (sl * sr * (sr + sl)) : T(0);
-        for (int b = 0; b < cnt; ++b) acc += V[b * lda + r] * dl[b];
-      } else {
-        gW[r] = (r < ntrue) ? t_sqrt(km1 / le) : T(0);
-        for (int b = 0; b < k; ++b) acc += V[b * lda + r] * zb[b];
-      }
-      gM[r] = (r < ntrue) ? T(1) / le : T(0);
-      av[r] = acc * gM[r];
-    }
-    __syncthreads();
-    // u = V (gM o V^T b)
-    for (int b = tid; b < n; b += NT) {
-      T acc = T(0);
-      for (int r = 0; r < n; ++r) acc += V[b * lda + r] * av[r];
-      uv[b] = acc;
-    }
-    __syncthreads();
-    // w_mean: dual Yl u, primal u
-    for (int i = tid; i < k; i += NT) {
-      T acc;
-      if (P.dual) { acc = T(0); for (int b = 0; b < cnt; ++b) acc += Yl[i * ldy + b] * uv[b]; }
-      else acc = uv[i];
-      wbar[i] = acc;
-    }
-    __syncthreads();
-    // ---- ensemble transform, one state row at a time
-    for (int mi = 0; mi < P.m; ++mi) {
-      const T* xrow = P.X + (int64_t)mi * k * P.ldx + g;
-      for (int i = tid; i < k; i += NT) xp[i] = xrow[(int64_t)i * P.ldx];
-      __syncthreads();
-      if (tid == 0) {
-        T s = T(0);
-        for (int i = 0; i < k; ++i) s += xp[i];
-        red[2] = s / T(k);
-      }
-      __syncthreads();
-      const T xm = red[2];
-      for (int i = tid; i < k; i += NT) xp[i] -= xm;
-      __syncthreads();
-      if (tid == 0) {
-        T s = T(0);
-        for (int i = 0; i < k; ++i) s += xp[i] * wbar[i];
-        red[3] = s;
-      }
-      // z = X' B   (dual: B = Yl, primal: B = I)
-      for (int b = tid; b < n; b += NT) {
-        T acc = T(0);
-        if (P.dual) { if (b < cnt) for (int i = 0; i < k; ++i) acc += xp[i] * Yl[i * ldy + b]; }
-        else acc = b < k ? xp[b] : T(0);
-        zb[b] = acc;
-      }
-      __syncthreads();
-      for (int r = tid; r < n; r += NT) {
-        T acc = T(0);
-        for (int b = 0; b < n; ++b) acc += zb[b] * V[b * lda + r];
-        qb[r] = acc * gW[r];
-      }
-      __syncthreads();
-      for (int b = tid; b < n; b += NT) {
-        T acc = T(0);
-        for (int r = 0; r < n; ++r) acc += qb[r] * V[b * lda + r];
-        sb[b] = acc;
-      }
-      __syncthreads();
-      const T mterm = xm + red[3];
-      T* orow = P.Xa + (int64_t)mi * k * P.ldo + P.o0 + pt;
-      for (int j = tid; j < k; j += NT) {
-        T acc;
-        if (P.dual) { acc = f0 * xp[j]; for (int b = 0; b < cnt; ++b) acc += sb[b] * Yl[j * ldy + b]; }
-        else acc = sb[j];
-        const T out = mterm + acc;
-        if (!(out == out) || t_abs(out) > T(1e30)) flag |= MIA_FLAG_NONFINITE;
-        orow[(int64_t)j * P.ldo] = out;
-      }
-      __syncthreads();
-    }
-    // ---- optional weights output: w_mean_i + f0*delta_ij + sum_r gW_r M_ir M_jr,  M = B V
-    if (P.W) {
-      const T* Mm = V;
-      if (P.dual) {
-        for (int it = tid; it < k * n; it += NT) {
-          const int i = it / n, r = it - i * n;
-          T acc = T(0);
-          for (int b = 0; b < cnt; ++b) acc += Yl[i * ldy + b] * V[b * lda + r];
-          Mq[i * lda + r] = acc;
-        }
-        Mm = Mq;
-        __syncthreads();
-      }
-      T* wout = P.W + pt * (int64_t)k * k;
-      for (int it = tid; it < k * k; it += NT) {
-        const int i = it / k, j = it - i * k;
-        T acc = wbar[i] + (i == j ? f0 : T(0));
-        for (int r = 0; r < n; ++r) acc += gW[r] * Mm[i * lda + r] * Mm[j * lda + r];
-        wout[it] = acc;
-      }
-    }
-    if (P.flags) {
-      // any thread may have seen a non-finite value
-      if (tid == 0) iflag[2] = 0;
-      __syncthreads();
-      if (flag) atomicOr(&iflag[2], flag);
-      __syncthreads();
-      if (tid == 0) P.flags[pt] = iflag[2];
-    }
-  }
-}
-
 // [k][P] (+ d[P]) -> obs-major records [P][kp]: one observation's k perturbations and its
 // innovation become one contiguous, coalescable 4*kp-byte record for the gather
 template <typename T>
 __global__ __launch_bounds__(256) void pack_obs_kernel(const T* Yb, const T* d, int k, int64_t P, int kp, T* rec) {
   __shared__ T tile[32][33];
   pack_obs_tile<T>(Yb, d, k, P, kp, rec, (int64_t)blockIdx.x, tile);
-}
-
-template <typename T>
-static size_t generic_lds_bytes(int k, int p_max, int nmax, int lda, int ldy, bool want_mq) {
-  size_t e = (size_t)k * ldy + (p_max + 2) + 2 * (size_t)nmax * lda + 5 * (size_t)nmax + 2 * (size_t)k +
-             3 * (size_t)nmax + 4;
-  size_t b = e * sizeof(T) + 4 * sizeof(int);
-  if (want_mq) b += (size_t)k * lda * sizeof(T);
-  b += (size_t)((p_max + 2) & ~1) * sizeof(int) + (size_t)(p_max + 2) * sizeof(T);
-  return align_up(b, 16);
 }
 
 template <typename T>
@@ -369,53 +74,14 @@ static int analysis_packed_impl(const T* X, int64_t ldx, int m, int k, int64_t g
   if (kernel_mode == 2)   // kernel expression: runtime-order kernel only
     return wave_analysis_launch<T>(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
                                    kernel_mode, gamma, Xa, ldo, o0, W_opt, flags_opt, only_flagged, stream, prog, n_ops);
-  const char* which = getenv("MIA_KERNEL");   // experiments: "generic" | "wave" | default (systolic, then wave)
-  if constexpr (sizeof(T) == 4) {
-    if (!which || which[0] == 's') {
-      const int rc = sys_analysis_launch(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
-                                         kernel_mode, gamma, Xa, ldo, o0, W_opt, flags_opt, only_flagged, stream);
-      if (rc != MIA_ERR_UNSUPPORTED) return rc;
-    }
+  if constexpr (sizeof(T) == 4) {     // float32, order <= 64: the systolic-Jacobi kernel (letkf_sys.hip)
+    const int rc = sys_analysis_launch(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
+                                       kernel_mode, gamma, Xa, ldo, o0, W_opt, flags_opt, only_flagged, stream);
+    if (rc != MIA_ERR_UNSUPPORTED) return rc;
   }
-  if (!which || which[0] != 'g')   // runtime-order kernel (letkf_wave.hip): float64 and orders > 64
-    return wave_analysis_launch<T>(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
-                                   kernel_mode, gamma, Xa, ldo, o0, W_opt, flags_opt, only_flagged, stream);
-  if (only_flagged) return MIA_ERR_UNSUPPORTED;
-  AnaParams<T> ap;
-  ap.X = X; ap.ldx = ldx; ap.m = m; ap.k = k; ap.g0 = g0; ap.ng = ng; ap.rec = rec; ap.kp = kp;
-  ap.cnt = nbr_cnt; ap.idx = nbr_idx; ap.w = nbr_w; ap.p_cap = p_cap; ap.p_max = p_max;
-  ap.reg = T(k - 1) / inf_factor;
-  ap.Xa = Xa; ap.ldo = ldo; ap.o0 = o0; ap.W = W_opt; ap.flags = flags_opt;
-  ap.kernel_mode = kernel_mode; ap.gamma = gamma;
-  ap.dual = (kernel_mode == 0 && p_max <= k) ? 1 : 0;
-  const int ntrue = ap.dual ? p_max : k;
-  ap.nmax = (ntrue + 1) & ~1;
-  if (ap.nmax < 2) ap.nmax = 2;
-  ap.lda = ap.nmax | 1;
-  ap.ldy = (p_max + 1) | 1;
-  ap.max_sweeps = sizeof(T) == 4 ? 16 : 24;
-  ap.tol = sizeof(T) == 4 ? T(2.4e-7) : T(9e-16);
-  const size_t lds = generic_lds_bytes<T>(k, p_max, ap.nmax, ap.lda, ap.ldy, W_opt != nullptr && ap.dual);
-  if (lds > (long long)kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
-  const bool big = ap.nmax > 32;
-  // enough workgroups to fill 256 CUs several times over, but contiguous runs per workgroup
-  int ppb = (int)((ng + 8191) / 8192);
-  if (ppb < 1) ppb = 1;
-  if (ppb > 16) ppb = 16;
-  ap.pts_per_block = ppb;
-  const int64_t nblk = (ng + ppb - 1) / ppb;
-  if (nblk > 2147483647LL) return MIA_ERR_UNSUPPORTED;
-  if (big) {
-    auto kern = letkf_generic_kernel<T, 256>;
-    if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    kern<<<dim3((unsigned)nblk), dim3(256), lds, stream>>>(ap);
-  } else {
-    auto kern = letkf_generic_kernel<T, 64>;
-    if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    kern<<<dim3((unsigned)nblk), dim3(64), lds, stream>>>(ap);
-  }
-  MIA_LAUNCH_CHECK();
-  return MIA_OK;
+  // runtime-order kernel (letkf_wave.hip): float64 and orders > 64
+  return wave_analysis_launch<T>(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
+                                 kernel_mode, gamma, Xa, ldo, o0, W_opt, flags_opt, only_flagged, stream);
 }
 
 template <typename T>

@@ -1,6 +1,6 @@
 // Third-generation fused LETKF analysis kernel for gfx950 (float32): "systolic" Jacobi.
 //
-// Mathematics and reference citations as in letkf_wave.hip / letkf_generic.hip.  What changes
+// Mathematics and reference citations as in letkf_wave.hip / letkf_entry.hip.  What changes
 // is the eigensolver's data movement, because rocprofv3 showed the second-generation kernel to
 // be VALU-issue bound on index arithmetic (22.5k VALU instructions per analysis, ~2/3 of them
 // integer):
@@ -19,6 +19,7 @@
 //    out in natural order at every sweep boundary (the only place the loop can stop).
 #include <cstdlib>
 #include "mia_common.h"
+#include "mia_options.h"
 
 namespace mia {
 
@@ -636,16 +637,16 @@ int sys_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, i
   if (nmax == 0) return MIA_ERR_UNSUPPORTED;
   ap.rows = ap.dual ? nmax : (p_max > 0 ? p_max : 1);
   ap.max_sweeps = 16;
-  if (const char* e = getenv("MIA_MAX_SWEEPS")) ap.max_sweeps = atoi(e);             // experiments only
-  if (getenv("MIA_EXPERIMENT_NO_V")) ap.max_sweeps |= 256;
-  if (const char* e = getenv("MIA_EXPERIMENT_SKIP")) ap.max_sweeps |= atoi(e) << 9;
+  MIA_EXP_SET(ap.max_sweeps, "MIA_MAX_SWEEPS", atoi);
+  if (MIA_EXP_FLAG("MIA_EXPERIMENT_NO_V")) ap.max_sweeps |= 256;
+  { int skip = 0; MIA_EXP_SET(skip, "MIA_EXPERIMENT_SKIP", atoi); ap.max_sweeps |= skip << 9; }
   // stop at ~sqrt(eps): the first-order correction (also applied to the weights output) leaves O(stop_tol^2)
   float stop_tol = 1.0e-3f;   // 4*sqrt(eps): second-order remainder ~1e-6
   // weights output on the primal route (KETKF): the mean weights of a centred kernel matrix are small differences of
   // O(1) terms, and W is judged entry by entry, not through an analysis it is applied to: one more (quadratically
   // converging) sweep puts the remainder at ~1e-9 (measured at 1e-3: 4e-5 relative error against the reference)
   if (W_opt && !ap.dual) stop_tol = 3.0e-5f;
-  if (const char* e = getenv("MIA_JACOBI_STOP_TOL")) stop_tol = (float)atof(e);   // experiments only
+  MIA_EXP_SET(stop_tol, "MIA_JACOBI_STOP_TOL", (float)atof);
   const float rot_tol = 1e-7f;
   ap.stop_tol2 = stop_tol * stop_tol;
   ap.rot_tol2 = rot_tol * rot_tol;

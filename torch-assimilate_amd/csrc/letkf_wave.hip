@@ -1,6 +1,6 @@
 // Fused per-grid-point LETKF analysis for gfx950, second generation ("wave" kernel).
 //
-// Same mathematics and reference citations as letkf_generic.hip (mask/scale wrapper.py:91-97,
+// Same mathematics and reference citations as letkf_entry.hip (mask/scale wrapper.py:91-97,
 // Gram utils.py:172, eigensolve + clamp + shift utils.py:57-60 / etkf.py:67, w_mean and W
 // etkf.py:70-76, transform base.py:257-278; RBF route ketkf.py:65-94), restructured around the
 // measured bottleneck of the first kernel (instruction issue: ~1.1e5 wave-instructions per
@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "mia_common.h"
+#include "mia_options.h"
 #include "mia_jacobi.h"
 #include "mia_jacobi_sym.h"
 #include "mia_kernel_prog.h"
@@ -440,7 +441,7 @@ int wave_analysis_launch(const T* X, int64_t ldx, int m, int k, int64_t g0, int6
   // output W uses the diagonal part only, so it asks for full convergence.
   T stop_tol = sizeof(T) == 4 ? T(2.4e-4) : T(1.5e-8);
   if (W_opt) stop_tol = sizeof(T) == 4 ? T(2.4e-7) : T(9e-16);
-  if (const char* e = getenv("MIA_JACOBI_STOP_TOL")) stop_tol = T(atof(e));   // experiments only
+  MIA_EXP_SET(stop_tol, "MIA_JACOBI_STOP_TOL", (T)atof);
   const T rot_tol = stop_tol * T(0.5);
   ap.stop_tol2 = stop_tol * stop_tol;
   ap.rot_tol2 = rot_tol * rot_tol;

@@ -10,6 +10,7 @@
 // survivors with a wave ballot.  Integer/byte work, HBM/L2-bound: no MFMA here.
 #include <cstdlib>
 #include "mia_common.h"
+#include "mia_options.h"
 #include "mia_localize_dev.h"
 #include "mia_pack_dev.h"
 
@@ -510,7 +511,7 @@ int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* 
   lp.cnt = nbr_cnt; lp.idx = nbr_idx; lp.w = nbr_w; lp.stats = stats;
   // one-wave workgroups: beside a bulk kernel that holds every wave slot (pipelined steps) a single freed slot is
   // enough to place one, whereas a 4-wave workgroup waited for four slots on one CU (200 us instead of 35)
-  if (p_cap >= 64 && ng <= 2147483647LL && !getenv("MIA_LOCALIZE_THREAD")) {   // long lists: one wavefront per grid point
+  if (p_cap >= 64 && ng <= 2147483647LL && !MIA_EXP_FLAG("MIA_LOCALIZE_THREAD")) {   // long lists: one wavefront per grid point
     localize_wave_kernel<<<dim3((unsigned)ng), dim3(64), 0, stream>>>(lp);
     MIA_LAUNCH_CHECK();
     return MIA_OK;

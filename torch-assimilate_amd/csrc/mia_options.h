@@ -1,0 +1,28 @@
+// Route options shared by the translation units (set through mia_set_option, include/mia_letkf.h).
+#pragma once
+
+enum {
+  MIA_OPT_CHEB_DMAX = 0,     // largest Chebyshev degree the matfun kernels accept before declining a point (3 .. 62)
+  MIA_OPT_CHEB_TABLE,        // coefficients from the per-device table (1) or computed in the kernel (0)
+  MIA_OPT_CHEB_ROWBATCH,     // many state rows: 16-row MFMA batches (1) or the row-by-row path (0)
+  MIA_OPT_CHEB_BIG,          // 64 < k <= 128 with > 64 local observations: two-rows-per-lane matfun kernel (1) or eigensolver (0)
+  MIA_OPT_TILE,              // sixteen grid points per wavefront (letkf_tile.hip) where the shape allows (1) or one (0)
+  MIA_OPT_SEGMENT_SIGNAL,    // step driver with several pieces: one segmented launch (1) or one launch + event per piece (0)
+  MIA_OPT_COUNT_
+};
+
+namespace mia {
+int option(int id);
+}
+
+// Timing / accuracy experiments of tools/ (phase skipping, tolerances, alternative launch shapes) read the environment --
+// in builds with -DMIA_EXPERIMENTS only (MIA_BUILD_FLAGS=-DMIA_EXPERIMENTS python tools/...).  The default build compiles
+// these to constants: no environment variable changes what the shipped library computes.
+#ifdef MIA_EXPERIMENTS
+#include <cstdlib>
+#define MIA_EXP_SET(var, name, conv) do { if (const char* e_ = std::getenv(name)) (var) = conv(e_); } while (0)
+#define MIA_EXP_FLAG(name) (std::getenv(name) != nullptr)
+#else
+#define MIA_EXP_SET(var, name, conv) do { } while (0)
+#define MIA_EXP_FLAG(name) false
+#endif

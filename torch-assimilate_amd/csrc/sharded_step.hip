@@ -20,6 +20,7 @@
 
 #include "mia_common.h"
 #include "mia_kernels.h"
+#include "mia_options.h"
 #include "mia_pack_dev.h"
 
 // ---- the few RCCL declarations needed (ABI of rccl.h 2.x: opaque comm, 128-byte id, C enums)
@@ -332,7 +333,7 @@ extern "C" int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int
   hipStream_t s = (hipStream_t)stream, cs = (hipStream_t)comm_stream;
   hipStream_t ps = prep_stream ? (hipStream_t)prep_stream : s;      // records, index, lists
   // MIA_SEGMENT_SIGNAL=0: one launch + one event per piece instead of the segmented launch (fallback / A-B runs)
-  const bool signal_mode = !(getenv("MIA_SEGMENT_SIGNAL") && atoi(getenv("MIA_SEGMENT_SIGNAL")) == 0);
+  const bool signal_mode = mia::option(MIA_OPT_SEGMENT_SIGNAL) != 0;
   char* base = (char*)ws;
   float* rec = (float*)(base + L.rec);
   int32_t* cnt = (int32_t*)(base + L.cnt);

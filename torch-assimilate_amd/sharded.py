@@ -68,8 +68,10 @@ class ShardedLetkf:
     def dominant_kernel_name(self):
         if self.method == "eig":
             return "letkf_sys_kernel<20, 64>"
-        import os
-        return "letkf_cheb_kernel<20, 1, false>" if os.environ.get("MIA_NO_TILE") else "letkf_tile_kernel<2, 3, false>"
+        import ctypes as C
+        v = C.c_int(1)
+        self.engine.lib.mia_get_option(b"tile", C.byref(v))
+        return "letkf_tile_kernel<2, 3, false>" if v.value else "letkf_cheb_kernel<20, 1, false>"
 
     @property
     def exchange_route(self):
@@ -457,13 +459,11 @@ class ShardedLetkf:
             # a segment waiter gave up (the analysis launch and the exchange stream must be able to run
             # concurrently: e.g. more HIP streams than hardware queues): all ranks switch to one launch + one
             # event per piece and repeat the step
-            import os
             import warnings
-            if os.environ.get("MIA_SEGMENT_SIGNAL") == "0":
+            if _cabi.set_option("segment_signal", 0) == 0:
                 raise _cabi.MiaError("native step driver: exchange error bits %d" % cnt[7])
             warnings.warn("segmented launch timed out waiting for a segment; falling back to per-piece launches",
                           RuntimeWarning)
-            os.environ["MIA_SEGMENT_SIGNAL"] = "0"
             redo = "same"
         elif n_over or p_seen > p["hint"]:
             self._p_max_hint = None                            # bound broken on some rank: all ranks redo
