@@ -17,7 +17,12 @@ STAMP = os.path.join(LIB_DIR, "libmia_letkf.stamp")
 SOURCES = ["localize.hip", "letkf_entry.hip", "etkf_global.hip", "letkf_wave.hip", "letkf_sys.hip", "letkf_cheb.hip", "letkf_tile.hip", "sharded_step.hip", "obs_space.hip", "ienks.hip", "api.cc"]
 HEADERS = ["mia_common.h", "mia_options.h", "mia_jacobi.h", "mia_jacobi_sym.h", "mia_kernel_prog.h", "mia_localize_dev.h", "mia_kernels.h", "mia_pack_dev.h", os.path.join(ROOT, "include", "mia_letkf.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get("MIA_BUILD_FLAGS", "").split()   # (A/B builds, tools/)
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
+def _flags():
+    """Compile flags; MIA_BUILD_FLAGS (read when build() runs) adds defines for the A/B and experiment builds of tools/."""
+    return FLAGS + os.environ.get("MIA_BUILD_FLAGS", "").split()
 
 
 def _sources():
@@ -29,7 +34,7 @@ def _digest():
     for f in _sources() + [f if os.path.isabs(f) else os.path.join(CSRC, f) for f in HEADERS]:
         with open(f, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(_flags()).encode())
     return h.hexdigest()
 
 
@@ -42,13 +47,13 @@ def _object_digest(src):
     for f in [src] + [f if os.path.isabs(f) else os.path.join(CSRC, f) for f in HEADERS]:
         with open(f, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(_flags()).encode())
     return h.hexdigest()[:24]
 
 
 def _compile(job):
     src, obj, verbose = job
-    cmd = [hipcc_path()] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", obj + ".tmp"]
+    cmd = [hipcc_path()] + [f for f in _flags() if f != "-shared"] + ["-c", src, "-o", obj + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
