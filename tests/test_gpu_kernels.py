@@ -154,3 +154,29 @@ def test_global_ketkf_with_many_observations(mia, eng, dtype, tol):
     np.testing.assert_allclose(prior.cpu().numpy(), np.sqrt(1.3) * np.eye(k), rtol=1e-6)
     with pytest.raises(ValueError):
         mia.KETKFModule(K.PolyKernel(), 1.0)(torch.ones(k, 4), torch.ones(3))
+
+
+def test_global_ketkf_with_per_observation_lengthscales(mia):
+    """GaussKernel with a lengthscale VECTOR (one per observation: the reference divides both kernel arguments by it,
+    kernels/rbf.py:75-78, pinned by tests/unit_tests/kernels/test_rbf.py:52-96) in the global KETKF; refused under
+    localisation, where the observation axis differs from grid point to grid point."""
+    rs = np.random.RandomState(21)
+    k, p = 12, 30
+    hx = rs.normal(size=(k, p))
+    yb, d = hx - hx.mean(axis=0), rs.normal(size=p)
+    ls = rs.uniform(0.5, 3.0, size=p)
+    kern = lambda x, y: O.rbf_kernel(x / torch.from_numpy(ls), y / torch.from_numpy(ls), 0.5)
+    ref = O.ketkf_weights(torch.from_numpy(yb), torch.from_numpy(d), kern, 1.1).numpy()
+    for lengthscale in (ls, torch.from_numpy(ls)):
+        mod = mia.KETKFModule(mia.GaussKernel(lengthscale), 1.1)
+        w = mod(torch.from_numpy(yb), torch.from_numpy(d)).cpu().numpy()
+        assert rel_fro(w, ref) < 1e-9
+    state = rs.normal(size=(1, k, 6))
+    xa = mia.KETKF(mia.GaussKernel(ls), inf_factor=1.1, dtype=torch.float64).analyse_arrays(state, yb, d)
+    assert rel_fro(xa.cpu().numpy(), O.apply_weights(state, ref)) < 1e-9
+    with pytest.raises(ValueError):
+        mia.KETKFModule(mia.GaussKernel(ls[:-1]), 1.1)(torch.from_numpy(yb), torch.from_numpy(d))
+    loc = mia.GaspariCohn(10.0, mia.AbsoluteDistance())
+    with pytest.raises(NotImplementedError):
+        mia.LKETKF(mia.GaussKernel(ls), localization=loc).analyse_arrays(state, yb, d, grid_coords=np.arange(6.0),
+                                                                         obs_coords=np.arange(30.0))

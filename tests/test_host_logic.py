@@ -23,6 +23,11 @@ def test_kernel_descriptors():
     assert mia.RBFKernel(10.0).lengthscale == pytest.approx((0.5 / 10.0) ** 0.5)
     assert mia.GaussKernel(1.0).gamma == mia.RBFKernel(0.5).gamma        # tests/unit_tests/kernels/test_rbf.py:112-116
     assert mia.GaussKernel(2.0).gamma == pytest.approx(0.125)
+    vec = mia.GaussKernel(np.array([1.0, 2.0, 0.5]))                     # per-observation lengthscales: global KETKF only
+    assert vec.gamma == 0.5 and np.allclose(vec.feature_scale, [1.0, 0.5, 2.0]) and mia.GaussKernel(2.0).feature_scale is None
+    assert mia.KETKF(vec)._kernel_args()["rbf_gamma"] == 0.5
+    with pytest.raises(NotImplementedError):
+        mia.LKETKF(vec)._kernel_args()
     assert mia.LinearKernel().gamma is None
     assert str(mia.LinearKernel()) == "LinearKernel" and repr(mia.RBFKernel()) == "RBFKernel"
 

@@ -85,7 +85,7 @@ class KETKFModule(ETKFModule):
     def __call__(self, normed_perts, normed_obs) -> torch.Tensor:
         """One global block of any size: pair statistics over observation chunks + one k x k solve
         (``mia_ketkf_weights_*``); a LinearKernel is the ETKF (linear.py:66-67)."""
-        gamma, prog = kernel_route(self.kernel)
+        gamma, prog = kernel_route(self.kernel, allow_feature_scale=True)
         if gamma is None and prog is None:
             return super().__call__(normed_perts, normed_obs)
         if prog is None:
@@ -97,7 +97,15 @@ class KETKFModule(ETKFModule):
         dtype = perts.dtype if perts.dtype in (torch.float32, torch.float64) else torch.float64
         k = perts.shape[-2] if perts.dim() >= 2 else 1
         perts = perts.reshape(k, perts.shape[-1]).to(device=eng.device, dtype=dtype)
-        return eng.ketkf_weights(perts, obs.reshape(-1).to(device=eng.device, dtype=dtype), prog, self.inf_factor)
+        obs = obs.reshape(-1).to(device=eng.device, dtype=dtype)
+        scale = getattr(self.kernel, "feature_scale", None)
+        if scale is not None:          # per-observation lengthscales (rbf.py:75-78): both kernel arguments divided by l
+            if len(scale) != perts.shape[-1]:
+                raise ValueError("GaussKernel lengthscale vector has {0:d} entries for {1:d} observations".format(
+                    len(scale), perts.shape[-1]))
+            sc = torch.as_tensor(scale, device=eng.device, dtype=dtype)
+            perts, obs = perts * sc, obs * sc
+        return eng.ketkf_weights(perts, obs, prog, self.inf_factor)
 
     forward = __call__
 

@@ -249,6 +249,8 @@ extern "C" int mia_comm_set_place_stream(mia_comm_t* c, void* stream) {
 extern "C" int mia_comm_destroy(mia_comm_t* c) {
   if (!c) return MIA_OK;
   for (int i = 0; i < c->n_ev; ++i) (void)hipEventDestroy(c->ev[i]);
+  if (c->n_ev)
+    for (int i = 0; i < kMaxChunks; ++i) (void)hipEventDestroy(c->evp[i]);
   if (c->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(c->nccl);
   delete c;
   return MIA_OK;

@@ -74,7 +74,8 @@ class ETKF:
         return self._engine
 
     def _kernel_args(self) -> dict:
-        gamma, prog = kernel_route(self._kernel)
+        # (a per-observation lengthscale vector is meaningful for the global solve only: kernels.GaussKernel)
+        gamma, prog = kernel_route(self._kernel, allow_feature_scale=not hasattr(self, "localization"))
         return dict(rbf_gamma=gamma, kernel_program=prog)
 
     def __str__(self):
@@ -198,6 +199,9 @@ class LETKF(ETKF):
         if self.localization is None:
             # no localisation: every grid point sees every observation with weight 1 (wrapper.py:87), i.e. the one
             # global solve repeated G times in the reference -- done once here, for any number of observations
+            if grid_coords is None and g1 is None:
+                raise ValueError("estimate_weights_arrays without localisation needs grid_coords or g1 (the number of "
+                                 "grid points the (G, k, k) weights are repeated for)")
             G = len(grid_coords) if g1 is None else g1
             W = ETKF.estimate_weights_arrays(self, yb, d)
             return W[None].expand(G - g0, -1, -1).contiguous()
@@ -233,6 +237,9 @@ class LETKF(ETKF):
             raise RuntimeError("LETKF kernel: local observation list overflow (engine bug: lists are sized from counts)")
         if bad & 4:
             warnings.warn("LETKF kernel met non-finite values in at least one local block", RuntimeWarning)
+        if bad & 2:
+            warnings.warn("LETKF eigensolver reached its sweep cap for at least one grid point (result returned)",
+                          RuntimeWarning)
         return xa.reshape(shp[:-1] + (nb.g1 - nb.g0,))
 
 

@@ -11,8 +11,8 @@ Fast routes: a plain LinearKernel is the ETKF (dual-space kernels), a plain RBFK
 own specialised kernels (incl. the eigensolver-free matfun route); everything else runs the expression route.
 
 Not mirrored: ``ModuleKernel`` (module_kernel.py) applies an arbitrary torch.nn.Module to every localised
-block -- user code that cannot run inside a HIP kernel -- and per-feature (vector) lengthscales, which index
-the local observations and so have no meaning under localisation.
+block -- user code that cannot run inside a HIP kernel.  Per-feature (vector) lengthscales of the Gauss kernel index
+the observations: accepted by the global KETKF (inputs pre-divided, see GaussKernel), refused under localisation.
 """
 from __future__ import annotations
 
@@ -122,10 +122,22 @@ class LinearKernel(BaseKernel):
 
 
 class GaussKernel(BaseKernel):
-    """K(x, y) = exp(-|x - y|^2 / (2 l^2)); scalar lengthscale only (rbf.py:41-81)."""
+    """K(x, y) = exp(-sum_j ((x_j - y_j) / l_j)^2 / 2) (rbf.py:41-81).  A scalar lengthscale works everywhere.  A
+    per-feature (vector) lengthscale -- one value per OBSERVATION, rbf.py:75-78 divides both arguments by it -- is accepted
+    by the global KETKF, where the observation axis is fixed: the engine divides Yb's columns and d by it and runs the
+    unit-lengthscale kernel (``feature_scale``).  Under localisation every grid point sees a different subset of the
+    observations, so a per-observation vector has no meaning there: LKETKF raises NotImplementedError."""
 
-    def __init__(self, lengthscale: float = 1.0):
-        self.lengthscale = _scalar(lengthscale, "lengthscale")
+    def __init__(self, lengthscale=1.0):
+        import numpy as np
+        ls = lengthscale.detach().cpu().numpy() if hasattr(lengthscale, "detach") else np.asarray(lengthscale, dtype=np.float64)
+        if ls.size == 1:
+            self.lengthscale = float(ls.reshape(-1)[0])
+            self.feature_scale = None
+        else:
+            self.lengthscale = 1.0                       # what the kernels see after the inputs were divided by the vector
+            self.feature_scale = 1.0 / ls.reshape(-1).astype(np.float64)
+            self.lengthscale_vector = ls.reshape(-1).astype(np.float64)
 
     @property
     def gamma(self) -> float:
@@ -135,7 +147,7 @@ class GaussKernel(BaseKernel):
         return [(KOP_SQDIST, 0.0), (KOP_CONST, -self.gamma), (KOP_MUL, 0.0), (KOP_EXP, 0.0)]
 
     def __str__(self):
-        return "GaussKernel(l={0})".format(self.lengthscale)
+        return "GaussKernel(l={0})".format(self.lengthscale if self.feature_scale is None else self.lengthscale_vector)
 
     def __repr__(self):
         return "GaussKernel"
@@ -296,12 +308,15 @@ def check_program(prog: Program) -> None:
         raise ValueError("malformed kernel expression")
 
 
-def kernel_route(kernel) -> Tuple[Optional[float], Optional[Program]]:
+def kernel_route(kernel, allow_feature_scale: bool = False) -> Tuple[Optional[float], Optional[Program]]:
     """(rbf_gamma, program) for a kernel object: (None, None) = ETKF route, (gamma, None) = specialised RBF
     kernels, (None, program) = kernel-expression route."""
     if kernel is None or type(kernel) is LinearKernel:
         return None, None
     if type(kernel) in (GaussKernel, RBFKernel):
+        if getattr(kernel, "feature_scale", None) is not None and not allow_feature_scale:
+            raise NotImplementedError("a per-observation (vector) lengthscale has no meaning under localisation, where every "
+                                      "grid point sees another subset of the observations; it is accepted by the global KETKF")
         return float(kernel.gamma), None
     if not isinstance(kernel, BaseKernel):
         raise NotImplementedError(

@@ -80,7 +80,7 @@ class ShardedLetkf:
     def __init__(self, device, rank: int = 0, world: int = 1, radii: Sequence[float] = (10.0,),
                  inf_factor: float = 1.0, coord_group: Optional[Sequence[int]] = None, eps: float = 1e-5,
                  rbf_gamma: Optional[float] = None, compute_shard: Optional[Callable] = None, group=None,
-                 method: str = "auto", fused_localization: bool = False, use_graph: bool = False,
+                 method: str = "auto", fused_localization: bool = False,
                  comm_chunks: int = 4, chunk_compute: Optional[Callable] = None, native_step: bool = True,
                  max_in_flight: int = 3):
         self.device, self.rank, self.world = device, rank, world
@@ -88,7 +88,6 @@ class ShardedLetkf:
         self.rbf_gamma = rbf_gamma
         self.method = method
         self.fused_localization = fused_localization
-        self.use_graph = use_graph
         self.comm_chunks = int(comm_chunks)
         self._chunk_compute = chunk_compute
         self._comm_stream = None
@@ -102,8 +101,6 @@ class ShardedLetkf:
         self._submitted = 0
         self._force_comm = False      # tests / tools: a one-rank RCCL communicator drives the exchange route
         self.native_steps = 0
-        self._graph = None
-        self.graph_replays = 0
         self.last_retries = 0
         self.group = group
         self._engine = None
@@ -138,30 +135,9 @@ class ShardedLetkf:
         # explicit neighbour lists.  After the first call on a geometry the previous maximum list length is
         # assumed, so nothing is read back before the analysis launch; the assumption is confirmed right
         # after the launch (the one host sync of the step) and the shard redone if it did not hold.
-        # The steady-state launch sequence (memset, 6 index kernels, list kernel, pack, analysis = ~11 nodes,
-        # ~0.4 ms of GPU work) is partly launch-bound from Python; with use_graph=True it is captured once
-        # into a HIP graph and replayed while the caller keeps passing the same device buffers (0.498 ->
-        # 0.457 ms per step on MI355X).  OFF by default: on this ROCm 7.2 / torch 2.10 stack the replay raised
-        # 'Memory access fault by GPU' after ~15-50 replays although every captured stage replays correctly
-        # on its own; root cause not isolated yet.
-        key = tuple((t.data_ptr(), tuple(t.shape), t.dtype) for t in (X, grid_xyz, obs_xyz, Yb, d)
-                    if torch.is_tensor(t)) + (g0, g1, self._p_max_hint, self.inf_factor)
-        if self.use_graph and self._p_max_hint is not None and all(torch.is_tensor(t) and t.is_cuda for t in
-                                                                   (X, grid_xyz, obs_xyz, Yb, d)):
-            if self._graph is None or self._graph["key"] != key:
-                self._graph = self._capture(key, X, grid_xyz, obs_xyz, Yb, d, g0, g1)
-            if self._graph is not None:
-                gr = self._graph
-                gr["graph"].replay()
-                self.graph_replays += 1
-                p_max, n_over = (int(v) for v in gr["nb"].stats.tolist())       # the host sync of the step
-                if n_over == 0 and p_max <= gr["nb"].p_max:
-                    self.last_retries = gr["finish"]()
-                    self._p_max_hint = p_max
-                    self.last_p_max, self._last_flags = p_max, gr["flags"]
-                    return gr["xa"]
-                self._graph = None          # assumption broken: fall through to the eager route
-                self._p_max_hint = None
+        # (Round 1 could replay this launch sequence from a HIP graph; the replay faulted after 15-50 replays, the cause
+        #  was never isolated, and the one-call native step driver removed the launch overhead the graph was meant to hide:
+        #  the path is gone, see DESIGN.md.)
         nb = eng.localize(grid_xyz, obs_xyz, self.radii, self.coord_group, self.eps, g0, g1,
                           assume_p_max=self._p_max_hint)
         xa, flags, finish = eng.analysis(X, Yb, d, nb, self.inf_factor, rbf_gamma=self.rbf_gamma,
@@ -176,34 +152,12 @@ class ShardedLetkf:
         self._last_flags = flags
         return xa
 
-    def _capture(self, key, X, grid_xyz, obs_xyz, Yb, d, g0, g1):
-        """Record the steady-state launch sequence of this shard into a HIP graph (None if capture fails)."""
-        eng = self.engine
-        try:
-            graph = torch.cuda.CUDAGraph()
-            side = torch.cuda.Stream(device=self.device)
-            side.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(side):
-                with torch.cuda.graph(graph, stream=side):
-                    nb = eng.localize(grid_xyz, obs_xyz, self.radii, self.coord_group, self.eps, g0, g1,
-                                      assume_p_max=self._p_max_hint)
-                    xa, flags, finish = eng.analysis(X, Yb, d, nb, self.inf_factor, rbf_gamma=self.rbf_gamma,
-                                                     return_flags=True, method=self.method, defer_retry=True)
-            torch.cuda.current_stream(self.device).wait_stream(side)
-            return dict(key=key, graph=graph, nb=nb, xa=xa, flags=flags, finish=finish,
-                        keep=(X, grid_xyz, obs_xyz, Yb, d))
-        except Exception as err:      # capture unsupported in this environment: stay eager
-            import warnings
-            warnings.warn("HIP graph capture failed (%s); using eager launches" % (err,), RuntimeWarning)
-            self.use_graph = False
-            return None
-
     def assimilate(self, X, grid_xyz, obs_xyz, Yb, d) -> torch.Tensor:
         G = X.shape[-1]
         g0, g1 = block_partition(G, self.world)[self.rank]
         if (self.native_step and self._compute == self._engine_shard and self._chunk_compute is None
                 and torch.is_tensor(X) and X.is_cuda and X.dtype == torch.float32 and X.dim() == 3
-                and not self.fused_localization and not self.use_graph):
+                and not self.fused_localization):
             return self._assimilate_native(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1)
         if self.world > 1 and self.comm_chunks > 1:
             return self._assimilate_overlapped(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1)
@@ -313,12 +267,15 @@ class ShardedLetkf:
         preparation of a later step (a chain of small latency-bound launches) runs beside the analysis kernel of
         an earlier one, and at N > 1 the all-gather of step i (the collectives keep one order on every rank)
         travels while step i+1 is computed.  A slot whose previous step was not collected
-        yet is collected first; all ranks must submit and collect in the same order."""
+        yet is collected first; all ranks must submit and collect in the same order.
+
+        The library reads X, Yb, d and the coordinates on ITS streams after this call has returned: the caller must not
+        modify those tensors (in place, on any stream) before ``result()`` of this step -- pass clones if it has to."""
         G = X.shape[-1]
         g0, g1 = block_partition(G, self.world)[self.rank]
         if not (self.native_step and self._compute == self._engine_shard and self._chunk_compute is None
                 and torch.is_tensor(X) and X.is_cuda and X.dtype == torch.float32 and X.dim() == 3
-                and not self.fused_localization and not self.use_graph):
+                and not self.fused_localization):
             return PendingStep(self, None, out=self.assimilate(X, grid_xyz, obs_xyz, Yb, d))
         return self._native_submit(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, pipelined=True)
 
@@ -471,6 +428,8 @@ class ShardedLetkf:
         if redo:
             for other in list(self._in_flight):                # steps enqueued behind this one used the same bound
                 other.result()
+            if redo == "exact":
+                self._p_max_hint = None                        # (draining may have set a hint again: exact lists now)
             p["cur"].wait_stream(p["comp"])
             p["cur"].wait_stream(p["last"])
             h._out = self._assimilate_native(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1)

@@ -160,6 +160,10 @@ def _stream_in(data: np.ndarray, dev: torch.device, dtype: torch.dtype, chunk_po
     out = torch.empty((G, k, k), dtype=dtype, device=dev)
     step = max(1, min(int(chunk_points), G))
     side = torch.cuda.Stream(device=dev)
+    # `out` comes from the caching allocator on the current stream: work enqueued there that still uses the block's
+    # previous contents must finish before the side stream writes into it
+    side.wait_stream(torch.cuda.current_stream(dev))
+    out.record_stream(side)
     bufs = [torch.empty((step, k, k), dtype=dtype, pin_memory=True) for _ in range(2)]
     evs = [None, None]
     for i, (c0, c1) in enumerate(_chunks(G, step)):
