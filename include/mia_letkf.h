@@ -435,6 +435,26 @@ int mia_comm_create_custom(int rank, int world, mia_allgather_fn allgather, mia_
 /* Optional stream for the placement of gathered pieces (NULL: the exchange stream).  Used only by steps enqueued with
  * MIA_STEP_NO_JOIN: the result and counters[4..7] of such a step are complete once THIS stream has drained. */
 int mia_comm_set_place_stream(mia_comm_t* comm, void* stream);
+/* Direct exchange (csrc/sharded_step.hip, "Direct exchange"): library-owned, peer-mapped result buffers, so that every rank
+ * writes its block of the analysis ensemble straight into all peers' (m, k, G) result over its xGMI links -- no ring, no
+ * staging, no placement copy.  No reference counterpart (the reference's only distribution is dask on one host,
+ * interface/letkf.py:118-131).
+ *   mia_comm_peer_alloc   n_slots (<= 8, one per step in flight) result buffers of result_bytes + a fine-grained flag area;
+ *                         ipc_handles_out: NULL or (n_slots + 1) x 64 bytes of hipIpcMemHandle_t to hand to the other ranks
+ *   mia_comm_peer_open    all_handles = [world][n_slots + 1][64]: every rank's table (host-side all-gather); maps the peers
+ *   mia_comm_peer_attach  the same for ranks that share an address space: the peer's buffer pointers and flag area
+ *   mia_comm_peer_buffer / _sync_area: this rank's pointers
+ *   mia_comm_peer_exchange  the exchange alone (block [rows][b0, b1) of buffer `slot`, counters int32[8] on the device)
+ * mia_letkf_sharded_step_streams_f32 takes this route by itself when Xa is mia_comm_peer_buffer(comm, slot) of a
+ * communicator whose peers are all mapped (n_chunks is then 1); every rank must pass the same slot.  Failures (IPC not
+ * available, a waiter timing out: error bit 2 of counters[3] / [7]) leave RCCL as the route. */
+int mia_comm_peer_alloc(mia_comm_t* comm, size_t result_bytes, int n_slots, void* ipc_handles_out);
+int mia_comm_peer_open(mia_comm_t* comm, const void* all_handles);
+int mia_comm_peer_attach(mia_comm_t* comm, int peer, void* const* result_bufs, void* sync_area);
+void* mia_comm_peer_buffer(mia_comm_t* comm, int slot);
+void* mia_comm_peer_sync_area(mia_comm_t* comm);
+int mia_comm_peer_exchange(mia_comm_t* comm, int slot, int rows, int64_t G, int64_t b0, int64_t b1, int32_t* counters,
+                           void* stream);
 int mia_comm_destroy(mia_comm_t* comm);
 const char* mia_comm_last_error(void);
 int mia_letkf_sharded_step_workspace_bytes(int64_t G, int m, int k, int64_t P, int n_coord, int world,

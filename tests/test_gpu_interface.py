@@ -481,3 +481,155 @@ def test_assimilate_filter_and_smoother_mode_on_the_reference_fixture(mia, golde
     with pytest.warns(UserWarning, match="is not within state"):
         ana = mia.ETKF(inf_factor=1.1, dtype=dtype).assimilate(state, obs, analysis_time=g["state_time"][0] + 60.0)
     assert rel_fro(ana.values.cpu().numpy(), g["analysis_global_1p1"]) < tol
+
+
+def _peer_rank_stub(mia, runner, rank, ref, G, n_slots=3):
+    """Rank `rank` of a 2-rank world with the direct (peer-mapped) exchange, the OTHER rank played by plain tensors: its
+    result buffers and flag area are attached with mia_comm_peer_attach, its blocks (cut from a reference analysis) and its
+    flags (free / ready at a sequence number no step reaches) are put in place beforehand, as a peer that is always ahead
+    would have.  What the step under test pushes into the stub's buffers and flag area is then inspected."""
+    import ctypes as C
+    from torch_assimilate_amd import _cabi
+    lib = _cabi.lib()
+    dev = ref.device
+    m, k = ref.shape[0], ref.shape[1]
+    peer = 1 - rank
+    cb = (_cabi.ALLGATHER_FN(lambda *a: 1), _cabi.ALLREDUCE_MAX_I32_FN(lambda *a: 1))        # never called on this route
+    handle = C.c_void_p()
+    _cabi.check(lib.mia_comm_create_custom(rank, 2, C.cast(cb[0], C.c_void_p), C.cast(cb[1], C.c_void_p), None,
+                                           C.byref(handle)), "mia_comm_create_custom")
+    _cabi.check(lib.mia_comm_peer_alloc(handle, m * k * G * 4, n_slots, None), "mia_comm_peer_alloc")
+    stub_bufs = [torch.full((m, k, G), -7.0, dtype=torch.float32, device=dev) for _ in range(n_slots)]
+    stub_sync = torch.zeros(8 * 16 * 6, dtype=torch.int32, device=dev)
+    ptrs = (C.c_void_p * n_slots)(*[b.data_ptr() for b in stub_bufs])
+    _cabi.check(lib.mia_comm_peer_attach(handle, peer, ptrs, C.c_void_p(stub_sync.data_ptr())), "mia_comm_peer_attach")
+    mine = [runner._wrap_device(lib.mia_comm_peer_buffer(handle, s), (m, k, G), dev) for s in range(n_slots)]
+    my_sync = runner._wrap_device(lib.mia_comm_peer_sync_area(handle), (8 * 16 * 6,), dev).view(torch.int32)
+    n = (G + 1) // 2
+    lo, hi = min(G, peer * n), min(G, (peer + 1) * n)
+    for s in range(n_slots):
+        mine[s].fill_(-3.0)
+        mine[s][:, :, lo:hi] = ref[:, :, lo:hi]                   # the peer's block has "arrived"
+        w0 = s * 96
+        my_sync[w0 + peer] = 1 << 20                               # ready[slot][peer]
+        my_sync[w0 + 16 + peer] = 1 << 20                          # free[slot][peer]
+        my_sync[w0 + 32 + 4 * peer:w0 + 32 + 4 * peer + 4] = 0     # the peer's counters
+    torch.cuda.synchronize()
+    return handle, cb, mine, stub_bufs, stub_sync, (lo, hi)
+
+
+@pytest.mark.parametrize("G,strong", [(2000, False), (1999, False), (1001, True)])
+@pytest.mark.parametrize("rank", [0, 1])
+def test_direct_peer_exchange_layout_and_protocol_on_one_gpu(mia, G, strong, rank):
+    """The peer-write exchange of mia_letkf_sharded_step_streams_f32 (Xa = a library-owned, peer-mapped result buffer): this
+    rank's block is analysed straight into its own (m, k, G) buffer, pushed into the peer's buffer at the same place, its
+    counters and the free / ready flags land in the peer's flag area with the step's sequence number, the redo decision is
+    folded from both ranks' counters, and a phase-1 redo (declined points) exchanges again.  Bit for bit the single-rank
+    result, serial and with three steps in flight."""
+    dev = torch.device("cuda:0")
+    case = O.synthetic_case(G, 40, 2)
+    scale = 12.0 if strong else 1.0
+    args = (torch.as_tensor(case["state"], dtype=torch.float32, device=dev), torch.as_tensor(case["grid_x"], device=dev),
+            torch.as_tensor(case["obs_x"], device=dev),
+            torch.as_tensor(case["yb"] * scale, dtype=torch.float32, device=dev),
+            torch.as_tensor(case["d"] * scale, dtype=torch.float32, device=dev))
+    plain = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1, native_step=False)
+    ref = plain.assimilate(*args)
+    runner = mia.ShardedLetkf(dev, rank, 2, radii=[10.0], inf_factor=1.1, max_in_flight=3)
+    runner._p_max_hint = plain._p_max_hint
+    handle, keep, mine, stub_bufs, stub_sync, (lo, hi) = _peer_rank_stub(mia, runner, rank, ref, G)
+    runner._native = dict(comm=handle, custom=True, stream=torch.cuda.Stream(device=dev), slots=[{}, {}, {}],
+                          peer=mine, peer_shape=tuple(ref.shape))
+    n = (G + 1) // 2
+    b0, b1 = min(G, rank * n), min(G, (rank + 1) * n)
+    try:
+        for it in range(2):
+            out = runner.assimilate(*args)                 # serial steps use slot 0
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref) and runner.last_flags_ok()
+            assert torch.equal(stub_bufs[0][:, :, b0:b1], ref[:, :, b0:b1])          # pushed into the peer's buffer ...
+            assert float(stub_bufs[0][:, :, lo:hi].max()) == -7.0                     # ... and nowhere else
+            sync = stub_sync.cpu().numpy()
+            n_exch = (it + 1) * (2 if strong else 1)                                  # a redo exchanges a second time
+            assert sync[rank] == n_exch and sync[16 + rank] == n_exch                 # ready / free carry the sequence number
+            assert sync[32 + 4 * rank] == runner.last_p_max or sync[32 + 4 * rank] <= runner.last_p_max
+        if strong:
+            assert 0 < runner.last_retries <= plain.last_retries          # (this rank's declined points)
+        pend = []
+        for _ in range(6):                                  # three steps in flight: slots 0, 1, 2 in turn
+            pend.append(runner.submit(*args))
+            if len(pend) == 3:
+                assert torch.equal(pend.pop(0).result(), ref)
+        while pend:
+            assert torch.equal(pend.pop(0).result(), ref)
+        assert runner.native_steps == 8 and runner.exchange_route.startswith("direct")
+        for s in (1, 2):
+            assert torch.equal(stub_bufs[s][:, :, b0:b1], ref[:, :, b0:b1])
+    finally:
+        from torch_assimilate_amd import _cabi
+        runner._native = None
+        _cabi.lib().mia_comm_destroy(handle)
+
+
+def _peer_ipc_worker(rank, port, G, out_path):
+    """One of two PROCESSES sharing cuda:0: real hipIpcGetMemHandle / hipIpcOpenMemHandle mapping of the other process's result
+    buffers and flag area, handle exchange over torch.distributed (gloo), the exchange self-test, then real steps of both
+    ranks running concurrently (each waits on flags the other process's kernels write)."""
+    import ctypes as C
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    import torch_assimilate_amd as mia
+    from torch_assimilate_amd import _cabi
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    case = O.synthetic_case(G, 40, 2)
+    args = (torch.as_tensor(case["state"], dtype=torch.float32, device=dev), torch.as_tensor(case["grid_x"], device=dev),
+            torch.as_tensor(case["obs_x"], device=dev), torch.as_tensor(case["yb"], dtype=torch.float32, device=dev),
+            torch.as_tensor(case["d"], dtype=torch.float32, device=dev))
+    plain = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1, native_step=False)
+    ref = plain.assimilate(*args)
+    runner = mia.ShardedLetkf(dev, rank, 2, radii=[10.0], inf_factor=1.1, max_in_flight=2, copy_results=True)
+    runner._p_max_hint = plain._p_max_hint
+    cb = (_cabi.ALLGATHER_FN(lambda *a: 1), _cabi.ALLREDUCE_MAX_I32_FN(lambda *a: 1))
+    handle = C.c_void_p()
+    _cabi.check(_cabi.lib().mia_comm_create_custom(rank, 2, C.cast(cb[0], C.c_void_p), C.cast(cb[1], C.c_void_p), None,
+                                                   C.byref(handle)), "mia_comm_create_custom")
+    st = dict(comm=handle, custom=True, stream=torch.cuda.Stream(device=dev, priority=-1), slots=[{}, {}])
+    import warnings
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        bufs = runner._peer_setup(st, 1, 40, G)
+    result = {"rank": rank, "ipc": bufs is not None, "why": [str(w.message) for w in wlist], "ok": False}
+    if bufs is not None:
+        st["peer"], st["peer_shape"] = bufs, (1, 40, G)
+        runner._native = st
+        ok = True
+        pend = []
+        for _ in range(6):                                     # two steps in flight per rank, both ranks concurrently
+            pend.append(runner.submit(*args))
+            if len(pend) == 2:
+                ok = ok and bool(torch.equal(pend.pop(0).result(), ref))
+        while pend:
+            ok = ok and bool(torch.equal(pend.pop(0).result(), ref))
+        result["ok"] = ok and runner.last_flags_ok() and runner.native_steps == 6
+    dist.barrier()
+    runner._native = None
+    _cabi.lib().mia_comm_destroy(handle)
+    import json
+    with open(out_path + ".%d" % rank, "w") as fh:
+        json.dump(result, fh)
+    dist.destroy_process_group()
+
+
+def test_direct_peer_exchange_between_two_processes_on_one_gpu(tmp_path):
+    import json, socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "peer")
+    mp.spawn(_peer_ipc_worker, args=(port, 3000, out), nprocs=2, join=True)
+    res = [json.load(open(out + ".%d" % r)) for r in (0, 1)]
+    if not all(r["ipc"] for r in res):
+        pytest.skip("device-memory IPC between processes is not available on this box: %s" % (res[0]["why"] or res[1]["why"]))
+    assert all(r["ok"] for r in res), res

@@ -89,6 +89,12 @@ _PROTOS = {
     "mia_comm_create": ([vp, i32, i32, C.POINTER(vp)], i32),
     "mia_comm_create_custom": ([i32, i32, vp, vp, vp, C.POINTER(vp)], i32),
     "mia_comm_set_place_stream": ([vp, vp], i32),
+    "mia_comm_peer_alloc": ([vp, sz, i32, vp], i32),
+    "mia_comm_peer_open": ([vp, vp], i32),
+    "mia_comm_peer_attach": ([vp, i32, C.POINTER(vp), vp], i32),
+    "mia_comm_peer_buffer": ([vp, i32], vp),
+    "mia_comm_peer_sync_area": ([vp], vp),
+    "mia_comm_peer_exchange": ([vp, i32, i32, i64, i64, i64, vp, vp], i32),
     "mia_comm_destroy": ([vp], i32),
     "mia_comm_last_error": ([], C.c_char_p),
     "mia_letkf_sharded_step_workspace_bytes": ([i64, i32, i32, i64, i32, i32, i32, i32, C.POINTER(sz)], i32),

@@ -54,6 +54,10 @@ void set_error(const char* what, int code) {
 }
 
 constexpr int kMaxChunks = 16;   // pieces per block; events: [c] piece c, [kMaxChunks-1] records packed (pieces <= 15)
+constexpr int kMaxRanks = 16, kMaxSlots = 8;     // direct exchange: ranks of one node, steps in flight
+// synchronisation area of one rank, in uint32 words: per slot [kMaxRanks] ready, [kMaxRanks] free, [kMaxRanks][4] counters
+constexpr int kSyncSlotWords = kMaxRanks * 6;
+constexpr size_t kSyncBytes = (size_t)kMaxSlots * kSyncSlotWords * sizeof(uint32_t);
 
 }  // namespace
 
@@ -67,6 +71,15 @@ struct mia_comm {
   hipEvent_t evp[kMaxChunks] = {};      // piece c gathered (exchange stream -> placement stream)
   hipStream_t place_stream = nullptr;   // optional: mia_comm_set_place_stream
   int n_ev = 0;
+  // ---- direct (peer-mapped) exchange, see "Direct exchange" below
+  int peer_slots = 0;                    // result buffers this rank owns (one per step in flight)
+  size_t peer_bytes = 0;                 // bytes of one result buffer
+  float* peer_buf[kMaxRanks][kMaxSlots] = {};   // [rank][slot]: rank's result buffers as mapped into this process
+  uint32_t* peer_sync[kMaxRanks] = {};   // [rank]: its synchronisation area (fine-grained device memory)
+  bool peer_owned = false;               // buffers of `rank` were allocated by mia_comm_peer_alloc (freed on destroy)
+  bool peer_opened[kMaxRanks] = {};      // mapped through hipIpcOpenMemHandle (closed on destroy)
+  int peer_ready = 0;                    // every rank attached
+  uint32_t peer_seq[kMaxSlots] = {};     // exchanges done per slot (the sequence number the flags carry)
 };
 
 namespace {
@@ -135,6 +148,128 @@ __global__ void __launch_bounds__(kPlaceThreads) place_chunk_kernel(const float*
   for (int v = 0; v < VEC; ++v)
     if (i + v < nc && in_block + v < n && col + v < G) dst[v] = src[v];
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Direct exchange.  The all-gather of the analysis ensemble moves world x (m k n) floats into every rank; RCCL's ring
+// forwards each block hop by hop (per-link bound, (world - 1) latencies) into a staging buffer that a placement kernel then
+// copies into the (m, k, G) result.  xGMI is point to point, so every rank can instead WRITE ITS BLOCK STRAIGHT INTO THE
+// RESULT BUFFER OF ALL PEERS, over its world - 1 links at once: the result buffers are library-owned, exported with
+// hipIpcGetMemHandle and mapped by every rank of the node.  Per step and slot, with sequence number q:
+//   submit       free[slot][me] = q in every peer's sync area: "my buffer `slot` may be overwritten for step q" (its previous
+//                result was collected, or the caller would not reuse the slot)
+//   analysis     this rank's block, written into its own result buffer (no staging)
+//   exchange stream:  wait  free[slot][p] >= q for all peers
+//                     push  block (16-byte accesses) + this rank's four redo counters -> every peer
+//                     signal ready[slot][me] = q in every peer's sync area (a kernel of its own: the push kernel's end is the
+//                            system-scope release of its stores)
+//                     wait  ready[slot][p] >= q for all peers; fold the counters (max over ranks)
+// Flags live in fine-grained device memory and are accessed with system-scope atomics; waits are bounded (error bit 1 of
+// counters[3] / [7], never a hung grid).  No collective, no staging copy, no placement kernel: 2 x block bytes of local HBM
+// traffic instead of 2 x world x block.  RCCL stays the fallback (and the route of the first, exact-list step).
+struct PeerPtrs { float* buf[kMaxRanks]; uint32_t* sync[kMaxRanks]; };
+
+__global__ void __launch_bounds__(64) peer_flag_kernel(PeerPtrs pp, int world, int word, uint32_t value) {
+  const int p = threadIdx.x;      // one lane per rank (own area included: keeps the arithmetic uniform)
+  if (p < world) __hip_atomic_store(pp.sync[p] + word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void __launch_bounds__(64) peer_wait_kernel(const uint32_t* flags /* [kMaxRanks] of this rank's area */, int world,
+                                                       int rank, uint32_t seq, int32_t* err, int max_polls,
+                                                       const int32_t* ctr_all /* [kMaxRanks][4] or null */, int32_t* counters) {
+  const int p = threadIdx.x;
+  bool ok = false;
+  for (int poll = 0; poll < max_polls; ++poll) {
+    const uint32_t v = (p < world && p != rank) ? __hip_atomic_load(flags + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) : seq;
+    ok = (int32_t)(v - seq) >= 0;
+    if (__all(ok)) break;
+    __builtin_amdgcn_s_sleep(32);
+  }
+  if (!__all(ok) && p == 0) atomicOr(err, 2);      // exit condition every wave reaches: ~seconds, then report
+  if (ctr_all && p < 4) {                             // redo decision: max over the ranks' counters (or of the error bits)
+    int mx = 0;
+    for (int q = 0; q < world; ++q) {
+      const int v = __hip_atomic_load(ctr_all + q * 4 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      mx = q == 0 ? v : (p == 3 ? (mx | v) : (v > mx ? v : mx));
+    }
+    counters[4 + p] = p == 3 ? (mx | counters[3]) : mx;
+  }
+}
+
+// block [rows][n] at column b0 of the (rows, G) result -> the same place in every peer's buffer; blockIdx.z = peer
+__global__ void __launch_bounds__(256) peer_push_kernel(PeerPtrs pp, int world, int rank, int64_t G, int64_t b0, int64_t n,
+                                                        int rows, int slot_word0, const int32_t* own_counters) {
+  int peer = blockIdx.z;
+  if (peer >= rank) ++peer;                           // (world - 1 peers)
+  const float* src = pp.buf[rank] + (size_t)blockIdx.y * G + b0;
+  float* dst = pp.buf[peer] + (size_t)blockIdx.y * G + b0;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) {      // this rank's counters: to the peer, and (once) to itself
+    const int32_t v = own_counters[threadIdx.x];
+    __hip_atomic_store(reinterpret_cast<int32_t*>(pp.sync[peer]) + slot_word0 + 2 * kMaxRanks + 4 * rank + threadIdx.x, v,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (blockIdx.z == 0)
+      __hip_atomic_store(reinterpret_cast<int32_t*>(pp.sync[rank]) + slot_word0 + 2 * kMaxRanks + 4 * rank + threadIdx.x, v,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // 16-byte accesses where source and destination rows are aligned alike (b0, G multiples of 4), scalars otherwise
+  const bool vec = ((G | b0) & 3) == 0 && ((reinterpret_cast<uintptr_t>(pp.buf[rank]) | reinterpret_cast<uintptr_t>(pp.buf[peer])) & 15) == 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (vec) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+      reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+  }
+}
+
+int peer_slot_of(const mia_comm* c, const float* Xa) {
+  if (!c || !c->peer_ready) return -1;
+  for (int s = 0; s < c->peer_slots; ++s)
+    if (c->peer_buf[c->rank][s] == Xa) return s;
+  return -1;
+}
+
+PeerPtrs peer_ptrs(const mia_comm* c, int slot) {
+  PeerPtrs pp;
+  for (int r = 0; r < kMaxRanks; ++r) {
+    pp.buf[r] = r < c->world ? c->peer_buf[r][slot] : nullptr;
+    pp.sync[r] = r < c->world ? c->peer_sync[r] : nullptr;
+  }
+  return pp;
+}
+
+// first half of an exchange: new sequence number, "my buffer of this slot may be overwritten" to every peer (stream ps)
+int peer_begin(mia_comm* c, int slot, hipStream_t ps, uint32_t* seq_out) {
+  const uint32_t seq = ++c->peer_seq[slot];
+  peer_flag_kernel<<<1, 64, 0, ps>>>(peer_ptrs(c, slot), c->world, slot * kSyncSlotWords + kMaxRanks + c->rank, seq);
+  MIA_LAUNCH_CHECK();
+  *seq_out = seq;
+  return MIA_OK;
+}
+
+// second half, on the exchange stream cs (the caller has ordered it behind the block's producer): wait for the peers'
+// buffers, push block [rows][b0, b1) and the four counters, signal, wait for the peers' blocks, fold the counters
+int peer_finish(mia_comm* c, int slot, uint32_t seq, int64_t G, int64_t b0, int64_t b1, int rows, int32_t* counters,
+                hipStream_t cs) {
+  const int world = c->world, rank = c->rank, sw0 = slot * kSyncSlotWords;
+  const PeerPtrs pp = peer_ptrs(c, slot);
+  const uint32_t* my = c->peer_sync[rank] + sw0;
+  peer_wait_kernel<<<1, 64, 0, cs>>>(my + kMaxRanks, world, rank, seq, counters + 3, 1 << 21, nullptr, nullptr);
+  MIA_LAUNCH_CHECK();
+  const int64_t nb = b1 > b0 ? b1 - b0 : 0;
+  unsigned gx = (unsigned)((nb / 4 + 255) / 256);
+  gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+  peer_push_kernel<<<dim3(gx, (unsigned)(nb ? rows : 1), (unsigned)(world - 1)), 256, 0, cs>>>(pp, world, rank, G, nb ? b0 : 0, nb,
+                                                                                          rows, sw0, counters);
+  MIA_LAUNCH_CHECK();
+  peer_flag_kernel<<<1, 64, 0, cs>>>(pp, world, sw0 + rank, seq);
+  MIA_LAUNCH_CHECK();
+  peer_wait_kernel<<<1, 64, 0, cs>>>(my, world, rank, seq, counters + 3, 1 << 21,
+                                     reinterpret_cast<const int32_t*>(my + 2 * kMaxRanks), counters);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
 }
 
 struct StepLayout {
@@ -246,8 +381,108 @@ extern "C" int mia_comm_set_place_stream(mia_comm_t* c, void* stream) {
   return MIA_OK;
 }
 
+// ---- direct exchange: buffers, handles, attachment (protocol: see "Direct exchange" above)
+extern "C" int mia_comm_peer_alloc(mia_comm_t* c, size_t result_bytes, int n_slots, void* ipc_handles_out) {
+  if (!c) return MIA_ERR_NULL;
+  if (n_slots < 1 || n_slots > kMaxSlots || result_bytes == 0 || c->world > kMaxRanks) return MIA_ERR_SIZE;
+  if (c->peer_slots) return MIA_ERR_UNSUPPORTED;          // one allocation per communicator
+  (void)hipGetLastError();
+  hipIpcMemHandle_t* hs = reinterpret_cast<hipIpcMemHandle_t*>(ipc_handles_out);
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle table of mia_comm_peer_alloc / _open is 64 bytes per entry");
+  for (int s = 0; s < n_slots; ++s) {
+    void* b = nullptr;
+    if (hipMalloc(&b, mia::align_up(result_bytes, 256)) != hipSuccess) { set_error("hipMalloc of a result buffer failed", 0); (void)hipGetLastError(); return MIA_ERR_COMM; }
+    c->peer_buf[c->rank][s] = (float*)b;
+    c->peer_slots = s + 1;
+    c->peer_owned = true;
+    if (hs && hipIpcGetMemHandle(&hs[s], b) != hipSuccess) { set_error("hipIpcGetMemHandle(result buffer) failed", 0); (void)hipGetLastError(); return MIA_ERR_COMM; }
+  }
+  void* sy = nullptr;
+  if (hipExtMallocWithFlags(&sy, kSyncBytes, hipDeviceMallocFinegrained) != hipSuccess) { set_error("fine-grained allocation of the sync area failed", 0); (void)hipGetLastError(); return MIA_ERR_COMM; }
+  c->peer_sync[c->rank] = (uint32_t*)sy;
+  if (hipMemset(sy, 0, kSyncBytes) != hipSuccess) { (void)hipGetLastError(); return MIA_ERR_COMM; }
+  if (hs && hipIpcGetMemHandle(&hs[n_slots], sy) != hipSuccess) { set_error("hipIpcGetMemHandle(sync area) failed", 0); (void)hipGetLastError(); return MIA_ERR_COMM; }
+  c->peer_bytes = result_bytes;
+  if (c->world == 1) c->peer_ready = 1;
+  return MIA_OK;
+}
+
+static void peer_check_ready(mia_comm* c) {
+  int ok = c->peer_slots > 0;
+  for (int r = 0; r < c->world && ok; ++r) {
+    ok = c->peer_sync[r] != nullptr;
+    for (int s = 0; s < c->peer_slots && ok; ++s) ok = c->peer_buf[r][s] != nullptr;
+  }
+  c->peer_ready = ok;
+}
+
+// all_handles: [world][n_slots + 1] handles as every rank's mia_comm_peer_alloc filled them (any all-gather of the host's)
+extern "C" int mia_comm_peer_open(mia_comm_t* c, const void* all_handles) {
+  if (!c || !all_handles) return MIA_ERR_NULL;
+  if (!c->peer_slots) return MIA_ERR_SIZE;
+  (void)hipGetLastError();
+  const hipIpcMemHandle_t* hs = reinterpret_cast<const hipIpcMemHandle_t*>(all_handles);
+  const int per = c->peer_slots + 1;
+  for (int r = 0; r < c->world; ++r) {
+    if (r == c->rank) continue;
+    for (int s = 0; s < per; ++s) {
+      void* ptr = nullptr;
+      if (hipIpcOpenMemHandle(&ptr, hs[(size_t)r * per + s], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+        set_error("hipIpcOpenMemHandle failed", r);
+        (void)hipGetLastError();
+        return MIA_ERR_COMM;
+      }
+      if (s < c->peer_slots) c->peer_buf[r][s] = (float*)ptr; else c->peer_sync[r] = (uint32_t*)ptr;
+    }
+    c->peer_opened[r] = true;
+  }
+  peer_check_ready(c);
+  return c->peer_ready ? MIA_OK : MIA_ERR_COMM;
+}
+
+// in-process attachment of a peer's buffers (ranks that share an address space: tests, one process driving several GPUs)
+extern "C" int mia_comm_peer_attach(mia_comm_t* c, int peer, void* const* result_bufs, void* sync_area) {
+  if (!c || !result_bufs || !sync_area) return MIA_ERR_NULL;
+  if (peer < 0 || peer >= c->world || peer == c->rank || !c->peer_slots) return MIA_ERR_SIZE;
+  for (int s = 0; s < c->peer_slots; ++s) c->peer_buf[peer][s] = (float*)result_bufs[s];
+  c->peer_sync[peer] = (uint32_t*)sync_area;
+  peer_check_ready(c);
+  return MIA_OK;
+}
+
+extern "C" void* mia_comm_peer_buffer(mia_comm_t* c, int slot) {
+  return (c && slot >= 0 && slot < c->peer_slots) ? (void*)c->peer_buf[c->rank][slot] : nullptr;
+}
+extern "C" void* mia_comm_peer_sync_area(mia_comm_t* c) { return c ? (void*)c->peer_sync[c->rank] : nullptr; }
+
+// The exchange alone: block [rows][b0, b1) of result buffer `slot` (already written by work enqueued on `stream`) goes to
+// every peer; when `stream` has passed this call, the peers' blocks have landed in this rank's buffer and counters[4..7]
+// hold the maximum over the ranks of everybody's counters[0..3] (device int32[8]).  All ranks call it in the same order.
+extern "C" int mia_comm_peer_exchange(mia_comm_t* c, int slot, int rows, int64_t G, int64_t b0, int64_t b1, int32_t* counters,
+                                      void* stream) {
+  if (!c || !counters) return MIA_ERR_NULL;
+  if (!c->peer_ready || slot < 0 || slot >= c->peer_slots || rows < 1 || G < 1 || b0 < 0 || b1 > G) return MIA_ERR_SIZE;
+  if ((size_t)rows * G * sizeof(float) > c->peer_bytes) return MIA_ERR_SIZE;
+  if (c->world == 1) return MIA_OK;
+  (void)hipGetLastError();
+  uint32_t seq = 0;
+  int rc = peer_begin(c, slot, (hipStream_t)stream, &seq);
+  if (rc != MIA_OK) return rc;
+  return peer_finish(c, slot, seq, G, b0, b1, rows, counters, (hipStream_t)stream);
+}
+
 extern "C" int mia_comm_destroy(mia_comm_t* c) {
   if (!c) return MIA_OK;
+  for (int r = 0; r < c->world && r < kMaxRanks; ++r) {
+    if (r == c->rank || !c->peer_opened[r]) continue;
+    for (int s = 0; s < c->peer_slots; ++s) if (c->peer_buf[r][s]) (void)hipIpcCloseMemHandle(c->peer_buf[r][s]);
+    if (c->peer_sync[r]) (void)hipIpcCloseMemHandle(c->peer_sync[r]);
+  }
+  if (c->peer_owned) {
+    for (int s = 0; s < c->peer_slots; ++s) if (c->peer_buf[c->rank][s]) (void)hipFree(c->peer_buf[c->rank][s]);
+    if (c->peer_sync[c->rank]) (void)hipFree(c->peer_sync[c->rank]);
+  }
+  (void)hipGetLastError();
   for (int i = 0; i < c->n_ev; ++i) (void)hipEventDestroy(c->ev[i]);
   if (c->n_ev)
     for (int i = 0; i < kMaxChunks; ++i) (void)hipEventDestroy(c->evp[i]);
@@ -326,12 +561,17 @@ extern "C" int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int
   if (!comm) n_chunks = 1;
   // exchange route: any real multi-rank world; a one-rank communicator takes it only when chunking is asked
   // for (lets a single-GPU box drive the RCCL calls and the chunk pipeline)
-  const bool exch = comm && (world > 1 || n_chunks > 1);
+  // direct exchange: Xa is one of the communicator's peer-mapped result buffers (every rank passes the same slot)
+  const int peer_slot = (comm && world > 1) ? peer_slot_of(comm, Xa) : -1;
+  const bool peer = peer_slot >= 0;
+  if (peer) n_chunks = 1;
+  const bool exch = comm && !peer && (world > 1 || n_chunks > 1);
   StepLayout L;
   int rc = step_layout(G, m, k, P, n_coord, world, n_chunks, p_max_assumed, &L);
   if (rc != MIA_OK) return rc;
   if (ws_bytes < L.total) return MIA_ERR_WORKSPACE;
-  if (exch && !comm_stream) return MIA_ERR_NULL;
+  if ((exch || peer) && !comm_stream) return MIA_ERR_NULL;
+  if (peer && (size_t)m * k * G * sizeof(float) > comm->peer_bytes) return MIA_ERR_SIZE;
   hipStream_t s = (hipStream_t)stream, cs = (hipStream_t)comm_stream;
   hipStream_t ps = prep_stream ? (hipStream_t)prep_stream : s;      // records, index, lists
   // MIA_SEGMENT_SIGNAL=0: one launch + one event per piece instead of the segmented launch (fallback / A-B runs)
@@ -351,8 +591,13 @@ extern "C" int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int
   int32_t* ctr = exch ? (int32_t*)(base + L.bufs + L.chunk_bytes * (n_chunks - 1) + (size_t)rows * L.nc * sizeof(float))
                       : counters;
   (void)hipGetLastError();
-  if (exch) {
+  if (exch || peer) {
     rc = comm_events(comm);
+    if (rc != MIA_OK) return rc;
+  }
+  uint32_t seq = 0;
+  if (peer) {      // "my buffer of this slot may be overwritten": told to every peer before anything else of the step
+    rc = peer_begin(comm, peer_slot, ps, &seq);
     if (rc != MIA_OK) return rc;
   }
 
@@ -468,10 +713,16 @@ extern "C" int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int
     }
   }
 
+  if (peer) {      // block analysed (stream s) -> exchange stream: wait, push, signal, wait (see "Direct exchange")
+    MIA_HIP_TRY(hipEventRecord(comm->ev[0], s));
+    MIA_HIP_TRY(hipStreamWaitEvent(cs, comm->ev[0], 0));
+    rc = peer_finish(comm, peer_slot, seq, G, b0, b1, rows, counters, cs);
+    if (rc != MIA_OK) return rc;
+  }
   if (phase == 0 && t_time_stop) MIA_HIP_TRY(hipEventRecord(t_time_stop, s));
   t_time_start = t_time_stop = nullptr;
   // (without the exchange route counters[4..7] stay zero: the rank's own [0..3] are the whole story)
-  if (exch && !(step_flags & MIA_STEP_NO_JOIN)) {   // the caller's stream continues after the exchange
+  if ((exch || peer) && !(step_flags & MIA_STEP_NO_JOIN)) {   // the caller's stream continues after the exchange
     MIA_HIP_TRY(hipEventRecord(comm->ev[kMaxChunks + 1], cs));
     MIA_HIP_TRY(hipStreamWaitEvent(s, comm->ev[kMaxChunks + 1], 0));
   }

@@ -75,14 +75,92 @@ class ShardedLetkf:
 
     @property
     def exchange_route(self):
+        if self._native is not None and self._native.get("peer"):
+            return "direct peer writes into IPC-mapped result buffers"
         return "RCCL all-gather + placement kernel"
+
+    # ------------------------------------------------------------------ direct exchange (peer-mapped result buffers)
+    @staticmethod
+    def _wrap_device(ptr: int, shape, device) -> torch.Tensor:
+        """float32 tensor over library-owned device memory (no copy, no ownership)."""
+        class _Ext:
+            pass
+        e = _Ext()
+        e.__cuda_array_interface__ = dict(shape=tuple(shape), typestr="<f4", data=(int(ptr), False), version=3, strides=None)
+        return torch.as_tensor(e, device=device)
+
+    def _peer_setup(self, st, m: int, k: int, G: int):
+        """Collective (every rank, same step): allocate the slot result buffers, exchange their IPC handles through
+        torch.distributed, map the peers, and run a pattern self-test of the exchange on every slot.  Any failure on any
+        rank leaves every rank on the RCCL route.  Returns the per-slot result tensors or None."""
+        import ctypes as C
+        import warnings
+        import torch.distributed as dist
+        from . import _cabi
+        lib, comm, dev = self.engine.lib, st["comm"], self.device
+        n_slots = len(st["slots"])
+        nbytes = m * k * G * 4
+        handles = C.create_string_buffer(64 * (n_slots + 1))
+
+        def agree(ok):
+            # (a CPU tensor under gloo, which the two-processes-on-one-GPU test uses for the rendezvous)
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if dist.get_backend(self.group) == "gloo" else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            return bool(t.item())
+
+        with torch.cuda.device(dev):
+            ok = lib.mia_comm_peer_alloc(comm, nbytes, n_slots, handles) == 0
+        why = "buffer allocation / hipIpcGetMemHandle"
+        if agree(ok):
+            tables = [None] * self.world
+            dist.all_gather_object(tables, handles.raw, group=self.group)
+            with torch.cuda.device(dev):
+                ok = lib.mia_comm_peer_open(comm, C.create_string_buffer(b"".join(tables), 64 * (n_slots + 1) * self.world)) == 0
+            why = "hipIpcOpenMemHandle"
+            if agree(ok):
+                bufs = [self._wrap_device(lib.mia_comm_peer_buffer(comm, s), (m, k, G), dev) for s in range(n_slots)]
+                ok = self._peer_selftest(st, bufs, m * k, G)
+                why = "exchange self-test"
+                if agree(ok):
+                    return bufs
+        warnings.warn("direct peer exchange unavailable (%s failed on some rank: %s); using the RCCL all-gather"
+                      % (why, lib.mia_comm_last_error().decode()), RuntimeWarning)
+        return None
+
+    def _peer_selftest(self, st, bufs, rows: int, G: int) -> bool:
+        """Every rank writes a rank-specific pattern into its block of every slot buffer, runs the bare exchange and checks
+        that all blocks of all ranks arrived (mapping, protocol, visibility -- before any analysis depends on them)."""
+        import ctypes as C
+        from .engine import _ptr
+        lib, comm = self.engine.lib, st["comm"]
+        parts = block_partition(G, self.world)
+        g0, g1 = parts[self.rank]
+        col = torch.arange(G, device=self.device, dtype=torch.float32)
+        ctr = torch.zeros(8, dtype=torch.int32, device=self.device)
+        ok = True
+        for s, buf in enumerate(bufs):
+            flat = buf.view(rows, G)
+            flat.fill_(-1.0)
+            pat = lambda r, a, b: (r + 1) * 4096.0 + (col[a:b] % 61.0)[None] + (torch.arange(rows, device=self.device) % 64)[:, None] * 64.0
+            flat[:, g0:g1] = pat(self.rank, g0, g1)
+            torch.cuda.synchronize(self.device)
+            ctr.zero_()
+            ctr[0] = 100 + self.rank
+            rc = lib.mia_comm_peer_exchange(comm, s, rows, G, g0, g1, _ptr(ctr), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+            torch.cuda.synchronize(self.device)
+            want = torch.empty_like(flat)
+            for r, (a, b) in enumerate(parts):
+                want[:, a:b] = pat(r, a, b)
+            c = ctr.tolist()
+            ok = ok and rc == 0 and bool(torch.equal(flat, want)) and c[4] == 100 + self.world - 1 and c[7] == 0
+        return ok
 
     def __init__(self, device, rank: int = 0, world: int = 1, radii: Sequence[float] = (10.0,),
                  inf_factor: float = 1.0, coord_group: Optional[Sequence[int]] = None, eps: float = 1e-5,
                  rbf_gamma: Optional[float] = None, compute_shard: Optional[Callable] = None, group=None,
                  method: str = "auto", fused_localization: bool = False,
                  comm_chunks: int = 4, chunk_compute: Optional[Callable] = None, native_step: bool = True,
-                 max_in_flight: int = 3):
+                 max_in_flight: int = 3, peer_exchange: str = "auto", copy_results: bool = True):
         self.device, self.rank, self.world = device, rank, world
         self.radii, self.inf_factor, self.coord_group, self.eps = list(radii), inf_factor, coord_group, eps
         self.rbf_gamma = rbf_gamma
@@ -97,7 +175,13 @@ class ShardedLetkf:
         self._in_flight = []
         self._time_next = False        # time_next_step(): the next native step brackets its analysis kernel with events
         self.kernel_timings = []       # [(start, stop)] torch events recorded on the analysis stream by the library
-        self.max_in_flight = max(1, int(max_in_flight))
+        self.max_in_flight = max(1, min(int(max_in_flight), 8))
+        # exchange of the analysis blocks at world > 1: "auto" = direct peer writes into library-owned, IPC-mapped result
+        # buffers when the node allows it and a self-test of the mapping passes, RCCL all-gather otherwise; "off" = RCCL.
+        # With the direct route a result lives in its pipeline slot's buffer: copy_results (default) hands out a copy,
+        # False the buffer itself, valid until max_in_flight further steps have been submitted.
+        self.peer_exchange = peer_exchange
+        self.copy_results = copy_results
         self._submitted = 0
         self._force_comm = False      # tests / tools: a one-rank RCCL communicator drives the exchange route
         self.native_steps = 0
@@ -313,9 +397,14 @@ class ShardedLetkf:
         if Yb.shape != (k, P) or d.shape[0] != P or grid.shape[0] != G:
             raise ValueError("inconsistent shapes: X (m,k,G), Yb (k,P), d (P,), grid (G,nc), obs (P,nc)")
         hint = int(self._p_max_hint)
-        C_chunks = self.comm_chunks if st["comm"] is not None else 1
+        if (st["comm"] is not None and self.world > 1 and "peer" not in st and not st.get("custom")):
+            st["peer"] = self._peer_setup(st, m, k, G) if self.peer_exchange != "off" else None
+            st["peer_shape"] = (m, k, G)
+        peer = st.get("peer") if st.get("peer_shape") == (m, k, G) else None
+        C_chunks = 1 if peer else (self.comm_chunks if st["comm"] is not None else 1)
         key = (G, m, k, P, nc, hint, C_chunks)
-        slot = st["slots"][self._submitted % len(st["slots"]) if pipelined else 0]
+        slot_idx = self._submitted % len(st["slots"]) if pipelined else 0
+        slot = st["slots"][slot_idx]
         if slot.get("busy") is not None:                          # its previous step was never collected
             slot["busy"].result()
         if slot.get("key") != key:
@@ -330,7 +419,8 @@ class ShardedLetkf:
             slot["counters"] = torch.zeros(8, dtype=torch.int32, device=X.device)
             slot["host"] = torch.zeros(8, dtype=torch.int32).pin_memory()
             slot["key"] = key
-        out = torch.empty((m, k, G), dtype=torch.float32, device=X.device)
+        # direct exchange: the result IS the slot's peer-mapped buffer (every rank uses the same slot for the same step)
+        out = peer[slot_idx] if peer else torch.empty((m, k, G), dtype=torch.float32, device=X.device)
         flags = torch.empty(max(g1 - g0, 1), dtype=torch.int32, device=X.device)
         method = {"auto": 0, "eig": 1, "matfun": 2}[self.method]
         gamma = float(self.rbf_gamma) if self.rbf_gamma is not None else 0.0
@@ -349,7 +439,7 @@ class ShardedLetkf:
             comp, prep = st["astream"], st["pstream"]
             prep.wait_stream(cur)                                 # inputs (and `out`'s memory) are ready
             # where the step's last work is enqueued: the placement stream when there is one, else the exchange stream
-            last = (st.get("xstream") or st["stream"]) if exch else comp
+            last = ((st["stream"] if peer else (st.get("xstream") or st["stream"])) if exch else comp)
         else:
             comp, prep, last = cur, None, cur
 
@@ -386,7 +476,7 @@ class ShardedLetkf:
                 ev = torch.cuda.Event()
                 ev.record(last)
         h = PendingStep(self, dict(slot=slot, call=call, comp=comp, cur=cur, ev=ev, out=out, flags=flags, hint=hint,
-                                   last=last,
+                                   last=last, peer=bool(peer),
                                    C_chunks=C_chunks, args=(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1),
                                    keep=(X, grid, obs, Yb, d)))
         slot["busy"] = h
@@ -412,6 +502,8 @@ class ShardedLetkf:
             cnt[4:8] = cnt[0:4]                                # no exchange route: the rank's own counters
         p_seen, n_over, n_retry = cnt[4], cnt[5], cnt[6]
         redo = None
+        if cnt[7] & 2:
+            raise _cabi.MiaError("direct exchange: a peer did not deliver within the waiter's bound (error bits %d)" % cnt[7])
         if cnt[7]:
             # a segment waiter gave up (the analysis launch and the exchange stream must be able to run
             # concurrently: e.g. more HIP streams than hardware queues): all ranks switch to one launch + one
@@ -454,7 +546,7 @@ class ShardedLetkf:
         self._p_max_hint = p_seen if self.world > 1 else max(p_seen, 0)
         self.last_p_max = p["hint"]
         self._last_flags = p["flags"][:g1 - g0]
-        h._out, h._st = p["out"], None
+        h._out, h._st = (p["out"].clone() if p.get("peer") and self.copy_results else p["out"]), None
         return h._out
 
     # ------------------------------------------------------------------ compute / exchange overlap
