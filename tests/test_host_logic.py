@@ -122,7 +122,8 @@ def test_kernel_programs_reproduce_the_reference_kernels(golden):
     with pytest.raises(NotImplementedError):
         K.kernel_route(torch.nn.Linear(2, 2))          # ModuleKernel-style user code is not mirrored
     with pytest.raises(NotImplementedError):
-        K.GaussKernel(torch.ones(3))                    # per-feature lengthscale
+        K.kernel_route(K.GaussKernel(torch.ones(3)))    # per-observation lengthscales: global KETKF only ...
+    assert K.kernel_route(K.GaussKernel(torch.ones(3)), allow_feature_scale=True) == (0.5, None)
     with pytest.raises(TypeError):
         K.PolyKernel() + 3.0
     deep = K.ScaleKernel(1.0)
