@@ -15,7 +15,8 @@ for f in glob.glob(d + "/pmc*/**/*counter_collection.csv", recursive=True):
             vals[name].append(v)
 c = {k: sum(v) / len(v) for k, v in vals.items()}
 G = 100000
-out = {"kernel": kern, "workload": "C2: 1e5 grid points, k=40, <=20 local obs, m=1 (tools/prof_kernel.py --reps 3)",
+workload = sys.argv[3] if len(sys.argv) > 3 else "C2: 1e5 grid points, k=40, <=20 local obs, m=1 (tools/prof_kernel.py --reps 3)"
+out = {"kernel": kern, "workload": workload,
        "command": "rocprofv3 --pmc <set> --output-format csv -- python3 tools/prof_kernel.py (one pass per counter set; "
                   "FETCH_SIZE and WRITE_SIZE in their own passes)",
        "counters_per_launch": c, "derived": {}}
