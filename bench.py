@@ -484,7 +484,7 @@ def main():
                    "rel_frobenius_error_64_points_vs_oracle": float(np.linalg.norm(got - ref) / np.linalg.norm(ref)),
                    "reference_algorithm_credit_TFLOPs": algorithmic_flops(k2, pm2, 1) * gpg / (ms2 * 1e-3) / 1e12}
             if gamma2 is None and deg2:
-                kk = "tile" if (k2 <= 64 and pm2 + 8 <= 64) else "point"
+                kk = "tile" if (k2 <= 96 and pm2 + 8 <= 96) else "point"
                 exf = executed_flops(k2, pm2, 1, deg2, kk)
                 rec.update(executed_flops_per_analysis=exf, executed_frac=exf * gpg / (ms2 * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
                            kernel="letkf_tile_kernel" if kk == "tile" else "letkf_cheb_kernel (one grid point per wavefront)")

@@ -31,14 +31,16 @@ def run(eng, case, nb, inf=1.1, **kw):
 
 
 @pytest.mark.parametrize("k,stride,c,m", [(40, 2, 10.0, 1), (40, 2, 10.0, 3), (10, 1, 1.6, 1), (24, 2, 6.5, 2), (64, 2, 12.0, 1),
-                                          (40, 1, 10.0, 1), (64, 1, 13.0, 2), (20, 3, 12.0, 1), (33, 2, 3.0, 5)])
+                                          (40, 1, 10.0, 1), (64, 1, 13.0, 2), (20, 3, 12.0, 1), (33, 2, 3.0, 5),
+                                          (80, 1, 16.5, 1), (96, 1, 20.0, 2), (72, 1, 12.0, 1)])
 def test_tile_kernel_vs_oracle_and_per_point_kernel(eng, monkeypatch, k, stride, c, m):
-    """Union tiles of 1 .. 4 sixteen-row blocks (p_max 4 .. 52), 1 .. 4 member blocks, ragged last tile (G = 203),
+    """Union tiles of 1 .. 6 sixteen-row blocks (p_max 4 .. 80, incl. config 4's k = 80 with 64 local observations), 1 .. 6
+    member blocks, ragged last tile (G = 203),
     several state rows.  Against the oracle (north-star tolerance, also on the increments) and against the per-point
     kernel on the same lists (option tile = 0): same mathematics, different summation order."""
     case = O.synthetic_case(203, k, stride, seed=k + m, m=m)
     nb = eng.localize(case["grid_x"], case["obs_x"], [c])
-    assert nb.p_max <= min(k, 56)
+    assert nb.p_max <= min(k, 88)
     for inf in (1.0, 1.1):
         xa, fl = run(eng, case, nb, inf)
         assert int((fl & 0xff).max()) == 0 and int(((fl >> 8) & 0xff).min()) >= 3

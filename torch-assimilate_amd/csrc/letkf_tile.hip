@@ -27,8 +27,8 @@
 // always summed in ascending index order with exact zeros in between, whatever else is in the tile: results do not
 // depend on tile composition, shard boundaries or launch geometry, bit for bit.
 //
-// A tile whose union exceeds the 16 UT slots the instantiation has is processed in halves (quarters, ...) -- one point
-// always fits (p_max <= 16 UT is checked on the host); degree cap / non-finite / overflow / retry protocol are those
+// A tile whose union exceeds the 16 UT slots the instantiation has (UT <= 6: 96 slots) is processed in halves (quarters, ...)
+// -- one point always fits (p_max <= 16 UT is checked on the host); degree cap / non-finite / overflow / retry protocol are those
 // of letkf_cheb.hip (MIA_FLAG_RETRY points are redone by the eigensolver kernel).
 #include "mia_common.h"
 #include "mia_kernels.h"
@@ -106,11 +106,12 @@ __device__ long long g_tile_stamps[kStampTiles * kStampN];
 #endif
 
 template <int UT, int KT, bool SEG>
-__global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 1))) void letkf_tile_kernel(TileParams P) {
+__global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 1)))   /* UT >= 4: one wavefront per SIMD, up to 512 registers */ void letkf_tile_kernel(TileParams P) {
   constexpr int UMAX = 16 * UT, NU = 4 * UT;
   constexpr int LOGHS = UT <= 1 ? 6 : (UT <= 2 ? 7 : 8), HS = 1 << LOGHS, HR = HS / 64;
   constexpr int DS = UMAX + 4;
-  constexpr int CL = (16 * DS + 2 * HS + UMAX + 128) / 32;   // degrees whose coefficients fit the union scratch (31 at UT = 2)
+  constexpr int CLraw = (16 * DS + 2 * HS + UMAX + 2 * (UMAX > 64 ? UMAX : 64)) / 32;
+  constexpr int CL = CLraw > kTabDeg ? kTabDeg : CLraw;      // degrees whose coefficients fit the union scratch (31 at UT = 2)
   constexpr int CQ = (CL + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane0 = threadIdx.x;
@@ -120,8 +121,9 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
   int* H = reinterpret_cast<int*>(Dl + 16 * DS);             // [HS]       hash table of observation indices / index bitmap
   int* Hs = H + HS;                                          // [HS]       slot of a table position
   int* ukey = Hs + HS;                                       // [UMAX]     observation index of a slot, -1 = unused
-  int* comp = ukey + UMAX;                                   // [64]       compacted keys
-  int* cpos = comp + 64;                                     // [64]       their table positions
+  constexpr int UC = UMAX > 64 ? UMAX : 64;
+  int* comp = ukey + UMAX;                                   // [UC]       compacted keys
+  int* cpos = comp + UC;                                     // [UC]       their table positions
   float2* Cl = reinterpret_cast<float2*>(Dl);                // [CL][16]   scaled Chebyshev coefficients (reuses Dl .. cpos)
 
   // XCD-aware block -> tile map: blocks b, b + 8, ... share an XCD (and its L2) and take consecutive tiles, whose
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
     for (;;) {
       hi = lo + n < npts ? lo + n : npts;
       const bool act = lp >= lo && lp < hi;
-      if (lane < UMAX) ukey[lane] = -1;
+      for (int i = lane; i < UMAX; i += 64) ukey[i] = -1;
       unsigned mx1 = 0u, mninv = 0u;             // range of the observation indices (wave-uniform after the reductions)
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
@@ -324,13 +326,13 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
         for (int r = 0; r < HR; ++r)
           if (myci[r] >= 0) { comp[myci[r]] = mykey[r]; cpos[myci[r]] = lane * HR + r; }
         MIA_TILE_SYNC();
-        if (lane < U) {
-          const int key = comp[lane];
+        for (int i = lane; i < U; i += 64) {
+          const int key = comp[i];
           int rk = 0;
           for (int j = 0; j < U; ++j) rk += comp[j] < key ? 1 : 0;
           const int slot = 16 * (rk >> 4) + 4 * (rk & 3) + ((rk >> 2) & 3);
           ukey[slot] = key;
-          Hs[cpos[lane]] = slot;
+          Hs[cpos[i]] = slot;
         }
         MIA_TILE_SYNC();
 #pragma unroll
@@ -632,7 +634,8 @@ extern "C" int mia_debug_tile_stamps(long long* host, int n_tiles) {
 
 static size_t tile_lds_bytes(int ut, int kp) {
   const int umax = 16 * ut, hs = ut <= 1 ? 64 : (ut <= 2 ? 128 : 256);
-  return align_up(((size_t)umax * kp + 16 + 16 * (size_t)(umax + 4)) * sizeof(float) + ((size_t)2 * hs + umax + 128) * sizeof(int), 16);
+  return align_up(((size_t)umax * kp + 16 + 16 * (size_t)(umax + 4)) * sizeof(float) +
+                  ((size_t)2 * hs + umax + 2 * (size_t)(umax > 64 ? umax : 64)) * sizeof(int), 16);
 }
 
 template <int UT, int KT, bool SEG>
@@ -650,9 +653,19 @@ static int tile_launch_s(const TileParams& tp, hipStream_t stream) {
   return MIA_OK;
 }
 
+// Instantiations: UT <= KT + 1 (the dual route has p <= k, so a union of p + slack slots never needs more row blocks than
+// that); the segmented variant (step driver with several pieces) up to UT = 4.
 template <int UT, int KT>
 static int tile_launch_t(const TileParams& tp, hipStream_t stream) {
-  return tp.seg_len > 0 ? tile_launch_s<UT, KT, true>(tp, stream) : tile_launch_s<UT, KT, false>(tp, stream);
+  if constexpr (UT <= KT + 1) {
+    if (tp.seg_len > 0) {
+      if constexpr (UT <= 4 && KT <= 4) return tile_launch_s<UT, KT, true>(tp, stream);
+      else return MIA_ERR_UNSUPPORTED;
+    }
+    return tile_launch_s<UT, KT, false>(tp, stream);
+  } else {
+    return MIA_ERR_UNSUPPORTED;
+  }
 }
 
 template <int UT>
@@ -662,6 +675,8 @@ static int tile_launch_u(const TileParams& tp, int kt, hipStream_t stream) {
     case 2: return tile_launch_t<UT, 2>(tp, stream);
     case 3: return tile_launch_t<UT, 3>(tp, stream);
     case 4: return tile_launch_t<UT, 4>(tp, stream);
+    case 5: return tile_launch_t<UT, 5>(tp, stream);
+    case 6: return tile_launch_t<UT, 6>(tp, stream);
   }
   return MIA_ERR_UNSUPPORTED;
 }
@@ -671,7 +686,7 @@ static int tile_launch_u(const TileParams& tp, int kt, hipStream_t stream) {
 constexpr int kTileSlack = 8;
 
 bool tile_route_covers(int m, int k, int p_max) {
-  return m < 8 && k >= 2 && k <= 64 && p_max <= k && p_max + kTileSlack <= 64;
+  return m < 8 && k >= 2 && k <= 96 && p_max <= k && p_max + kTileSlack <= 96;
 }
 
 int tile_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
@@ -709,6 +724,8 @@ int tile_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
     case 2: return tile_launch_u<2>(tp, kt, stream);
     case 3: return tile_launch_u<3>(tp, kt, stream);
     case 4: return tile_launch_u<4>(tp, kt, stream);
+    case 5: return tile_launch_u<5>(tp, kt, stream);
+    case 6: return tile_launch_u<6>(tp, kt, stream);
   }
   return MIA_ERR_UNSUPPORTED;
 }
