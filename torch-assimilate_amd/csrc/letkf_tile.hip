@@ -162,24 +162,29 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
   //      Count and entries are requested before anything is waited for.  The entries are loop-carried: loaded here for
   //      the first pass and, at the bottom of the loop, for the next one (only a split tile has one) -- dead in between.
   const int nl = pm < P.p_cap ? pm : P.p_cap;
-  const int nu = (nl + 3) >> 2;                  // entries a lane can hold a valid one in (wave-uniform): 5 of 8 at config 2
   int eidx[NU];
-  float ew[NU];
+  double ewd[NU];        // weights as loaded (float64 lists); converted where they are used -- a conversion next to its load
+                         // would wait for that load before the next one is requested
   auto load_lists = [&](int64_t pt0, int lp, int sub) {
     const unsigned rowb = (unsigned)(lp < npts ? lp : 0) * (unsigned)P.p_cap;
     const int32_t* ib = P.idx + pt0 * P.p_cap;
-    const char* wb = reinterpret_cast<const char*>(P.w) + pt0 * P.p_cap * (P.w_f32 ? 4 : 8);
+    const double* wb = reinterpret_cast<const double*>(P.w) + pt0 * P.p_cap;
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      eidx[u] = -1; ew[u] = 0.0f;
-      if (u < nu) {                          // (unconditional loads inside the row's storage; masked when consumed)
-        const int pos = sub + 4 * u;
-        const unsigned e = rowb + (unsigned)(pos < nl ? pos : 0);
-        eidx[u] = ld_off<int32_t>(ib, e * 4u);
-        ew[u] = P.w_f32 ? ld_off<float>(wb, e * 4u) : float(ld_off<double>(wb, e * 8u));
-      }
+    for (int u = 0; u < NU; ++u) {           // unconditional loads inside the row's storage (no branch, no predicate to keep);
+      const int pos = sub + 4 * u;           // masked by mask_lists
+      const unsigned e = rowb + (unsigned)(pos < nl ? pos : 0);
+      eidx[u] = ld_off<int32_t>(ib, e * 4u);
+      ewd[u] = ld_off<double>(wb, e * 8u);
     }
   };
+  // entries beyond the point's count (and those of points that are not analysed) become index -1: the ONE validity test of
+  // everything that follows
+  auto mask_lists = [&](int sub, int cnt_) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      if (sub + 4 * u >= cnt_) eidx[u] = -1;
+  };
+  auto entry_weight = [&](int u) -> float { return float(ewd[u]); };
   int lcnt;
   unsigned long long badmask;
   {
@@ -197,6 +202,7 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
     }
     if (lp >= npts || pbad) lcnt = 0;
     badmask = __ballot(pbad);
+    mask_lists(sub, lcnt);
   }
 
   int lo = 0;
@@ -246,12 +252,10 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         es[u] = -1;
-        if (u < nu) {
-          const bool v = act && sub + 4 * u < lcnt;
-          const unsigned key = (unsigned)eidx[u];
-          mx1 = (v && key + 1u > mx1) ? key + 1u : mx1;
-          mninv = (v && ~key > mninv) ? ~key : mninv;
-        }
+        const bool v = act && eidx[u] >= 0;
+        const unsigned key = (unsigned)eidx[u];
+        mx1 = (v && key + 1u > mx1) ? key + 1u : mx1;
+        mninv = (v && ~key > mninv) ? ~key : mninv;
       }
       mx1 = tile_wave_max_u32(mx1);
       mninv = tile_wave_max_u32(mninv);
@@ -267,18 +271,20 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
         MIA_TILE_SYNC();
 #pragma unroll
         for (int u = 0; u < NU; ++u)
-          if (u < nu && act && sub + 4 * u < lcnt) {
+          if (act && eidx[u] >= 0) {
             const unsigned off = (unsigned)(eidx[u] - ibase);
             atomicOr(reinterpret_cast<unsigned*>(H) + (off >> 5), 1u << (off & 31u));
           }
         MIA_TILE_SYNC();
         const unsigned long long m0 = bm[0], m1 = bm[1], m2 = bm[2], m3 = bm[3];
         const int c0 = __popcll(m0), c1 = c0 + __popcll(m1), c2 = c1 + __popcll(m2);
-        U = c2 + __popcll(m3);
+        // (the count is the same in every lane but comes from vector registers: as a scalar, the "step beyond the union"
+        //  tests of the products below are s_cmp / s_cbranch instead of eight 64-bit lane masks kept in scalar registers)
+        U = __builtin_amdgcn_readfirstlane(c2 + __popcll(m3));
         if (U > UMAX) { n >>= 1; continue; }      // (n = 1 always fits: a single list has at most UMAX entries)
 #pragma unroll
         for (int u = 0; u < NU; ++u)
-          if (u < nu && act && sub + 4 * u < lcnt) {
+          if (act && eidx[u] >= 0) {
             const unsigned off = (unsigned)(eidx[u] - ibase), wsel = off >> 6;
             const unsigned long long mw = wsel == 0 ? m0 : (wsel == 1 ? m1 : (wsel == 2 ? m2 : m3));
             const int pre = wsel == 0 ? 0 : (wsel == 1 ? c0 : (wsel == 2 ? c1 : c2));
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
           epos[u] = 0;
-          if (u < nu && act && sub + 4 * u < lcnt) {
+          if (act && eidx[u] >= 0) {
             unsigned hh = ((unsigned)eidx[u] * 2654435761u) >> (32 - LOGHS);
             int it = 0;
 #pragma clang loop unroll(disable)
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
           myci[r] = occ ? tot + __popcll(mask & lt_mask) : -1;
           tot += __popcll(mask);
         }
-        U = __any(full) ? (1 << 20) : tot;
+        U = __builtin_amdgcn_readfirstlane(__any(full) ? (1 << 20) : tot);
         if (U > UMAX) { n >>= 1; continue; }
 #pragma unroll
         for (int r = 0; r < HR; ++r)
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
         MIA_TILE_SYNC();
 #pragma unroll
         for (int u = 0; u < NU; ++u)
-          if (u < nu && act && sub + 4 * u < lcnt) es[u] = Hs[epos[u]];
+          if (act && eidx[u] >= 0) es[u] = Hs[epos[u]];
       }
       MIA_STAMP(2);
       // ---- the union's records, unscaled (the sqrt(rho) factors differ per point: they live in D)
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
     MIA_TILE_SYNC();
 #pragma unroll
     for (int u = 0; u < NU; ++u)
-      if (es[u] >= 0) Dl[lp * DS + es[u]] = ew[u];
+      if (es[u] >= 0) Dl[lp * DS + es[u]] = entry_weight(u);
     MIA_TILE_SYNC();
     const bool colact = colok && lr >= lo && lr < hi;
     f4t dreg[UT];
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
     }
     lo = hi;
     MIA_TILE_SYNC();
-    if (lo < npts) load_lists(p0v, lp, sub);       // a split tile: the entries of the next pass
+    if (lo < npts) { load_lists(p0v, lp, sub); mask_lists(sub, lcnt); }       // a split tile: the entries of the next pass
   }
   if constexpr (SEG) {
     // all output stores of this wavefront have been acknowledged before it counts its points
@@ -695,7 +701,7 @@ int tile_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
                          int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c, hipStream_t stream,
                          int seg_len, int64_t seg_stride, int32_t* done) {
   if (seg_len > 0 && (!done || ng >= (int64_t)1 << 31)) return MIA_ERR_UNSUPPORTED;
-  if (!tile_route_covers(m, k, p_max) || !flags || !retry_count || !tab_hdr || !tab_c) return MIA_ERR_UNSUPPORTED;
+  if (!tile_route_covers(m, k, p_max) || !flags || !retry_count || !tab_hdr || !tab_c || w_f32) return MIA_ERR_UNSUPPORTED;
   // every global access is base + 32-bit byte offset: the largest offsets are a column of one state row block (k ld
   // floats), the record array, one tile's list rows
   if ((int64_t)k * ldx * 4 >= ((int64_t)1 << 31) || (int64_t)k * ldo * 4 >= ((int64_t)1 << 31) ||

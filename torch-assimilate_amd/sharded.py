@@ -432,11 +432,14 @@ class ShardedLetkf:
             # of small launches that runs beside an earlier step's analysis; the priority gives it a hardware queue
             # of its own -- same-priority HIP streams share a small pool of queues and then serialise -- and lets its
             # workgroups in first when the bulk kernel's drain), ONE analysis stream (two analysis kernels sharing
-            # the CUs are slower than one after the other), the exchange stream
+            # the CUs are slower than one after the other: re-measured with the tile kernel, 7.9e8 -> 7.5e8 /s), the exchange stream
             if st.get("astream") is None:
                 st["astream"] = torch.cuda.Stream(device=X.device)
-                st["pstream"] = torch.cuda.Stream(device=X.device, priority=-1)
-            comp, prep = st["astream"], st["pstream"]
+                # TWO preparation streams taken in turn: with the sixteen-point analysis kernel (~75 us) the chain of small,
+                # latency-bound index / list launches of ONE stream (~100 us per step) had become what bounds the pipeline
+                # (0.127 -> 0.107 ms per step at depth 4; a third stream gains nothing)
+                st["pstreams"] = [torch.cuda.Stream(device=X.device, priority=-1) for _ in range(2)]
+            comp, prep = st["astream"], st["pstreams"][self._submitted % len(st["pstreams"])]
             prep.wait_stream(cur)                                 # inputs (and `out`'s memory) are ready
             # where the step's last work is enqueued: the placement stream when there is one, else the exchange stream
             last = ((st["stream"] if peer else (st.get("xstream") or st["stream"])) if exch else comp)
