@@ -434,6 +434,29 @@ int mia_comm_create_custom(int rank, int world, mia_allgather_fn allgather, mia_
                            void* ctx, mia_comm_t** comm);
 /* Optional stream for the placement of gathered pieces (NULL: the exchange stream).  Used only by steps enqueued with
  * MIA_STEP_NO_JOIN: the result and counters[4..7] of such a step are complete once THIS stream has drained. */
+/* Host-overhead helpers of a pipelined step loop (no reference counterpart): copy a step's eight counters to pinned host
+ * memory on `on_stream` once `after_stream` has passed its current point and record *done_event there (created on first
+ * use when *done_event is NULL; owned by the caller afterwards: mia_event_destroy); wait for such an event on the host or
+ * make a stream wait for it.  One call each where a Python host would need five torch calls per step. */
+/* Launch thread: the step call (+ its read-back) executed by one worker thread of the library, in submission order, so
+ * that the ~65 us of HIP runtime calls a step needs overlap the caller's own per-step work.  mia_letkf_step_submit takes
+ * the arguments of mia_letkf_sharded_step_streams_f32 followed by those of mia_letkf_step_readback (host8 NULL: no
+ * read-back) and optional timing events (mia_letkf_step_timing_events), and returns a job; mia_letkf_step_join waits until
+ * that job's launches are enqueued and returns the step call's status; mia_letkf_step_drain waits for the thread to run
+ * dry (call it before a synchronous step call that must not overtake queued ones). */
+int mia_letkf_step_submit(const float* X, int64_t G, int m, int k, const float* Yb, const float* d, int64_t P,
+                          const double* grid_xyz, const double* obs_xyz, int n_coord, const int32_t* coord_group,
+                          const double* gc_c, int n_r, double gc_eps, float inf_factor, float gamma, int method,
+                          int p_max_assumed, mia_comm_t* comm, int n_chunks, int phase, float* Xa, int32_t* flags,
+                          int32_t* counters, void* ws, size_t ws_bytes, void* stream, void* comm_stream, void* prep_stream,
+                          int step_flags, int32_t* host8, void* after_stream, void* on_stream, void** done_event,
+                          void* time_start_event, void* time_stop_event, void** job_out);
+int mia_letkf_step_join(void* job);
+int mia_letkf_step_drain(void);
+int mia_letkf_step_readback(const int32_t* counters, int32_t* host8, void* after_stream, void* on_stream, void** done_event);
+int mia_event_synchronize(void* event);
+int mia_stream_wait_event(void* stream, void* event);
+int mia_event_destroy(void* event);
 int mia_comm_set_place_stream(mia_comm_t* comm, void* stream);
 /* Direct exchange (csrc/sharded_step.hip, "Direct exchange"): library-owned, peer-mapped result buffers, so that every rank
  * writes its block of the analysis ensemble straight into all peers' (m, k, G) result over its xGMI links -- no ring, no

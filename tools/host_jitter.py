@@ -11,7 +11,7 @@ dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
 G = 100000
 X, gx, ox, Yb, d = bench.make_case(G, bench.K_ENS, bench.OBS_STRIDE, dev)
-r = ShardedLetkf(dev, 0, 1, radii=[bench.GC_RADIUS], inf_factor=bench.INF, method="auto", comm_chunks=1, native_step=True, max_in_flight=3)
+r = ShardedLetkf(dev, 0, 1, radii=[bench.GC_RADIUS], inf_factor=bench.INF, method="auto", comm_chunks=1, native_step=True, max_in_flight=4)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 timing = len(sys.argv) > 2 and sys.argv[2] == "events"
 for rep in range(3):
@@ -25,7 +25,7 @@ for rep in range(3):
         t0 = time.perf_counter()
         pend.append(r.submit(X, gx, ox, Yb, d))
         t1 = time.perf_counter()
-        if len(pend) == 3:
+        if len(pend) == 4:
             pend.popleft().result()
         t2 = time.perf_counter()
         ts.append(t1 - t0); tr.append(t2 - t1)

@@ -89,6 +89,15 @@ _PROTOS = {
     "mia_comm_create": ([vp, i32, i32, C.POINTER(vp)], i32),
     "mia_comm_create_custom": ([i32, i32, vp, vp, vp, C.POINTER(vp)], i32),
     "mia_comm_set_place_stream": ([vp, vp], i32),
+    "mia_letkf_step_submit": ([vp, i64, i32, i32, vp, vp, i64, vp, vp, i32, C.POINTER(C.c_int32), C.POINTER(f64), i32, f64,
+                               f32, f32, i32, i32, vp, i32, i32, vp, vp, vp, vp, sz, vp, vp, vp, i32,
+                               vp, vp, vp, C.POINTER(vp), vp, vp, C.POINTER(vp)], i32),
+    "mia_letkf_step_join": ([vp], i32),
+    "mia_letkf_step_drain": ([], i32),
+    "mia_letkf_step_readback": ([vp, vp, vp, vp, C.POINTER(vp)], i32),
+    "mia_event_synchronize": ([vp], i32),
+    "mia_stream_wait_event": ([vp, vp], i32),
+    "mia_event_destroy": ([vp], i32),
     "mia_comm_peer_alloc": ([vp, sz, i32, vp], i32),
     "mia_comm_peer_open": ([vp, vp], i32),
     "mia_comm_peer_attach": ([vp, i32, C.POINTER(vp), vp], i32),

@@ -13,7 +13,10 @@
 // HIP runtime.
 #include <dlfcn.h>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
+#include <thread>
 #include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -310,6 +313,8 @@ int step_layout(int64_t G, int m, int k, int64_t P, int n_coord, int world, int 
 
 }  // namespace
 
+static int prep_event_fwd(hipEvent_t* ev);      // (ring of ordering events, defined with the step driver below)
+
 extern "C" const char* mia_comm_last_error(void) { return g_comm_error; }
 
 extern "C" int mia_comm_load(const char* rccl_path) {
@@ -491,6 +496,45 @@ extern "C" int mia_comm_destroy(mia_comm_t* c) {
   return MIA_OK;
 }
 
+// Host-overhead helpers of the pipelined step loop (one ctypes call each instead of five torch calls): the eight counters
+// of a step are copied to pinned host memory on `on_stream` once `after_stream` has passed its current point, and an event
+// the library owns (created on first use, reused by the caller for the same slot) marks the copy's completion.
+extern "C" int mia_letkf_step_readback(const int32_t* counters, int32_t* host8, void* after_stream, void* on_stream,
+                                       void** done_event) {
+  if (!counters || !host8 || !done_event) return MIA_ERR_NULL;
+  (void)hipGetLastError();
+  hipStream_t a = (hipStream_t)after_stream, o = (hipStream_t)on_stream;
+  hipEvent_t ev = (hipEvent_t)*done_event;
+  if (!ev) {
+    MIA_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    *done_event = (void*)ev;
+  }
+  if (a != o) {
+    hipEvent_t pe;
+    int rc = prep_event_fwd(&pe);
+    if (rc != MIA_OK) return rc;
+    MIA_HIP_TRY(hipEventRecord(pe, a));
+    MIA_HIP_TRY(hipStreamWaitEvent(o, pe, 0));
+  }
+  MIA_HIP_TRY(hipMemcpyAsync(host8, counters, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, o));
+  MIA_HIP_TRY(hipEventRecord(ev, o));
+  return MIA_OK;
+}
+extern "C" int mia_event_synchronize(void* event) {
+  if (!event) return MIA_ERR_NULL;
+  MIA_HIP_TRY(hipEventSynchronize((hipEvent_t)event));
+  return MIA_OK;
+}
+extern "C" int mia_stream_wait_event(void* stream, void* event) {
+  if (!event) return MIA_ERR_NULL;
+  MIA_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+  return MIA_OK;
+}
+extern "C" int mia_event_destroy(void* event) {
+  if (event) (void)hipEventDestroy((hipEvent_t)event);
+  return MIA_OK;
+}
+
 extern "C" int mia_letkf_sharded_step_workspace_bytes(int64_t G, int m, int k, int64_t P, int n_coord, int world,
                                                       int n_chunks, int p_max_assumed, size_t* bytes) {
   if (!bytes) return MIA_ERR_NULL;
@@ -537,6 +581,8 @@ int prep_event(hipEvent_t* ev) {
 }
 }  // namespace
 
+static int prep_event_fwd(hipEvent_t* ev) { return prep_event(ev); }
+
 extern "C" int mia_letkf_step_timing_events(void* start_event, void* stop_event) {
   if ((start_event == nullptr) != (stop_event == nullptr)) return MIA_ERR_NULL;
   t_time_start = (hipEvent_t)start_event;
@@ -544,15 +590,16 @@ extern "C" int mia_letkf_step_timing_events(void* start_event, void* stop_event)
   return MIA_OK;
 }
 
-extern "C" int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int m, int k,
-                                                  const float* Yb, const float* d, int64_t P,
-                                                  const double* grid_xyz, const double* obs_xyz, int n_coord,
-                                                  const int32_t* coord_group, const double* gc_c, int n_r, double gc_eps,
-                                                  float inf_factor, float gamma, int method, int p_max_assumed,
-                                                  mia_comm_t* comm, int n_chunks, int phase,
-                                                  float* Xa, int32_t* flags, int32_t* counters,
-                                                  void* ws, size_t ws_bytes, void* stream, void* comm_stream,
-                                                  void* prep_stream, int step_flags) {
+// stage 0: the whole step.  The launch threads split it: stage 1 = what goes to the preparation stream (free flags of the
+// direct exchange, records, index, lists) up to the event that orders the analysis behind it (*pe_io, *seq_io out);
+// stage 2 = everything from that wait on (analysis, exchange), with *pe_io / *seq_io as stage 1 left them.
+static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, const float* d, int64_t P,
+                     const double* grid_xyz, const double* obs_xyz, int n_coord, const int32_t* coord_group,
+                     const double* gc_c, int n_r, double gc_eps, float inf_factor, float gamma, int method, int p_max_assumed,
+                     mia_comm_t* comm, int n_chunks, int phase, float* Xa, int32_t* flags, int32_t* counters, void* ws,
+                     size_t ws_bytes, void* stream, void* comm_stream, void* prep_stream, int step_flags, int stage,
+                     hipEvent_t* pe_io, uint32_t* seq_io, hipEvent_t t_start, hipEvent_t t_stop) {
+  const bool do1 = stage != 2, do2 = stage != 1;
   if (!X || !Xa || !flags || !counters || !ws || !grid_xyz || !coord_group || !gc_c) return MIA_ERR_NULL;
   if (P > 0 && (!Yb || !d || !obs_xyz)) return MIA_ERR_NULL;
   if (method < 0 || method > 2 || (phase != 0 && phase != 1)) return MIA_ERR_SIZE;
@@ -595,10 +642,11 @@ extern "C" int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int
     rc = comm_events(comm);
     if (rc != MIA_OK) return rc;
   }
-  uint32_t seq = 0;
-  if (peer) {      // "my buffer of this slot may be overwritten": told to every peer before anything else of the step
+  uint32_t seq = *seq_io;
+  if (peer && do1) {      // "my buffer of this slot may be overwritten": told to every peer before anything else of the step
     rc = peer_begin(comm, peer_slot, ps, &seq);
     if (rc != MIA_OK) return rc;
+    *seq_io = seq;
   }
 
   bool segmented = false;
@@ -608,6 +656,7 @@ extern "C" int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int
     // (every fill launch of its own costs ~5-8 us of the ~100 us this phase takes)
     const bool zero_in_kernel = P > 0 && b1 > b0;
     const size_t done_ints = (size_t)n_chunks * 64 * mia::kSlotStride;
+    if (do1) {
     if (!zero_in_kernel) {
       MIA_HIP_TRY(hipMemsetAsync(counters, 0, 8 * sizeof(int32_t), ps));
       if (exch) {
@@ -626,17 +675,17 @@ extern "C" int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int
       if (rc != MIA_OK) return rc;
     }
     if (ps != s) {   // the analysis stream starts once the preparation stream has produced records and lists
-      hipEvent_t pe;
-      rc = prep_event(&pe);
+      rc = prep_event(pe_io);
       if (rc != MIA_OK) return rc;
-      MIA_HIP_TRY(hipEventRecord(pe, ps));
-      MIA_HIP_TRY(hipStreamWaitEvent(s, pe, 0));
+      MIA_HIP_TRY(hipEventRecord(*pe_io, ps));
     }
-    if (exch) {   // the side stream starts once the lists exist (and the slots it polls have been cleared)
-      MIA_HIP_TRY(hipEventRecord(comm->ev[kMaxChunks], ps));
-      MIA_HIP_TRY(hipStreamWaitEvent(cs, comm->ev[kMaxChunks], 0));
-    }
-    if (t_time_start) MIA_HIP_TRY(hipEventRecord(t_time_start, s));   // (after the wait for the lists: kernel time only)
+    if (exch) MIA_HIP_TRY(hipEventRecord(comm->ev[kMaxChunks], ps));
+    }   // do1
+    if (!do2) return MIA_OK;
+    if (ps != s) MIA_HIP_TRY(hipStreamWaitEvent(s, *pe_io, 0));
+    // the side stream starts once the lists exist (and the slots it polls have been cleared)
+    if (exch) MIA_HIP_TRY(hipStreamWaitEvent(cs, comm->ev[kMaxChunks], 0));
+    if (t_start) MIA_HIP_TRY(hipEventRecord(t_start, s));   // (after the wait for the lists: kernel time only)
     // one launch over the whole block whose segments are exchanged as they complete (no kernel boundary, no
     // event between the pieces: a 1e5-point block in 4 launches costs 292 us instead of 245 us on MI355X)
     if (exch && n_chunks > 1 && !eig_only && b1 > b0 && signal_mode) {
@@ -647,6 +696,7 @@ extern "C" int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int
       else if (rc != MIA_ERR_UNSUPPORTED) return rc;
     }
   }
+  if (!do2) return MIA_OK;
 
   for (int c = 0; c < n_chunks; ++c) {
     const int64_t c0 = b0 + c * L.nc < b1 ? b0 + c * L.nc : b1;
@@ -719,12 +769,176 @@ extern "C" int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int
     rc = peer_finish(comm, peer_slot, seq, G, b0, b1, rows, counters, cs);
     if (rc != MIA_OK) return rc;
   }
-  if (phase == 0 && t_time_stop) MIA_HIP_TRY(hipEventRecord(t_time_stop, s));
-  t_time_start = t_time_stop = nullptr;
+  if (phase == 0 && t_stop) MIA_HIP_TRY(hipEventRecord(t_stop, s));
   // (without the exchange route counters[4..7] stay zero: the rank's own [0..3] are the whole story)
   if ((exch || peer) && !(step_flags & MIA_STEP_NO_JOIN)) {   // the caller's stream continues after the exchange
     MIA_HIP_TRY(hipEventRecord(comm->ev[kMaxChunks + 1], cs));
     MIA_HIP_TRY(hipStreamWaitEvent(s, comm->ev[kMaxChunks + 1], 0));
   }
+  return MIA_OK;
+}
+
+extern "C" int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int m, int k,
+                                                  const float* Yb, const float* d, int64_t P,
+                                                  const double* grid_xyz, const double* obs_xyz, int n_coord,
+                                                  const int32_t* coord_group, const double* gc_c, int n_r, double gc_eps,
+                                                  float inf_factor, float gamma, int method, int p_max_assumed,
+                                                  mia_comm_t* comm, int n_chunks, int phase,
+                                                  float* Xa, int32_t* flags, int32_t* counters,
+                                                  void* ws, size_t ws_bytes, void* stream, void* comm_stream,
+                                                  void* prep_stream, int step_flags) {
+  hipEvent_t pe = nullptr;
+  uint32_t seq = 0;
+  const hipEvent_t t0 = t_time_start, t1 = t_time_stop;
+  t_time_start = t_time_stop = nullptr;
+  return step_impl(X, G, m, k, Yb, d, P, grid_xyz, obs_xyz, n_coord, coord_group, gc_c, n_r, gc_eps, inf_factor, gamma, method,
+                   p_max_assumed, comm, n_chunks, phase, Xa, flags, counters, ws, ws_bytes, stream, comm_stream, prep_stream,
+                   step_flags, 0, &pe, &seq, t0, t1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Launch threads.  One step is ~9 kernel launches, a copy and half a dozen event operations: ~100 us of HIP runtime calls
+// on the calling thread -- more than a step's GPU time since the sixteen-point kernel (host-bound pipeline: 0.104 ms per
+// step with the GPU ~75 % busy, whichever thread made the calls).  mia_letkf_step_submit hands the step to TWO worker threads
+// of the library (no throughput gain measured at N = 1, where the analysis stream is the bound; the caller's submit() drops
+// from 80 to 24 us): thread A enqueues what goes to the preparation stream (stage 1 of step_impl), thread B what follows
+// (analysis, exchange, read-back), each in submission order -- every stream sees its work in step order, every rank enqueues
+// its exchanges in the same order -- so that the host time per step is the larger half, not the sum, and overlaps the
+// caller's own per-step work.  mia_letkf_step_join waits until the job's launches are enqueued (not until the GPU has run
+// them: that is what the read-back event is for).
+namespace {
+struct StepJob {
+  const float* X; int64_t G; int m, k; const float* Yb; const float* d; int64_t P; const double* grid; const double* obs;
+  int n_coord; int32_t cg[MIA_MAX_COORD]; double rc_[MIA_MAX_RADII]; int n_r; double eps; float inf, gamma; int method, hint;
+  mia_comm_t* comm; int n_chunks, phase; float* Xa; int32_t* flags; int32_t* counters; void* ws; size_t ws_bytes;
+  void *stream, *comm_stream, *prep_stream; int step_flags;
+  int32_t* host8; void *after, *on; void** done_event; void *t0, *t1;
+  hipEvent_t pe = nullptr; uint32_t seq = 0;
+  int device = 0;
+  int rc = 0;
+  bool done = false;
+  int run(int stage) {
+    return step_impl(X, G, m, k, Yb, d, P, grid, obs, n_coord, cg, rc_, n_r, eps, inf, gamma, method, hint, comm, n_chunks, phase,
+                     Xa, flags, counters, ws, ws_bytes, stream, comm_stream, prep_stream, step_flags, stage, &pe, &seq,
+                     (hipEvent_t)t0, (hipEvent_t)t1);
+  }
+};
+struct LaunchThreads {
+  std::thread ta, tb;
+  std::mutex mu;
+  std::condition_variable cv_a, cv_b, cv_done;
+  std::deque<StepJob*> qa, qb;
+  int device = 0;
+  bool stop = false, started = false;
+  int busy = 0;          // jobs handed in and not yet finished by thread B
+  void run_a() {
+    int cur_a = device;
+    (void)hipSetDevice(device);
+    for (;;) {
+      StepJob* j;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_a.wait(lk, [&] { return stop || !qa.empty(); });
+        if (qa.empty()) return;
+        j = qa.front();
+        qa.pop_front();
+      }
+      if (j->device != cur_a) { (void)hipSetDevice(j->device); cur_a = j->device; }
+      const int rc = j->run(1);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        j->rc = rc;
+        qb.push_back(j);
+      }
+      cv_b.notify_one();
+    }
+  }
+  void run_b() {
+    int cur_b = device;
+    (void)hipSetDevice(device);
+    for (;;) {
+      StepJob* j;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_b.wait(lk, [&] { return stop || !qb.empty(); });
+        if (qb.empty()) return;
+        j = qb.front();
+        qb.pop_front();
+      }
+      if (j->device != cur_b) { (void)hipSetDevice(j->device); cur_b = j->device; }
+      int rc = j->rc;
+      if (rc == MIA_OK) rc = j->run(2);
+      if (rc == MIA_OK && j->host8) rc = mia_letkf_step_readback(j->counters, j->host8, j->after, j->on, j->done_event);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        j->rc = rc;
+        j->done = true;
+        --busy;
+      }
+      cv_done.notify_all();
+    }
+  }
+  ~LaunchThreads() {
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    cv_a.notify_all();
+    cv_b.notify_all();
+    if (ta.joinable()) ta.join();
+    if (tb.joinable()) tb.join();
+  }
+};
+LaunchThreads g_launcher;
+}  // namespace
+
+extern "C" int mia_letkf_step_submit(const float* X, int64_t G, int m, int k, const float* Yb, const float* d, int64_t P,
+                                     const double* grid_xyz, const double* obs_xyz, int n_coord, const int32_t* coord_group,
+                                     const double* gc_c, int n_r, double gc_eps, float inf_factor, float gamma, int method,
+                                     int p_max_assumed, mia_comm_t* comm, int n_chunks, int phase, float* Xa, int32_t* flags,
+                                     int32_t* counters, void* ws, size_t ws_bytes, void* stream, void* comm_stream,
+                                     void* prep_stream, int step_flags, int32_t* host8, void* after_stream, void* on_stream,
+                                     void** done_event, void* time_start_event, void* time_stop_event, void** job_out) {
+  if (!job_out || !coord_group || !gc_c) return MIA_ERR_NULL;
+  if (n_coord < 1 || n_coord > MIA_MAX_COORD || n_r < 1 || n_r > MIA_MAX_RADII) return MIA_ERR_SIZE;
+  StepJob* j = new StepJob();
+  j->X = X; j->G = G; j->m = m; j->k = k; j->Yb = Yb; j->d = d; j->P = P; j->grid = grid_xyz; j->obs = obs_xyz;
+  j->n_coord = n_coord; j->n_r = n_r; j->eps = gc_eps; j->inf = inf_factor; j->gamma = gamma; j->method = method;
+  for (int c = 0; c < n_coord; ++c) j->cg[c] = coord_group[c];
+  for (int r = 0; r < n_r; ++r) j->rc_[r] = gc_c[r];
+  j->hint = p_max_assumed; j->comm = comm; j->n_chunks = n_chunks; j->phase = phase; j->Xa = Xa; j->flags = flags;
+  j->counters = counters; j->ws = ws; j->ws_bytes = ws_bytes; j->stream = stream; j->comm_stream = comm_stream;
+  j->prep_stream = prep_stream; j->step_flags = step_flags; j->host8 = host8; j->after = after_stream; j->on = on_stream;
+  j->done_event = done_event; j->t0 = time_start_event; j->t1 = time_stop_event;
+  if (hipGetDevice(&j->device) != hipSuccess) { (void)hipGetLastError(); delete j; return MIA_ERR_UNSUPPORTED; }
+  {
+    std::lock_guard<std::mutex> lk(g_launcher.mu);
+    if (!g_launcher.started) {
+      g_launcher.device = j->device;
+      g_launcher.started = true;
+      g_launcher.ta = std::thread([] { g_launcher.run_a(); });
+      g_launcher.tb = std::thread([] { g_launcher.run_b(); });
+    }
+    g_launcher.qa.push_back(j);
+    ++g_launcher.busy;
+  }
+  g_launcher.cv_a.notify_one();
+  *job_out = j;
+  return MIA_OK;
+}
+
+// waits until the job's launches are enqueued; returns the step call's status and frees the job
+extern "C" int mia_letkf_step_join(void* job) {
+  if (!job) return MIA_ERR_NULL;
+  StepJob* j = (StepJob*)job;
+  std::unique_lock<std::mutex> lk(g_launcher.mu);
+  g_launcher.cv_done.wait(lk, [&] { return j->done; });
+  const int rc = j->rc;
+  lk.unlock();
+  delete j;
+  return rc;
+}
+
+// waits until nothing is queued or running on the launch thread (before a synchronous call that must not overtake it)
+extern "C" int mia_letkf_step_drain(void) {
+  std::unique_lock<std::mutex> lk(g_launcher.mu);
+  g_launcher.cv_done.wait(lk, [&] { return g_launcher.busy == 0; });
   return MIA_OK;
 }

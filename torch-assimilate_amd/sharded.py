@@ -382,18 +382,25 @@ class ShardedLetkf:
             return PendingStep(self, None, out=self.assimilate(X, grid_xyz, obs_xyz, Yb, d))
         st = self._native_state()
         lib = eng.lib
-        X = X.contiguous()
+        # (tensors that already are what the library reads -- device, dtype, contiguous: the steady state of a cycled run --
+        #  pass through untouched: the conversions below cost ~15 us of host time per step when they are no-ops)
+        def ready(t, dtype):
+            return torch.is_tensor(t) and t.dtype is dtype and t.device == X.device and t.is_contiguous()
+        if not X.is_contiguous():
+            X = X.contiguous()
         m, k = X.shape[0], X.shape[1]
-        grid = eng._dev(grid_xyz, torch.float64)
-        obs = eng._dev(obs_xyz, torch.float64)
+        grid = grid_xyz if ready(grid_xyz, torch.float64) else eng._dev(grid_xyz, torch.float64)
+        obs = obs_xyz if ready(obs_xyz, torch.float64) else eng._dev(obs_xyz, torch.float64)
         if grid.dim() == 1:
             grid = grid[:, None]
         if obs.dim() == 1:
             obs = obs[:, None]
         nc = grid.shape[1]
         P = obs.shape[0]
-        Yb = Yb.to(device=X.device, dtype=torch.float32).contiguous()
-        d = d.to(device=X.device, dtype=torch.float32).contiguous().reshape(-1)
+        if not ready(Yb, torch.float32):
+            Yb = Yb.to(device=X.device, dtype=torch.float32).contiguous()
+        if not (ready(d, torch.float32) and d.dim() == 1):
+            d = d.to(device=X.device, dtype=torch.float32).contiguous().reshape(-1)
         if Yb.shape != (k, P) or d.shape[0] != P or grid.shape[0] != G:
             raise ValueError("inconsistent shapes: X (m,k,G), Yb (k,P), d (P,), grid (G,nc), obs (P,nc)")
         hint = int(self._p_max_hint)
@@ -418,10 +425,12 @@ class ShardedLetkf:
             slot["rc"] = (C.c_double * len(self.radii))(*[float(r) for r in self.radii])
             slot["counters"] = torch.zeros(8, dtype=torch.int32, device=X.device)
             slot["host"] = torch.zeros(8, dtype=torch.int32).pin_memory()
+            slot["flags"] = torch.empty(max(g1 - g0, 1), dtype=torch.int32, device=X.device)
+            slot["event"] = slot.get("event") or C.c_void_p()          # completion event of the read-back (library-made)
             slot["key"] = key
         # direct exchange: the result IS the slot's peer-mapped buffer (every rank uses the same slot for the same step)
         out = peer[slot_idx] if peer else torch.empty((m, k, G), dtype=torch.float32, device=X.device)
-        flags = torch.empty(max(g1 - g0, 1), dtype=torch.int32, device=X.device)
+        flags = slot["flags"]          # (per slot: a step's flags are read when it is collected, before the slot is reused)
         method = {"auto": 0, "eig": 1, "matfun": 2}[self.method]
         gamma = float(self.rbf_gamma) if self.rbf_gamma is not None else 0.0
         cur = torch.cuda.current_stream(X.device)
@@ -446,14 +455,20 @@ class ShardedLetkf:
         else:
             comp, prep, last = cur, None, cur
 
+        # (plain integers for the pointer arguments: ctypes converts them itself, a C.c_void_p object per argument was a
+        #  third of this function's host time)
+        cargs = [X.data_ptr(), G, m, k, Yb.data_ptr(), d.data_ptr(), P, grid.data_ptr(), obs.data_ptr(), nc, slot["cg"],
+                 slot["rc"], len(self.radii), float(self.eps), float(self.inf_factor), gamma, method, hint, st["comm"],
+                 C_chunks, 0, out.data_ptr(), flags.data_ptr(), slot["counters"].data_ptr(), slot["ws"].data_ptr(),
+                 slot["ws"].numel(), comp.cuda_stream, side, prep.cuda_stream if prep is not None else None,
+                 1 if pipelined else 0]
+        step_fn = lib.mia_letkf_sharded_step_streams_f32
+
         def call(phase):
-            _cabi.check(lib.mia_letkf_sharded_step_streams_f32(
-                _ptr(X), G, m, k, _ptr(Yb), _ptr(d), P, _ptr(grid), _ptr(obs), nc, slot["cg"], slot["rc"],
-                len(self.radii), float(self.eps), float(self.inf_factor), gamma, method, hint, st["comm"], C_chunks,
-                phase, _ptr(out), _ptr(flags), _ptr(slot["counters"]), _ptr(slot["ws"]), slot["ws"].numel(),
-                C.c_void_p(comp.cuda_stream), C.c_void_p(side) if side is not None else None,
-                C.c_void_p(prep.cuda_stream) if prep is not None else None, 1 if pipelined else 0),
-                "mia_letkf_sharded_step_streams_f32")
+            cargs[20] = phase
+            rc = step_fn(*cargs)
+            if rc != 0:
+                _cabi.check(rc, "mia_letkf_sharded_step_streams_f32")
 
         timing = None
         if self._time_next:                                        # bench: bracket this step's analysis kernel
@@ -461,24 +476,34 @@ class ShardedLetkf:
             timing = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             for e in timing:
                 e.record(cur)                                      # creates the underlying hipEvent_t
-            _cabi.check(lib.mia_letkf_step_timing_events(C.c_void_p(timing[0].cuda_event),
-                                                         C.c_void_p(timing[1].cuda_event)), "mia_letkf_step_timing_events")
             self.kernel_timings.append(timing)
-        call(0)
-        ev = None
+        ev = job = None
         if pipelined:
+            after = last
             if not exch:
                 # read the counters back on the (otherwise idle) exchange stream: a copy enqueued on the analysis
                 # stream sits between two analysis kernels and costs ~15 us of dispatch gaps per step
-                done = torch.cuda.Event()
-                done.record(comp)
-                last = st["stream"]
-                last.wait_event(done)
-            with torch.cuda.stream(last):
-                slot["host"].copy_(slot["counters"], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(last)
-        h = PendingStep(self, dict(slot=slot, call=call, comp=comp, cur=cur, ev=ev, out=out, flags=flags, hint=hint,
+                after, last = comp, st["stream"]
+            # The step call and its read-back (wait for `after`, copy the counters to pinned memory on `last`, record the
+            # slot's event) run on the library's launch thread, in submission order: their ~65 us of HIP runtime calls
+            # overlap this thread's own per-step work instead of adding to it: submit() 80 -> 24 us of the caller's time.
+            # (No throughput gain at N = 1, where the analysis stream is the bound: 83 us of kernel per step beside the
+            # preparation kernels + ~15 us of event / barrier packets between two kernels of one queue = the 0.102 ms
+            # measured; the whole step on per-step streams instead was slower, 0.111 ms.)
+            job = C.c_void_p()
+            rc = lib.mia_letkf_step_submit(*cargs, slot["host"].data_ptr(), after.cuda_stream, last.cuda_stream,
+                                           C.byref(slot["event"]), timing[0].cuda_event if timing else None,
+                                           timing[1].cuda_event if timing else None, C.byref(job))
+            if rc != 0:
+                _cabi.check(rc, "mia_letkf_step_submit")
+            ev = slot["event"]
+        else:
+            lib.mia_letkf_step_drain()                             # (a synchronous step must not overtake queued ones)
+            if timing:
+                _cabi.check(lib.mia_letkf_step_timing_events(timing[0].cuda_event, timing[1].cuda_event),
+                            "mia_letkf_step_timing_events")
+            call(0)
+        h = PendingStep(self, dict(slot=slot, call=call, comp=comp, cur=cur, ev=ev, job=job, out=out, flags=flags, hint=hint,
                                    last=last, peer=bool(peer),
                                    C_chunks=C_chunks, args=(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1),
                                    keep=(X, grid, obs, Yb, d)))
@@ -494,7 +519,10 @@ class ShardedLetkf:
         p = h._st
         slot, st = p["slot"], self._native_state()
         if p["ev"] is not None:
-            p["ev"].synchronize()                              # the one host wait of the step
+            rc = self.engine.lib.mia_letkf_step_join(p["job"])  # the launch thread has enqueued this step ...
+            if rc != 0:
+                _cabi.check(rc, "mia_letkf_sharded_step_streams_f32 (launch thread)")
+            self.engine.lib.mia_event_synchronize(p["ev"])     # ... and this is the one host wait for the GPU
             cnt = slot["host"].tolist()
         else:
             cnt = slot["counters"].tolist()                    # serial route: synchronous read-back
@@ -531,6 +559,7 @@ class ShardedLetkf:
             h._st = None
             return h._out
         if n_retry:
+            self.engine.lib.mia_letkf_step_drain()             # (after the steps already handed to the launch thread)
             p["call"](1)                                       # eigensolver redoes declined points; re-exchange
         if p["comp"] is not p["cur"]:
             # consumers on torch's stream see the result.  Wait for THIS step's completion event only: waiting for
@@ -543,7 +572,7 @@ class ShardedLetkf:
                     e2.record(strm)
                     now.wait_event(e2)
             else:
-                now.wait_event(p["ev"])
+                self.engine.lib.mia_stream_wait_event(now.cuda_stream, p["ev"])
         self.native_steps += 1
         self.last_retries = cnt[2]
         self._p_max_hint = p_seen if self.world > 1 else max(p_seen, 0)
