@@ -516,8 +516,15 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
         MIA_TILE_SYNC();
       }
       MIA_STAMP(6);
-      // ---- the recurrence on the 16 columns at once; vectors stay in the result layout
-      f4t tp[UT], tc[UT], aphi[UT], apsi[UT], y[UT];
+      // ---- the recurrence on the 16 columns at once; vectors stay in the result layout.
+      //      Run on v with t = D o v (t_j = T_j(A) t_0, A = alpha D G D - I, t_0 = D o Z  <=>  v_0 = Z,
+      //      v_{j+1} = 2 (alpha G (D^2 o v_j) - v_j) - v_{j-1}): one multiply per value and step less than on t, D enters as
+      //      D^2 in the products' right-hand side and once at the end; slots that are not local to a column (D = 0) carry
+      //      bounded junk that D^2 = 0 keeps out of every product.  Two steps per trip, so that the three-term update swaps
+      //      roles instead of moving registers.
+      f4t va[UT], vb[UT], aphi[UT], apsi[UT], y[UT], d2[UT];
+#pragma unroll
+      for (int t = 0; t < UT; ++t) d2[t] = dreg[t] * dreg[t];
       auto product = [&](const f4t (&tv)[UT]) {
 #pragma unroll
         for (int t = 0; t < UT; ++t) y[t] = f4t{0.f, 0.f, 0.f, 0.f};
@@ -526,7 +533,7 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             if (16 * tk + 4 * q < U) {
-              const float b = dreg[tk][q] * tv[tk][q];
+              const float b = d2[tk][q] * tv[tk][q];
 #pragma unroll
               for (int t = 0; t < UT; ++t) y[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(G[tk][t][q], b, y[t], 0, 0, 0);
             }
@@ -536,27 +543,35 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
         const float2 c = ld_off<float2>(P.tab_c, ((unsigned)tab_idx * (unsigned)kTabDeg + (unsigned)(j < kTabDeg ? j : kTabDeg - 1)) * 8u);
         return float2{c.x * P.cs_phi, c.y * P.cs_psi};
       };
-      const float2 c0 = coef(0), c1 = coef(1);
-#pragma unroll
-      for (int t = 0; t < UT; ++t) tp[t] = dreg[t] * Z[t];
-      product(tp);
-#pragma unroll
-      for (int t = 0; t < UT; ++t) {
-        tc[t] = alpha * (dreg[t] * y[t]) - tp[t];
-        aphi[t] = c0.x * tp[t] + c1.x * tc[t];
-        apsi[t] = c0.y * tp[t] + c1.y * tc[t];
-      }
-      for (int j = 2; j <= degmax; ++j) {
-        const float2 cj = coef(j);
-        product(tc);
+      // vnew = 2 (alpha y - vcur) - vold, written over vold; the two weight functions accumulate c_j vnew
+      auto advance = [&](f4t (&vold)[UT], const f4t (&vcur)[UT], const float2 cj) {
+        product(vcur);
 #pragma unroll
         for (int t = 0; t < UT; ++t) {
-          const f4t tn = 2.0f * (alpha * (dreg[t] * y[t]) - tc[t]) - tp[t];
-          tp[t] = tc[t]; tc[t] = tn;
-          aphi[t] = cj.x * tn + aphi[t];
-          apsi[t] = cj.y * tn + apsi[t];
+          vold[t] = 2.0f * (alpha * y[t] - vcur[t]) - vold[t];
+          aphi[t] = cj.x * vold[t] + aphi[t];
+          apsi[t] = cj.y * vold[t] + apsi[t];
+        }
+      };
+      {
+        const float2 c0 = coef(0), c1 = coef(1);
+#pragma unroll
+        for (int t = 0; t < UT; ++t) va[t] = Z[t];
+        product(va);
+#pragma unroll
+        for (int t = 0; t < UT; ++t) {
+          vb[t] = alpha * y[t] - va[t];
+          aphi[t] = c0.x * va[t] + c1.x * vb[t];
+          apsi[t] = c0.y * va[t] + c1.y * vb[t];
         }
       }
+      int j = 2;
+      for (; j + 1 <= degmax; j += 2) {
+        const float2 cj = coef(j), cj1 = coef(j + 1);
+        advance(va, vb, cj);          // va = v_j
+        advance(vb, va, cj1);         // vb = v_{j+1}
+      }
+      if (j <= degmax) advance(va, vb, coef(j));
       MIA_STAMP(7);
       // ---- x' w_mean = sum_b d_b (w_b psi_b): one more product, row vector of the innovations (column k of the records)
       //      times D o Psi -- on the matrix cores like everything else, because their enumeration IS the canonical
@@ -573,11 +588,11 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
         for (int q = 0; q < 4; ++q)
           if (16 * tk + 4 * q < U) {
             const float a = lrv == 0 ? Yw[(16 * tk + 4 * hv + q) * kp + k] : 0.0f;
-            zacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, dreg[tk][q] * apsi[tk][q], zacc, 0, 0, 0);
+            zacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, d2[tk][q] * apsi[tk][q], zacc, 0, 0, 0);
           }
       const float zu = __shfl(zacc[0], lrv, 64);
 #pragma unroll
-      for (int t = 0; t < UT; ++t) aphi[t] *= dreg[t];        // s = D o phi: right-hand side of the last product
+      for (int t = 0; t < UT; ++t) aphi[t] *= d2[t];          // D o phi(S) z = D^2 o (accumulated v): right-hand side of the last product
       const float mterm = xm + zu;
       f4t acc[KT];
 #pragma unroll
