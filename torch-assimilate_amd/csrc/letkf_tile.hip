@@ -706,8 +706,12 @@ static int tile_launch_u(const TileParams& tp, int kt, hipStream_t stream) {
 // network add ~one observation per second point (config 2: 20 -> 28); below this slack most tiles would be split.
 constexpr int kTileSlack = 8;
 
+// Any number of state rows: the Gram matrix, the union and the coefficients are shared by the rows of a tile, a further row
+// costs Z + recurrence + output (C2, 1e5 points: 76 us for the first row, ~37 us per further row -- m = 8 / 16 / 32:
+// 0.34 / 0.63 / 1.23 ms against 0.76 / 0.92 / 1.61 ms of the 16-row MFMA batches of letkf_cheb_rows_kernel, which remains the
+// route of the shapes this kernel does not cover).
 bool tile_route_covers(int m, int k, int p_max) {
-  return m < 8 && k >= 2 && k <= 96 && p_max <= k && p_max + kTileSlack <= 96;
+  return m >= 1 && k >= 2 && k <= 96 && p_max <= k && p_max + kTileSlack <= 96;
 }
 
 int tile_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
