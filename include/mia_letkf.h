@@ -70,6 +70,9 @@ const char* mia_status_string(int status);
  *   "cheb_rowbatch"    1  m >= 8 state rows in 16-row MFMA batches / 0: row by row
  *   "cheb_big"         1  64 < k <= 128 with more than 64 local observations: matrix-function kernel / 0: eigensolver
  *   "tile"             1  sixteen grid points per wavefront where the shape allows (csrc/letkf_tile.hip) / 0: one
+ *   "tile_split"       1  the products of that kernel as split-precision half MFMAs (f32 operands carried as pairs of halves,
+ *                         f32 accumulation; same accuracy as f32 MFMAs) / 0: f32 MFMAs (results then do
+ *                         not depend on which tile a grid point falls into, bit for bit)
  *   "segment_signal"   1  step driver with several pieces: one segmented launch / 0: one launch + event per piece
  * Returns MIA_ERR_UNSUPPORTED for an unknown name, MIA_ERR_SIZE for a value out of range. */
 int mia_set_option(const char* name, int value);

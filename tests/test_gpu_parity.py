@@ -214,10 +214,17 @@ def test_large_grid_properties(eng):
     xe = eng.analysis(X, yb, d, nb, 1.1, method="eig")           # the two routes agree at full size
     assert float(torch.linalg.norm(xa - xe) / torch.linalg.norm(xe)) < TOL32
     assert torch.isfinite(xa).all()
-    # shard [30000, 30100) equals the same columns of the full run, bit for bit
+    # shard [30000, 30100) equals the same columns of the full run: to rounding per point on the split-precision products
+    # (the last four points sit in a tile of their own, whose operand scale differs), bit for bit on the f32 products
     nb_s = eng.localize(case["grid_x"], case["obs_x"], [10.0], g0=30000, g1=30100)
     xs = eng.analysis(X, yb, d, nb_s, 1.1)
-    assert torch.equal(xs, xa[:, :, 30000:30100])
+    part = xa[:, :, 30000:30100]
+    assert float(((xs - part).norm(dim=(0, 1)) / part.norm(dim=(0, 1))).max()) < 2e-6
+    set_option("tile_split", 0)
+    xf = eng.analysis(X, yb, d, nb, 1.1)
+    assert float(torch.linalg.norm(xf - xa) / torch.linalg.norm(xa)) < 1e-6
+    assert torch.equal(eng.analysis(X, yb, d, nb_s, 1.1), xf[:, :, 30000:30100])
+    set_option("tile_split", 1)
     # oracle on a random subset of points
     sel = np.random.RandomState(1).choice(100000, 64, replace=False)
     for gi in sel:

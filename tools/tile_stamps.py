@@ -23,6 +23,8 @@ for G in [int(a) for a in sys.argv[1:]] or [16, 100000]:
     buf = np.zeros((nt, 12), dtype=np.int64)
     assert lib.mia_debug_tile_stamps(buf.ctypes.data_as(C.c_void_p), nt) == 0
     dt = np.diff(buf[:, :9], axis=1).astype(np.float64)
+    os.makedirs('gpurun_out', exist_ok=True)
+    np.save('gpurun_out/tile_stamps_%d.npy' % G, buf)
     print("G = %d: %d tiles; per-tile wave lifetime median %.0f cycles (s_memtime ticks = shader cycles? see guide)" % (G, nt, np.median(buf[:, 8] - buf[:, 0])))
     for i, n in enumerate(names[:8]):
         print("  %-28s median %8.0f   p90 %8.0f" % (n, np.median(dt[:, i]), np.percentile(dt[:, i], 90)))

@@ -11,8 +11,12 @@ ap.add_argument("configs", nargs="*", default=["c2"])
 ap.add_argument("--methods", default="matfun,eig")
 ap.add_argument("--batches", type=int, default=7)
 ap.add_argument("--grid", type=int, default=100000)
+ap.add_argument("--option", action="append", default=[], help="name=value for mia_set_option (e.g. tile_split=0)")
 a = ap.parse_args()
 mia.build()
+from torch_assimilate_amd import _cabi
+for o in a.option:
+    _cabi.set_option(o.split("=")[0], int(o.split("=")[1]))
 dev = torch.device("cuda:0")
 eng = mia.LetkfEngine(dev)
 cfgs = {"c2": (40, 2, 10.0, None), "c4": (80, 1, 16.5, None), "c5": (40, 2, 10.0, 0.5)}

@@ -32,10 +32,15 @@
 // of letkf_cheb.hip (MIA_FLAG_RETRY points are redone by the eigensolver kernel).
 #include "mia_common.h"
 #include "mia_kernels.h"
+#include "mia_options.h"
 
 namespace mia {
 
 using f4t = __attribute__((ext_vector_type(4))) float;
+using f2v = __attribute__((ext_vector_type(2))) float;
+using h2t = __attribute__((ext_vector_type(2))) _Float16;
+using h8t = __attribute__((ext_vector_type(8))) _Float16;
+using u4t = __attribute__((ext_vector_type(4))) unsigned;
 
 #define MIA_TILE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 
@@ -53,6 +58,10 @@ struct TileParams {
   // writes its own (m k, seg_len) buffer at Xa + s * seg_stride with write-through stores and counts its finished POINTS
   // in done[(s * 64 + j) * kSlotStride]; tiles never straddle a segment
   int seg_len; int64_t seg_stride; int32_t* done;
+  // split-precision variant (SPL): a union record occupies nc chunks of eight values (hi halves | lo halves, 32 bytes),
+  // rows rsb = 32 nc + 16 bytes apart (an odd multiple of 16: sixteen rows read side by side touch every bank once)
+  int nc, rsb;
+  int lds_bytes;       // (diagnostic builds)
 };
 
 __device__ __forceinline__ float tile_add_h(float v) {       // sum over the four lanes (lr, h = 0..3), in every one of them
@@ -84,6 +93,52 @@ __device__ __forceinline__ unsigned tile_wave_max_u32(unsigned u) {     // wave-
   return ab > cd ? ab : cd;
 }
 
+// ---- split precision (SPL instantiations) ---------------------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32 occupies the SIMD for 33 cycles per 2048 flop and shares the FP32 pipe with the vector
+// instructions (measured: tools/mfma_rate.hip -- the two never overlap, one wavefront or several).
+// v_mfma_f32_16x16x32_f16 takes 16 cycles for EIGHT times the summation depth and runs beside vector instructions.  An
+// f32 operand x is carried as two halves, hi = f16(x), lo = f16(x - hi) (round to nearest both times: hi + lo holds
+// 22-23 significant bits of x, products of halves are exact in the f32 accumulator), and a product A B becomes
+// Ah Bh + Ah Bl + Al Bh (the term Al Bl is below 2^-22 of the result).  Operands are first scaled by a power of two
+// (exact) into the middle of the f16 range; results are unscaled by the inverse.  Accuracy equals the f32 route's
+// (tools/split_emul.py: 1.65e-7 against 1.52e-7 relative error of the recurrence's output over 40 random tiles).
+__device__ __forceinline__ void tile_split8(const float (&x)[8], h8t& hi, h8t& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f2v v = {x[2 * i], x[2 * i + 1]};
+    const h2t a = __builtin_convertvector(v, h2t);
+    const f2v r = {v[0] - (float)a[0], v[1] - (float)a[1]};
+    const h2t b = __builtin_convertvector(r, h2t);
+    hi[2 * i] = a[0]; hi[2 * i + 1] = a[1];
+    lo[2 * i] = b[0]; lo[2 * i + 1] = b[1];
+  }
+}
+__device__ __forceinline__ h8t tile_hi8(const float (&x)[8]) {
+  h8t hi;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f2v v = {x[2 * i], x[2 * i + 1]};
+    const h2t a = __builtin_convertvector(v, h2t);
+    hi[2 * i] = a[0]; hi[2 * i + 1] = a[1];
+  }
+  return hi;
+}
+__device__ __forceinline__ f4t tile_mfma3(f4t acc, const h8t ah, const h8t al, const h8t bh, const h8t bl) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+}
+// power of two that brings a magnitude (given by its bit pattern, sign cleared) to [2^target, 2^(target+1)); the
+// exponent of the scale is returned too.  Zero / subnormal magnitudes are left alone; exponents are clamped to +-60 (the
+// squares and products of scales formed below then stay inside f32).
+__device__ __forceinline__ float tile_pow2_scale(unsigned magbits, int target, int* es_out) {
+  const int e = (int)(magbits >> 23) - 127;
+  int es = (magbits >> 23) == 0u ? 0 : target - e;
+  es = es < -60 ? -60 : (es > 60 ? 60 : es);
+  *es_out = es;
+  return __uint_as_float((unsigned)(127 + es) << 23);
+}
+
 // Every global access of the kernel is `wave-uniform base + 32-bit lane offset in bytes` (the saddr + voffset form of
 // global_load / global_store): the host checks that the offsets fit, and no 64-bit address ever lives in vector registers.
 template <typename T>
@@ -97,7 +152,14 @@ __device__ __forceinline__ T ld_off(const void* base, unsigned byte_off) {
 constexpr int kStampN = 12, kStampTiles = 8192;
 __device__ long long g_tile_stamps[kStampTiles * kStampN];
 #define MIA_STAMP(i) do { if (lane0 == 0 && bid < kStampTiles) g_tile_stamps[bid * kStampN + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+// slot 9: where the wavefront ran (HW_ID in the low word: wave 3:0, SIMD 5:4, CU 11:8, SH 12, SE 15:13; XCC_ID in the high word)
+#define MIA_STAMP_HWID() do { if (lane0 == 0 && bid < kStampTiles) g_tile_stamps[bid * kStampN + 9] = \
+    (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } while (0)
+// slots 10, 11: the constant 100 MHz counter (comparable across CUs, which s_memtime is not) at start and end of the wavefront
+#define MIA_STAMP_REAL(i) do { if (lane0 == 0 && bid < kStampTiles) g_tile_stamps[bid * kStampN + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
+#define MIA_STAMP_HWID() do { } while (0)
+#define MIA_STAMP_REAL(i) do { } while (0)
 #define MIA_STAMP(i) do { } while (0)
 #endif
 
@@ -105,9 +167,10 @@ __device__ long long g_tile_stamps[kStampTiles * kStampN];
 #define MIA_TILE_WAVES_UT2 3
 #endif
 
-template <int UT, int KT, bool SEG>
+template <int UT, int KT, bool SEG, bool SPL>
 __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 1)))   /* UT >= 4: one wavefront per SIMD, up to 512 registers */ void letkf_tile_kernel(TileParams P) {
   constexpr int UMAX = 16 * UT, NU = 4 * UT;
+  constexpr int NB = (KT + 1) / 2, NKB = (UT + 1) / 2;       // SPL: blocks of 32 members / of 32 union slots (= two row blocks)
   constexpr int LOGHS = UT <= 1 ? 6 : (UT <= 2 ? 7 : 8), HS = 1 << LOGHS, HR = HS / 64;
   constexpr int DS = UMAX + 4;
   constexpr int CLraw = (16 * DS + 2 * HS + UMAX + 2 * (UMAX > 64 ? UMAX : 64)) / 32;
@@ -117,7 +180,10 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
   const int lane0 = threadIdx.x;
   const int k = P.k, kp = P.kp, pm = P.p_max;
   float* Yw = reinterpret_cast<float*>(smem_raw);            // [UMAX][kp] union records (+ 16 zero floats)
-  float* Dl = Yw + UMAX * kp + 16;                           // [16][DS]   sqrt(rho) of (point, slot), 0 = not local
+  unsigned char* YwB = smem_raw;                             // SPL: [UMAX] rows of P.rsb bytes, see TileParams
+  const unsigned RSB = (unsigned)P.rsb;
+  float* Dl = SPL ? reinterpret_cast<float*>(smem_raw + UMAX * P.rsb)
+                  : Yw + UMAX * kp + 16;                     // [16][DS]   sqrt(rho) of (point, slot), 0 = not local
   int* H = reinterpret_cast<int*>(Dl + 16 * DS);             // [HS]       hash table of observation indices / index bitmap
   int* Hs = H + HS;                                          // [HS]       slot of a table position
   int* ukey = Hs + HS;                                       // [UMAX]     observation index of a slot, -1 = unused
@@ -156,7 +222,14 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
     npts = P.ng - p0 < 16 ? (int)(P.ng - p0) : 16;
     oc0 = P.o0 + p0;
   }
+#ifdef MIA_TILE_POISON
+  // diagnostic builds: every LDS byte starts as NaN (f32 and f16), so that a read of unwritten storage shows
+  for (unsigned i = (unsigned)lane0; i < (unsigned)P.lds_bytes / 4u; i += 64u) reinterpret_cast<unsigned*>(smem_raw)[i] = 0xffffffffu;
+  MIA_TILE_SYNC();
+#endif
   MIA_STAMP(0);
+  MIA_STAMP_HWID();
+  MIA_STAMP_REAL(10);
 
   // ---- the tile's neighbour lists: lane (lp, sub) = (lane >> 2, lane & 3) holds entries sub, sub + 4, ... of point lp.
   //      Count and entries are requested before anything is waited for.  The entries are loop-carried: loaded here for
@@ -236,13 +309,28 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
           xr[tm][q] = ld_off<float>(xbase, off);
         }
     };
+    // SPL: member (b, i) of lane group h = 32 b + 8 h + i (the summation index of a 32-deep product: lane group h supplies
+    // eight consecutive values), column lr
+    auto load_xs = [&](int mi, float (&xr)[NB][8]) {
+      const float* xbase = P.X + (int64_t)mi * k * P.ldx + P.g0 + p0v;
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int mem = 32 * b + 8 * h + i;
+          xr[b][i] = ld_off<float>(xbase, (unsigned)(mem < k ? mem : k - 1) * ldxb + (unsigned)lrc * 4u);
+        }
+    };
     f4t xb[KT];
-    load_x(0, xb);
+    float xsb[NB][8];
+    if constexpr (SPL) load_xs(0, xsb);
+    else load_x(0, xb);
     MIA_STAMP(1);
 
     // ---- union of the lists of points [lo, hi), slots by RANK of the observation index (the enumeration order of the
     //      products = ascending rank); shrink the range until the union fits
     int n = 16, hi, U;
+    unsigned ymax_bits = 0u;
     int es[NU];            // slot of this lane's entries
     for (;;) {
       hi = lo + n < npts ? lo + n : npts;
@@ -348,6 +436,7 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
       MIA_STAMP(2);
       // ---- the union's records, unscaled (the sqrt(rho) factors differ per point: they live in D)
       float fin = 0.0f;       // stays 0 while every value is finite (inf * 0 = NaN)
+      unsigned mxi = 0u;      // SPL: largest magnitude of the union's records as a bit pattern (NaN > inf > finite)
       {
         const unsigned kpv = (unsigned)kp >> 2;
         const int total = UMAX * (int)kpv;
@@ -373,12 +462,26 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
             const int it = base + 64 * u + lane;
             if (it < total) {
               const float4 t = kk[u] < 0 ? float4{0.f, 0.f, 0.f, 0.f} : v[u];
-              fin = fmaf(t.x, 0.0f, fmaf(t.y, 0.0f, fmaf(t.z, 0.0f, fmaf(t.w, 0.0f, fin))));
-              Yw4[it] = t;
+              if constexpr (SPL) {
+                const unsigned a0 = __float_as_uint(t.x) & 0x7fffffffu, a1 = __float_as_uint(t.y) & 0x7fffffffu;
+                const unsigned a2 = __float_as_uint(t.z) & 0x7fffffffu, a3 = __float_as_uint(t.w) & 0x7fffffffu;
+                const unsigned m01 = a0 > a1 ? a0 : a1, m23 = a2 > a3 ? a2 : a3, m4 = m01 > m23 ? m01 : m23;
+                mxi = m4 > mxi ? m4 : mxi;
+                const unsigned j = ((unsigned)it * (unsigned)P.kpv_magic) >> 20;
+                *reinterpret_cast<float4*>(YwB + j * RSB + ((unsigned)it - j * kpv) * 16u) = t;
+              } else {
+                fin = fmaf(t.x, 0.0f, fmaf(t.y, 0.0f, fmaf(t.z, 0.0f, fmaf(t.w, 0.0f, fin))));
+                Yw4[it] = t;
+              }
             }
           }
         }
-        if (lane < 4) Yw4[total + lane] = float4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (!SPL) { if (lane < 4) Yw4[total + lane] = float4{0.f, 0.f, 0.f, 0.f}; }
+      }
+      if constexpr (SPL) {
+        mxi = tile_wave_max_u32(mxi);
+        fin = mxi >= 0x7f800000u ? __builtin_nanf("") : 0.0f;
+        ymax_bits = mxi;
       }
       // A non-finite record would reach EVERY column of the tile through the shared Gram matrix (NaN * 0 = NaN), also
       // the points that do not see that observation.  Such a tile is analysed point by point: the union is then the
@@ -387,6 +490,34 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
       break;
     }
     MIA_STAMP(3);
+    // SPL: the union's records become scaled half pairs, in place (a chunk of eight f32 = 32 bytes -> 8 hi | 8 lo halves).
+    // One power of two for the tile, from the largest magnitude the gather saw; two lanes share a row.
+    float inv_sy = 1.0f;
+    int esy = 0;
+    if constexpr (SPL) {
+      const float sy = tile_pow2_scale(ymax_bits, 9, &esy);
+      inv_sy = __uint_as_float((unsigned)(127 - esy) << 23);
+      // (every row: a row the union does not use holds zeros, but the lo halves of its last chunk would be read from the
+      //  padding behind the record, which nothing writes)
+      const int rows = UMAX, nc = P.nc;
+      MIA_TILE_SYNC();
+#pragma clang loop unroll(disable)
+      for (int r0 = 0; r0 < rows; r0 += 32) {
+        const int r = r0 + (lane >> 1);
+        if (r < rows) {
+#pragma clang loop unroll(disable)
+          for (int c = lane & 1; c < nc; c += 2) {
+            unsigned char* q = YwB + (unsigned)r * RSB + (unsigned)c * 32u;
+            const f4t a = *reinterpret_cast<const f4t*>(q), b = *reinterpret_cast<const f4t*>(q + 16);
+            const float x[8] = {a[0] * sy, a[1] * sy, a[2] * sy, a[3] * sy, b[0] * sy, b[1] * sy, b[2] * sy, b[3] * sy};
+            h8t hh, ll;
+            tile_split8(x, hh, ll);
+            *reinterpret_cast<h8t*>(q) = hh;
+            *reinterpret_cast<h8t*>(q + 16) = ll;
+          }
+        }
+      }
+    }
     for (int i = lane; i < 4 * DS; i += 64) reinterpret_cast<f4t*>(Dl)[i] = f4t{0.f, 0.f, 0.f, 0.f};
     MIA_TILE_SYNC();
 #pragma unroll
@@ -400,6 +531,7 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
     MIA_STAMP(4);
 
     f4t G[UT][UT];          // G[t1][t2][q] = Gram[16 t1 + 4 h + q][16 t2 + lr]
+    h8t GAh[UT][NKB], GAl[UT][NKB];   // SPL: the same matrix as A fragments of the 32-deep products, 2^-16 G as half pairs
     float alpha = 0.0f;
     int deg = 0, tab_idx = 0, degmax = 0, pflag = 0;
     bool decl = false;
@@ -408,24 +540,62 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
       //  first-row-only phases -- would otherwise be hoisted in front of it and spilled there)
       int hv = h, lrv = lr;
       asm volatile("" : "+v"(hv), "+v"(lrv));
-      if (mi > 0) load_x(mi, xb);
-      float xs = 0.0f;
+      float xm;
+      float inv_sx = 1.0f;          // SPL: 1 / (power of two that scaled this column's x')
+      h8t xh[NB], xl[NB];           // SPL: x' of the column as half pairs, member block b
+      if constexpr (SPL) {
+        if (mi > 0) load_xs(mi, xsb);
+        float xs = 0.0f;
 #pragma unroll
-      for (int tm = 0; tm < KT; ++tm)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const bool live = colact && (tm < KT - 1 || 16 * tm + 4 * hv + q < k);       // (only the last member block is ragged)
-          xb[tm][q] = live ? xb[tm][q] : 0.0f;
-          xs += xb[tm][q];
+          for (int i = 0; i < 8; ++i) {
+            const bool live = colact && (b < NB - 1 || 32 * b + 8 * hv + i < k);       // (only the last member block is ragged)
+            xsb[b][i] = live ? xsb[b][i] : 0.0f;
+            xs += xsb[b][i];
+          }
+        xm = tile_add_h(xs) * P.inv_k;
+        unsigned xmax = 0u;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const bool live = colact && (b < NB - 1 || 32 * b + 8 * hv + i < k);
+            xsb[b][i] = live ? xsb[b][i] - xm : 0.0f;
+            const unsigned a = __float_as_uint(xsb[b][i]) & 0x7fffffffu;
+            xmax = a > xmax ? a : xmax;
+          }
+        xmax = __float_as_uint(tile_max_h(__uint_as_float(xmax)));
+        int esx;
+        const float sx = tile_pow2_scale(xmax, 9, &esx);
+        inv_sx = __uint_as_float((unsigned)(127 - esx) << 23);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          float t8[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) t8[i] = xsb[b][i] * sx;
+          tile_split8(t8, xh[b], xl[b]);
         }
-      const float xm = tile_add_h(xs) * P.inv_k;
+      } else {
+        if (mi > 0) load_x(mi, xb);
+        float xs = 0.0f;
 #pragma unroll
-      for (int tm = 0; tm < KT; ++tm)
+        for (int tm = 0; tm < KT; ++tm)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const bool live = colact && (tm < KT - 1 || 16 * tm + 4 * hv + q < k);
-          xb[tm][q] = live ? xb[tm][q] - xm : 0.0f;
-        }
+          for (int q = 0; q < 4; ++q) {
+            const bool live = colact && (tm < KT - 1 || 16 * tm + 4 * hv + q < k);       // (only the last member block is ragged)
+            xb[tm][q] = live ? xb[tm][q] : 0.0f;
+            xs += xb[tm][q];
+          }
+        xm = tile_add_h(xs) * P.inv_k;
+#pragma unroll
+        for (int tm = 0; tm < KT; ++tm)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bool live = colact && (tm < KT - 1 || 16 * tm + 4 * hv + q < k);
+            xb[tm][q] = live ? xb[tm][q] - xm : 0.0f;
+          }
+      }
       // ---- G = Yw Yw^T (first row only) and Z = Yw X'
       f4t Z[UT];
 #pragma unroll
@@ -436,32 +606,68 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
 #pragma unroll
           for (int t2 = 0; t2 < UT; ++t2) G[t1][t2] = f4t{0.f, 0.f, 0.f, 0.f};
       }
+      if constexpr (SPL) {
+        // lane (lr, h) reads, of row 16 t + lr, the chunk of members 32 b + 8 h .. + 7: A fragment of row block t and, the
+        // product being symmetric, B fragment of column block t
 #pragma unroll
-      for (int tm = 0; tm < KT; ++tm) {
-        f4t av[UT];
+        for (int b = 0; b < NB; ++b) {
+          h8t ah[UT], al[UT];
+          const int chunk = 4 * b + hv;
+          const int vc = k - (32 * b + 8 * hv);          // members of this chunk that exist (the rest: innovation, padding)
 #pragma unroll
-        for (int t = 0; t < UT; ++t) {
-          av[t] = *reinterpret_cast<const f4t*>(Yw + (16 * t + lrv) * kp + 16 * tm + 4 * hv);
-          if (tm == KT - 1) {
+          for (int t = 0; t < UT; ++t) {
+            const unsigned ro = (unsigned)(16 * t + lrv) * RSB + (unsigned)(chunk < P.nc ? chunk : 0) * 32u;
+            u4t wh = *reinterpret_cast<const u4t*>(YwB + ro), wl = *reinterpret_cast<const u4t*>(YwB + ro + 16);
+            if (b == NB - 1) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (16 * tm + 4 * hv + q >= k) av[t][q] = 0.0f;        // innovation / pad columns, next row's start
+              for (int w = 0; w < 4; ++w) {
+                const int lim = vc - 2 * w;
+                const unsigned msk = lim >= 2 ? 0xffffffffu : (lim == 1 ? 0x0000ffffu : 0u);
+                wh[w] &= msk;
+                wl[w] &= msk;
+              }
+            }
+            ah[t] = __builtin_bit_cast(h8t, wh);
+            al[t] = __builtin_bit_cast(h8t, wl);
           }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
           if (mi == 0) {
 #pragma unroll
             for (int t2 = 0; t2 < UT; ++t2)
 #pragma unroll
-              for (int t1 = 0; t1 < UT; ++t1)
-                G[t1][t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t1][q], av[t2][q], G[t1][t2], 0, 0, 0);
+              for (int t1 = 0; t1 < UT; ++t1) G[t1][t2] = tile_mfma3(G[t1][t2], ah[t1], al[t1], ah[t2], al[t2]);
           }
 #pragma unroll
-          for (int t = 0; t < UT; ++t) Z[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][q], xb[tm][q], Z[t], 0, 0, 0);
+          for (int t = 0; t < UT; ++t) Z[t] = tile_mfma3(Z[t], ah[t], al[t], xh[b], xl[b]);
+        }
+      } else {
+#pragma unroll
+        for (int tm = 0; tm < KT; ++tm) {
+          f4t av[UT];
+#pragma unroll
+          for (int t = 0; t < UT; ++t) {
+            av[t] = *reinterpret_cast<const f4t*>(Yw + (16 * t + lrv) * kp + 16 * tm + 4 * hv);
+            if (tm == KT - 1) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (16 * tm + 4 * hv + q >= k) av[t][q] = 0.0f;        // innovation / pad columns, next row's start
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (mi == 0) {
+#pragma unroll
+              for (int t2 = 0; t2 < UT; ++t2)
+#pragma unroll
+                for (int t1 = 0; t1 < UT; ++t1)
+                  G[t1][t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t1][q], av[t2][q], G[t1][t2], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < UT; ++t) Z[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][q], xb[tm][q], Z[t], 0, 0, 0);
+          }
         }
       }
       MIA_STAMP(5);
+      const int esg = 16 - 2 * esy;        // SPL: (matrix the products see) = 2^-esg (true Gram matrix)
       if (mi == 0) {
         // ---- Gershgorin bound of every point: L_g = max_a w_a sum_b |G_ab| w_b, then degree / interval from the table
         //      (step (tk, q) of a product over the union covers ranks 16 tk + 4 q .. + 3: steps beyond the union are
@@ -469,16 +675,49 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
         f4t R[UT];
 #pragma unroll
         for (int t = 0; t < UT; ++t) R[t] = f4t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int tk = 0; tk < UT; ++tk)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (16 * tk + 4 * q < U) {
-#pragma unroll
-              for (int t = 0; t < UT; ++t)
-                R[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fabsf(G[tk][t][q]), dreg[tk][q], R[t], 0, 0, 0);
-            }
         float L = 0.0f;
+        if constexpr (SPL) {
+          // A fragments of G for the 32-deep products: lane group h supplies slots 16 (2 kb + tt) + 4 h + q, i.e. the values
+          // this lane holds of the tiles (2 kb, t) and (2 kb + 1, t) -- no data moves.  |G| times D needs the hi halves only
+          // (a bound: the rounding of both operands is covered by the margin below)
+#pragma unroll
+          for (int t = 0; t < UT; ++t)
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+              float gv[8];
+#pragma unroll
+              for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gv[4 * tt + q] = 2 * kb + tt < UT ? G[2 * kb + tt < UT ? 2 * kb + tt : 0][t][q] * 0x1p-16f : 0.0f;
+              tile_split8(gv, GAh[t][kb], GAl[t][kb]);
+            }
+#pragma unroll
+          for (int kb = 0; kb < NKB; ++kb)
+            if (32 * kb < U) {
+              float dv[8];
+#pragma unroll
+              for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dv[4 * tt + q] = 2 * kb + tt < UT ? dreg[2 * kb + tt < UT ? 2 * kb + tt : 0][q] : 0.0f;
+              const h8t dh = tile_hi8(dv);
+#pragma unroll
+              for (int t = 0; t < UT; ++t) {
+                u4t ag = __builtin_bit_cast(u4t, GAh[t][kb]);
+                ag &= 0x7fff7fffu;
+                R[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8t, ag), dh, R[t], 0, 0, 0);
+              }
+            }
+        } else {
+#pragma unroll
+          for (int tk = 0; tk < UT; ++tk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (16 * tk + 4 * q < U) {
+#pragma unroll
+                for (int t = 0; t < UT; ++t)
+                  R[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fabsf(G[tk][t][q]), dreg[tk][q], R[t], 0, 0, 0);
+              }
+        }
 #pragma unroll
         for (int t = 0; t < UT; ++t)
 #pragma unroll
@@ -487,26 +726,31 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
             L = (v > L || v != v) ? v : L;
           }
         L = tile_max_h(L);
-        L = fmaxf(L, 1e-30f * P.reg) * 1.0001f;
-        if (!(L == L) || !(fabsf(L) < 1e30f)) { pflag |= MIA_FLAG_NONFINITE; L = P.reg; }
-        tab_idx = (int)ceilf(float(kTabPerOctave) * __builtin_amdgcn_logf(L * P.inv_reg)) + kTabIdx0;
+        if constexpr (SPL) L = fmaxf(L, 1e-37f) * 1.002f;       // (in units of 2^-esg; half-precision operands: 2 x 2^-11)
+        else L = fmaxf(L, 1e-30f * P.reg) * 1.0001f;
+        if (!(L == L) || !(fabsf(L) < 1e30f)) { pflag |= MIA_FLAG_NONFINITE; L = SPL ? 1.0f : P.reg; }
+        if constexpr (SPL) tab_idx = (int)ceilf(float(kTabPerOctave) * (__builtin_amdgcn_logf(L * P.inv_reg) + float(esg))) + kTabIdx0;
+        else tab_idx = (int)ceilf(float(kTabPerOctave) * __builtin_amdgcn_logf(L * P.inv_reg)) + kTabIdx0;
         tab_idx = tab_idx < 0 ? 0 : (tab_idx > kTabN - 1 ? kTabN - 1 : tab_idx);
         // header and coefficients are requested together: the coefficients of the 16 points go, scaled, to LDS --
         // [degree][point] pairs in the storage of the union scratch (D, hash table, slot tables: dead until the next
         // pass) -- for every degree that storage holds (the table is zero beyond an entry's degree): one memory round trip
-        // in all, none per recurrence step
+        // in all, none per recurrence step.  (SPL: unscaled -- the universal coefficients are O(1), which keeps the
+        // accumulated vectors in the range of the half-precision operands; the route's constants multiply the results)
         const int2 hd = ld_off<int2>(P.tab_hdr, (unsigned)tab_idx * 8u);
         {
           const unsigned cb = (unsigned)tab_idx * (unsigned)(kTabDeg * 8);
+          const float sphi = SPL ? 1.0f : P.cs_phi, spsi = SPL ? 1.0f : P.cs_psi;
           float2 cst[CQ];
 #pragma unroll
           for (int u = 0; u < CQ; ++u) cst[u] = ld_off<float2>(P.tab_c, cb + (unsigned)(hv + 4 * u < kTabDeg ? hv + 4 * u : kTabDeg - 1) * 8u);
 #pragma unroll
           for (int u = 0; u < CQ; ++u)
-            if (hv + 4 * u < CL) Cl[(hv + 4 * u) * 16 + lrv] = float2{cst[u].x * P.cs_phi, cst[u].y * P.cs_psi};
+            if (hv + 4 * u < CL) Cl[(hv + 4 * u) * 16 + lrv] = float2{cst[u].x * sphi, cst[u].y * spsi};
         }
         deg = hd.x;
-        alpha = __int_as_float(hd.y) * P.inv_reg;
+        if constexpr (SPL) alpha = __builtin_ldexpf(__int_as_float(hd.y) * P.inv_reg, esg);
+        else alpha = __int_as_float(hd.y) * P.inv_reg;
         decl = colact && (deg > P.dmax || deg > kTabDeg - 1);
         if (decl && hv == 0) {
           P.flags[p0v + lrv] = MIA_FLAG_RETRY;
@@ -522,26 +766,51 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
       //      D^2 in the products' right-hand side and once at the end; slots that are not local to a column (D = 0) carry
       //      bounded junk that D^2 = 0 keeps out of every product.  Two steps per trip, so that the three-term update swaps
       //      roles instead of moving registers.
+      //      SPL: the vectors are carried times a power of two per column (|v_0| -> 2^8; |v_j| <= sqrt(U) |v_0| stays far
+      //      inside the half-precision range); every step splits the 4 UT values D^2 o v_j of the lane.
       f4t va[UT], vb[UT], aphi[UT], apsi[UT], y[UT], d2[UT];
 #pragma unroll
       for (int t = 0; t < UT; ++t) d2[t] = dreg[t] * dreg[t];
+      // the right-hand side D^2 o tv of a 32-deep product, slots 16 (2 kb + tt) + 4 h + q of this lane's column, as half pairs
+      auto rhs_split = [&](const f4t (&tv)[UT], int kb, h8t& bh, h8t& bl) {
+        float bv[8];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int tk = 2 * kb + tt < UT ? 2 * kb + tt : 0;
+            bv[4 * tt + q] = 2 * kb + tt < UT ? d2[tk][q] * tv[tk][q] : 0.0f;
+          }
+        tile_split8(bv, bh, bl);
+      };
       auto product = [&](const f4t (&tv)[UT]) {
 #pragma unroll
         for (int t = 0; t < UT; ++t) y[t] = f4t{0.f, 0.f, 0.f, 0.f};
+        if constexpr (SPL) {
 #pragma unroll
-        for (int tk = 0; tk < UT; ++tk)
+          for (int kb = 0; kb < NKB; ++kb)
+            if (32 * kb < U) {
+              h8t bh, bl;
+              rhs_split(tv, kb, bh, bl);
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (16 * tk + 4 * q < U) {
-              const float b = d2[tk][q] * tv[tk][q];
-#pragma unroll
-              for (int t = 0; t < UT; ++t) y[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(G[tk][t][q], b, y[t], 0, 0, 0);
+              for (int t = 0; t < UT; ++t) y[t] = tile_mfma3(y[t], GAh[t][kb], GAl[t][kb], bh, bl);
             }
+        } else {
+#pragma unroll
+          for (int tk = 0; tk < UT; ++tk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (16 * tk + 4 * q < U) {
+                const float b = d2[tk][q] * tv[tk][q];
+#pragma unroll
+                for (int t = 0; t < UT; ++t) y[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(G[tk][t][q], b, y[t], 0, 0, 0);
+              }
+        }
       };
       auto coef = [&](int j) -> float2 {                              // (zero beyond a point's own degree)
         if (j < CL) return Cl[j * 16 + lrv];
         const float2 c = ld_off<float2>(P.tab_c, ((unsigned)tab_idx * (unsigned)kTabDeg + (unsigned)(j < kTabDeg ? j : kTabDeg - 1)) * 8u);
-        return float2{c.x * P.cs_phi, c.y * P.cs_psi};
+        return SPL ? c : float2{c.x * P.cs_phi, c.y * P.cs_psi};
       };
       // vnew = 2 (alpha y - vcur) - vold, written over vold; the two weight functions accumulate c_j vnew
       auto advance = [&](f4t (&vold)[UT], const f4t (&vcur)[UT], const float2 cj) {
@@ -553,10 +822,28 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
           apsi[t] = cj.y * vold[t] + apsi[t];
         }
       };
+      float inv_s2 = 1.0f;       // SPL: 1 / (power of two the column's vectors are carried at, relative to Z)
       {
         const float2 c0 = coef(0), c1 = coef(1);
+        if constexpr (SPL) {
+          unsigned zmax = 0u;
 #pragma unroll
-        for (int t = 0; t < UT; ++t) va[t] = Z[t];
+          for (int t = 0; t < UT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const unsigned a = __float_as_uint(Z[t][q]) & 0x7fffffffu;
+              zmax = a > zmax ? a : zmax;
+            }
+          zmax = __float_as_uint(tile_max_h(__uint_as_float(zmax)));
+          int es2;
+          const float s2 = tile_pow2_scale(zmax, 8, &es2);
+          inv_s2 = __uint_as_float((unsigned)(127 - es2) << 23);
+#pragma unroll
+          for (int t = 0; t < UT; ++t) va[t] = Z[t] * s2;
+        } else {
+#pragma unroll
+          for (int t = 0; t < UT; ++t) va[t] = Z[t];
+        }
         product(va);
 #pragma unroll
         for (int t = 0; t < UT; ++t) {
@@ -582,32 +869,87 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
       f4t xre[KT];
       load_x(mi, xre);
       f4t zacc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int tk = 0; tk < UT; ++tk)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (16 * tk + 4 * q < U) {
-            const float a = lrv == 0 ? Yw[(16 * tk + 4 * hv + q) * kp + k] : 0.0f;
-            zacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, d2[tk][q] * apsi[tk][q], zacc, 0, 0, 0);
-          }
-      const float zu = __shfl(zacc[0], lrv, 64);
-#pragma unroll
-      for (int t = 0; t < UT; ++t) aphi[t] *= d2[t];          // D o phi(S) z = D^2 o (accumulated v): right-hand side of the last product
-      const float mterm = xm + zu;
       f4t acc[KT];
+      float mterm;
+      if constexpr (SPL) {
+        // the results carry (scale of the records)^2 x (scale of x') x (scale of the vectors); the route's constants, left out of
+        // the coefficients, come in here
+        const float funs = (inv_s2 * inv_sx) * inv_sy * inv_sy;
+        // a record value as a half pair from its chunk: row = slot, value index v (member, or k = the innovation)
+        auto slot_of = [&](int kb, int i) -> unsigned { return (unsigned)(16 * (2 * kb + (i >> 2)) + 4 * hv + (i & 3)); };
+        auto a_frag = [&](int kb, int v, bool on, h8t& ah, h8t& al) {
+          const unsigned vo = (unsigned)(v >> 3) * 32u + (unsigned)(v & 7) * 2u;
 #pragma unroll
-      for (int tj = 0; tj < KT; ++tj) {
-        acc[tj] = f4t{0.f, 0.f, 0.f, 0.f};
+          for (int i = 0; i < 8; ++i) {
+            const bool have = 2 * kb + (i >> 2) < UT;
+            const _Float16* ph = reinterpret_cast<const _Float16*>(YwB + (have ? slot_of(kb, i) : 0u) * RSB + vo);
+            ah[i] = ph[0];
+            al[i] = ph[8];
+          }
+          if (!on) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { ah[i] = (_Float16)0.0f; al[i] = (_Float16)0.0f; }
+          }
+        };
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+          if (32 * kb < U) {
+            h8t ah, al, bh, bl;
+            a_frag(kb, k, lrv == 0, ah, al);
+            rhs_split(apsi, kb, bh, bl);
+            zacc = tile_mfma3(zacc, ah, al, bh, bl);
+          }
+        const float zu = __shfl(zacc[0], lrv, 64) * (P.cs_psi * funs);
+        mterm = xm + zu;
+        h8t ph_[NKB], pl_[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) rhs_split(aphi, kb, ph_[kb], pl_[kb]);
+        const float fo = P.cs_phi * funs;
+        const int vlast = 8 * P.nc - 1;
+#pragma unroll
+        for (int tj = 0; tj < KT; ++tj) {
+          acc[tj] = f4t{0.f, 0.f, 0.f, 0.f};
+          const int mem = 16 * tj + lrv;                 // the output row this lane supplies to the A operand
+#pragma unroll
+          for (int kb = 0; kb < NKB; ++kb)
+            if (32 * kb < U) {
+              h8t ah, al;
+              a_frag(kb, mem < vlast ? mem : vlast, true, ah, al);
+              acc[tj] = tile_mfma3(acc[tj], ah, al, ph_[kb], pl_[kb]);
+            }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc[tj][q] = acc[tj][q] * fo + (mterm + P.f0 * (xre[tj][q] - xm));
+            if (!(fabsf(acc[tj][q]) <= 1e30f) && (tj < KT - 1 || 16 * tj + 4 * hv + q < k)) pflag |= MIA_FLAG_NONFINITE;
+          }
+        }
+      } else {
 #pragma unroll
         for (int tk = 0; tk < UT; ++tk)
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            if (16 * tk + 4 * q < U)
-              acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(Yw[(16 * tk + 4 * hv + q) * kp + 16 * tj + lrv], aphi[tk][q], acc[tj], 0, 0, 0);
+            if (16 * tk + 4 * q < U) {
+              const float a = lrv == 0 ? Yw[(16 * tk + 4 * hv + q) * kp + k] : 0.0f;
+              zacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, d2[tk][q] * apsi[tk][q], zacc, 0, 0, 0);
+            }
+        const float zu = __shfl(zacc[0], lrv, 64);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc[tj][q] += mterm + P.f0 * (xre[tj][q] - xm);
-          if (!(fabsf(acc[tj][q]) <= 1e30f) && (tj < KT - 1 || 16 * tj + 4 * hv + q < k)) pflag |= MIA_FLAG_NONFINITE;
+        for (int t = 0; t < UT; ++t) aphi[t] *= d2[t];          // D o phi(S) z = D^2 o (accumulated v): right-hand side of the last product
+        mterm = xm + zu;
+#pragma unroll
+        for (int tj = 0; tj < KT; ++tj) {
+          acc[tj] = f4t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int tk = 0; tk < UT; ++tk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (16 * tk + 4 * q < U)
+                acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(Yw[(16 * tk + 4 * hv + q) * kp + 16 * tj + lrv], aphi[tk][q], acc[tj], 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc[tj][q] += mterm + P.f0 * (xre[tj][q] - xm);
+            if (!(fabsf(acc[tj][q]) <= 1e30f) && (tj < KT - 1 || 16 * tj + 4 * hv + q < k)) pflag |= MIA_FLAG_NONFINITE;
+          }
         }
       }
       if (colact && !decl) {
@@ -628,6 +970,7 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
       }
     }
     MIA_STAMP(8);
+    MIA_STAMP_REAL(11);
     {
       const unsigned long long fb = __ballot(pflag != 0);
       const bool anyf = ((fb >> lr) & 0x0001000100010001ull) != 0ull;
@@ -647,57 +990,65 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
 }
 
 #ifdef MIA_TILE_STAMPS
+#ifdef MIA_TILE_TU_SPLIT
+extern "C" int mia_debug_tile_split_stamps(long long* host, int n_tiles) {
+#else
 extern "C" int mia_debug_tile_stamps(long long* host, int n_tiles) {
+#endif
   if (n_tiles > kStampTiles) n_tiles = kStampTiles;
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tile_stamps), sizeof(long long) * kStampN * (size_t)n_tiles);
 }
 #endif
 
-static size_t tile_lds_bytes(int ut, int kp) {
+// rsb = 0: f32 records; otherwise the row stride of the split-precision layout
+static size_t tile_lds_bytes(int ut, int kp, int rsb) {
   const int umax = 16 * ut, hs = ut <= 1 ? 64 : (ut <= 2 ? 128 : 256);
-  return align_up(((size_t)umax * kp + 16 + 16 * (size_t)(umax + 4)) * sizeof(float) +
+  const size_t yw = rsb ? (size_t)umax * rsb : ((size_t)umax * kp + 16) * sizeof(float);
+  return align_up(yw + 16 * (size_t)(umax + 4) * sizeof(float) +
                   ((size_t)2 * hs + umax + 2 * (size_t)(umax > 64 ? umax : 64)) * sizeof(int), 16);
 }
 
-template <int UT, int KT, bool SEG>
+template <int UT, int KT, bool SEG, bool SPL>
 static int tile_launch_s(const TileParams& tp, hipStream_t stream) {
-  const size_t lds = tile_lds_bytes(UT, tp.kp);
+  const size_t lds = tile_lds_bytes(UT, tp.kp, SPL ? tp.rsb : 0);
   if (lds > kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
-  auto kern = letkf_tile_kernel<UT, KT, SEG>;
+  TileParams tpl = tp;
+  tpl.lds_bytes = (int)lds;
+  auto kern = letkf_tile_kernel<UT, KT, SEG, SPL>;
   if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t ntile = SEG ? (((int64_t)tp.seg_len + 15) >> 4) * ((tp.ng + tp.seg_len - 1) / tp.seg_len) : (tp.ng + 15) >> 4;
   const int64_t gx = ntile < 65536 ? ntile : 65536;
   const int64_t gy = (ntile + gx - 1) / gx;
   if (gy > 65535) return MIA_ERR_UNSUPPORTED;
-  kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64), lds, stream>>>(tp);
+  kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64), lds, stream>>>(tpl);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
 
 // Instantiations: UT <= KT + 1 (the dual route has p <= k, so a union of p + slack slots never needs more row blocks than
 // that); the segmented variant (step driver with several pieces) up to UT = 4.
-template <int UT, int KT>
+template <int UT, int KT, bool SPL>
 static int tile_launch_t(const TileParams& tp, hipStream_t stream) {
   if constexpr (UT <= KT + 1) {
     if (tp.seg_len > 0) {
-      if constexpr (UT <= 4 && KT <= 4) return tile_launch_s<UT, KT, true>(tp, stream);
+      if constexpr (UT <= 4 && KT <= 4) return tile_launch_s<UT, KT, true, SPL>(tp, stream);
       else return MIA_ERR_UNSUPPORTED;
     }
-    return tile_launch_s<UT, KT, false>(tp, stream);
+    return tile_launch_s<UT, KT, false, SPL>(tp, stream);
   } else {
     return MIA_ERR_UNSUPPORTED;
   }
 }
 
-template <int UT>
+template <int UT, bool SPL>
 static int tile_launch_u(const TileParams& tp, int kt, hipStream_t stream) {
   switch (kt) {
-    case 1: return tile_launch_t<UT, 1>(tp, stream);
-    case 2: return tile_launch_t<UT, 2>(tp, stream);
-    case 3: return tile_launch_t<UT, 3>(tp, stream);
-    case 4: return tile_launch_t<UT, 4>(tp, stream);
-    case 5: return tile_launch_t<UT, 5>(tp, stream);
-    case 6: return tile_launch_t<UT, 6>(tp, stream);
+    case 1: return tile_launch_t<UT, 1, SPL>(tp, stream);
+    case 2: return tile_launch_t<UT, 2, SPL>(tp, stream);
+    case 3: return tile_launch_t<UT, 3, SPL>(tp, stream);
+    case 4: return tile_launch_t<UT, 4, SPL>(tp, stream);
+    case 5: return tile_launch_t<UT, 5, SPL>(tp, stream);
+    case 6: return tile_launch_t<UT, 6, SPL>(tp, stream);
   }
   return MIA_ERR_UNSUPPORTED;
 }
@@ -706,21 +1057,18 @@ static int tile_launch_u(const TileParams& tp, int kt, hipStream_t stream) {
 // network add ~one observation per second point (config 2: 20 -> 28); below this slack most tiles would be split.
 constexpr int kTileSlack = 8;
 
-// Any number of state rows: the Gram matrix, the union and the coefficients are shared by the rows of a tile, a further row
-// costs Z + recurrence + output (C2, 1e5 points: 76 us for the first row, ~37 us per further row -- m = 8 / 16 / 32:
-// 0.34 / 0.63 / 1.23 ms against 0.76 / 0.92 / 1.61 ms of the 16-row MFMA batches of letkf_cheb_rows_kernel, which remains the
-// route of the shapes this kernel does not cover).
-bool tile_route_covers(int m, int k, int p_max) {
+static bool tile_shape_ok(int m, int k, int p_max) {
   return m >= 1 && k >= 2 && k <= 96 && p_max <= k && p_max + kTileSlack <= 96;
 }
 
-int tile_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
-                         const int32_t* nbr_cnt, const int32_t* nbr_idx, const void* nbr_w, int w_f32, int p_cap,
-                         int p_max, float inf_factor, float* Xa, int64_t ldo, int64_t o0, int32_t* flags,
-                         int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c, hipStream_t stream,
-                         int seg_len, int64_t seg_stride, int32_t* done) {
+template <bool SPL>
+static int tile_launch_impl(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
+                            const int32_t* nbr_cnt, const int32_t* nbr_idx, const void* nbr_w, int w_f32, int p_cap,
+                            int p_max, float inf_factor, float* Xa, int64_t ldo, int64_t o0, int32_t* flags,
+                            int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c, hipStream_t stream,
+                            int seg_len, int64_t seg_stride, int32_t* done) {
   if (seg_len > 0 && (!done || ng >= (int64_t)1 << 31)) return MIA_ERR_UNSUPPORTED;
-  if (!tile_route_covers(m, k, p_max) || !flags || !retry_count || !tab_hdr || !tab_c || w_f32) return MIA_ERR_UNSUPPORTED;
+  if (!tile_shape_ok(m, k, p_max) || !flags || !retry_count || !tab_hdr || !tab_c || w_f32) return MIA_ERR_UNSUPPORTED;
   // every global access is base + 32-bit byte offset: the largest offsets are a column of one state row block (k ld
   // floats), the record array, one tile's list rows
   if ((int64_t)k * ldx * 4 >= ((int64_t)1 << 31) || (int64_t)k * ldo * 4 >= ((int64_t)1 << 31) ||
@@ -742,17 +1090,49 @@ int tile_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
   tp.cs_psi = (float)(1.0 / rg);
   tp.kpv_magic = ((1 << 20) + (tp.kp >> 2) - 1) / (tp.kp >> 2);
   tp.seg_len = seg_len; tp.seg_stride = seg_stride; tp.done = done;
+  tp.nc = (k + 1 + 7) >> 3;                  // k members + the innovation, in chunks of eight
+  tp.rsb = 32 * tp.nc + 16;
   const int kt = (k + 15) >> 4;
   const int ut = (p_max + kTileSlack + 15) >> 4;
   switch (ut < 1 ? 1 : ut) {
-    case 1: return tile_launch_u<1>(tp, kt, stream);
-    case 2: return tile_launch_u<2>(tp, kt, stream);
-    case 3: return tile_launch_u<3>(tp, kt, stream);
-    case 4: return tile_launch_u<4>(tp, kt, stream);
-    case 5: return tile_launch_u<5>(tp, kt, stream);
-    case 6: return tile_launch_u<6>(tp, kt, stream);
+    case 1: return tile_launch_u<1, SPL>(tp, kt, stream);
+    case 2: return tile_launch_u<2, SPL>(tp, kt, stream);
+    case 3: return tile_launch_u<3, SPL>(tp, kt, stream);
+    case 4: return tile_launch_u<4, SPL>(tp, kt, stream);
+    case 5: return tile_launch_u<5, SPL>(tp, kt, stream);
+    case 6: return tile_launch_u<6, SPL>(tp, kt, stream);
   }
   return MIA_ERR_UNSUPPORTED;
 }
+
+#ifdef MIA_TILE_TU_SPLIT
+// (this translation unit = letkf_tile_split.hip: the split-precision instantiations, compiled beside the f32 ones)
+int tile_split_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
+                               const int32_t* nbr_cnt, const int32_t* nbr_idx, const void* nbr_w, int w_f32, int p_cap,
+                               int p_max, float inf_factor, float* Xa, int64_t ldo, int64_t o0, int32_t* flags,
+                               int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c, hipStream_t stream,
+                               int seg_len, int64_t seg_stride, int32_t* done) {
+  return tile_launch_impl<true>(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, w_f32, p_cap, p_max, inf_factor, Xa, ldo, o0,
+                                flags, retry_count, dmax, tab_hdr, tab_c, stream, seg_len, seg_stride, done);
+}
+#else
+// Any number of state rows: the Gram matrix, the union and the coefficients are shared by the rows of a tile, a further row
+// costs Z + recurrence + output (C2, 1e5 points: 76 us for the first row, ~37 us per further row -- m = 8 / 16 / 32:
+// 0.34 / 0.63 / 1.23 ms against 0.76 / 0.92 / 1.61 ms of the 16-row MFMA batches of letkf_cheb_rows_kernel, which remains the
+// route of the shapes this kernel does not cover).
+bool tile_route_covers(int m, int k, int p_max) { return tile_shape_ok(m, k, p_max); }
+
+int tile_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
+                         const int32_t* nbr_cnt, const int32_t* nbr_idx, const void* nbr_w, int w_f32, int p_cap,
+                         int p_max, float inf_factor, float* Xa, int64_t ldo, int64_t o0, int32_t* flags,
+                         int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c, hipStream_t stream,
+                         int seg_len, int64_t seg_stride, int32_t* done) {
+  if (option(MIA_OPT_TILE_SPLIT))
+    return tile_split_analysis_launch(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, w_f32, p_cap, p_max, inf_factor, Xa, ldo,
+                                      o0, flags, retry_count, dmax, tab_hdr, tab_c, stream, seg_len, seg_stride, done);
+  return tile_launch_impl<false>(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, w_f32, p_cap, p_max, inf_factor, Xa, ldo, o0,
+                                 flags, retry_count, dmax, tab_hdr, tab_c, stream, seg_len, seg_stride, done);
+}
+#endif
 
 }  // namespace mia

@@ -38,6 +38,13 @@ int tile_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
                          int p_max, float inf_factor, float* Xa, int64_t ldo, int64_t o0, int32_t* flags,
                          int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c, hipStream_t stream,
                          int seg_len = 0, int64_t seg_stride = 0, int32_t* done = nullptr);
+// (letkf_tile_split.hip) the same launch on the split-precision instantiations: every product on v_mfma_f32_16x16x32_f16
+// with operands carried as pairs of halves; tile_analysis_launch forwards here when the option tile_split is on
+int tile_split_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
+                               const int32_t* nbr_cnt, const int32_t* nbr_idx, const void* nbr_w, int w_f32, int p_cap,
+                               int p_max, float inf_factor, float* Xa, int64_t ldo, int64_t o0, int32_t* flags,
+                               int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c, hipStream_t stream,
+                               int seg_len, int64_t seg_stride, int32_t* done);
 
 // one-wave kernel on `stream` that returns once the 64 slot counters at done64[j * kSlotStride] sum to `expected` (bounded
 // polling: after ~seconds it sets bit 0 of *err and returns, so the grid always drains)
