@@ -35,6 +35,7 @@ GC_RADIUS = 10.0
 INF = 1.1
 G_PER_GPU = 100000
 PEAK_FP32_TFLOPS = 157.3     # MI355X FP32 vector = FP32 MFMA peak (MI355X_MICROARCH.md)
+PEAK_F16_TFLOPS = 2516.8      # dense F16 / BF16 MFMA: 16 x the F32 rate (same guide)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -53,6 +54,18 @@ def executed_flops(k, p, m, deg, kernel="tile"):
     point (letkf_cheb_kernel): Gram on 16x16x4 tiles over the padded order, z / output products, recurrence."""
     if not deg:
         return None
+    if kernel == "tile_split":
+        # split-precision instantiations: every product is THREE v_mfma_f32_16x16x32_f16 (hi hi, hi lo, lo hi; 16384 flop
+        # each) per pair of 16-row blocks and 32 summation indices; the Gershgorin product takes one.  Returned: the f32
+        # products these implement (one per triple), padding included, + the vector-unit update -- `f16` (second value)
+        # is what the matrix cores execute
+        ut, kt, u = (p + 8 + 15) // 16, (k + 15) // 16, p + 8
+        nb, nkb = (kt + 1) // 2, (u + 31) // 32
+        dmax = int(deg + 0.999)
+        triples = ut * ut * nb + m * (ut * nb + dmax * ut * nkb + nkb + kt * nkb)
+        singles = ut * nkb
+        valu = m * dmax * 16 * ut * 16 * 10
+        return ((triples + singles) * 16384 + valu) / 16.0, (3 * triples + singles) * 16384 / 16.0
     if kernel == "tile":
         ut, kt, u = (p + 8 + 15) // 16, (k + 15) // 16, p + 8
         nks = (u + 3) // 4
@@ -328,14 +341,12 @@ def main():
 
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
-
     import torch_assimilate_amd as mia
     from torch_assimilate_amd.sharded import ShardedLetkf
     mia.build()
+    for opt in os.environ.get("MIA_BENCH_OPTIONS", "").split():       # A/B runs of tools/ab_options.sh: name=value ...
+        from torch_assimilate_amd import _cabi
+        _cabi.set_option(opt.split("=")[0], int(opt.split("=")[1]))
     gpg = args.grid_per_gpu
     G = gpg * world
     X, grid_x, obs_x, Yb, d = make_case(G, K_ENS, OBS_STRIDE, device)
@@ -421,15 +432,18 @@ def main():
     p_max = runner.last_p_max
     deg = runner.mean_degree()
     kname = runner.dominant_kernel_name
-    kkind = "tile" if "tile" in kname else "point"
+    kkind = ("tile_split" if "true>" in kname else "tile") if "tile" in kname else "point"
 
     def rates(k, p, m, dg, n_pts, ms, kind):
         """executed / useful / reference-credit flop rates of one launch of n_pts analyses in `ms`"""
         ex, us = executed_flops(k, p, m, dg, kind), useful_flops(k, p, m, dg)
+        f16 = None
+        if isinstance(ex, tuple):
+            ex, f16 = ex
         tf = lambda f: None if f is None else f * n_pts / (ms * 1e-3) / 1e12
-        return ex, us, tf(ex), tf(us), tf(algorithmic_flops(k, p, m))
+        return ex, us, tf(ex), tf(us), tf(algorithmic_flops(k, p, m)), f16, tf(f16)
 
-    ex_f, us_f, ex_tf, us_tf, credit_tf = rates(K_ENS, 20, 1, deg, gpg, kern_ms, kkind)
+    ex_f, us_f, ex_tf, us_tf, credit_tf, f16_f, f16_tf = rates(K_ENS, 20, 1, deg, gpg, kern_ms, kkind)
     hbm_alg = algorithmic_bytes(K_ENS, 1, P / G) * gpg / (kern_ms * 1e-3) / 1e9
 
     # secondary figure: the fused Jacobi-eigensolver route on the same shard (kernel only)
@@ -484,10 +498,15 @@ def main():
                    "rel_frobenius_error_64_points_vs_oracle": float(np.linalg.norm(got - ref) / np.linalg.norm(ref)),
                    "reference_algorithm_credit_TFLOPs": algorithmic_flops(k2, pm2, 1) * gpg / (ms2 * 1e-3) / 1e12}
             if gamma2 is None and deg2:
-                kk = "tile" if (k2 <= 96 and pm2 + 8 <= 96) else "point"
+                kk = (kkind if kkind != "point" else "tile") if (k2 <= 96 and pm2 + 8 <= 96) else "point"
                 exf = executed_flops(k2, pm2, 1, deg2, kk)
+                if isinstance(exf, tuple):
+                    rec.update(f16_mfma_flops_per_analysis=exf[1],
+                               matrix_core_frac=exf[1] * gpg / (ms2 * 1e-3) / 1e12 / PEAK_F16_TFLOPS)
+                    exf = exf[0]
                 rec.update(executed_flops_per_analysis=exf, executed_frac=exf * gpg / (ms2 * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
-                           kernel="letkf_tile_kernel" if kk == "tile" else "letkf_cheb_kernel (one grid point per wavefront)")
+                           kernel="letkf_tile_kernel (%s)" % ("split half-precision products" if kk == "tile_split" else "f32 products")
+                                  if kk != "point" else "letkf_cheb_kernel (one grid point per wavefront)")
             secondary[name] = rec
 
     if rank == 0:
@@ -506,9 +525,18 @@ def main():
                        "ranks": world},
             # frac <= 1 by construction: flops the kernel EXECUTES (MFMA tiles incl. padding + the vector-unit update),
             # per launch, over the measured launch duration, against the fp32 peak (vector = f32-MFMA = 157.3 TFLOP/s)
-            "roofline": {"bound": "mfma" if kkind == "tile" else "valu_issue",
+            "roofline": {"bound": "mfma" if kkind != "point" else "valu_issue",
                          "achieved": ex_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": None if ex_tf is None else ex_tf / PEAK_FP32_TFLOPS,
+                         "frac_basis": ("f32-equivalent: the f32 products (padding included) that the kernel's split half-precision "
+                                        "MFMA triples implement + its vector-unit update, against the f32 peak -- the rate an "
+                                        "ideal f32-MFMA kernel of the same products could reach; the matrix cores themselves: "
+                                        "matrix_core") if kkind == "tile_split" else
+                                       "flops the kernel executes (f32 MFMA tiles incl. padding + vector-unit update) against the f32 peak",
+                         "matrix_core": None if f16_tf is None else {
+                             "executed_f16_mfma_flops_per_analysis": f16_f, "achieved": f16_tf, "peak": PEAK_F16_TFLOPS,
+                             "unit": "TFLOP/s", "frac": f16_tf / PEAK_F16_TFLOPS,
+                             "note": "v_mfma_f32_16x16x32_f16, three per f32 product; no longer what bounds the kernel"},
                          "executed_flops_per_analysis": ex_f,
                          "useful_flops_per_analysis": us_f, "useful_TFLOPs": us_tf,
                          "useful_frac": None if us_tf is None else us_tf / PEAK_FP32_TFLOPS,
@@ -527,9 +555,11 @@ def main():
                                              if loop_kernel_ms else "burst of 5 launches after the timed loop",
                          "kernel_ms_alone": alone_ms,
                          "hbm_algorithmic_GBs": hbm_alg, "hbm_frac": hbm_alg / PEAK_HBM_GBS,
-                         "note": "the matrix cores do every contraction (16 grid points per wavefront share one Gram matrix); "
-                                 "profiles/r02_*_pmc.json: MFMA pipe ~32 % busy, VALU ~29 %: the kernel is latency-bound between "
-                                 "them at 3 wavefronts per SIMD, MFMA pipe time is its floor"},
+                         "note": "the matrix cores do every contraction (16 grid points per wavefront share one Gram matrix).  f32 "
+                                 "MFMAs share the FP32 pipe with the vector instructions (never overlap: tools/mfma_rate.hip), so "
+                                 "the products run as split half-precision MFMAs (16 cycles per 16x16x32, beside the vector unit) "
+                                 "at f32 accuracy; what bounds the kernel now is vector issue + the latency of its prologue "
+                                 "(lists, union, gather) at 3 wavefronts per SIMD: profiles/r02_v5_*"},
             "route": {"method": args.method, "mean_chebyshev_degree": deg, "declined_points_last_step": runner.last_retries,
                       "eigensolver_route_kernel_ms": eig_ms,
                       "eigensolver_route_kernel_analyses_per_s": (gpg / (eig_ms * 1e-3)) if eig_ms else None},

@@ -73,6 +73,7 @@ const char* mia_status_string(int status);
  *   "tile_split"       1  the products of that kernel as split-precision half MFMAs (f32 operands carried as pairs of halves,
  *                         f32 accumulation; same accuracy as f32 MFMAs) / 0: f32 MFMAs (results then do
  *                         not depend on which tile a grid point falls into, bit for bit)
+ *   "localize_quad"    1  neighbour lists (capacity < 64): four lanes per grid point / 0: one thread per grid point (same lists)
  *   "segment_signal"   1  step driver with several pieces: one segmented launch / 0: one launch + event per piece
  * Returns MIA_ERR_UNSUPPORTED for an unknown name, MIA_ERR_SIZE for a value out of range. */
 int mia_set_option(const char* name, int value);
@@ -460,6 +461,9 @@ int mia_letkf_step_readback(const int32_t* counters, int32_t* host8, void* after
 int mia_event_synchronize(void* event);
 int mia_stream_wait_event(void* stream, void* event);
 int mia_event_destroy(void* event);
+/* Host time the library's two launch threads have spent enqueueing since start-up (microseconds; preparation stage and
+ * analysis / exchange / read-back stage) and the number of steps handed to them. */
+int mia_letkf_step_launch_stats(double* prep_us, double* rest_us, long long* steps);
 int mia_comm_set_place_stream(mia_comm_t* comm, void* stream);
 /* Direct exchange (csrc/sharded_step.hip, "Direct exchange"): library-owned, peer-mapped result buffers, so that every rank
  * writes its block of the analysis ensemble straight into all peers' (m, k, G) result over its xGMI links -- no ring, no
@@ -504,6 +508,10 @@ int mia_letkf_sharded_step_f32(const float* X /* [m][k][G] */, int64_t G, int m,
  * exchange at the end (the next step's analysis need not wait for this step's all-gather): the result and
  * counters[4..7] are then complete once comm_stream has drained, which the caller orders itself. */
 #define MIA_STEP_NO_JOIN 1
+/* MIA_STEP_WS_CLEAN: the caller guarantees that `ws` was last used by a COMPLETED step of this entry with the same sizes
+ * and has not been written since: the observation index then needs no fill launch (its kernels leave the header as they
+ * found it).  Never set it for a fresh or recycled allocation. */
+#define MIA_STEP_WS_CLEAN 4
 int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int m, int k,
                                        const float* Yb, const float* d, int64_t P,
                                        const double* grid_xyz, const double* obs_xyz,

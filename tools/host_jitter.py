@@ -37,3 +37,7 @@ for rep in range(3):
     big = sorted(range(n), key=lambda i: -tot[i])[:6]
     print("rep %d: %.4f ms/step   submit mean %.1f us  result mean %.1f us   gc counts %s" % (rep, 1e3 * el / n, 1e6 * sum(ts) / n, 1e6 * sum(tr) / n, gc.get_count()))
     print("   largest steps:", ", ".join("#%d submit %.0f us result %.0f us" % (i, 1e6 * ts[i], 1e6 * tr[i]) for i in big), flush=True)
+import ctypes as C
+a, b, nj = C.c_double(), C.c_double(), C.c_longlong()
+r.engine.lib.mia_letkf_step_launch_stats(C.byref(a), C.byref(b), C.byref(nj))
+print("launch threads: preparation stage %.1f us per step, analysis + read-back stage %.1f us per step (%d steps)" % (a.value / nj.value, b.value / nj.value, nj.value))

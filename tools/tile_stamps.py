@@ -11,7 +11,11 @@ mia.build()
 dev = torch.device("cuda:0")
 eng = mia.LetkfEngine(dev)
 lib = C.CDLL(mia.LIB_PATH)
-names = ["lists req", "lists+X req -> union", "gather", "D scatter + dreg", "X wait + Gram + Z", "Gershgorin + table + coef", "recurrence", "zu + output", "flags"]
+names = ["lists req", "lists+X req -> union", "gather", "convert + D scatter + dreg", "X wait + Gram + Z", "Gershgorin + table + coef", "recurrence", "zu + output", "flags"]
+from torch_assimilate_amd import _cabi
+SPLIT = int(os.environ.get("TILE_SPLIT", "1"))
+_cabi.set_option("tile_split", SPLIT)
+fetch = lib.mia_debug_tile_split_stamps if SPLIT else lib.mia_debug_tile_stamps
 for G in [int(a) for a in sys.argv[1:]] or [16, 100000]:
     X, gx, ox, Yb, d = bench.make_case(G, 40, 2, dev)
     nb = eng.localize(gx, ox, [10.0])
@@ -21,7 +25,7 @@ for G in [int(a) for a in sys.argv[1:]] or [16, 100000]:
     torch.cuda.synchronize()
     nt = min((G + 15) // 16, 8192)
     buf = np.zeros((nt, 12), dtype=np.int64)
-    assert lib.mia_debug_tile_stamps(buf.ctypes.data_as(C.c_void_p), nt) == 0
+    assert fetch(buf.ctypes.data_as(C.c_void_p), nt) == 0
     dt = np.diff(buf[:, :9], axis=1).astype(np.float64)
     os.makedirs('gpurun_out', exist_ok=True)
     np.save('gpurun_out/tile_stamps_%d.npy' % G, buf)

@@ -98,6 +98,7 @@ _PROTOS = {
     "mia_event_synchronize": ([vp], i32),
     "mia_stream_wait_event": ([vp, vp], i32),
     "mia_event_destroy": ([vp], i32),
+    "mia_letkf_step_launch_stats": ([C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)], i32),
     "mia_comm_peer_alloc": ([vp, sz, i32, vp], i32),
     "mia_comm_peer_open": ([vp, vp], i32),
     "mia_comm_peer_attach": ([vp, i32, C.POINTER(vp), vp], i32),

@@ -311,19 +311,33 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
     };
     // SPL: member (b, i) of lane group h = 32 b + 8 h + i (the summation index of a 32-deep product: lane group h supplies
     // eight consecutive values), column lr
-    auto load_xs = [&](int mi, float (&xr)[NB][8]) {
+    // (ONE lane offset per member block -- the lane group's first member -- and a wave-uniform row pointer that walks the
+    //  eight members: sixteen per-lane offsets would be hoisted out of the state-row loop and spilled.  A chunk without
+    //  any member reads the block's first chunk instead; an ensemble size that is not a multiple of eight clamps per value)
+    auto load_xs = [&](int mi, int hh, float (&xr)[NB][8]) {
       const float* xbase = P.X + (int64_t)mi * k * P.ldx + P.g0 + p0v;
 #pragma unroll
-      for (int b = 0; b < NB; ++b)
+      for (int b = 0; b < NB; ++b) {
+        const float* pr = xbase + (int64_t)(32 * b) * P.ldx;
+        if (b < NB - 1 || (k & 7) == 0) {
+          const unsigned vo = (unsigned)(32 * b + 8 * hh < k ? 8 * hh : 0) * ldxb + (unsigned)lrc * 4u;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int mem = 32 * b + 8 * h + i;
-          xr[b][i] = ld_off<float>(xbase, (unsigned)(mem < k ? mem : k - 1) * ldxb + (unsigned)lrc * 4u);
+          for (int i = 0; i < 8; ++i) {
+            xr[b][i] = ld_off<float>(pr, vo);
+            pr += P.ldx;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int mem = 32 * b + 8 * hh + i;
+            xr[b][i] = ld_off<float>(xbase, (unsigned)(mem < k ? mem : k - 1) * ldxb + (unsigned)lrc * 4u);
+          }
         }
+      }
     };
     f4t xb[KT];
     float xsb[NB][8];
-    if constexpr (SPL) load_xs(0, xsb);
+    if constexpr (SPL) load_xs(0, h, xsb);
     else load_x(0, xb);
     MIA_STAMP(1);
 
@@ -544,7 +558,7 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
       float inv_sx = 1.0f;          // SPL: 1 / (power of two that scaled this column's x')
       h8t xh[NB], xl[NB];           // SPL: x' of the column as half pairs, member block b
       if constexpr (SPL) {
-        if (mi > 0) load_xs(mi, xsb);
+        if (mi > 0) load_xs(mi, hv, xsb);
         float xs = 0.0f;
 #pragma unroll
         for (int b = 0; b < NB; ++b)

@@ -37,6 +37,7 @@ struct IndexParams {
   unsigned nb_bbox;      // workgroups of the first kernel that reduce the bounding box ...
   PackJob pack;          // ... the others (if any) pack observation records (pack.rec != nullptr)
   ZeroJob zero;          // small caller buffers cleared by the first kernel (saves their fill launches)
+  uint32_t* cells; size_t cell_words;   // start + cursor: cleared by the first kernel too (their first user is the second)
 };
 
 __device__ inline unsigned long long dkey(double x) {     // total order of doubles as unsigned integers
@@ -59,6 +60,10 @@ __device__ inline void index_dims(const IndexParams& p) {
     const unsigned long long kmax_c = __hip_atomic_load(&p.hdr->kmax[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long kmin_c = __hip_atomic_load(&p.hdr->kmin_inv[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (kmax_c != 0ull) { mx = dkey_inv(kmax_c); mn = dkey_inv(~kmin_c); }
+    // (the extrema have been read by their only reader: back to zero, which is what the next build on this workspace
+    //  starts from -- the chain leaves the header as it found it and needs no fill launch per step)
+    __hip_atomic_store(&p.hdr->kmax[c], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&p.hdr->kmin_inv[c], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     p.hdr->mn[c] = mn;
     ext[c] = mx - mn;
     h[c] = p.cutoff[c] > 0.0 ? p.cutoff[c] : 1.0;
@@ -80,6 +85,7 @@ __device__ inline void index_dims(const IndexParams& p) {
   }
   for (int c = p.nc; c < MIA_MAX_COORD; ++c) { p.hdr->invh[c] = 1.0; p.hdr->n[c] = 1; }
   p.hdr->ncell = int(n[0] * n[1] * n[2]);
+  __hip_atomic_store(&p.hdr->done_bbox, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // bounding box of the observations: wave + workgroup reduction, one pair of 64-bit atomics per
@@ -97,6 +103,7 @@ __global__ __launch_bounds__(256) void index_bbox_dims_kernel(IndexParams p) {
   const int64_t stride = (int64_t)p.nb_bbox * blockDim.x;
   for (int q = 0; q < 3; ++q)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < p.zero.n[q]; i += stride) p.zero.ptr[q][i] = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < p.cell_words; i += (size_t)stride) p.cells[i] = 0u;
   for (int c = 0; c < p.nc; ++c) {
     unsigned long long kx = 0ull, kn = 0ull;
     for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < p.P; j += stride) {
@@ -134,11 +141,10 @@ __device__ inline int obs_cell(const IndexHeader* h, const double* x, int nc) {
 
 // exclusive scan of start[0 .. ncell] (entry ncell receives the total) by ONE wavefront, in tiles of 16 entries per
 // lane: the 16 loads of a lane are independent (one memory round trip per tile), the wave scan runs on shuffles and the
-// carry stays in a register.  A launch of its own with a single-wave workgroup, not the tail of the counting kernel's
-// last 256-thread workgroup as it used to be: when consecutive steps are pipelined these kernels run beside the
-// previous step's analysis kernel, which keeps 6 waves x 80 VGPRs on every SIMD.  That leaves 32 VGPRs per SIMD, so
-// a 4-wave workgroup that needs more (the fused kernel took 61) finds no CU until the analysis grid has drained
-// (160 us instead of 22), while a single wave gets the slot of the next analysis wave that retires.
+// carry stays in a register.  A launch of its own with a single-wave workgroup.  (Not the tail of the counting kernel:
+// as the tail of its last 256-thread workgroup it waited for four wave slots on one CU beside a bulk kernel -- 160 us
+// instead of 22; as the tail of the last of its single-wave workgroups it had to read the other workgroups' counts with
+// agent-scope loads, and count + scan took 52 us beside the analysis kernel instead of 10 + 19.)
 __global__ __launch_bounds__(64) void index_scan_kernel(IndexParams p) {
   MIA_PREP_PRIORITY();
   constexpr int T = 16;
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(64) void index_clear_kernel(uint32_t* p, size_t n) 
 
 // cell of every observation + per-cell counts.  256-thread workgroups of 15 VGPRs: they fit beside the analysis
 // kernel's waves (see index_scan_kernel).
-__global__ __launch_bounds__(256) void index_count_kernel(IndexParams p) {
+__global__ __launch_bounds__(64) void index_count_kernel(IndexParams p) {
   MIA_PREP_PRIORITY();
   const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (j < p.P) {
@@ -328,6 +334,85 @@ __global__ __launch_bounds__(64) void localize_kernel(LocalizeParams p) {
   }
 }
 
+// FOUR LANES per grid point (sixteen points per wavefront): the candidate loop of localize_kernel, which evaluates four
+// candidates per trip in every lane, spread over a quad -- one candidate per lane and trip, survivors compacted in lane
+// order with a ballot, so the lists come out identical (cell order, ascending index inside a cell, same weights).  Four
+// times as many wavefronts, each a quarter as long and half the registers: alone on the GPU the thread-per-point kernel
+// runs at 1.5 waves per SIMD (1563 waves for 1e5 points) and is all latency; beside the analysis kernel of an earlier step
+// (pipelined steps) its long-lived 106-register waves each kept a 168-register analysis wave out of its SIMD.
+__global__ __launch_bounds__(64) void localize_quad_kernel(LocalizeParams p) {
+  MIA_PREP_PRIORITY();
+  const int lane = threadIdx.x, sub = lane & 3;
+  const int64_t pt = blockIdx.x * (int64_t)16 + (lane >> 2);
+  const unsigned qshift = (unsigned)(lane & ~3);
+  int count = 0;
+  if (pt < p.ng) {
+    const ScanParams& q = p.scan;
+    const IndexHeader* h = q.hdr;
+    const int nc = q.nc;
+    double gx[MIA_MAX_COORD];
+    int cg[MIA_MAX_COORD];
+    for (int c = 0; c < MIA_MAX_COORD; ++c) { gx[c] = 0.0; cg[c] = 0; }
+    for (int c = 0; c < nc; ++c) {
+      gx[c] = q.grid[(p.g0 + pt) * nc + c];
+      cg[c] = cell_coord(gx[c], h->mn[c], h->invh[c], h->n[c]);
+    }
+    int* my_idx = p.idx + pt * p.p_cap;
+    double* my_w = p.w + pt * p.p_cap;
+    const int n_outer = nc == 1 ? 1 : (nc == 2 ? 3 : 9);
+    const int last = nc - 1;
+    int lo_l = cg[last] - 1, hi_l = cg[last] + 1;
+    lo_l = lo_l < 0 ? 0 : lo_l;
+    hi_l = hi_l > h->n[last] - 1 ? h->n[last] - 1 : hi_l;
+    for (int o = 0; o < n_outer; ++o) {
+      int base_cell = 0;
+      bool ok = lo_l <= hi_l;
+      if (nc >= 2) {
+        const int d0 = (nc == 2) ? (o - 1) : (o / 3 - 1);
+        const int c0 = cg[0] + d0;
+        ok = ok && c0 >= 0 && c0 < h->n[0];
+        base_cell = c0;
+        if (nc == 3) {
+          const int c1 = cg[1] + (o % 3 - 1);
+          ok = ok && c1 >= 0 && c1 < h->n[1];
+          base_cell = base_cell * h->n[1] + c1;
+        }
+        base_cell *= h->n[last];
+      }
+      if (!ok) continue;
+      const int beg = q.start[base_cell + lo_l], end = q.start[base_cell + hi_l + 1];
+      for (int pos0 = beg; pos0 < end; pos0 += 4) {          // (the same bounds in the four lanes of a quad)
+        const bool have = pos0 + sub < end;
+        const int pos = have ? pos0 + sub : end - 1;
+        const int oj = q.sorted[pos];
+        double d2[MIA_MAX_RADII] = {0.0, 0.0, 0.0};
+        for (int c = 0; c < nc; ++c) {
+          const double dx = q.sxyz[(int64_t)pos * nc + c] - gx[c];
+          d2[q.group[c]] += dx * dx;
+        }
+        double wgt = 1.0;
+        for (int r = 0; r < q.n_r; ++r) wgt *= taper_d2(q.taper, d2[r], q.inv_c[r], q.cc[r]);
+        const bool use = have && wgt > q.eps;
+        const unsigned quad = (unsigned)(__ballot(use) >> qshift) & 0xfu;
+        if (use) {
+          const int slot = count + __popc(quad & ((1u << sub) - 1u));
+          if (slot < p.p_cap) { my_idx[slot] = oj; my_w[slot] = wgt * rsqrt_f64(wgt); }
+        }
+        count += __popc(quad);
+      }
+    }
+    for (int s_ = count + sub; s_ < p.p_cap; s_ += 4) { my_idx[s_] = -1; my_w[s_] = 0.0; }
+    if (sub == 0) p.cnt[pt] = count;
+  }
+  // statistics: one (conditional) atomic per wavefront
+  int mx = count, over = (pt < p.ng && sub == 0 && count > p.p_cap) ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) { const int a = __shfl_xor(mx, o, 64); mx = a > mx ? a : mx; over += __shfl_xor(over, o, 64); }
+  if (lane == 0) {
+    if (mx > __hip_atomic_load(&p.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&p.stats[0], mx);
+    if (over) atomicAdd(&p.stats[1], over);
+  }
+}
+
 // One WAVEFRONT per grid point, for long lists (dense observation networks): the thread-per-point kernel above walks a
 // list of several hundred candidates serially in every lane (p ~ 1000: 13 ms for 2e4 points, 20x the analysis itself);
 // here 64 candidates are evaluated per trip and compacted with a ballot (scan_neighbours, the routine the fused
@@ -415,7 +500,7 @@ static int taper_launch(const T* r, int64_t n, T* w, hipStream_t stream) {
 // builds the cell index of the observations in ws (all kernels enqueued on stream)
 int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_t* coord_group,
                      const double* gc_c, int n_r, void* ws, size_t ws_bytes, hipStream_t stream, const PackJob* pack,
-                     const ZeroJob* zero) {
+                     const ZeroJob* zero, bool header_clean) {
   if (P < 0 || n_coord < 1 || n_coord > MIA_MAX_COORD || n_r < 1 || n_r > MIA_MAX_RADII) return MIA_ERR_SIZE;
   if (P > 2000000000LL) return MIA_ERR_UNSUPPORTED;
   if (!coord_group || !gc_c) return MIA_ERR_NULL;
@@ -437,14 +522,18 @@ int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_
   constexpr unsigned kPrepThreads = 64;
   const unsigned nbP = (unsigned)((P + kPrepThreads - 1) / kPrepThreads);
   ip.nb_bbox = nbP < 256 ? nbP : 256;
-  {   // header, start and cursor are adjacent: one fill clears all three (a kernel of single-wave workgroups, not
-      // hipMemsetAsync: the runtime's fill kernel has 256-thread workgroups and waited 30-60 us for a CU, see above)
-    const size_t words = ((char*)ip.sorted - (char*)ip.hdr) / sizeof(uint32_t);
-    const unsigned nb = (unsigned)((words + kPrepThreads * 16 - 1) / (kPrepThreads * 16));
-    index_clear_kernel<<<dim3(nb < 1024 ? (nb ? nb : 1) : 1024), dim3(kPrepThreads), 0, stream>>>(
-        reinterpret_cast<uint32_t*>(ip.hdr), words);
+  // The chain reads the header's extrema / completion counters as running maxima / counts from zero and puts them back to
+  // zero once read; the per-cell tables (start, cursor: adjacent) are cleared by the first kernel, whose successor is
+  // their first user.  So a workspace whose last use was a complete build (header_clean: the step driver's slots) needs
+  // no fill launch at all; any other gets a one-wave fill of the header (not hipMemsetAsync: the runtime's fill kernel has
+  // 256-thread workgroups and waited 30-60 us for a CU beside a bulk kernel).
+  if (!header_clean) {
+    index_clear_kernel<<<dim3(1), dim3(kPrepThreads), 0, stream>>>(reinterpret_cast<uint32_t*>(ip.hdr),
+                                                                   ((char*)ip.start - (char*)ip.hdr) / sizeof(uint32_t));
     MIA_LAUNCH_CHECK();
   }
+  ip.cells = reinterpret_cast<uint32_t*>(ip.start);
+  ip.cell_words = ((char*)ip.sorted - (char*)ip.start) / sizeof(uint32_t);
   ip.pack = PackJob{nullptr, nullptr, nullptr, 0, 0};
   ip.zero = zero ? *zero : ZeroJob{{nullptr, nullptr, nullptr}, {0, 0, 0}};
   unsigned nb_pack = 0;
@@ -486,7 +575,8 @@ int make_scan_params(ScanParams* sp, const double* grid_xyz, int64_t P, int n_co
 int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* obs_xyz, int64_t P, int n_coord,
                   const int32_t* coord_group, const double* gc_c, int n_r, double gc_eps, int p_cap,
                   int32_t* nbr_cnt, int32_t* nbr_idx, double* nbr_w, int32_t* stats, void* ws, size_t ws_bytes,
-                  hipStream_t stream, const PackJob* pack, bool stats_zeroed, const ZeroJob* zero, int taper) {
+                  hipStream_t stream, const PackJob* pack, bool stats_zeroed, const ZeroJob* zero, int taper,
+                  bool header_clean) {
   if (g1 < g0 || g0 < 0 || P < 0) return MIA_ERR_SIZE;
   if (n_coord < 1 || n_coord > MIA_MAX_COORD || n_r < 1 || n_r > MIA_MAX_RADII || p_cap < 1) return MIA_ERR_SIZE;
   if (!coord_group || !gc_c || !stats) return MIA_ERR_NULL;
@@ -502,7 +592,7 @@ int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* 
     MIA_HIP_TRY(hipMemsetAsync(nbr_w, 0, ng * (size_t)p_cap * sizeof(double), stream));
     return MIA_OK;
   }
-  int rc = index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, ws, ws_bytes, stream, pack, zero);
+  int rc = index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, ws, ws_bytes, stream, pack, zero, header_clean);
   if (rc != MIA_OK) return rc;
   LocalizeParams lp;
   rc = make_scan_params(&lp.scan, grid_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, ws, taper);
@@ -513,6 +603,13 @@ int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* 
   // enough to place one, whereas a 4-wave workgroup waited for four slots on one CU (200 us instead of 35)
   if (p_cap >= 64 && ng <= 2147483647LL && !MIA_EXP_FLAG("MIA_LOCALIZE_THREAD")) {   // long lists: one wavefront per grid point
     localize_wave_kernel<<<dim3((unsigned)ng), dim3(64), 0, stream>>>(lp);
+    MIA_LAUNCH_CHECK();
+    return MIA_OK;
+  }
+  if (mia::option(MIA_OPT_LOCALIZE_QUAD)) {       // four lanes per grid point
+    const int64_t nbq = (ng + 15) / 16;
+    if (nbq > 2147483647LL) return MIA_ERR_UNSUPPORTED;
+    localize_quad_kernel<<<dim3((unsigned)nbq), dim3(64), 0, stream>>>(lp);
     MIA_LAUNCH_CHECK();
     return MIA_OK;
   }

@@ -13,6 +13,7 @@
 // HIP runtime.
 #include <dlfcn.h>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -564,7 +565,7 @@ thread_local hipEvent_t t_time_start = nullptr, t_time_stop = nullptr;
 
 // events that order the preparation stream before the analysis stream (no communicator, hence no event storage of
 // its own, on the single-rank route): a small ring, created on first use
-hipEvent_t g_prep_ev[16];
+hipEvent_t g_prep_ev[64];
 std::atomic<unsigned> g_prep_next{0};
 std::mutex g_prep_mutex;
 bool g_prep_init = false;
@@ -572,11 +573,11 @@ int prep_event(hipEvent_t* ev) {
   {
     std::lock_guard<std::mutex> lock(g_prep_mutex);
     if (!g_prep_init) {
-      for (int i = 0; i < 16; ++i) MIA_HIP_TRY(hipEventCreateWithFlags(&g_prep_ev[i], hipEventDisableTiming));
+      for (int i = 0; i < 64; ++i) MIA_HIP_TRY(hipEventCreateWithFlags(&g_prep_ev[i], hipEventDisableTiming));
       g_prep_init = true;
     }
   }
-  *ev = g_prep_ev[g_prep_next.fetch_add(1) & 15];
+  *ev = g_prep_ev[g_prep_next.fetch_add(1) & 63];
   return MIA_OK;
 }
 }  // namespace
@@ -671,7 +672,7 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
                             {8, exch ? 4 : 0, exch ? (int64_t)done_ints : 0}};
       rc = mia::localize_impl(grid_xyz, b0, b1, obs_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, L.cap,
                               cnt, idx, w, ctr, base + L.loc, L.loc_bytes, ps, P > 0 ? &job : nullptr, true,
-                              zero_in_kernel ? &zj : nullptr);
+                              zero_in_kernel ? &zj : nullptr, MIA_TAPER_GC, (step_flags & MIA_STEP_WS_CLEAN) != 0);
       if (rc != MIA_OK) return rc;
     }
     if (ps != s) {   // the analysis stream starts once the preparation stream has produced records and lists
@@ -831,6 +832,7 @@ struct LaunchThreads {
   int device = 0;
   bool stop = false, started = false;
   int busy = 0;          // jobs handed in and not yet finished by thread B
+  std::atomic<long long> ns_a{0}, ns_b{0}, n_jobs{0};     // host time spent enqueueing (mia_letkf_step_launch_stats)
   void run_a() {
     int cur_a = device;
     (void)hipSetDevice(device);
@@ -844,7 +846,10 @@ struct LaunchThreads {
         qa.pop_front();
       }
       if (j->device != cur_a) { (void)hipSetDevice(j->device); cur_a = j->device; }
+      const auto ta0 = std::chrono::steady_clock::now();
       const int rc = j->run(1);
+      ns_a += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - ta0).count();
+      ++n_jobs;
       {
         std::lock_guard<std::mutex> lk(mu);
         j->rc = rc;
@@ -867,8 +872,10 @@ struct LaunchThreads {
       }
       if (j->device != cur_b) { (void)hipSetDevice(j->device); cur_b = j->device; }
       int rc = j->rc;
+      const auto tb0 = std::chrono::steady_clock::now();
       if (rc == MIA_OK) rc = j->run(2);
       if (rc == MIA_OK && j->host8) rc = mia_letkf_step_readback(j->counters, j->host8, j->after, j->on, j->done_event);
+      ns_b += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tb0).count();
       {
         std::lock_guard<std::mutex> lk(mu);
         j->rc = rc;
@@ -921,6 +928,16 @@ extern "C" int mia_letkf_step_submit(const float* X, int64_t G, int m, int k, co
   }
   g_launcher.cv_a.notify_one();
   *job_out = j;
+  return MIA_OK;
+}
+
+// host time the two launch threads have spent enqueueing so far (microseconds: preparation stage, analysis / exchange /
+// read-back stage) and the number of steps: tells a pipeline that waits for its launches from one that waits for the GPU
+extern "C" int mia_letkf_step_launch_stats(double* prep_us, double* rest_us, long long* steps) {
+  if (!prep_us || !rest_us || !steps) return MIA_ERR_NULL;
+  *prep_us = g_launcher.ns_a.load() * 1e-3;
+  *rest_us = g_launcher.ns_b.load() * 1e-3;
+  *steps = g_launcher.n_jobs.load();
   return MIA_OK;
 }
 

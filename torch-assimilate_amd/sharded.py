@@ -69,9 +69,10 @@ class ShardedLetkf:
         if self.method == "eig":
             return "letkf_sys_kernel<20, 64>"
         import ctypes as C
-        v = C.c_int(1)
+        v, sp = C.c_int(1), C.c_int(1)
         self.engine.lib.mia_get_option(b"tile", C.byref(v))
-        return "letkf_tile_kernel<2, 3, false>" if v.value else "letkf_cheb_kernel<20, 1, false>"
+        self.engine.lib.mia_get_option(b"tile_split", C.byref(sp))
+        return ("letkf_tile_kernel<2, 3, false, %s>" % ("true" if sp.value else "false")) if v.value else "letkf_cheb_kernel<20, 1, false>"
 
     @property
     def exchange_route(self):
@@ -428,6 +429,7 @@ class ShardedLetkf:
             slot["flags"] = torch.empty(max(g1 - g0, 1), dtype=torch.int32, device=X.device)
             slot["event"] = slot.get("event") or C.c_void_p()          # completion event of the read-back (library-made)
             slot["key"] = key
+            slot["ws_clean"] = False                                   # fresh workspace: the first step clears the index header
         # direct exchange: the result IS the slot's peer-mapped buffer (every rank uses the same slot for the same step)
         out = peer[slot_idx] if peer else torch.empty((m, k, G), dtype=torch.float32, device=X.device)
         flags = slot["flags"]          # (per slot: a step's flags are read when it is collected, before the slot is reused)
@@ -461,7 +463,10 @@ class ShardedLetkf:
                  slot["rc"], len(self.radii), float(self.eps), float(self.inf_factor), gamma, method, hint, st["comm"],
                  C_chunks, 0, out.data_ptr(), flags.data_ptr(), slot["counters"].data_ptr(), slot["ws"].data_ptr(),
                  slot["ws"].numel(), comp.cuda_stream, side, prep.cuda_stream if prep is not None else None,
-                 1 if pipelined else 0]
+                 # MIA_STEP_NO_JOIN for steps in flight; MIA_STEP_WS_CLEAN: this slot's workspace was last used by a step that
+                 # ran to completion (its index kernels leave the header zeroed)
+                 (1 if pipelined else 0) | (4 if slot.get("ws_clean") else 0)]
+        slot["ws_clean"] = False            # (until this step has been collected without an error)
         step_fn = lib.mia_letkf_sharded_step_streams_f32
 
         def call(phase):
@@ -527,6 +532,7 @@ class ShardedLetkf:
         else:
             cnt = slot["counters"].tolist()                    # serial route: synchronous read-back
         slot["busy"] = None
+        slot["ws_clean"] = True                                # the step's kernels have all run: its index header is zero again
         self._in_flight.remove(h)
         X, grid_xyz, obs_xyz, Yb, d, G, g0, g1 = p["args"]
         if st["comm"] is None or (self.world == 1 and p["C_chunks"] == 1):
