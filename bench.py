@@ -341,6 +341,11 @@ def main():
 
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
     import torch_assimilate_amd as mia
     from torch_assimilate_amd.sharded import ShardedLetkf
     mia.build()

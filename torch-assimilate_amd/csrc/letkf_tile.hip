@@ -106,8 +106,13 @@ __device__ __forceinline__ void tile_split8(const float (&x)[8], h8t& hi, h8t& l
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const f2v v = {x[2 * i], x[2 * i + 1]};
-    const h2t a = __builtin_convertvector(v, h2t);
-    const f2v r = {v[0] - (float)a[0], v[1] - (float)a[1]};
+    const h2t a = __builtin_convertvector(v, h2t);                  // v_cvt_pk_f16_f32, round to nearest
+    const unsigned au = __builtin_bit_cast(unsigned, a);
+    // the remainders x - hi straight from the packed halves (v_fma_mix_f32 reads an f16 operand in place; the compiler's
+    // own form is two conversions + a packed subtraction, and packed f32 instructions are slow beside MFMAs)
+    f2v r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(au), "v"(v[0]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(au), "v"(v[1]));
     const h2t b = __builtin_convertvector(r, h2t);
     hi[2 * i] = a[0]; hi[2 * i + 1] = a[1];
     lo[2 * i] = b[0]; lo[2 * i + 1] = b[1];

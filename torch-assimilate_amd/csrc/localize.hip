@@ -94,8 +94,8 @@ __device__ inline void index_dims(const IndexParams& p) {
 __global__ __launch_bounds__(256) void index_bbox_dims_kernel(IndexParams p) {
   MIA_PREP_PRIORITY();
   if (blockIdx.x >= p.nb_bbox) {        // independent passenger: observation records for the analysis kernel
-    __shared__ float tile[32][33];
-    pack_obs_tile<float>(p.pack.Yb, p.pack.d, p.pack.k, p.P, p.pack.kp, p.pack.rec, (int64_t)(blockIdx.x - p.nb_bbox), tile);
+    extern __shared__ __attribute__((aligned(16))) float pack_lds[];       // 64 x (kp + 1), sized by the launch
+    pack_obs_wave<float>(p.pack.Yb, p.pack.d, p.pack.k, p.P, p.pack.kp, p.pack.rec, (int64_t)(blockIdx.x - p.nb_bbox), pack_lds);
     return;
   }
   __shared__ unsigned long long sx[4], sn[4];
@@ -538,11 +538,12 @@ int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_
   ip.zero = zero ? *zero : ZeroJob{{nullptr, nullptr, nullptr}, {0, 0, 0}};
   unsigned nb_pack = 0;
   if (pack && pack->rec) {
-    if ((P + 31) / 32 > 2000000000LL) return MIA_ERR_UNSUPPORTED;
+    if ((P + 63) / 64 > 2000000000LL) return MIA_ERR_UNSUPPORTED;
     ip.pack = *pack;
-    nb_pack = (unsigned)((P + 31) / 32);
+    nb_pack = (unsigned)((P + 63) / 64);
   }
-  index_bbox_dims_kernel<<<dim3(ip.nb_bbox + nb_pack), dim3(kPrepThreads), 0, stream>>>(ip);
+  const size_t pack_lds = nb_pack ? (size_t)64 * (ip.pack.kp + 1) * sizeof(float) : 0;      // (kp <= 132: 34 KB)
+  index_bbox_dims_kernel<<<dim3(ip.nb_bbox + nb_pack), dim3(kPrepThreads), pack_lds, stream>>>(ip);
   MIA_LAUNCH_CHECK();
   index_count_kernel<<<dim3(nbP), dim3(kPrepThreads), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
