@@ -171,9 +171,17 @@ __device__ long long g_tile_stamps[kStampTiles * kStampN];
 #ifndef MIA_TILE_WAVES_UT2
 #define MIA_TILE_WAVES_UT2 3
 #endif
+#ifndef MIA_TILE_WAVES_SPLIT_UT2
+#define MIA_TILE_WAVES_SPLIT_UT2 2
+#endif
 
 template <int UT, int KT, bool SEG, bool SPL>
-__global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 1)))   /* UT >= 4: one wavefront per SIMD, up to 512 registers */ void letkf_tile_kernel(TileParams P) {
+// Wavefronts per SIMD.  f32 products, UT <= 2: three (168 registers; four spilled and measured no faster).  Split products:
+// TWO -- the three-wave build spilled 24 registers (40 MB of scratch traffic per launch, twice the kernel's own) and was no
+// faster alone (58 us either way: the half-precision MFMAs leave the kernel short of vector issue slots, not of waves); with
+// two, 6250 tiles fill 2048 slots three times almost exactly (no tail round), and the registers left over let the
+// preparation kernels of later steps run beside it without displacing its waves: pipelined step 0.101 -> 0.094 ms.
+__global__ __launch_bounds__(64, (UT <= 2 ? (SPL ? MIA_TILE_WAVES_SPLIT_UT2 : MIA_TILE_WAVES_UT2) : (UT == 3 ? 2 : 1)))   /* UT >= 4: one wavefront per SIMD, up to 512 registers */ void letkf_tile_kernel(TileParams P) {
   constexpr int UMAX = 16 * UT, NU = 4 * UT;
   constexpr int NB = (KT + 1) / 2, NKB = (UT + 1) / 2;       // SPL: blocks of 32 members / of 32 union slots (= two row blocks)
   constexpr int LOGHS = UT <= 1 ? 6 : (UT <= 2 ? 7 : 8), HS = 1 << LOGHS, HR = HS / 64;
@@ -791,6 +799,8 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
 #pragma unroll
       for (int t = 0; t < UT; ++t) d2[t] = dreg[t] * dreg[t];
       // the right-hand side D^2 o tv of a 32-deep product, slots 16 (2 kb + tt) + 4 h + q of this lane's column, as half pairs
+      // (SPL carries u = D^2 o v instead of v: u_{j+1} = 2 (alpha D^2 o (G u_j) - u_j) - u_{j-1} -- the vectors ARE the right-hand
+      //  sides, and the accumulated sums are what the last two products need)
       auto rhs_split = [&](const f4t (&tv)[UT], int kb, h8t& bh, h8t& bl) {
         float bv[8];
 #pragma unroll
@@ -798,7 +808,7 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int tk = 2 * kb + tt < UT ? 2 * kb + tt : 0;
-            bv[4 * tt + q] = 2 * kb + tt < UT ? d2[tk][q] * tv[tk][q] : 0.0f;
+            bv[4 * tt + q] = 2 * kb + tt < UT ? tv[tk][q] : 0.0f;
           }
         tile_split8(bv, bh, bl);
       };
@@ -832,11 +842,17 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
         return SPL ? c : float2{c.x * P.cs_phi, c.y * P.cs_psi};
       };
       // vnew = 2 (alpha y - vcur) - vold, written over vold; the two weight functions accumulate c_j vnew
+      f4t ad2[UT];              // SPL: alpha D^2
+      if constexpr (SPL) {
+#pragma unroll
+        for (int t = 0; t < UT; ++t) ad2[t] = alpha * d2[t];
+      }
       auto advance = [&](f4t (&vold)[UT], const f4t (&vcur)[UT], const float2 cj) {
         product(vcur);
 #pragma unroll
         for (int t = 0; t < UT; ++t) {
-          vold[t] = 2.0f * (alpha * y[t] - vcur[t]) - vold[t];
+          if constexpr (SPL) vold[t] = 2.0f * (ad2[t] * y[t] - vcur[t]) - vold[t];
+          else vold[t] = 2.0f * (alpha * y[t] - vcur[t]) - vold[t];
           aphi[t] = cj.x * vold[t] + aphi[t];
           apsi[t] = cj.y * vold[t] + apsi[t];
         }
@@ -847,18 +863,20 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
         if constexpr (SPL) {
           unsigned zmax = 0u;
 #pragma unroll
-          for (int t = 0; t < UT; ++t)
+          for (int t = 0; t < UT; ++t) {
+            va[t] = Z[t] * d2[t];                     // u_0
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const unsigned a = __float_as_uint(Z[t][q]) & 0x7fffffffu;
+              const unsigned a = __float_as_uint(va[t][q]) & 0x7fffffffu;
               zmax = a > zmax ? a : zmax;
             }
+          }
           zmax = __float_as_uint(tile_max_h(__uint_as_float(zmax)));
           int es2;
           const float s2 = tile_pow2_scale(zmax, 8, &es2);
           inv_s2 = __uint_as_float((unsigned)(127 - es2) << 23);
 #pragma unroll
-          for (int t = 0; t < UT; ++t) va[t] = Z[t] * s2;
+          for (int t = 0; t < UT; ++t) va[t] *= s2;
         } else {
 #pragma unroll
           for (int t = 0; t < UT; ++t) va[t] = Z[t];
@@ -866,7 +884,8 @@ __global__ __launch_bounds__(64, (UT <= 2 ? MIA_TILE_WAVES_UT2 : (UT == 3 ? 2 : 
         product(va);
 #pragma unroll
         for (int t = 0; t < UT; ++t) {
-          vb[t] = alpha * y[t] - va[t];
+          if constexpr (SPL) vb[t] = ad2[t] * y[t] - va[t];
+          else vb[t] = alpha * y[t] - va[t];
           aphi[t] = c0.x * va[t] + c1.x * vb[t];
           apsi[t] = c0.y * va[t] + c1.y * vb[t];
         }
