@@ -73,7 +73,7 @@ const char* mia_status_string(int status);
  *   "tile_split"       1  the products of that kernel as split-precision half MFMAs (f32 operands carried as pairs of halves,
  *                         f32 accumulation; same accuracy as f32 MFMAs) / 0: f32 MFMAs (results then do
  *                         not depend on which tile a grid point falls into, bit for bit)
- *   "localize_quad"    1  neighbour lists (capacity < 64): four lanes per grid point / 0: one thread per grid point (same lists)
+ *   "localize_quad"    1  neighbour lists of capacity <= 32: four lanes per grid point / 0: one thread per grid point (same lists)
  *   "segment_signal"   1  step driver with several pieces: one segmented launch / 0: one launch + event per piece
  * Returns MIA_ERR_UNSUPPORTED for an unknown name, MIA_ERR_SIZE for a value out of range. */
 int mia_set_option(const char* name, int value);

@@ -607,7 +607,10 @@ int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* 
     MIA_LAUNCH_CHECK();
     return MIA_OK;
   }
-  if (mia::option(MIA_OPT_LOCALIZE_QUAD)) {       // four lanes per grid point
+  // four lanes per grid point: short lists only.  It trades 4x the wavefronts for a quarter of the serial candidate loop --
+  // a gain while the kernel is latency-bound (C2, ~30 candidates per point: 33 -> 43 us beside the analysis kernel against
+  // 66), a loss once the candidate loop itself is the work (C4 geometry, ~200 candidates: 316 us against 116)
+  if (mia::option(MIA_OPT_LOCALIZE_QUAD) && p_cap <= 32) {
     const int64_t nbq = (ng + 15) / 16;
     if (nbq > 2147483647LL) return MIA_ERR_UNSUPPORTED;
     localize_quad_kernel<<<dim3((unsigned)nbq), dim3(64), 0, stream>>>(lp);
