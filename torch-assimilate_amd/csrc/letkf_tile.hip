@@ -24,8 +24,13 @@
 //
 // Summation order is canonical: union slots are assigned by RANK of the observation index (hash-dedupe, then a counting
 // rank), permuted so that the enumeration above visits them in ascending rank.  A grid point's own observations are thus
-// always summed in ascending index order with exact zeros in between, whatever else is in the tile: results do not
-// depend on tile composition, shard boundaries or launch geometry, bit for bit.
+// always summed in ascending index order with exact zeros in between, whatever else is in the tile: on the f32 products
+// (SPL = false) results do not depend on tile composition, shard boundaries or launch geometry, bit for bit.
+//
+// SPL = true (the default route, letkf_tile_split.hip): the same products as THREE half-precision MFMAs each
+// (v_mfma_f32_16x16x32_f16 on operands carried as pairs of halves, see "split precision" below) -- f32 accuracy at a
+// fifth of the matrix-pipe time, beside the vector unit instead of in its way.  The operand scale is the tile's, so there a
+// point's result depends on its tile at rounding level.
 //
 // A tile whose union exceeds the 16 UT slots the instantiation has (UT <= 6: 96 slots) is processed in halves (quarters, ...)
 // -- one point always fits (p_max <= 16 UT is checked on the host); degree cap / non-finite / overflow / retry protocol are those
