@@ -203,3 +203,30 @@ def test_empty_and_tiny_lists(eng, split):
     far = nb.cnt.cpu().numpy() == 0
     mean = state.mean(axis=1, keepdims=True)
     np.testing.assert_allclose(xa.cpu().numpy()[:, :, far], (mean + 1.1 * (state - mean))[:, :, far], rtol=2e-6, atol=1e-6)
+
+
+def test_split_products_follow_the_magnitude_of_their_operands(eng):
+    """The half-precision operands are scaled by powers of two taken from the data (records per tile, x' and the recurrence
+    vectors per column): a state 2^40 times larger or smaller gives the same analysis times 2^+-40 BIT FOR BIT (every scale
+    moves with it), and observation-space inputs a million times weaker or sixty times stronger stay inside the north-star
+    tolerance (weak: analysis = inflated prior to 1e-7; strong: the points the polynomial route declines go to the eigensolver)."""
+    set_option("tile_split", 1)
+    case = O.synthetic_case(203, 40, 2, seed=77)
+    nb = eng.localize(case["grid_x"], case["obs_x"], [10.0])
+    base, fl = run(eng, case, nb)
+    assert int((fl & 0xff).max()) == 0
+    for e in (40, -40):
+        scaled = dict(case)
+        scaled["state"] = case["state"] * 2.0 ** e
+        xa, fl = run(eng, scaled, nb)
+        assert int((fl & 0xff).max()) == 0
+        np.testing.assert_array_equal(xa, base * np.float32(2.0 ** e))
+    for s in (2.0 ** -20, 1e-3, 7.0, 60.0):
+        scaled = dict(case)
+        scaled["yb"], scaled["d"] = case["yb"] * s, case["d"] * s
+        xa, fl, fin = eng.analysis(dev(scaled["state"]), dev(scaled["yb"]), dev(scaled["d"]), nb, 1.1, return_flags=True,
+                                   method="matfun", defer_retry=True)
+        fin()
+        assert int((fl.cpu().numpy() & 0xff & ~8).max()) == 0
+        ref, _ = O.letkf_analysis(scaled["state"], scaled["grid_x"], scaled["obs_x"], scaled["yb"], scaled["d"], 10.0, 1.1)
+        assert rel_fro(xa.cpu().numpy(), ref) < TOL32, s
