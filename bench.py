@@ -522,6 +522,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": warm,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_detail": ("inputs, outputs, accumulation and every vector operation float32; the matrix products run as "
+                             "three half-precision MFMAs per f32 product on operands carried as pairs of halves (22-23 "
+                             "significant bits; measured error equal to f32 products', DESIGN.md 3.0)")
+                            if kkind == "tile_split" else "float32 throughout",
             "config": {"workload": "LETKF config %s: G=%d grid points (%d per GPU), k=%d members, P=%d obs, "
                                    "Gaspari-Cohn radius %g (<=%d local obs), inf %.1f, m=1"
                                    % ("2" if world == 1 else "3-style", G, gpg, K_ENS, P, GC_RADIUS, p_max, INF),
