@@ -74,6 +74,9 @@ const char* mia_status_string(int status);
  *                         f32 accumulation; same accuracy as f32 MFMAs) / 0: f32 MFMAs (results then do
  *                         not depend on which tile a grid point falls into, bit for bit)
  *   "localize_quad"    1  neighbour lists of capacity <= 32: four lanes per grid point / 0: one thread per grid point (same lists)
+ *   "step_hostwait"    1  steps handed to the launch threads (mia_letkf_step_submit, MIA_STEP_NO_JOIN): the launch thread
+ *                         waits for the step's preparation on the host and enqueues the analysis kernel without a stream
+ *                         wait in front of it / 0: the analysis stream waits for the preparation's event
  *   "segment_signal"   1  step driver with several pieces: one segmented launch / 0: one launch + event per piece
  * Returns MIA_ERR_UNSUPPORTED for an unknown name, MIA_ERR_SIZE for a value out of range. */
 int mia_set_option(const char* name, int value);

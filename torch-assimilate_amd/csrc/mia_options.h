@@ -9,6 +9,7 @@ enum {
   MIA_OPT_TILE,              // sixteen grid points per wavefront (letkf_tile.hip) where the shape allows (1) or one (0)
   MIA_OPT_TILE_SPLIT,        // the tile kernel's products as split half-precision MFMAs (1) or f32 MFMAs (0)
   MIA_OPT_LOCALIZE_QUAD,     // neighbour lists of short lists: four lanes per grid point (1) or one (0)
+  MIA_OPT_STEP_HOSTWAIT,     // steps in flight: the launch thread waits for a step's preparation on the host (1) or the analysis stream does (0)
   MIA_OPT_SEGMENT_SIGNAL,    // step driver with several pieces: one segmented launch (1) or one launch + event per piece (0)
   MIA_OPT_COUNT_
 };

@@ -449,8 +449,8 @@ class ShardedLetkf:
                 st["astream"] = torch.cuda.Stream(device=X.device)
                 # TWO preparation streams taken in turn: with the sixteen-point analysis kernel (~75 us) the chain of small,
                 # latency-bound index / list launches of ONE stream (~100 us per step) had become what bounds the pipeline
-                # (0.127 -> 0.107 ms per step at depth 4; a third stream gains nothing)
-                st["pstreams"] = [torch.cuda.Stream(device=X.device, priority=-1) for _ in range(int(os.environ.get("MIA_PSTREAMS", "2")))]
+                # (0.127 -> 0.107 ms per step at depth 4; a third stream: 0.117 with the split-precision kernel, a fourth 0.167)
+                st["pstreams"] = [torch.cuda.Stream(device=X.device, priority=-1) for _ in range(2)]
             comp, prep = st["astream"], st["pstreams"][self._submitted % len(st["pstreams"])]
             prep.wait_stream(cur)                                 # inputs (and `out`'s memory) are ready
             # where the step's last work is enqueued: the placement stream when there is one, else the exchange stream
