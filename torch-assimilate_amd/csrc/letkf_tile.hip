@@ -36,6 +36,7 @@
 // -- one point always fits (p_max <= 16 UT is checked on the host); degree cap / non-finite / overflow / retry protocol are those
 // of letkf_cheb.hip (MIA_FLAG_RETRY points are redone by the eigensolver kernel).
 #include "mia_common.h"
+#include <hip/hip_ext.h>
 #include "mia_kernels.h"
 #include "mia_options.h"
 
@@ -1063,7 +1064,13 @@ static int tile_launch_s(const TileParams& tp, hipStream_t stream) {
   const int64_t gx = ntile < 65536 ? ntile : 65536;
   const int64_t gy = (ntile + gx - 1) / gx;
   if (gy > 65535) return MIA_ERR_UNSUPPORTED;
-  kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64), lds, stream>>>(tpl);
+  hipEvent_t& stop = launch_stop_event();
+  if (stop) {
+    hipExtLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(64), (unsigned)lds, stream, nullptr, stop, 0, tpl);
+    stop = nullptr;        // taken
+  } else {
+    kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64), lds, stream>>>(tpl);
+  }
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
@@ -1164,6 +1171,11 @@ int tile_split_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_
 // 0.34 / 0.63 / 1.23 ms against 0.76 / 0.92 / 1.61 ms of the 16-row MFMA batches of letkf_cheb_rows_kernel, which remains the
 // route of the shapes this kernel does not cover).
 bool tile_route_covers(int m, int k, int p_max) { return tile_shape_ok(m, k, p_max); }
+
+hipEvent_t& launch_stop_event() {
+  static thread_local hipEvent_t ev = nullptr;
+  return ev;
+}
 
 int tile_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
                          const int32_t* nbr_cnt, const int32_t* nbr_idx, const void* nbr_w, int w_f32, int p_cap,

@@ -46,6 +46,12 @@ int tile_split_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_
                                int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c, hipStream_t stream,
                                int seg_len, int64_t seg_stride, int32_t* done);
 
+// Completion event for the next tile-kernel launch of this thread (set by the step driver around the analysis call of a
+// step in flight): the launch then carries the event in its own dispatch packet (hipExtLaunchKernel) instead of the caller
+// recording a marker packet behind it -- one packet less between two kernels of the analysis queue.  Cleared by the launch
+// that takes it.
+hipEvent_t& launch_stop_event();
+
 // one-wave kernel on `stream` that returns once the 64 slot counters at done64[j * kSlotStride] sum to `expected` (bounded
 // polling: after ~seconds it sets bit 0 of *err and returns, so the grid always drains)
 int segment_wait_launch(const int32_t* done64, int expected, int32_t* err, hipStream_t stream);

@@ -521,6 +521,20 @@ extern "C" int mia_letkf_step_readback(const int32_t* counters, int32_t* host8, 
   MIA_HIP_TRY(hipEventRecord(ev, o));
   return MIA_OK;
 }
+static int readback_after_event(const int32_t* counters, int32_t* host8, hipEvent_t after, void* on_stream, void** done_event) {
+  if (!counters || !host8 || !done_event || !after) return MIA_ERR_NULL;
+  (void)hipGetLastError();
+  hipStream_t o = (hipStream_t)on_stream;
+  hipEvent_t ev = (hipEvent_t)*done_event;
+  if (!ev) {
+    MIA_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    *done_event = (void*)ev;
+  }
+  MIA_HIP_TRY(hipStreamWaitEvent(o, after, 0));
+  MIA_HIP_TRY(hipMemcpyAsync(host8, counters, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, o));
+  MIA_HIP_TRY(hipEventRecord(ev, o));
+  return MIA_OK;
+}
 extern "C" int mia_event_synchronize(void* event) {
   if (!event) return MIA_ERR_NULL;
   MIA_HIP_TRY(hipEventSynchronize((hipEvent_t)event));
@@ -601,8 +615,9 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
                      const double* gc_c, int n_r, double gc_eps, float inf_factor, float gamma, int method, int p_max_assumed,
                      mia_comm_t* comm, int n_chunks, int phase, float* Xa, int32_t* flags, int32_t* counters, void* ws,
                      size_t ws_bytes, void* stream, void* comm_stream, void* prep_stream, int step_flags, int stage,
-                     hipEvent_t* pe_io, uint32_t* seq_io, hipEvent_t t_start, hipEvent_t t_stop) {
+                     hipEvent_t* pe_io, uint32_t* seq_io, hipEvent_t t_start, hipEvent_t t_stop, hipEvent_t* kdone_out) {
   const bool do1 = stage != 2, do2 = stage != 1;
+  if (kdone_out) *kdone_out = nullptr;
   if (!X || !Xa || !flags || !counters || !ws || !grid_xyz || !coord_group || !gc_c) return MIA_ERR_NULL;
   if (P > 0 && (!Yb || !d || !obs_xyz)) return MIA_ERR_NULL;
   if (method < 0 || method > 2 || (phase != 0 && phase != 1)) return MIA_ERR_SIZE;
@@ -718,9 +733,21 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
         if (rc != MIA_OK) return rc;
       } else {
         rc = MIA_ERR_UNSUPPORTED;
-        if (!eig_only)
+        if (!eig_only) {
+          // a step in flight whose analysis is one plain launch: the launch carries its completion event itself
+          hipEvent_t kstop = nullptr;
+          if (kdone_out && phase == 0 && !exch && !peer && n_chunks == 1 && !t_stop && (step_flags & kStepPrepDone)) {
+            rc = prep_event(&kstop);
+            if (rc != MIA_OK) return rc;
+            mia::launch_stop_event() = kstop;
+          }
           rc = mia_letkf_analysis_matfun_f32(X, G, m, k, c0, c1, rec, P, ccnt, cidx, cw, L.cap, p_max_assumed,
                                              inf_factor, gamma, dst, ldo, o0, cfl, ctr + 2, stream);
+          if (kstop) {
+            if (mia::launch_stop_event() == nullptr) *kdone_out = kstop;      // (taken by the tile kernel's launch)
+            mia::launch_stop_event() = nullptr;
+          }
+        }
         if (rc == MIA_ERR_UNSUPPORTED)
           rc = mia_letkf_analysis_packed_f32(X, G, m, k, c0, c1, rec, P, ccnt, cidx, cw, L.cap, p_max_assumed,
                                              inf_factor, gamma, dst, ldo, o0, nullptr, cfl, stream);
@@ -796,7 +823,7 @@ extern "C" int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int
   t_time_start = t_time_stop = nullptr;
   return step_impl(X, G, m, k, Yb, d, P, grid_xyz, obs_xyz, n_coord, coord_group, gc_c, n_r, gc_eps, inf_factor, gamma, method,
                    p_max_assumed, comm, n_chunks, phase, Xa, flags, counters, ws, ws_bytes, stream, comm_stream, prep_stream,
-                   step_flags, 0, &pe, &seq, t0, t1);
+                   step_flags, 0, &pe, &seq, t0, t1, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -817,13 +844,14 @@ struct StepJob {
   void *stream, *comm_stream, *prep_stream; int step_flags;
   int32_t* host8; void *after, *on; void** done_event; void *t0, *t1;
   hipEvent_t pe = nullptr; uint32_t seq = 0;
+  hipEvent_t kdone = nullptr;      // completion event carried by the analysis launch itself (stage 2), if any
   int device = 0;
   int rc = 0;
   bool done = false;
   int run(int stage) {
     return step_impl(X, G, m, k, Yb, d, P, grid, obs, n_coord, cg, rc_, n_r, eps, inf, gamma, method, hint, comm, n_chunks, phase,
                      Xa, flags, counters, ws, ws_bytes, stream, comm_stream, prep_stream, step_flags, stage, &pe, &seq,
-                     (hipEvent_t)t0, (hipEvent_t)t1);
+                     (hipEvent_t)t0, (hipEvent_t)t1, stage == 2 ? &kdone : nullptr);
   }
 };
 struct LaunchThreads {
@@ -887,7 +915,11 @@ struct LaunchThreads {
       }
       const auto tb0 = std::chrono::steady_clock::now();
       if (rc == MIA_OK) rc = j->run(2);
-      if (rc == MIA_OK && j->host8) rc = mia_letkf_step_readback(j->counters, j->host8, j->after, j->on, j->done_event);
+      if (rc == MIA_OK && j->host8) {
+        // (the read-back waits for the kernel's own completion event when the launch carried one: no marker on the stream)
+        if (j->kdone && j->after == j->stream) rc = readback_after_event(j->counters, j->host8, j->kdone, j->on, j->done_event);
+        else rc = mia_letkf_step_readback(j->counters, j->host8, j->after, j->on, j->done_event);
+      }
       ns_b += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tb0).count();
       {
         std::lock_guard<std::mutex> lk(mu);
