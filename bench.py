@@ -559,8 +559,8 @@ def main():
                                            "workload, committed as profiles/latest_traffic.json (bench.py cannot profile itself)",
                          "traffic_detail": traffic,
                          "kernel": kname, "kernel_ms": kern_ms,
-                         "kernel_ms_source": ("HIP events recorded by the library on the analysis stream around the kernel of "
-                                              "every 4th step of the timed loop (%d launches, mia_letkf_step_timing_events)" % n_timed)
+                         "kernel_ms_source": ("start / stop HIP events of the kernel's own dispatch (hipExtLaunchKernel, analysis "
+                                              "stream) on every 4th step of the timed loop (%d launches)" % n_timed)
                                              if loop_kernel_ms else "burst of 5 launches after the timed loop",
                          "kernel_ms_alone": alone_ms,
                          "hbm_algorithmic_GBs": hbm_alg, "hbm_frac": hbm_alg / PEAK_HBM_GBS,

@@ -1066,8 +1066,10 @@ static int tile_launch_s(const TileParams& tp, hipStream_t stream) {
   if (gy > 65535) return MIA_ERR_UNSUPPORTED;
   hipEvent_t& stop = launch_stop_event();
   if (stop) {
-    hipExtLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(64), (unsigned)lds, stream, nullptr, stop, 0, tpl);
+    hipExtLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(64), (unsigned)lds, stream, launch_start_event(), stop, 0,
+                          tpl);
     stop = nullptr;        // taken
+    launch_start_event() = nullptr;
   } else {
     kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64), lds, stream>>>(tpl);
   }
@@ -1173,6 +1175,10 @@ int tile_split_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_
 bool tile_route_covers(int m, int k, int p_max) { return tile_shape_ok(m, k, p_max); }
 
 hipEvent_t& launch_stop_event() {
+  static thread_local hipEvent_t ev = nullptr;
+  return ev;
+}
+hipEvent_t& launch_start_event() {
   static thread_local hipEvent_t ev = nullptr;
   return ev;
 }

@@ -19,8 +19,13 @@ namespace mia {
 // The preparation kernels are short, latency-bound chains.  When consecutive steps are pipelined they share the
 // SIMDs with the previous step's analysis kernel (VALU-bound, every wave slot taken): at equal priority the
 // round-robin issue arbitration stretched localize_kernel from 35 to 200 us and made the preparation chain the
-// critical path.  Raising the waves' issue priority lets them through; alone on the GPU it changes nothing.
-#define MIA_PREP_PRIORITY() __builtin_amdgcn_s_setprio(3)
+// critical path.  Raising the waves' issue priority (3) let them through; alone on the GPU it changes nothing.
+// With the split-precision analysis kernel at two waves per SIMD the preparation fits beside it and the boost costs the
+// analysis kernel more than it gains the chain: 0.0863 -> 0.0844 ms per step with priority 0 (1: 0.0875), now the default.
+#ifndef MIA_PREP_PRIO
+#define MIA_PREP_PRIO 0
+#endif
+#define MIA_PREP_PRIORITY() __builtin_amdgcn_s_setprio(MIA_PREP_PRIO)
 
 struct IndexParams {
   const double* obs;  // [P][nc]

@@ -51,6 +51,7 @@ int tile_split_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_
 // recording a marker packet behind it -- one packet less between two kernels of the analysis queue.  Cleared by the launch
 // that takes it.
 hipEvent_t& launch_stop_event();
+hipEvent_t& launch_start_event();     // optional timing partner of the above (the dispatch's own start time)
 
 // one-wave kernel on `stream` that returns once the 64 slot counters at done64[j * kSlotStride] sum to `expected` (bounded
 // polling: after ~seconds it sets bit 0 of *err and returns, so the grid always drains)

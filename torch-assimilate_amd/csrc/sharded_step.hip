@@ -641,6 +641,10 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
   hipStream_t ps = prep_stream ? (hipStream_t)prep_stream : s;      // records, index, lists
   // MIA_SEGMENT_SIGNAL=0: one launch + one event per piece instead of the segmented launch (fallback / A-B runs)
   const bool signal_mode = mia::option(MIA_OPT_SEGMENT_SIGNAL) != 0;
+  // a step in flight whose analysis is ONE plain launch (stage 2 after the host-side wait): the launch carries its completion
+  // (and timing) events in its own dispatch packet
+  const bool carried = kdone_out && phase == 0 && !exch && !peer && n_chunks == 1 && method != 1 && (step_flags & kStepPrepDone) &&
+                       (!t_start == !t_stop);
   char* base = (char*)ws;
   float* rec = (float*)(base + L.rec);
   int32_t* cnt = (int32_t*)(base + L.cnt);
@@ -703,7 +707,7 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
     if (ps != s && !(step_flags & kStepPrepDone)) MIA_HIP_TRY(hipStreamWaitEvent(s, *pe_io, 0));
     // the side stream starts once the lists exist (and the slots it polls have been cleared)
     if (exch) MIA_HIP_TRY(hipStreamWaitEvent(cs, comm->ev[kMaxChunks], 0));
-    if (t_start) MIA_HIP_TRY(hipEventRecord(t_start, s));   // (after the wait for the lists: kernel time only)
+    if (t_start && !carried) MIA_HIP_TRY(hipEventRecord(t_start, s));   // (after the wait for the lists: kernel time only)
     // one launch over the whole block whose segments are exchanged as they complete (no kernel boundary, no
     // event between the pieces: a 1e5-point block in 4 launches costs 292 us instead of 245 us on MI355X)
     if (exch && n_chunks > 1 && !eig_only && b1 > b0 && signal_mode) {
@@ -736,16 +740,26 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
         if (!eig_only) {
           // a step in flight whose analysis is one plain launch: the launch carries its completion event itself
           hipEvent_t kstop = nullptr;
-          if (kdone_out && phase == 0 && !exch && !peer && n_chunks == 1 && !t_stop && (step_flags & kStepPrepDone)) {
-            rc = prep_event(&kstop);
-            if (rc != MIA_OK) return rc;
+          if (carried) {          // (a timed step: the dispatch's own start / stop times, no marker packets either)
+            kstop = t_stop;
+            if (!kstop) {
+              rc = prep_event(&kstop);
+              if (rc != MIA_OK) return rc;
+            }
             mia::launch_stop_event() = kstop;
+            mia::launch_start_event() = t_start;
           }
           rc = mia_letkf_analysis_matfun_f32(X, G, m, k, c0, c1, rec, P, ccnt, cidx, cw, L.cap, p_max_assumed,
                                              inf_factor, gamma, dst, ldo, o0, cfl, ctr + 2, stream);
           if (kstop) {
-            if (mia::launch_stop_event() == nullptr) *kdone_out = kstop;      // (taken by the tile kernel's launch)
+            if (mia::launch_stop_event() == nullptr) {
+              *kdone_out = kstop;      // (taken by the tile kernel's launch)
+            } else if (t_start) {      // another kernel served the shape: ordinary markers around it (late start: after the fact)
+              MIA_HIP_TRY(hipEventRecord(t_start, s));
+              MIA_HIP_TRY(hipEventRecord(t_stop, s));
+            }
             mia::launch_stop_event() = nullptr;
+            mia::launch_start_event() = nullptr;
           }
         }
         if (rc == MIA_ERR_UNSUPPORTED)
@@ -799,7 +813,7 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
     rc = peer_finish(comm, peer_slot, seq, G, b0, b1, rows, counters, cs);
     if (rc != MIA_OK) return rc;
   }
-  if (phase == 0 && t_stop) MIA_HIP_TRY(hipEventRecord(t_stop, s));
+  if (phase == 0 && t_stop && !carried) MIA_HIP_TRY(hipEventRecord(t_stop, s));
   // (without the exchange route counters[4..7] stay zero: the rank's own [0..3] are the whole story)
   if ((exch || peer) && !(step_flags & MIA_STEP_NO_JOIN)) {   // the caller's stream continues after the exchange
     MIA_HIP_TRY(hipEventRecord(comm->ev[kMaxChunks + 1], cs));
