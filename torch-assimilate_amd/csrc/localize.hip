@@ -251,7 +251,20 @@ struct LocalizeParams {
   int64_t g0, ng;
   int p_cap;
   int* cnt; int* idx; double* w; int* stats;
+  // independent passenger: workgroups nb_main, nb_main + 1, ... pack the observation records for the analysis kernel
+  // (single-wave workgroups, pack_obs_wave).  It used to ride in the FIRST kernel of the chain, whose successors then
+  // waited for 17 MB of traffic they do not depend on; only the analysis kernel needs the records.
+  unsigned nb_main;
+  PackJob pack;
+  int64_t P;
 };
+#define MIA_LOCALIZE_PASSENGER(p)                                                                                          \
+  if (blockIdx.x >= (p).nb_main) {                                                                                         \
+    extern __shared__ __attribute__((aligned(16))) float pack_lds_[];                                                       \
+    pack_obs_wave<float>((p).pack.Yb, (p).pack.d, (p).pack.k, (p).P, (p).pack.kp, (p).pack.rec,                             \
+                         (int64_t)(blockIdx.x - (p).nb_main), pack_lds_);                                                   \
+    return;                                                                                                                \
+  }
 
 // One THREAD per grid point.  A wavefront-per-point version of this kernel (the scan_neighbours device
 // function, still used by the fused analysis route) took 83 us for 1e5 points on MI355X although it
@@ -263,6 +276,7 @@ struct LocalizeParams {
 //  SIMD -- makes room, cost 24 spilled registers and gained nothing: 68 us beside the analysis kernel either way)
 __global__ __launch_bounds__(64) void localize_kernel(LocalizeParams p) {
   MIA_PREP_PRIORITY();
+  MIA_LOCALIZE_PASSENGER(p);
   const int64_t pt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int count = 0;
   if (pt < p.ng) {
@@ -347,6 +361,7 @@ __global__ __launch_bounds__(64) void localize_kernel(LocalizeParams p) {
 // (pipelined steps) its long-lived 106-register waves each kept a 168-register analysis wave out of its SIMD.
 __global__ __launch_bounds__(64) void localize_quad_kernel(LocalizeParams p) {
   MIA_PREP_PRIORITY();
+  MIA_LOCALIZE_PASSENGER(p);
   const int lane = threadIdx.x, sub = lane & 3;
   const int64_t pt = blockIdx.x * (int64_t)16 + (lane >> 2);
   const unsigned qshift = (unsigned)(lane & ~3);
@@ -424,6 +439,7 @@ __global__ __launch_bounds__(64) void localize_quad_kernel(LocalizeParams p) {
 // analysis route uses).  Same order (cell order, ascending index inside a cell), same weights: identical lists.
 __global__ __launch_bounds__(64) void localize_wave_kernel(LocalizeParams p) {
   MIA_PREP_PRIORITY();
+  MIA_LOCALIZE_PASSENGER(p);
   const int lane = threadIdx.x;
   const int64_t pt = blockIdx.x;
   if (pt >= p.ng) return;
@@ -598,17 +614,32 @@ int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* 
     MIA_HIP_TRY(hipMemsetAsync(nbr_w, 0, ng * (size_t)p_cap * sizeof(double), stream));
     return MIA_OK;
   }
-  int rc = index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, ws, ws_bytes, stream, pack, zero, header_clean);
+#ifndef MIA_PACK_IN_LOCALIZE
+#define MIA_PACK_IN_LOCALIZE 1
+#endif
+  int rc = index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, ws, ws_bytes, stream, MIA_PACK_IN_LOCALIZE ? nullptr : pack,
+                            zero, header_clean);
   if (rc != MIA_OK) return rc;
   LocalizeParams lp;
   rc = make_scan_params(&lp.scan, grid_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, ws, taper);
   if (rc != MIA_OK) return rc;
   lp.g0 = g0; lp.ng = ng; lp.p_cap = p_cap;
   lp.cnt = nbr_cnt; lp.idx = nbr_idx; lp.w = nbr_w; lp.stats = stats;
+  lp.pack = PackJob{nullptr, nullptr, nullptr, 0, 0};
+  lp.P = P;
+  unsigned nb_pack = 0;
+  size_t pack_lds = 0;
+  if (MIA_PACK_IN_LOCALIZE && pack && pack->rec) {
+    lp.pack = *pack;
+    nb_pack = (unsigned)((P + 63) / 64);
+    pack_lds = (size_t)64 * (pack->kp + 1) * sizeof(float);      // (kp <= 132: 34 KB)
+  }
   // one-wave workgroups: beside a bulk kernel that holds every wave slot (pipelined steps) a single freed slot is
   // enough to place one, whereas a 4-wave workgroup waited for four slots on one CU (200 us instead of 35)
   if (p_cap >= 64 && ng <= 2147483647LL && !MIA_EXP_FLAG("MIA_LOCALIZE_THREAD")) {   // long lists: one wavefront per grid point
-    localize_wave_kernel<<<dim3((unsigned)ng), dim3(64), 0, stream>>>(lp);
+    if (ng + nb_pack > 2147483647LL) return MIA_ERR_UNSUPPORTED;
+    lp.nb_main = (unsigned)ng;
+    localize_wave_kernel<<<dim3((unsigned)ng + nb_pack), dim3(64), pack_lds, stream>>>(lp);
     MIA_LAUNCH_CHECK();
     return MIA_OK;
   }
@@ -617,14 +648,16 @@ int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* 
   // 66), a loss once the candidate loop itself is the work (C4 geometry, ~200 candidates: 316 us against 116)
   if (mia::option(MIA_OPT_LOCALIZE_QUAD) && p_cap <= 32) {
     const int64_t nbq = (ng + 15) / 16;
-    if (nbq > 2147483647LL) return MIA_ERR_UNSUPPORTED;
-    localize_quad_kernel<<<dim3((unsigned)nbq), dim3(64), 0, stream>>>(lp);
+    if (nbq + nb_pack > 2147483647LL) return MIA_ERR_UNSUPPORTED;
+    lp.nb_main = (unsigned)nbq;
+    localize_quad_kernel<<<dim3((unsigned)nbq + nb_pack), dim3(64), pack_lds, stream>>>(lp);
     MIA_LAUNCH_CHECK();
     return MIA_OK;
   }
   const int64_t nb = (ng + 63) / 64;
-  if (nb > 2147483647LL) return MIA_ERR_UNSUPPORTED;
-  localize_kernel<<<dim3((unsigned)nb), dim3(64), 0, stream>>>(lp);
+  if (nb + nb_pack > 2147483647LL) return MIA_ERR_UNSUPPORTED;
+  lp.nb_main = (unsigned)nb;
+  localize_kernel<<<dim3((unsigned)nb + nb_pack), dim3(64), pack_lds, stream>>>(lp);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
