@@ -401,24 +401,36 @@ __global__ __launch_bounds__(64) void localize_quad_kernel(LocalizeParams p) {
       }
       if (!ok) continue;
       const int beg = q.start[base_cell + lo_l], end = q.start[base_cell + hi_l + 1];
-      for (int pos0 = beg; pos0 < end; pos0 += 4) {          // (the same bounds in the four lanes of a quad)
-        const bool have = pos0 + sub < end;
-        const int pos = have ? pos0 + sub : end - 1;
-        const int oj = q.sorted[pos];
-        double d2[MIA_MAX_RADII] = {0.0, 0.0, 0.0};
-        for (int c = 0; c < nc; ++c) {
-          const double dx = q.sxyz[(int64_t)pos * nc + c] - gx[c];
-          d2[q.group[c]] += dx * dx;
+      // two candidates per lane and trip (positions pos0 + sub and pos0 + 4 + sub: their loads are requested together,
+      // half as many dependent memory round trips per point); the survivors of the first four positions are placed
+      // before those of the second four, i.e. still in position order
+      for (int pos0 = beg; pos0 < end; pos0 += 8) {          // (the same bounds in the four lanes of a quad)
+        bool have[2];
+        int oj[2];
+        double wgt[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          have[u] = pos0 + 4 * u + sub < end;
+          const int pos = have[u] ? pos0 + 4 * u + sub : end - 1;
+          oj[u] = q.sorted[pos];
+          double d2[MIA_MAX_RADII] = {0.0, 0.0, 0.0};
+          for (int c = 0; c < nc; ++c) {
+            const double dx = q.sxyz[(int64_t)pos * nc + c] - gx[c];
+            d2[q.group[c]] += dx * dx;
+          }
+          wgt[u] = 1.0;
+          for (int r = 0; r < q.n_r; ++r) wgt[u] *= taper_d2(q.taper, d2[r], q.inv_c[r], q.cc[r]);
         }
-        double wgt = 1.0;
-        for (int r = 0; r < q.n_r; ++r) wgt *= taper_d2(q.taper, d2[r], q.inv_c[r], q.cc[r]);
-        const bool use = have && wgt > q.eps;
-        const unsigned quad = (unsigned)(__ballot(use) >> qshift) & 0xfu;
-        if (use) {
-          const int slot = count + __popc(quad & ((1u << sub) - 1u));
-          if (slot < p.p_cap) { my_idx[slot] = oj; my_w[slot] = wgt * rsqrt_f64(wgt); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const bool use = have[u] && wgt[u] > q.eps;
+          const unsigned quad = (unsigned)(__ballot(use) >> qshift) & 0xfu;
+          if (use) {
+            const int slot = count + __popc(quad & ((1u << sub) - 1u));
+            if (slot < p.p_cap) { my_idx[slot] = oj[u]; my_w[slot] = wgt[u] * rsqrt_f64(wgt[u]); }
+          }
+          count += __popc(quad);
         }
-        count += __popc(quad);
       }
     }
     for (int s_ = count + sub; s_ < p.p_cap; s_ += 4) { my_idx[s_] = -1; my_w[s_] = 0.0; }
