@@ -5,7 +5,7 @@ import glob, json, os, shutil, sys
 tag = sys.argv[1]
 src = os.path.join("gpurun_out", "prof_" + tag)
 os.makedirs("profiles", exist_ok=True)
-stats = glob.glob(src + "/trace/*/*kernel_stats.csv")[0]
+stats = max(glob.glob(src + "/trace/*/*kernel_stats.csv"), key=os.path.getmtime)      # (the newest run of this tag)
 shutil.copy(stats, "profiles/%s_kernel_stats.csv" % tag)
 line = [l for l in open(src + "/bench.log") if l.startswith('{"metric"')][-1] if os.path.exists(src + "/bench.log") else open(src + "/bench.json").read()
 open("profiles/%s_bench.json" % tag, "w").write(line)
