@@ -185,8 +185,9 @@ template <int UT, int KT, bool SEG, bool SPL>
 // Wavefronts per SIMD.  f32 products, UT <= 2: three (168 registers; four spilled and measured no faster).  Split products:
 // TWO -- the three-wave build spilled 24 registers (40 MB of scratch traffic per launch, twice the kernel's own) and was no
 // faster alone (58 us either way: the half-precision MFMAs leave the kernel short of vector issue slots, not of waves); with
-// two, 6250 tiles fill 2048 slots three times almost exactly (no tail round), and the registers left over let the
-// preparation kernels of later steps run beside it without displacing its waves: pipelined step 0.101 -> 0.094 ms.
+// two, a wave lives 13.8 us instead of 19 and the registers left over let the preparation kernels of later steps run beside
+// it without displacing its waves: pipelined step 0.101 -> 0.094 ms.  (Either way the 106 tiles beyond the last full round
+// -- 6250 = 3 x 2048 + 106 -- run alone for the last ~12 us of a stand-alone launch: tools/tile_stamps.py.)
 __global__ __launch_bounds__(64, (UT <= 2 ? (SPL ? MIA_TILE_WAVES_SPLIT_UT2 : MIA_TILE_WAVES_UT2) : (UT == 3 ? 2 : 1)))   /* UT >= 4: one wavefront per SIMD, up to 512 registers */ void letkf_tile_kernel(TileParams P) {
   constexpr int UMAX = 16 * UT, NU = 4 * UT;
   constexpr int NB = (KT + 1) / 2, NKB = (UT + 1) / 2;       // SPL: blocks of 32 members / of 32 union slots (= two row blocks)
