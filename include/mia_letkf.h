@@ -77,6 +77,9 @@ const char* mia_status_string(int status);
  *   "step_hostwait"    1  steps handed to the launch threads (mia_letkf_step_submit, MIA_STEP_NO_JOIN): the launch thread
  *                         waits for the step's preparation on the host and enqueues the analysis kernel without a stream
  *                         wait in front of it / 0: the analysis stream waits for the preparation's event
+ *   "step_lazy_sort"   1  step driver: when the block's analysis is one launch of the sixteen-points-per-wavefront kernel (which
+ *                         ranks observations itself), the observation index is built without its per-cell sort; the lists of
+ *                         declined points are sorted before the eigensolver redoes them (same results, bit for bit) / 0: always
  *   "segment_signal"   1  step driver with several pieces: one segmented launch / 0: one launch + event per piece
  * Returns MIA_ERR_UNSUPPORTED for an unknown name, MIA_ERR_SIZE for a value out of range. */
 int mia_set_option(const char* name, int value);

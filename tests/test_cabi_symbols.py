@@ -100,7 +100,7 @@ def test_engine_refuses_to_run_without_gpu():
 def test_route_options(lib):
     """mia_set_option / mia_get_option: names, defaults, ranges (no device work)."""
     v = C.c_int(-5)
-    for name, default in ((b"cheb_dmax", 62), (b"cheb_table", 1), (b"cheb_rowbatch", 1), (b"cheb_big", 1), (b"tile", 1), (b"tile_split", 1), (b"localize_quad", 1), (b"step_hostwait", 1),
+    for name, default in ((b"cheb_dmax", 62), (b"cheb_table", 1), (b"cheb_rowbatch", 1), (b"cheb_big", 1), (b"tile", 1), (b"tile_split", 1), (b"localize_quad", 1), (b"step_hostwait", 1), (b"step_lazy_sort", 1),
                           (b"segment_signal", 1)):
         assert lib.mia_get_option(name, C.byref(v)) == 0 and v.value == default
     assert lib.mia_set_option(b"cheb_dmax", 14) == 0 and lib.mia_get_option(b"cheb_dmax", C.byref(v)) == 0 and v.value == 14

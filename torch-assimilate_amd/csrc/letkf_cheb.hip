@@ -1544,6 +1544,17 @@ int segment_wait_launch(const int32_t* done64, int expected, int32_t* err, hipSt
 
 // MIA_ERR_UNSUPPORTED when the shape is outside this route (caller uses the eigensolver kernels).
 // seg_len > 0: segmented launch (see letkf_cheb_seg_kernel); Xa = first segment buffer, ldo = seg_len.
+// The dispatch rule below for the plain matfun call (no weights output, no fused localisation, no segments), without
+// launching: dual route of at most 64 local observations, coefficient table present, shape and sizes the tile kernel takes.
+bool cheb_tile_will_serve(int m, int k, int p_max, int p_cap, float gamma, int64_t ldx, int64_t ldo, int64_t ng, hipStream_t stream) {
+  if (gamma > 0.0f || m < 1 || k < 2 || k > 128) return false;
+  if (p_max > p_cap) p_max = p_cap;
+  if (p_max > k || p_max > 64) return false;
+  if (MIA_EXP_FLAG("MIA_EXPERIMENT_SKIP") || MIA_EXP_FLAG("MIA_CHEB_LOGTOL")) return false;
+  if (!tile_route_covers(m, k, p_max) || !tile_launch_would_serve(m, k, p_max, p_cap, ldx, ldo, ng, 0)) return false;
+  return cheb_coef_table(1, 12.0f, stream) != nullptr;
+}
+
 int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
                          const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
                          float inf_factor, int kernel_mode, float gamma, float* Xa, int64_t ldo, int64_t o0,

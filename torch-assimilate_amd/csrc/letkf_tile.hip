@@ -1074,6 +1074,7 @@ static int tile_launch_s(const TileParams& tp, hipStream_t stream) {
   } else {
     kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64), lds, stream>>>(tpl);
   }
+  ++tile_launch_count();
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
@@ -1114,6 +1115,23 @@ static bool tile_shape_ok(int m, int k, int p_max) {
   return m >= 1 && k >= 2 && k <= 96 && p_max <= k && p_max + kTileSlack <= 96;
 }
 
+// What a launch needs of its sizes (shared with tile_launch_would_serve): the shape, every global access as base + 32-bit
+// byte offset (the largest offsets are a column of one state row block -- k ld floats --, one tile's list rows), the LDS
+// budget of the instantiation, the grid, the segmented instantiations (UT, KT <= 4)
+static bool tile_launch_args_ok(int m, int k, int p_max, int p_cap, int64_t ldx, int64_t ldo, int64_t ng, int seg_len, bool spl) {
+  if (!tile_shape_ok(m, k, p_max)) return false;
+  if ((int64_t)k * ldx * 4 >= ((int64_t)1 << 31) || (int64_t)k * ldo * 4 >= ((int64_t)1 << 31) ||
+      (int64_t)p_cap * 16 * 8 >= ((int64_t)1 << 31))
+    return false;
+  const int kt = (k + 15) >> 4, ut0 = (p_max + kTileSlack + 15) >> 4, ut = ut0 < 1 ? 1 : ut0;
+  if (ut > kt + 1 || ut > 6 || kt > 6) return false;
+  if (seg_len > 0 && (ut > 4 || kt > 4)) return false;
+  const int kp = (k + 1 + 3) & ~3, rsb = 32 * ((k + 1 + 7) >> 3) + 16;
+  if (tile_lds_bytes(ut, kp, spl ? rsb : 0) > kMaxDynamicLds) return false;
+  const int64_t ntile = seg_len > 0 ? (((int64_t)seg_len + 15) >> 4) * ((ng + seg_len - 1) / seg_len) : (ng + 15) >> 4;
+  return ntile <= (int64_t)65536 * 65535;
+}
+
 template <bool SPL>
 static int tile_launch_impl(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
                             const int32_t* nbr_cnt, const int32_t* nbr_idx, const void* nbr_w, int w_f32, int p_cap,
@@ -1121,12 +1139,8 @@ static int tile_launch_impl(const float* X, int64_t ldx, int m, int k, int64_t g
                             int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c, hipStream_t stream,
                             int seg_len, int64_t seg_stride, int32_t* done) {
   if (seg_len > 0 && (!done || ng >= (int64_t)1 << 31)) return MIA_ERR_UNSUPPORTED;
-  if (!tile_shape_ok(m, k, p_max) || !flags || !retry_count || !tab_hdr || !tab_c || w_f32) return MIA_ERR_UNSUPPORTED;
-  // every global access is base + 32-bit byte offset: the largest offsets are a column of one state row block (k ld
-  // floats), the record array, one tile's list rows
-  if ((int64_t)k * ldx * 4 >= ((int64_t)1 << 31) || (int64_t)k * ldo * 4 >= ((int64_t)1 << 31) ||
-      (int64_t)p_cap * 16 * 8 >= ((int64_t)1 << 31))
-    return MIA_ERR_UNSUPPORTED;
+  if (!flags || !retry_count || !tab_hdr || !tab_c || w_f32) return MIA_ERR_UNSUPPORTED;
+  if (!tile_launch_args_ok(m, k, p_max, p_cap, ldx, ldo, ng, seg_len, SPL)) return MIA_ERR_UNSUPPORTED;
   TileParams tp;
   tp.X = X; tp.ldx = ldx; tp.m = m; tp.k = k; tp.kp = (k + 1 + 3) & ~3;
   tp.g0 = g0; tp.ng = ng; tp.rec = rec;
@@ -1182,6 +1196,13 @@ hipEvent_t& launch_stop_event() {
 hipEvent_t& launch_start_event() {
   static thread_local hipEvent_t ev = nullptr;
   return ev;
+}
+unsigned long long& tile_launch_count() {
+  static thread_local unsigned long long n = 0;
+  return n;
+}
+bool tile_launch_would_serve(int m, int k, int p_max, int p_cap, int64_t ldx, int64_t ldo, int64_t ng, int seg_len) {
+  return option(MIA_OPT_TILE) != 0 && tile_launch_args_ok(m, k, p_max, p_cap, ldx, ldo, ng, seg_len, option(MIA_OPT_TILE_SPLIT) != 0);
 }
 
 int tile_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,

@@ -43,6 +43,7 @@ struct IndexParams {
   PackJob pack;          // ... the others (if any) pack observation records (pack.rec != nullptr)
   ZeroJob zero;          // small caller buffers cleared by the first kernel (saves their fill launches)
   uint32_t* cells; size_t cell_words;   // start + cursor: cleared by the first kernel too (their first user is the second)
+  int scatter_xyz;       // the cell sort is skipped (see index_build_impl): the scatter lays the coordinates out itself
 };
 
 __device__ inline unsigned long long dkey(double x) {     // total order of doubles as unsigned integers
@@ -203,6 +204,48 @@ __global__ void index_scatter_kernel(IndexParams p) {
   int c = p.cell_of[j];
   int pos = p.start[c] + atomicAdd(&p.cursor[c], 1);
   p.sorted[pos] = int(j);
+  if (p.scatter_xyz)
+    for (int q = 0; q < p.nc; ++q) p.sxyz[(int64_t)pos * p.nc + q] = p.obs[j * p.nc + q];
+}
+
+// Lists built on an index whose cells were NOT sorted (lazy sort of the step driver) hold the right observations in
+// arrival order.  The sixteen-points-per-wavefront kernel does not care (it ranks the union by observation index); the
+// eigensolver kernel that redoes declined points sums in list order -- so the lists of exactly those points (flag
+// MIA_FLAG_RETRY) are put into the order a sorted index would have given them: ascending (cell, observation index).
+// One wavefront per flagged point, rank sort in place (lists of up to 128 entries: two per lane).
+struct SortListsParams { const int32_t* flags; const int32_t* cnt; int32_t* idx; double* w; const int* cell_of; int64_t ng; int p_cap; };
+__global__ __launch_bounds__(64) void sort_flagged_lists_kernel(SortListsParams p) {
+  const int lane = threadIdx.x;
+  for (int64_t pt = blockIdx.x; pt < p.ng; pt += gridDim.x) {
+    if (!(p.flags[pt] & MIA_FLAG_RETRY)) continue;
+    int n = p.cnt[pt];
+    n = n > p.p_cap ? p.p_cap : n;
+    n = n > 128 ? 128 : n;
+    int32_t* li = p.idx + pt * p.p_cap;
+    double* lw = p.w + pt * p.p_cap;
+    unsigned long long key[2];
+    int32_t id[2];
+    double wv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = lane + 64 * u;
+      id[u] = e < n ? li[e] : 0;
+      wv[u] = e < n ? lw[e] : 0.0;
+      key[u] = e < n ? (((unsigned long long)(unsigned)p.cell_of[id[u]] << 32) | (unsigned)id[u]) : ~0ull;
+    }
+    int rank[2] = {0, 0};
+    for (int u2 = 0; u2 < 2; ++u2)
+      for (int l = 0; l < 64; ++l) {
+        if (l + 64 * u2 >= n) break;                       // (wave-uniform)
+        const unsigned long long other = __shfl(key[u2], l, 64);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) rank[u] += other < key[u] ? 1 : 0;
+      }
+    __builtin_amdgcn_wave_barrier();                      // (every lane holds its entries: the stores below may overwrite)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (lane + 64 * u < n) { li[rank[u]] = id[u]; lw[rank[u]] = wv[u]; }
+  }
 }
 
 // the scatter order inside a cell depends on atomic arrival: sort each cell's slice by observation
@@ -533,7 +576,7 @@ static int taper_launch(const T* r, int64_t n, T* w, hipStream_t stream) {
 // builds the cell index of the observations in ws (all kernels enqueued on stream)
 int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_t* coord_group,
                      const double* gc_c, int n_r, void* ws, size_t ws_bytes, hipStream_t stream, const PackJob* pack,
-                     const ZeroJob* zero, bool header_clean) {
+                     const ZeroJob* zero, bool header_clean, bool sort_cells) {
   if (P < 0 || n_coord < 1 || n_coord > MIA_MAX_COORD || n_r < 1 || n_r > MIA_MAX_RADII) return MIA_ERR_SIZE;
   if (P > 2000000000LL) return MIA_ERR_UNSUPPORTED;
   if (!coord_group || !gc_c) return MIA_ERR_NULL;
@@ -582,8 +625,10 @@ int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_
   MIA_LAUNCH_CHECK();
   index_scan_kernel<<<dim3(1), dim3(64), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
+  ip.scatter_xyz = sort_cells ? 0 : 1;
   index_scatter_kernel<<<dim3(nbP), dim3(kPrepThreads), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
+  if (!sort_cells) return MIA_OK;      // (lazy sort: the scatter has laid the coordinates out; see sort_flagged_lists_kernel)
   const size_t sort_blocks = L.cap < 8192 ? (L.cap ? L.cap : 1) : 8192;      // one wave (cell) per workgroup
   index_sortcell_kernel<<<dim3((unsigned)sort_blocks), dim3(kPrepThreads), 0, stream>>>(ip);
   MIA_LAUNCH_CHECK();
@@ -610,7 +655,7 @@ int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* 
                   const int32_t* coord_group, const double* gc_c, int n_r, double gc_eps, int p_cap,
                   int32_t* nbr_cnt, int32_t* nbr_idx, double* nbr_w, int32_t* stats, void* ws, size_t ws_bytes,
                   hipStream_t stream, const PackJob* pack, bool stats_zeroed, const ZeroJob* zero, int taper,
-                  bool header_clean) {
+                  bool header_clean, bool sort_cells) {
   if (g1 < g0 || g0 < 0 || P < 0) return MIA_ERR_SIZE;
   if (n_coord < 1 || n_coord > MIA_MAX_COORD || n_r < 1 || n_r > MIA_MAX_RADII || p_cap < 1) return MIA_ERR_SIZE;
   if (!coord_group || !gc_c || !stats) return MIA_ERR_NULL;
@@ -630,7 +675,7 @@ int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* 
 #define MIA_PACK_IN_LOCALIZE 1
 #endif
   int rc = index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, ws, ws_bytes, stream, MIA_PACK_IN_LOCALIZE ? nullptr : pack,
-                            zero, header_clean);
+                            zero, header_clean, sort_cells);
   if (rc != MIA_OK) return rc;
   LocalizeParams lp;
   rc = make_scan_params(&lp.scan, grid_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, ws, taper);
@@ -670,6 +715,18 @@ int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* 
   if (nb + nb_pack > 2147483647LL) return MIA_ERR_UNSUPPORTED;
   lp.nb_main = (unsigned)nb;
   localize_kernel<<<dim3((unsigned)nb + nb_pack), dim3(64), pack_lds, stream>>>(lp);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+int sort_flagged_lists(const int32_t* flags, const int32_t* nbr_cnt, int32_t* nbr_idx, double* nbr_w, int64_t ng, int p_cap,
+                       void* ws, int64_t P, int n_coord, hipStream_t stream) {
+  if (ng <= 0 || P <= 0) return MIA_OK;
+  if (p_cap > 128) return MIA_ERR_UNSUPPORTED;
+  const IndexLayout L = index_layout(ws, P, n_coord);
+  SortListsParams sp{flags, nbr_cnt, nbr_idx, nbr_w, L.cell_of, ng, p_cap};
+  const int64_t nb = ng < 4096 ? ng : 4096;
+  sort_flagged_lists_kernel<<<dim3((unsigned)nb), dim3(64), 0, stream>>>(sp);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

@@ -52,6 +52,12 @@ int tile_split_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_
 // that takes it.
 hipEvent_t& launch_stop_event();
 hipEvent_t& launch_start_event();     // optional timing partner of the above (the dispatch's own start time)
+// launches of the tile kernel made by this thread so far; whether a launch with these sizes would be accepted by it
+unsigned long long& tile_launch_count();
+bool tile_launch_would_serve(int m, int k, int p_max, int p_cap, int64_t ldx, int64_t ldo, int64_t ng, int seg_len);
+// (letkf_cheb.hip) whether mia_letkf_analysis_matfun_f32 with these arguments ends in the tile kernel -- the dispatch rule
+// of cheb_analysis_launch, evaluated without launching (builds the coefficient table on `stream` if it does not exist yet)
+bool cheb_tile_will_serve(int m, int k, int p_max, int p_cap, float gamma, int64_t ldx, int64_t ldo, int64_t ng, hipStream_t stream);
 
 // one-wave kernel on `stream` that returns once the 64 slot counters at done64[j * kSlotStride] sum to `expected` (bounded
 // polling: after ~seconds it sets bit 0 of *err and returns, so the grid always drains)

@@ -165,7 +165,8 @@ struct PackJob;
 struct ZeroJob { int32_t* ptr[3]; int64_t n[3]; };
 int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_t* coord_group,
                      const double* gc_c, int n_r, void* ws, size_t ws_bytes, hipStream_t stream,
-                     const PackJob* pack = nullptr, const ZeroJob* zero = nullptr, bool header_clean = false);
+                     const PackJob* pack = nullptr, const ZeroJob* zero = nullptr, bool header_clean = false,
+                     bool sort_cells = true);
 // neighbour lists of grid points [g0, g1) (mia_letkf_localize_f64 without the argument checks of the C entry);
 // pack: float32 record packing job executed inside the first index kernel; stats_zeroed: stats are cleared by
 // the caller or listed in `zero`
@@ -173,7 +174,10 @@ int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* 
                   const int32_t* coord_group, const double* gc_c, int n_r, double gc_eps, int p_cap,
                   int32_t* nbr_cnt, int32_t* nbr_idx, double* nbr_w, int32_t* stats, void* ws, size_t ws_bytes,
                   hipStream_t stream, const PackJob* pack, bool stats_zeroed, const ZeroJob* zero,
-                  int taper = MIA_TAPER_GC, bool header_clean = false);
+                  int taper = MIA_TAPER_GC, bool header_clean = false, bool sort_cells = true);
+// lists of the points flagged MIA_FLAG_RETRY into the order a sorted index gives (see sort_flagged_lists_kernel)
+int sort_flagged_lists(const int32_t* flags, const int32_t* nbr_cnt, int32_t* nbr_idx, double* nbr_w, int64_t ng, int p_cap,
+                       void* ws, int64_t P, int n_coord, hipStream_t stream);
 int make_scan_params(ScanParams* sp, const double* grid_xyz, int64_t P, int n_coord, const int32_t* coord_group,
                      const double* gc_c, int n_r, double gc_eps, void* ws, int taper = MIA_TAPER_GC);
 

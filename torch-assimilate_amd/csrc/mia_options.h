@@ -10,6 +10,7 @@ enum {
   MIA_OPT_TILE_SPLIT,        // the tile kernel's products as split half-precision MFMAs (1) or f32 MFMAs (0)
   MIA_OPT_LOCALIZE_QUAD,     // neighbour lists of short lists: four lanes per grid point (1) or one (0)
   MIA_OPT_STEP_HOSTWAIT,     // steps in flight: the launch thread waits for a step's preparation on the host (1) or the analysis stream does (0)
+  MIA_OPT_STEP_LAZY_SORT,    // step driver: observation index without its per-cell sort when the tile kernel takes the analysis (1) / always sorted (0)
   MIA_OPT_SEGMENT_SIGNAL,    // step driver with several pieces: one segmented launch (1) or one launch + event per piece (0)
   MIA_OPT_COUNT_
 };

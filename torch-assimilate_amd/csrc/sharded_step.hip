@@ -641,6 +641,17 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
   hipStream_t ps = prep_stream ? (hipStream_t)prep_stream : s;      // records, index, lists
   // MIA_SEGMENT_SIGNAL=0: one launch + one event per piece instead of the segmented launch (fallback / A-B runs)
   const bool signal_mode = mia::option(MIA_OPT_SEGMENT_SIGNAL) != 0;
+  // Lazy sort: when the block's analysis is ONE plain launch that the sixteen-points-per-wavefront kernel will take -- it
+  // ranks every tile's union by observation index itself, so the order inside a neighbour list means nothing to it -- the
+  // observation index is built WITHOUT its per-cell sort (one kernel and one launch gap less in the preparation chain), and
+  // only a redo of declined points (phase 1: the eigensolver kernel, which sums in list order) first puts the lists of
+  // exactly those points into the order a sorted index gives.  The rule is evaluated from the call's arguments, so phase 0
+  // and phase 1 of a step agree; the analysis call below is checked against it.
+  const int64_t blk = (int64_t)rank * L.n < G ? (((int64_t)rank * L.n + L.n < G ? (int64_t)rank * L.n + L.n : G) - (int64_t)rank * L.n) : 0;
+  const bool lazy = mia::option(MIA_OPT_STEP_LAZY_SORT) != 0 && !exch && n_chunks == 1 && method != 1 && blk > 0 && P > 0 &&
+                    L.cap <= 128 &&
+                    mia::cheb_tile_will_serve(m, k, p_max_assumed < L.cap ? p_max_assumed : L.cap, L.cap, gamma, G, G, blk,
+                                              (hipStream_t)(prep_stream ? prep_stream : stream));
   // a step in flight whose analysis is ONE plain launch (stage 2 after the host-side wait): the launch carries its completion
   // (and timing) events in its own dispatch packet
   const bool carried = kdone_out && phase == 0 && !exch && !peer && n_chunks == 1 && method != 1 && (step_flags & kStepPrepDone) &&
@@ -693,7 +704,7 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
                             {8, exch ? 4 : 0, exch ? (int64_t)done_ints : 0}};
       rc = mia::localize_impl(grid_xyz, b0, b1, obs_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, L.cap,
                               cnt, idx, w, ctr, base + L.loc, L.loc_bytes, ps, P > 0 ? &job : nullptr, true,
-                              zero_in_kernel ? &zj : nullptr, MIA_TAPER_GC, (step_flags & MIA_STEP_WS_CLEAN) != 0);
+                              zero_in_kernel ? &zj : nullptr, MIA_TAPER_GC, (step_flags & MIA_STEP_WS_CLEAN) != 0, !lazy);
       if (rc != MIA_OK) return rc;
     }
     if (ps != s) {   // the analysis stream starts once the preparation stream has produced records and lists
@@ -732,6 +743,11 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
       const double* cw = w + (size_t)(c0 - b0) * L.cap;
       int32_t* cfl = flags + (c0 - b0);
       if (phase == 1) {
+        if (lazy) {      // (the lists of the declined points into sorted-index order, see above)
+          rc = mia::sort_flagged_lists(cfl, ccnt, const_cast<int32_t*>(cidx), const_cast<double*>(cw), c1 - c0, (int)L.cap,
+                                       base + L.loc, P, n_coord, (hipStream_t)stream);
+          if (rc != MIA_OK) return rc;
+        }
         rc = mia_letkf_analysis_retry_f32(X, G, m, k, c0, c1, rec, P, ccnt, cidx, cw, L.cap, p_max_assumed, inf_factor,
                                           gamma, dst, ldo, o0, cfl, stream);
         if (rc != MIA_OK) return rc;
@@ -749,8 +765,11 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
             mia::launch_stop_event() = kstop;
             mia::launch_start_event() = t_start;
           }
+          const unsigned long long tiles_before = mia::tile_launch_count();
           rc = mia_letkf_analysis_matfun_f32(X, G, m, k, c0, c1, rec, P, ccnt, cidx, cw, L.cap, p_max_assumed,
                                              inf_factor, gamma, dst, ldo, o0, cfl, ctr + 2, stream);
+          // (an unsorted index is only right for the kernel the rule above predicted)
+          if (lazy && rc == MIA_OK && mia::tile_launch_count() == tiles_before) return MIA_ERR_UNSUPPORTED;
           if (kstop) {
             if (mia::launch_stop_event() == nullptr) {
               *kdone_out = kstop;      // (taken by the tile kernel's launch)
