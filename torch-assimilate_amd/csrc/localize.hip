@@ -35,14 +35,14 @@ struct IndexParams {
   int cell_cap;
   IndexHeader* hdr;
   int* start;    // [cell_cap + 1]  counts -> exclusive starts
-  int* cursor;   // [cell_cap]
+  int* cursor;   // [cell_cap]  per-cell counts: zero outside the counting kernel .. the scan (which puts them back to zero)
   int* sorted;   // [P]      observation index, cell-major, ascending inside a cell
   int* cell_of;  // [P]
+  int* rank_of;  // [P]      arrival rank of an observation inside its cell (the counting kernel's atomic returns it)
   double* sxyz;  // [P][nc]  coordinates in the same order (no second indirection in the scan)
   unsigned nb_bbox;      // workgroups of the first kernel that reduce the bounding box ...
   PackJob pack;          // ... the others (if any) pack observation records (pack.rec != nullptr)
   ZeroJob zero;          // small caller buffers cleared by the first kernel (saves their fill launches)
-  uint32_t* cells; size_t cell_words;   // start + cursor: cleared by the first kernel too (their first user is the second)
   int scatter_xyz;       // the cell sort is skipped (see index_build_impl): the scatter lays the coordinates out itself
 };
 
@@ -109,7 +109,6 @@ __global__ __launch_bounds__(256) void index_bbox_dims_kernel(IndexParams p) {
   const int64_t stride = (int64_t)p.nb_bbox * blockDim.x;
   for (int q = 0; q < 3; ++q)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < p.zero.n[q]; i += stride) p.zero.ptr[q][i] = 0;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < p.cell_words; i += (size_t)stride) p.cells[i] = 0u;
   for (int c = 0; c < p.nc; ++c) {
     unsigned long long kx = 0ull, kn = 0ull;
     for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < p.P; j += stride) {
@@ -164,7 +163,8 @@ __global__ __launch_bounds__(64) void index_scan_kernel(IndexParams p) {
 #pragma unroll
     for (int u = 0; u < T; ++u) {
       const int i = lo + u;
-      vals[u] = (i < n - 1) ? p.start[i] : 0;      // (counts of the previous kernel: visible at its end)
+      vals[u] = (i < n - 1) ? p.cursor[i] : 0;     // (counts of the previous kernel: visible at its end)
+      if (i < n - 1) p.cursor[i] = 0;              // ... read by their only reader: zero again for the next build
       sum += vals[u];
     }
     int x = sum;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64) void index_count_kernel(IndexParams p) {
   if (j < p.P) {
     const int c = obs_cell(p.hdr, p.obs + j * p.nc, p.nc);
     p.cell_of[j] = c;
-    atomicAdd(&p.start[c], 1);
+    p.rank_of[j] = atomicAdd(&p.cursor[c], 1);      // (the count IS the observation's place inside its cell: no second atomic)
   }
 }
 
@@ -202,7 +202,7 @@ __global__ void index_scatter_kernel(IndexParams p) {
   int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (j >= p.P) return;
   int c = p.cell_of[j];
-  int pos = p.start[c] + atomicAdd(&p.cursor[c], 1);
+  int pos = p.start[c] + p.rank_of[j];
   p.sorted[pos] = int(j);
   if (p.scatter_xyz)
     for (int q = 0; q < p.nc; ++q) p.sxyz[(int64_t)pos * p.nc + q] = p.obs[j * p.nc + q];
@@ -590,7 +590,8 @@ int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_
   IndexParams ip;
   ip.obs = obs_xyz; ip.P = P; ip.nc = n_coord; ip.cell_cap = (int)L.cap;
   for (int c = 0; c < MIA_MAX_COORD; ++c) ip.cutoff[c] = c < n_coord ? 2.0 * gc_c[coord_group[c]] : 1.0;
-  ip.hdr = L.hdr; ip.start = L.start; ip.cursor = L.cursor; ip.sorted = L.sorted; ip.cell_of = L.cell_of; ip.sxyz = L.sxyz;
+  ip.hdr = L.hdr; ip.start = L.start; ip.cursor = L.cursor; ip.sorted = L.sorted; ip.cell_of = L.cell_of; ip.rank_of = L.rank_of;
+  ip.sxyz = L.sxyz;
   // SINGLE-WAVE workgroups throughout the chain: when steps are pipelined these kernels run beside the previous step's
   // analysis kernel, which fills every SIMD's register file (7 waves x 72 VGPRs at C2).  A lone wave takes the slot of
   // the next analysis wave that retires; a 4-wave workgroup needs one to retire on each SIMD of one CU at the same
@@ -598,18 +599,19 @@ int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_
   constexpr unsigned kPrepThreads = 64;
   const unsigned nbP = (unsigned)((P + kPrepThreads - 1) / kPrepThreads);
   ip.nb_bbox = nbP < 256 ? nbP : 256;
-  // The chain reads the header's extrema / completion counters as running maxima / counts from zero and puts them back to
-  // zero once read; the per-cell tables (start, cursor: adjacent) are cleared by the first kernel, whose successor is
-  // their first user.  So a workspace whose last use was a complete build (header_clean: the step driver's slots) needs
-  // no fill launch at all; any other gets a one-wave fill of the header (not hipMemsetAsync: the runtime's fill kernel has
-  // 256-thread workgroups and waited 30-60 us for a CU beside a bulk kernel).
+  // The chain leaves its workspace as it needs to find it: the header's extrema / completion counters are running maxima /
+  // counts from zero, put back to zero by their only reader; the per-cell counts are zeroed by the scan that reads them; the
+  // starts are overwritten whole.  So a workspace whose last use was a complete build (header_clean: the step driver's
+  // slots) needs no fill launch and no clearing pass at all; any other gets one fill of header + tables (single-wave
+  // workgroups, not hipMemsetAsync: the runtime's fill kernel has 256-thread workgroups and waited 30-60 us for a CU
+  // beside a bulk kernel).
   if (!header_clean) {
-    index_clear_kernel<<<dim3(1), dim3(kPrepThreads), 0, stream>>>(reinterpret_cast<uint32_t*>(ip.hdr),
-                                                                   ((char*)ip.start - (char*)ip.hdr) / sizeof(uint32_t));
+    const size_t words = ((char*)ip.sorted - (char*)ip.hdr) / sizeof(uint32_t);
+    const unsigned nb = (unsigned)((words + kPrepThreads * 16 - 1) / (kPrepThreads * 16));
+    index_clear_kernel<<<dim3(nb < 1024 ? (nb ? nb : 1) : 1024), dim3(kPrepThreads), 0, stream>>>(
+        reinterpret_cast<uint32_t*>(ip.hdr), words);
     MIA_LAUNCH_CHECK();
   }
-  ip.cells = reinterpret_cast<uint32_t*>(ip.start);
-  ip.cell_words = ((char*)ip.sorted - (char*)ip.start) / sizeof(uint32_t);
   ip.pack = PackJob{nullptr, nullptr, nullptr, 0, 0};
   ip.zero = zero ? *zero : ZeroJob{{nullptr, nullptr, nullptr}, {0, 0, 0}};
   unsigned nb_pack = 0;

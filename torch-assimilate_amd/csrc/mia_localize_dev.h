@@ -137,7 +137,7 @@ __device__ inline int scan_neighbours(const ScanParams& p, int64_t g, int lane, 
 
 // layout of the index workspace (built by mia_letkf_index_build_f64)
 struct IndexLayout {
-  IndexHeader* hdr; int* start; int* cursor; int* sorted; int* cell_of; double* sxyz; size_t bytes; size_t cap;
+  IndexHeader* hdr; int* start; int* cursor; int* sorted; int* cell_of; int* rank_of; double* sxyz; size_t bytes; size_t cap;
 };
 static inline size_t index_cell_cap(int64_t P) {
   int64_t cap = 2 * P;
@@ -154,6 +154,7 @@ static inline IndexLayout index_layout(void* ws, int64_t P, int nc) {
   L.cursor = (int*)base; base += align_up(L.cap * sizeof(int), 256);
   L.sorted = (int*)base; base += align_up((size_t)P * sizeof(int) + 4, 256);
   L.cell_of = (int*)base; base += align_up((size_t)P * sizeof(int) + 4, 256);
+  L.rank_of = (int*)base; base += align_up((size_t)P * sizeof(int) + 4, 256);
   L.sxyz = (double*)base; base += align_up((size_t)P * (size_t)nc * sizeof(double) + 8, 256);
   L.bytes = (size_t)(base - (char*)ws);
   return L;
