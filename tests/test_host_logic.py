@@ -184,3 +184,37 @@ def test_bench_launches_its_own_ranks(tmp_path):
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
                          env=dict(env, MIA_BENCH_DRYRUN_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "rank 1 exited with status 3" in bad.stderr
+
+
+def test_split_half_precision_products_keep_f32_accuracy():
+    """The arithmetic of the tile kernel's default route, restated in numpy (no GPU): an f32 operand carried as two
+    halves hi = f16(x), lo = f16(x - hi) after a power-of-two scaling into the middle of the f16 range, and a product
+    formed as Ah Bh + Ah Bl + Al Bh.  Over eight decades of operand magnitude the result is as close to the float64
+    product as a float32 product is (tools/split_emul.py runs the whole recurrence this way)."""
+    rs = np.random.RandomState(0)
+    f16 = lambda x: x.astype(np.float16).astype(np.float32)
+
+    def split(x):
+        m = np.abs(x).max()
+        s = np.float32(2.0 ** (9 - np.floor(np.log2(m)))) if m > 0 else np.float32(1.0)
+        xs = (x * s).astype(np.float32)
+        hi = f16(xs)
+        return hi, f16(xs - hi), s
+
+    worst = 0.0
+    for scale in (1e-4, 1e-2, 1.0, 30.0, 1e4):
+        A = (rs.normal(size=(32, 40)) * scale).astype(np.float32)
+        B = (rs.normal(size=(40, 16)) / scale * 3.0).astype(np.float32)
+        Ah, Al, sa = split(A)
+        Bh, Bl, sb = split(B)
+        # products of halves are exact in float32; the accumulation is float32 (numpy float32 matmul)
+        got = ((Ah @ Bh) + (Ah @ Bl) + (Al @ Bh)).astype(np.float64) / (float(sa) * float(sb))
+        ref = A.astype(np.float64) @ B.astype(np.float64)
+        f32 = (A @ B).astype(np.float64)
+        e_split = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        e_f32 = np.linalg.norm(f32 - ref) / np.linalg.norm(ref)
+        assert e_split < 3e-7 and e_split < 4 * e_f32 + 1e-7, (scale, e_split, e_f32)
+        # the representation itself: hi + lo carries 22-23 significant bits
+        assert np.abs((Ah + Al).astype(np.float64) / float(sa) - A).max() <= 2.0 ** -21 * np.abs(A).max()
+        worst = max(worst, e_split)
+    assert worst > 0.0
