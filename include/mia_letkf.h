@@ -81,6 +81,8 @@ const char* mia_status_string(int status);
  *                         ranks observations itself), the observation index is built without its per-cell sort; the lists of
  *                         declined points are sorted before the eigensolver redoes them (same results, bit for bit) / 0: always
  *   "segment_signal"   1  step driver with several pieces: one segmented launch / 0: one launch + event per piece
+ *   "tile_lists"       1  step driver: tile-shaped lists + split records + the analysis kernel of csrc/letkf_tile2.hip where the
+ *                         shape allows (needs "tile" and "tile_split") / 0: per-point lists and csrc/letkf_tile.hip
  * Returns MIA_ERR_UNSUPPORTED for an unknown name, MIA_ERR_SIZE for a value out of range. */
 int mia_set_option(const char* name, int value);
 int mia_get_option(const char* name, int* value);
@@ -232,6 +234,45 @@ int mia_letkf_weights_retry_f32(const float* X, int64_t ldx, int m, int k, int64
                                 const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w,
                                 int p_cap, int p_max, float inf_factor, float gamma,
                                 float* Xa, int64_t ldo, int64_t o0, float* W, int32_t* flags, void* stream);
+/* ------------------------------------------------------------------------------------
+ * Tile route (round 3): the same localisation + analysis with the unit of work a TILE of sixteen
+ * consecutive grid points.  Replaces, for the built-in metric family, the per-grid-point loop of
+ * LETKF.estimate_weights (interface/letkf.py:127-146) over wrapper_localization (interface/wrapper.py:86-98)
+ * -> GaspariCohn.localize_obs (localization/gaspari_cohn.py:97-136) -> ETKFModule (core/etkf.py:57-103),
+ * followed by _apply_weights (interface/base.py:257-278).
+ *
+ * mia_letkf_localize_tiles_f64  cell index of the observations (built in `ws`, as mia_letkf_localize_f64) and, per
+ *     tile, the UNION of its sixteen lists (observation indices by rank) + the 16 x U matrix of sqrt(GC weight)
+ *     (0 = not local) in the layout of the analysis wavefront's registers (csrc/mia_tiles.h).  float64 distance and
+ *     taper arithmetic: the use / skip decision is the reference's.  p_max = bound on the local observations of a
+ *     point; a tile offers 16 * (ceil((p_max + 8) / 16) + extra_blocks) <= 96 slots, at most 16 more than the ensemble
+ *     size rounded up to 16 (sixteen consecutive points of a 1-D network with one observation per grid step see
+ *     p_max + 15 observations: extra_blocks = 1 where p_max + 15 exceeds the default).
+ *     stats [2] i32: [0] longest list of the shard, [1] tiles whose union did not fit their slots -- such tiles are
+ *     NOT analysed by mia_letkf_analysis_tiles_f32 (MIA_FLAG_OVERFLOW, NaN); the caller repeats with more extra_blocks
+ *     or with the list route (mia_letkf_localize_f64 + mia_letkf_analysis_matfun_f32).
+ * mia_letkf_pack_split_f32  [k][P] perturbations + d[P] -> P + 1 split records of mia_letkf_split_record_bytes(k)
+ *     bytes: every record scaled by its own power of two and carried as pairs of halves (hi, lo) for the
+ *     half-precision matrix cores at f32 accuracy; record P is the all-zero record.
+ * mia_letkf_analysis_tiles_f32  analysis of grid points [g0, g1) from tile lists of exactly that range and split
+ *     records; dual route (p_max <= k <= 96, p_max <= 88), any number m of state rows.  flags / retry_count as
+ *     mia_letkf_analysis_matfun_f32: declined points (and every point of a tile that holds a non-finite record) get
+ *     MIA_FLAG_RETRY and are redone by mia_letkf_analysis_retry_f32 from per-point lists.
+ * ---------------------------------------------------------------------------------- */
+int mia_letkf_tile_lists_bytes(int64_t n_points, int p_max, int extra_blocks, size_t* bytes);
+int mia_letkf_localize_tiles_f64(int taper, const double* grid_xyz, int64_t g0, int64_t g1,
+                                 const double* obs_xyz, int64_t P, int n_coord,
+                                 const int32_t* coord_group /* host */, const double* gc_c /* host */, int n_r,
+                                 double gc_eps, int p_max, int extra_blocks, void* tile_lists, size_t tile_lists_bytes,
+                                 int32_t* stats, void* ws, size_t ws_bytes, void* stream);
+int mia_letkf_split_record_bytes(int k, size_t* bytes);
+int mia_letkf_pack_split_f32(const float* Yb, const float* d, int k, int64_t P, void* split_rec /* (P + 1) records */,
+                             void* stream);
+int mia_letkf_analysis_tiles_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                 const void* split_rec, int64_t P, const void* tile_lists, int p_max, int extra_blocks,
+                                 float inf_factor, float* Xa, int64_t ldo, int64_t o0, int32_t* flags,
+                                 int32_t* retry_count, void* stream);
+
 /* matfun route with the Gaspari-Cohn localisation fused in: every wavefront scans the observation index
  * (mia_letkf_index_build_f64) for its grid point itself, so no neighbour lists are written or read.
  * p_max_assumed sizes the launch (e.g. stats[0] of an earlier call on the same geometry); a grid point with
@@ -518,6 +559,11 @@ int mia_letkf_sharded_step_f32(const float* X /* [m][k][G] */, int64_t G, int m,
  * and has not been written since: the observation index then needs no fill launch (its kernels leave the header as they
  * found it).  Never set it for a fresh or recycled allocation. */
 #define MIA_STEP_WS_CLEAN 4
+#define MIA_STEP_TILE_EXTRA(n) (((n) & 7) << 4) /* tile route: n more row blocks of sixteen union slots per tile (after a step
+                                                   reported unions that did not fit; beyond what the ensemble size allows the
+                                                   step takes the per-point lists) */
+#define MIA_STEP_NO_TILE_LISTS 8 /* per-point lists even where the tile route would apply (after a step reported tiles whose
+                                   union did not fit: counters[1] != 0 with counters[0] <= p_max_assumed) */
 int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int m, int k,
                                        const float* Yb, const float* d, int64_t P,
                                        const double* grid_xyz, const double* obs_xyz,

@@ -148,6 +148,14 @@ static const CoefTable* cheb_coef_table(int dual, float log_tol, hipStream_t str
   return t;
 }
 
+// the dual-route table at the default truncation target, for the kernels of other translation units (letkf_tile2.hip)
+bool cheb_dual_table(hipStream_t stream, const int2** hdr, const float2** c) {
+  const CoefTable* t = cheb_coef_table(1, 12.0f, stream);
+  if (!t) return false;
+  *hdr = t->hdr; *c = t->c;
+  return true;
+}
+
 // v_rcp_f32 (1 ulp) where a correctly rounded quotient buys nothing: degree selection, interval scale, function samples
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 

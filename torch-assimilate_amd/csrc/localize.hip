@@ -679,6 +679,18 @@ int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* 
   int rc = index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, ws, ws_bytes, stream, MIA_PACK_IN_LOCALIZE ? nullptr : pack,
                             zero, header_clean, sort_cells);
   if (rc != MIA_OK) return rc;
+  return localize_lists_impl(grid_xyz, g0, g1, P, n_coord, coord_group, gc_c, n_r, gc_eps, p_cap, nbr_cnt, nbr_idx, nbr_w, stats, ws,
+                             stream, MIA_PACK_IN_LOCALIZE ? pack : nullptr, taper);
+}
+
+// neighbour lists of grid points [g0, g1) over an index that already exists in `ws` (second half of localize_impl; the
+// step driver's tile route calls it alone when declined points need per-point lists); P > 0
+int localize_lists_impl(const double* grid_xyz, int64_t g0, int64_t g1, int64_t P, int n_coord, const int32_t* coord_group,
+                        const double* gc_c, int n_r, double gc_eps, int p_cap, int32_t* nbr_cnt, int32_t* nbr_idx,
+                        double* nbr_w, int32_t* stats, void* ws, hipStream_t stream, const PackJob* pack, int taper) {
+  const int64_t ng = g1 - g0;
+  if (ng <= 0 || P <= 0) return MIA_OK;
+  int rc;
   LocalizeParams lp;
   rc = make_scan_params(&lp.scan, grid_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, ws, taper);
   if (rc != MIA_OK) return rc;
@@ -688,7 +700,7 @@ int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* 
   lp.P = P;
   unsigned nb_pack = 0;
   size_t pack_lds = 0;
-  if (MIA_PACK_IN_LOCALIZE && pack && pack->rec) {
+  if (pack && pack->rec) {
     lp.pack = *pack;
     nb_pack = (unsigned)((P + 63) / 64);
     pack_lds = (size_t)64 * (pack->kp + 1) * sizeof(float);      // (kp <= 132: 34 KB)

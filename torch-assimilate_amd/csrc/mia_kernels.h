@@ -59,6 +59,9 @@ bool tile_launch_would_serve(int m, int k, int p_max, int p_cap, int64_t ldx, in
 // of cheb_analysis_launch, evaluated without launching (builds the coefficient table on `stream` if it does not exist yet)
 bool cheb_tile_will_serve(int m, int k, int p_max, int p_cap, float gamma, int64_t ldx, int64_t ldo, int64_t ng, hipStream_t stream);
 
+// (letkf_cheb.hip) coefficient table of the dual route at the default truncation target (built on first use, per device)
+bool cheb_dual_table(hipStream_t stream, const int2** hdr, const float2** c);
+
 // one-wave kernel on `stream` that returns once the 64 slot counters at done64[j * kSlotStride] sum to `expected` (bounded
 // polling: after ~seconds it sets bit 0 of *err and returns, so the grid always drains)
 int segment_wait_launch(const int32_t* done64, int expected, int32_t* err, hipStream_t stream);

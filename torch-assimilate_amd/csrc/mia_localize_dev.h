@@ -176,6 +176,9 @@ int localize_impl(const double* grid_xyz, int64_t g0, int64_t g1, const double* 
                   int32_t* nbr_cnt, int32_t* nbr_idx, double* nbr_w, int32_t* stats, void* ws, size_t ws_bytes,
                   hipStream_t stream, const PackJob* pack, bool stats_zeroed, const ZeroJob* zero,
                   int taper = MIA_TAPER_GC, bool header_clean = false, bool sort_cells = true);
+int localize_lists_impl(const double* grid_xyz, int64_t g0, int64_t g1, int64_t P, int n_coord, const int32_t* coord_group,
+                        const double* gc_c, int n_r, double gc_eps, int p_cap, int32_t* nbr_cnt, int32_t* nbr_idx,
+                        double* nbr_w, int32_t* stats, void* ws, hipStream_t stream, const PackJob* pack, int taper);
 // lists of the points flagged MIA_FLAG_RETRY into the order a sorted index gives (see sort_flagged_lists_kernel)
 int sort_flagged_lists(const int32_t* flags, const int32_t* nbr_cnt, int32_t* nbr_idx, double* nbr_w, int64_t ng, int p_cap,
                        void* ws, int64_t P, int n_coord, hipStream_t stream);

@@ -12,6 +12,7 @@ enum {
   MIA_OPT_STEP_HOSTWAIT,     // steps in flight: the launch thread waits for a step's preparation on the host (1) or the analysis stream does (0)
   MIA_OPT_STEP_LAZY_SORT,    // step driver: observation index without its per-cell sort when the tile kernel takes the analysis (1) / always sorted (0)
   MIA_OPT_SEGMENT_SIGNAL,    // step driver with several pieces: one segmented launch (1) or one launch + event per piece (0)
+  MIA_OPT_TILE_LISTS,        // step driver: tile-shaped lists + split records + letkf_tile2_kernel where the shape allows (1) or the per-point lists (0)
   MIA_OPT_COUNT_
 };
 

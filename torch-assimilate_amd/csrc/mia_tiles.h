@@ -1,0 +1,118 @@
+// Tile lists + split-precision records: the data formats between the localisation kernel, the record packing kernel and
+// the sixteen-points-per-wavefront analysis kernel of letkf_tile2.hip (round 3).
+//
+// Reference path: GaspariCohn.localize_obs per grid point (pytassim/localization/gaspari_cohn.py:97-136) feeding the
+// mask + sqrt(rho) scaling of wrapper_localization (pytassim/interface/wrapper.py:86-98).  Round 2 wrote one neighbour
+// list per grid point and let every analysis wavefront rebuild, for its 16 points, the UNION of their lists, the rank of
+// every observation in it and the 16 x U matrix of sqrt(rho) -- a third of the analysis kernel's instructions and half of
+// its latency chain.  Here the localisation kernel emits that tile-shaped form directly:
+//
+//   hdr [ntile]            int4   {U = slots used (-1: the union does not fit 16 UT slots), longest list of the tile, points, 0}
+//   uidx[ntile][16 UT]     int32  observation index of slot s, -1 = unused.  Slots are numbered by RANK of the observation
+//                                 index, permuted so that the 32-deep matrix products enumerate them in ascending rank:
+//                                 slot(rk) = 16 (rk >> 4) + 4 (rk & 3) + ((rk >> 2) & 3)
+//   D   [ntile][UT][64]    float4 lane (lr, h) = (lane & 15, lane >> 4), component q: sqrt(rho) of (point lr, slot
+//                                 16 t + 4 h + q), 0 = not local -- the analysis wave's registers, one coalesced 1 KB read per t
+//
+// Split records (what `arg[..., use] * sqrt(w)` gathers, wrapper.py:94-97, prepared for half-precision matrix cores): an f32
+// value x is carried as hi = f16(x), lo = f16(x - hi); record j is first scaled by its OWN power of two 2^e_j that brings its
+// largest member magnitude to [2^9, 2^10) -- exact, and undone through the sqrt(rho) matrix (D_hat = D 2^-e), so records of
+// very different magnitudes keep their 22-23 bits each:
+//
+//   rec[j] = nc8 chunks of {8 hi halves | 8 lo halves} (members 8c .. 8c+7, zero padded), then a 16-byte tail
+//            {w = d_j 2^e_j (f32), E = 2^-e_j (f32; NaN = the record holds a non-finite value), 0, 0};
+//   record P (one past the last) is all zeros: the source of unused slots.
+#pragma once
+#include "mia_common.h"
+
+namespace mia {
+
+// Slots an instantiation offers a tile beyond the longest single list.  Sixteen consecutive points of a regular
+// network add ~one observation per second point (config 2: 20 -> 28); below this slack most tiles would not fit.
+constexpr int kTileSlack = 8;
+
+static inline int tile_ut_for(int p_max) {
+  const int ut = (p_max + kTileSlack + 15) >> 4;
+  return ut < 1 ? 1 : ut;
+}
+
+struct TileListLayout { size_t hdr, idx, D, bytes; int ut; int64_t ntile; };
+static inline TileListLayout tile_list_layout(int64_t ng, int ut) {
+  TileListLayout L;
+  L.ut = ut;
+  L.ntile = (ng + 15) >> 4;
+  size_t o = 0;
+  L.hdr = o; o = align_up(o + (size_t)(L.ntile > 0 ? L.ntile : 1) * 16, 256);
+  L.idx = o; o = align_up(o + (size_t)(L.ntile > 0 ? L.ntile : 1) * 16 * ut * sizeof(int32_t), 256);
+  L.D = o; o = align_up(o + (size_t)(L.ntile > 0 ? L.ntile : 1) * ut * 1024, 256);
+  L.bytes = o;
+  return L;
+}
+
+static inline int split_nc8(int k) { return (k + 7) >> 3; }
+static inline int split_rec_bytes(int k) { return 32 * split_nc8(k) + 16; }
+
+// power of two that brings a magnitude (given by its bit pattern, sign cleared) to [2^target, 2^(target+1)); the
+// exponent of the scale is returned too.  Zero / subnormal magnitudes are left alone; exponents are clamped to +-60 (the
+// squares and products of scales formed in the kernels then stay inside f32).
+__device__ __forceinline__ float pow2_scale(unsigned magbits, int target, int* es_out) {
+  const int e = (int)(magbits >> 23) - 127;
+  int es = (magbits >> 23) == 0u ? 0 : target - e;
+  es = es < -60 ? -60 : (es > 60 ? 60 : es);
+  *es_out = es;
+  return __uint_as_float((unsigned)(127 + es) << 23);
+}
+
+using h8v = __attribute__((ext_vector_type(8))) _Float16;
+using h2v = __attribute__((ext_vector_type(2))) _Float16;
+using f2w = __attribute__((ext_vector_type(2))) float;
+using f4w = __attribute__((ext_vector_type(4))) float;
+using u4w = __attribute__((ext_vector_type(4))) unsigned;
+
+// x (8 values) -> hi = f16(x), lo = f16(x - hi), both rounded to nearest.  The remainders come straight from the packed
+// halves (v_fma_mix_f32 reads an f16 operand in place; the compiler's own form is two conversions + a packed subtraction,
+// and packed f32 instructions are slow beside MFMAs).
+__device__ __forceinline__ void split8(const float (&x)[8], h8v& hi, h8v& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f2w v = {x[2 * i], x[2 * i + 1]};
+    const h2v a = __builtin_convertvector(v, h2v);                  // v_cvt_pk_f16_f32, round to nearest
+    const unsigned au = __builtin_bit_cast(unsigned, a);
+    f2w r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(au), "v"(v[0]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(au), "v"(v[1]));
+    const h2v b = __builtin_convertvector(r, h2v);
+    hi[2 * i] = a[0]; hi[2 * i + 1] = a[1];
+    lo[2 * i] = b[0]; lo[2 * i + 1] = b[1];
+  }
+}
+__device__ __forceinline__ h8v hi8(const float (&x)[8]) {
+  h8v hi;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f2w v = {x[2 * i], x[2 * i + 1]};
+    const h2v a = __builtin_convertvector(v, h2v);
+    hi[2 * i] = a[0]; hi[2 * i + 1] = a[1];
+  }
+  return hi;
+}
+
+// split-record packing job (rides in the tile-list kernel as extra single-wave workgroups, or runs as a launch of its own)
+struct SplitPackJob { const float* Yb; const float* d; unsigned char* rec; int k; };
+
+// host side (tile_lists.hip)
+struct ScanParams;
+int split_pack_launch(const float* Yb, const float* d, int k, int64_t P, void* rec, hipStream_t stream);
+// tile lists of grid points [g0, g0 + ng) over the index already built in `index_ws`; optional packing passenger.
+// stats: [0] longest list (running maximum), [1] tiles whose union did not fit (added)
+int tile_lists_launch(const double* grid_xyz, int64_t g0, int64_t ng, int64_t P, int n_coord, const int32_t* coord_group,
+                      const double* gc_c, int n_r, double gc_eps, int taper, int ut, void* tile_lists, int32_t* stats,
+                      void* index_ws, hipStream_t stream, const SplitPackJob* pack);
+// letkf_tile2.hip
+bool tile2_covers(int m, int k, int p_max, int extra_blocks, int64_t ldx, int64_t ldo, int64_t ng);
+int tile2_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const void* rec, int64_t P,
+                          const void* tile_lists, int ut, float inf_factor, float* Xa, int64_t ldo, int64_t o0,
+                          int32_t* flags, int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c,
+                          hipStream_t stream);
+
+}  // namespace mia

@@ -26,6 +26,7 @@
 #include "mia_kernels.h"
 #include "mia_options.h"
 #include "mia_pack_dev.h"
+#include "mia_tiles.h"
 
 // ---- the few RCCL declarations needed (ABI of rccl.h 2.x: opaque comm, 128-byte id, C enums)
 typedef struct ncclComm* ncclComm_t;
@@ -278,13 +279,14 @@ int peer_finish(mia_comm* c, int slot, uint32_t seq, int64_t G, int64_t b0, int6
 
 struct StepLayout {
   size_t rec, loc, cnt, idx, w, done, bufs, gath, total;
+  size_t hrec, tl, scratch;      // tile route: split records (P + 1), tile lists of the block, 256 bytes of scratch counters
   size_t loc_bytes, send_bytes, chunk_bytes;
-  int cap;
+  int cap, ut;
   int64_t n, nc;
 };
 
 int step_layout(int64_t G, int m, int k, int64_t P, int n_coord, int world, int n_chunks, int p_max_assumed,
-                StepLayout* L) {
+                StepLayout* L, int tile_extra = 0) {
   if (G < 0 || m <= 0 || k <= 0 || P < 0 || n_coord <= 0 || world <= 0 || n_chunks <= 0 || n_chunks > kMaxChunks - 1 ||
       p_max_assumed < 0)
     return MIA_ERR_SIZE;
@@ -301,6 +303,18 @@ int step_layout(int64_t G, int m, int k, int64_t P, int n_coord, int world, int 
   L->idx = o; o = mia::align_up(o + (size_t)L->n * L->cap * sizeof(int32_t), 256);
   L->w = o; o = mia::align_up(o + (size_t)L->n * L->cap * sizeof(double), 256);
   L->done = o; o = mia::align_up(o + (size_t)kMaxChunks * 64 * mia::kSlotStride * sizeof(int32_t), 256);
+  // (the workspace is sized for the largest tile lists the ensemble size allows, so that a caller may add slots -- MIA_STEP_TILE_EXTRA
+  //  -- without a new workspace query)
+  const int ut0 = mia::tile_ut_for(p_max_assumed < L->cap ? p_max_assumed : L->cap), kt = (k + 15) >> 4;
+  const int ut_most = kt + 1 < 6 ? kt + 1 : 6;
+  L->ut = ut0 + tile_extra;
+  L->hrec = L->tl = o;
+  if (ut0 <= ut_most) {
+    L->hrec = o; o = mia::align_up(o + (size_t)(P + 1) * mia::split_rec_bytes(k), 256);
+    L->tl = o; o = mia::align_up(o + mia::tile_list_layout(L->n, ut_most).bytes, 256);
+  }
+  if (L->ut > ut_most) L->ut = 7;      // (no tile route)
+  L->scratch = o; o += 256;
   L->bufs = L->gath = o;
   L->send_bytes = (size_t)m * k * L->nc * sizeof(float) + 16;   // piece + counter trailer
   L->chunk_bytes = mia::align_up(L->send_bytes, 256);
@@ -632,7 +646,7 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
   if (peer) n_chunks = 1;
   const bool exch = comm && !peer && (world > 1 || n_chunks > 1);
   StepLayout L;
-  int rc = step_layout(G, m, k, P, n_coord, world, n_chunks, p_max_assumed, &L);
+  int rc = step_layout(G, m, k, P, n_coord, world, n_chunks, p_max_assumed, &L, (step_flags >> 4) & 7);
   if (rc != MIA_OK) return rc;
   if (ws_bytes < L.total) return MIA_ERR_WORKSPACE;
   if ((exch || peer) && !comm_stream) return MIA_ERR_NULL;
@@ -652,6 +666,18 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
                     L.cap <= 128 &&
                     mia::cheb_tile_will_serve(m, k, p_max_assumed < L.cap ? p_max_assumed : L.cap, L.cap, gamma, G, G, blk,
                                               (hipStream_t)(prep_stream ? prep_stream : stream));
+  // Tile route (round 3): the localisation kernel emits tile-shaped lists (union + sqrt(rho) matrix per sixteen points), the
+  // records are packed as scaled half pairs, and letkf_tile2_kernel analyses from both -- no per-point lists are written or
+  // read.  Taken when the block's analysis is one plain launch of a shape the kernel covers; a tile whose union does not fit
+  // its slots is counted in counters[1] and the caller repeats the step with MIA_STEP_NO_TILE_LISTS (scattered grids).
+  // Declined points (phase 1) are redone from per-point lists built then, over the index this step left in its workspace.
+  const int pm_tl = p_max_assumed < L.cap ? p_max_assumed : L.cap;
+  const int2* tl_th = nullptr;
+  const float2* tl_tc = nullptr;
+  const bool tl_route = mia::option(MIA_OPT_TILE_LISTS) != 0 && !(step_flags & MIA_STEP_NO_TILE_LISTS) && n_chunks == 1 &&
+                        method != 1 && !(gamma > 0.0f) && blk > 0 && P > 0 && L.ut <= 6 && mia::option(MIA_OPT_TILE) != 0 &&
+                        mia::option(MIA_OPT_TILE_SPLIT) != 0 && mia::tile2_covers(m, k, pm_tl, (step_flags >> 4) & 7, G, exch ? L.nc : G, blk) &&
+                        mia::cheb_dual_table((hipStream_t)(prep_stream ? prep_stream : stream), &tl_th, &tl_tc);
   // a step in flight whose analysis is ONE plain launch (stage 2 after the host-side wait): the launch carries its completion
   // (and timing) events in its own dispatch packet
   const bool carried = kdone_out && phase == 0 && !exch && !peer && n_chunks == 1 && method != 1 && (step_flags & kStepPrepDone) &&
@@ -697,7 +723,17 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
         MIA_HIP_TRY(hipMemsetAsync(done, 0, done_ints * sizeof(int32_t), ps));
       }
     }
-    if (b1 > b0) {
+    if (b1 > b0 && tl_route) {
+      const mia::ZeroJob zj{{counters, exch ? ctr : nullptr, exch ? done : nullptr},
+                            {8, exch ? 4 : 0, exch ? (int64_t)done_ints : 0}};
+      rc = mia::index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, base + L.loc, L.loc_bytes, ps, nullptr,
+                                 zero_in_kernel ? &zj : nullptr, (step_flags & MIA_STEP_WS_CLEAN) != 0, false);
+      if (rc != MIA_OK) return rc;
+      const mia::SplitPackJob sj{Yb, d, (unsigned char*)(base + L.hrec), k};
+      rc = mia::tile_lists_launch(grid_xyz, b0, b1 - b0, P, n_coord, coord_group, gc_c, n_r, gc_eps, MIA_TAPER_GC, L.ut,
+                                  base + L.tl, ctr, base + L.loc, ps, &sj);
+      if (rc != MIA_OK) return rc;
+    } else if (b1 > b0) {
       // the record packing rides inside the first index kernel too (independent work, no launch of its own)
       const mia::PackJob job{Yb, d, rec, k, (k + 1 + 3) / 4 * 4};
       const mia::ZeroJob zj{{counters, exch ? ctr : nullptr, exch ? done : nullptr},
@@ -742,7 +778,22 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
       const int32_t* cidx = idx + (size_t)(c0 - b0) * L.cap;
       const double* cw = w + (size_t)(c0 - b0) * L.cap;
       int32_t* cfl = flags + (c0 - b0);
-      if (phase == 1) {
+      if (phase == 1 && tl_route) {
+        // declined points of the tile route: float32 records and per-point lists are built now (the step's index is still in
+        // its workspace, unsorted: the flagged points' lists are put into sorted-index order as on the lazy route)
+        rc = mia_letkf_pack_obs_f32(Yb, d, k, P, rec, stream);
+        if (rc != MIA_OK) return rc;
+        rc = mia::localize_lists_impl(grid_xyz, c0, c1, P, n_coord, coord_group, gc_c, n_r, gc_eps, L.cap, const_cast<int32_t*>(ccnt),
+                                      const_cast<int32_t*>(cidx), const_cast<double*>(cw), (int32_t*)(base + L.scratch),
+                                      base + L.loc, (hipStream_t)stream, nullptr, MIA_TAPER_GC);
+        if (rc != MIA_OK) return rc;
+        rc = mia::sort_flagged_lists(cfl, ccnt, const_cast<int32_t*>(cidx), const_cast<double*>(cw), c1 - c0, (int)L.cap,
+                                     base + L.loc, P, n_coord, (hipStream_t)stream);
+        if (rc != MIA_OK) return rc;
+        rc = mia_letkf_analysis_retry_f32(X, G, m, k, c0, c1, rec, P, ccnt, cidx, cw, L.cap, p_max_assumed, inf_factor,
+                                          gamma, dst, ldo, o0, cfl, stream);
+        if (rc != MIA_OK) return rc;
+      } else if (phase == 1) {
         if (lazy) {      // (the lists of the declined points into sorted-index order, see above)
           rc = mia::sort_flagged_lists(cfl, ccnt, const_cast<int32_t*>(cidx), const_cast<double*>(cw), c1 - c0, (int)L.cap,
                                        base + L.loc, P, n_coord, (hipStream_t)stream);
@@ -766,10 +817,18 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
             mia::launch_start_event() = t_start;
           }
           const unsigned long long tiles_before = mia::tile_launch_count();
-          rc = mia_letkf_analysis_matfun_f32(X, G, m, k, c0, c1, rec, P, ccnt, cidx, cw, L.cap, p_max_assumed,
-                                             inf_factor, gamma, dst, ldo, o0, cfl, ctr + 2, stream);
-          // (an unsorted index is only right for the kernel the rule above predicted)
-          if (lazy && rc == MIA_OK && mia::tile_launch_count() == tiles_before) return MIA_ERR_UNSUPPORTED;
+          if (tl_route)
+            rc = mia::tile2_analysis_launch(X, G, m, k, c0, c1 - c0, base + L.hrec, P, base + L.tl, L.ut, inf_factor, dst, ldo, o0,
+                                            cfl, ctr + 2, mia::option(MIA_OPT_CHEB_DMAX), tl_th, tl_tc, (hipStream_t)stream);
+          else
+            rc = mia_letkf_analysis_matfun_f32(X, G, m, k, c0, c1, rec, P, ccnt, cidx, cw, L.cap, p_max_assumed,
+                                               inf_factor, gamma, dst, ldo, o0, cfl, ctr + 2, stream);
+          // (an unsorted index is only right for the kernel the rule above predicted; the tile route has no other kernel)
+          if ((lazy || tl_route) && (rc != MIA_OK || mia::tile_launch_count() == tiles_before)) {
+            mia::launch_stop_event() = nullptr;
+            mia::launch_start_event() = nullptr;
+            return rc != MIA_OK ? rc : MIA_ERR_UNSUPPORTED;
+          }
           if (kstop) {
             if (mia::launch_stop_event() == nullptr) {
               *kdone_out = kstop;      // (taken by the tile kernel's launch)

@@ -1,0 +1,348 @@
+// Tile-shaped Gaspari-Cohn lists and split-precision observation records (formats: mia_tiles.h).
+//
+// localize_tiles_kernel: ONE wavefront per tile of 16 consecutive grid points.  It stands in for 16 evaluations of
+// GaspariCohn.localize_obs (pytassim/localization/gaspari_cohn.py:97-136) + the mask / sqrt(rho) of
+// wrapper_localization (pytassim/interface/wrapper.py:88-97) and writes what the analysis wave needs in the layout of
+// its registers: the union of the 16 lists (observation indices by rank) and the 16 x U matrix of sqrt(rho).
+// Candidate-major: the candidates of a tile are the observations of the cell box around its points (every point's 3^d
+// neighbourhood lies inside), each is loaded ONCE and weighed against the 16 points in float64 -- same distance, taper and
+// `w > eps` arithmetic as the per-point kernels of localize.hip, so the masks are the reference's.  Three dependent memory
+// round trips per tile (coordinates -> cell starts -> candidates) where the per-point kernels take six per point.
+//
+// pack_split_wave: [k][P] perturbations + d[P] -> per-observation split records (scaled hi | lo halves), 64 per wavefront.
+#include "mia_common.h"
+#include "mia_options.h"
+#include "mia_localize_dev.h"
+#include "mia_tiles.h"
+
+namespace mia {
+
+#define MIA_TL_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// ---- split records ---------------------------------------------------------------------------------------------------
+// One wavefront packs records j0 .. j0 + 63 (indices up to P: record P is the all-zero record).  Lane j reads entry j of
+// every row of Yb (256-byte row segments, sixteen rows requested before any is consumed) into an LDS image [64][ls], ls odd;
+// every lane then finds its record's largest member magnitude (-> power of two), writes the tail, and the chunks of the
+// 64 records are converted by all lanes, one chunk of eight members (32 bytes out) per lane and trip.
+// lds: 64 * ls floats + 64 floats, ls = (k + 1) | 1.
+__device__ inline void pack_split_wave(const SplitPackJob& J, int64_t P, int64_t block, float* lds) {
+  const int lane = threadIdx.x & 63;
+  const int k = J.k, nc8 = (k + 7) >> 3, rb = 32 * nc8 + 16;
+  const int ls = (k + 1) | 1;
+  float* scl = lds + 64 * ls;
+  const int64_t j0 = block * 64;
+  const int64_t j = j0 + lane;
+  const bool real = j < P;                    // (j == P: the zero record; j > P: nothing)
+  const int64_t jc = real ? j : (P > 0 ? P - 1 : 0);
+  for (int i0 = 0; i0 < k; i0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = i0 + u < k ? i0 + u : k - 1;
+      v[u] = (P > 0) ? J.Yb[(int64_t)i * P + jc] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (i0 + u < k) lds[lane * ls + i0 + u] = real ? v[u] : 0.0f;
+  }
+  const float dj = (real && P > 0) ? J.d[jc] : 0.0f;
+  MIA_TL_SYNC();
+  unsigned mx = 0u;
+  for (int i = 0; i < k; ++i) {
+    const unsigned a = __float_as_uint(lds[lane * ls + i]) & 0x7fffffffu;
+    mx = a > mx ? a : mx;
+  }
+  int es;
+  const float sc = pow2_scale(mx, 9, &es);
+  const float wd = dj * sc;
+  const bool bad = mx >= 0x7f800000u || !(fabsf(wd) < 3.0e38f);
+  scl[lane] = sc;
+  if (j <= P) {
+    const float E = bad ? __builtin_nanf("") : __uint_as_float((unsigned)(127 - es) << 23);
+    *reinterpret_cast<f4w*>(J.rec + j * rb + 32 * nc8) = f4w{wd, E, 0.0f, 0.0f};
+  }
+  MIA_TL_SYNC();
+  const int nvalid = P + 1 - j0 < 64 ? (int)(P + 1 - j0) : 64;
+  const int nq = nvalid * nc8;
+  int r = lane / nc8, c = lane - r * nc8;
+  const int dr = 64 / nc8, dc = 64 - dr * nc8;
+  for (int q = lane; q < nq; q += 64) {
+    const float s = scl[r];
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = 8 * c + i < k ? lds[r * ls + 8 * c + i] * s : 0.0f;
+    h8v hi, lo;
+    split8(x, hi, lo);
+    unsigned char* o = J.rec + (j0 + r) * rb + 32 * c;
+    *reinterpret_cast<h8v*>(o) = hi;
+    *reinterpret_cast<h8v*>(o + 16) = lo;
+    r += dr; c += dc;
+    if (c >= nc8) { c -= nc8; ++r; }
+  }
+}
+
+struct SplitPackParams { SplitPackJob job; int64_t P; };
+__global__ __launch_bounds__(64) void pack_split_kernel(SplitPackParams p) {
+  extern __shared__ __attribute__((aligned(16))) float pk_lds[];
+  pack_split_wave(p.job, p.P, (int64_t)blockIdx.x, pk_lds);
+}
+
+static size_t split_pack_lds(int k) { return ((size_t)64 * ((k + 1) | 1) + 64) * sizeof(float); }
+
+int split_pack_launch(const float* Yb, const float* d, int k, int64_t P, void* rec, hipStream_t stream) {
+  if (k < 1 || k > 1024 || P < 0) return MIA_ERR_SIZE;
+  if (!rec || (P > 0 && (!Yb || !d))) return MIA_ERR_NULL;
+  const int64_t nb = (P + 1 + 63) / 64;
+  if (nb > 2147483647LL) return MIA_ERR_UNSUPPORTED;
+  const size_t lds = split_pack_lds(k);
+  if (lds > kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
+  SplitPackParams sp{{Yb, d, (unsigned char*)rec, k}, P};
+  if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)pack_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  pack_split_kernel<<<dim3((unsigned)nb), dim3(64), lds, stream>>>(sp);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// ---- tile lists ------------------------------------------------------------------------------------------------------
+constexpr int kTlUmax = 96;           // largest union (UT = 6)
+constexpr int kTlMaxRows = 64;        // cell rows of a tile's box (outer coordinates); more = scattered points: no tile list
+
+struct TileLocParams {
+  ScanParams scan;
+  int64_t g0, ng;
+  int ut;
+  int4* hdr; int32_t* uidx; f4w* D;
+  int32_t* stats;
+  unsigned nb_main;          // workgroups nb_main, nb_main + 1, ... pack split records (independent passenger)
+  SplitPackJob pack;
+  int64_t P;
+};
+
+__global__ __launch_bounds__(64) void localize_tiles_kernel(TileLocParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tl_lds[];
+  if (blockIdx.x >= p.nb_main) {
+    pack_split_wave(p.pack, p.P, (int64_t)(blockIdx.x - p.nb_main), reinterpret_cast<float*>(tl_lds));
+    return;
+  }
+  const int lane = threadIdx.x, cl = lane & 15, pg = lane >> 4;
+  const int UMAX = 16 * p.ut;
+  double* gxs = reinterpret_cast<double*>(tl_lds);                    // [16][3] grid coordinates of the tile's points
+  int* cgs = reinterpret_cast<int*>(gxs + 16 * MIA_MAX_COORD);        // [16][3] their cells
+  int* ukey = cgs + 16 * MIA_MAX_COORD;                               // [kTlUmax] observation index of union member u
+  int* uinv = ukey + kTlUmax;                                         // [kTlUmax] member of slot s, -1 = unused
+  float* Wt = reinterpret_cast<float*>(uinv + kTlUmax);               // [kTlUmax][16] sqrt(rho) of (member, point), 0 = not local
+  const ScanParams& q = p.scan;
+  const IndexHeader* hd = q.hdr;
+  const int nc = q.nc;
+  const int64_t tile = blockIdx.x;
+  const int64_t p0 = tile << 4;
+  const int npts = p.ng - p0 < 16 ? (int)(p.ng - p0) : 16;
+  if (lane < 16) {
+    const int64_t pt = p.g0 + p0 + (lane < npts ? lane : npts - 1);
+    for (int c = 0; c < MIA_MAX_COORD; ++c) {
+      double gx = 0.0;
+      int cg = 0;
+      if (c < nc) {
+        gx = q.grid[pt * nc + c];
+        cg = cell_coord(gx, hd->mn[c], hd->invh[c], hd->n[c]);
+      }
+      gxs[lane * MIA_MAX_COORD + c] = gx;
+      cgs[lane * MIA_MAX_COORD + c] = cg;
+    }
+  }
+  for (int s = lane; s < kTlUmax; s += 64) uinv[s] = -1;
+  MIA_TL_SYNC();
+  // the tile's cell box: [min cell - 1, max cell + 1] per coordinate, clipped to the cell grid
+  int lo[MIA_MAX_COORD], hi[MIA_MAX_COORD];
+  for (int c = 0; c < MIA_MAX_COORD; ++c) {
+    int mn = 0x7fffffff, mx = -0x7fffffff;
+    for (int i = 0; i < npts; ++i) { const int v = cgs[i * MIA_MAX_COORD + c]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+    lo[c] = mn - 1 < 0 ? 0 : mn - 1;
+    hi[c] = mx + 1 > hd->n[c] - 1 ? hd->n[c] - 1 : mx + 1;
+    if (c >= nc) { lo[c] = 0; hi[c] = 0; }
+    lo[c] = __builtin_amdgcn_readfirstlane(lo[c]);       // (the same in every lane: scalar loop bounds below)
+    hi[c] = __builtin_amdgcn_readfirstlane(hi[c]);
+  }
+  const int last = nc - 1;
+  bool empty = false;
+  for (int c = 0; c < nc; ++c) empty = empty || lo[c] > hi[c];
+  // outer coordinates (all but the last, whose cells are contiguous in the index): rows of the box
+  const int n0 = nc >= 2 ? hi[0] - lo[0] + 1 : 1;
+  const int n1 = nc == 3 ? hi[1] - lo[1] + 1 : 1;
+  const long long nrows = empty ? 0 : (long long)n0 * n1;
+  bool overflow = nrows > kTlMaxRows;
+  int ubase = 0;
+  int cnt4[4] = {0, 0, 0, 0};          // local observations of points 4 pg + i so far (the same in every lane of a group)
+  for (int row = 0; row < (overflow ? 0 : (int)nrows); ++row) {
+    int base_cell = 0;
+    if (nc == 2) base_cell = (lo[0] + row) * hd->n[1];
+    else if (nc == 3) base_cell = ((lo[0] + row / n1) * hd->n[1] + (lo[1] + row % n1)) * hd->n[2];
+    const int beg = __builtin_amdgcn_readfirstlane(q.start[base_cell + lo[last]]);
+    const int end = __builtin_amdgcn_readfirstlane(q.start[base_cell + hi[last] + 1]);
+    for (int pos0 = beg; pos0 < end; pos0 += 16) {
+      const bool have = pos0 + cl < end;
+      const int pos = have ? pos0 + cl : end - 1;
+      const int oj = q.sorted[pos];
+      double ox[MIA_MAX_COORD] = {0.0, 0.0, 0.0};
+      for (int c = 0; c < nc; ++c) ox[c] = q.sxyz[(int64_t)pos * nc + c];
+      f4w wq = {0.f, 0.f, 0.f, 0.f};
+      bool anyu = false;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pt = 4 * pg + i;
+        double d2[MIA_MAX_RADII] = {0.0, 0.0, 0.0};
+        for (int c = 0; c < nc; ++c) {
+          const double dx = ox[c] - gxs[pt * MIA_MAX_COORD + c];
+          d2[q.group[c]] += dx * dx;
+        }
+        double wgt = 1.0;
+        for (int r = 0; r < q.n_r; ++r) wgt *= taper_d2(q.taper, d2[r], q.inv_c[r], q.cc[r]);
+        const bool use = have && pt < npts && wgt > q.eps;
+        wq[i] = use ? (float)(wgt * rsqrt_f64(wgt)) : 0.0f;
+        anyu = anyu || use;
+        const unsigned long long bal = __ballot(use);
+        cnt4[i] += __popc((unsigned)(bal >> (16 * pg)) & 0xffffu);
+      }
+      // a candidate is a member of the union when any of its four lanes (one per point group) uses it
+      const unsigned long long anyb = __ballot(anyu);
+      const unsigned memb = (unsigned)((anyb | (anyb >> 16) | (anyb >> 32) | (anyb >> 48)) & 0xffffull);
+      const bool member = (memb >> cl) & 1u;
+      const int u = ubase + __popc(memb & ((1u << cl) - 1u));
+      if (member && u < kTlUmax) {
+        if (pg == 0) ukey[u] = oj;
+        *reinterpret_cast<f4w*>(Wt + u * 16 + 4 * pg) = wq;
+      }
+      ubase += __popc(memb);
+    }
+  }
+  const int U = ubase;
+  overflow = overflow || U > UMAX;
+  MIA_TL_SYNC();
+  // rank of every member by observation index -> slot
+  if (!overflow) {
+    for (int u = lane; u < U; u += 64) {
+      const int key = ukey[u];
+      int rk = 0;
+      for (int v = 0; v < U; ++v) rk += ukey[v] < key ? 1 : 0;
+      uinv[16 * (rk >> 4) + 4 * (rk & 3) + ((rk >> 2) & 3)] = u;
+    }
+  }
+  MIA_TL_SYNC();
+  for (int s = lane; s < UMAX; s += 64) {
+    const int u = overflow ? -1 : uinv[s];
+    p.uidx[tile * UMAX + s] = u < 0 ? -1 : ukey[u];
+  }
+  for (int t = 0; t < p.ut; ++t) {
+    f4w v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const int u = overflow ? -1 : uinv[16 * t + 4 * pg + qq];
+      v[qq] = u < 0 ? 0.0f : Wt[u * 16 + cl];
+    }
+    p.D[(tile * p.ut + t) * 64 + lane] = v;
+  }
+  // longest list of the tile (every lane of a point group holds the counts of its four points)
+  int mx = cnt4[0] > cnt4[1] ? cnt4[0] : cnt4[1];
+  mx = cnt4[2] > mx ? cnt4[2] : mx;
+  mx = cnt4[3] > mx ? cnt4[3] : mx;
+  const int m0 = __builtin_amdgcn_readlane(mx, 0), m1 = __builtin_amdgcn_readlane(mx, 16);
+  const int m2 = __builtin_amdgcn_readlane(mx, 32), m3 = __builtin_amdgcn_readlane(mx, 48);
+  const int m01 = m0 > m1 ? m0 : m1, m23 = m2 > m3 ? m2 : m3;
+  const int longest = m01 > m23 ? m01 : m23;
+  if (lane == 0) {
+    p.hdr[tile] = make_int4(overflow ? -1 : U, longest, npts, 0);
+    if (longest > __hip_atomic_load(&p.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&p.stats[0], longest);
+    if (overflow) atomicAdd(&p.stats[1], 1);
+  }
+}
+
+static size_t tile_loc_lds() {
+  return 16 * MIA_MAX_COORD * (sizeof(double) + sizeof(int)) + 2 * kTlUmax * sizeof(int) + (size_t)kTlUmax * 16 * sizeof(float);
+}
+
+int tile_lists_launch(const double* grid_xyz, int64_t g0, int64_t ng, int64_t P, int n_coord, const int32_t* coord_group,
+                      const double* gc_c, int n_r, double gc_eps, int taper, int ut, void* tile_lists, int32_t* stats,
+                      void* index_ws, hipStream_t stream, const SplitPackJob* pack) {
+  if (ng < 0 || P < 0 || ut < 1 || ut > 6) return MIA_ERR_SIZE;
+  if (!tile_lists || !stats) return MIA_ERR_NULL;
+  const TileListLayout L = tile_list_layout(ng, ut);
+  unsigned nb_pack = 0;
+  size_t lds = tile_loc_lds();
+  TileLocParams tp;
+  tp.pack = SplitPackJob{nullptr, nullptr, nullptr, 0};
+  if (pack && pack->rec) {
+    tp.pack = *pack;
+    if ((P + 1 + 63) / 64 > 2000000000LL) return MIA_ERR_UNSUPPORTED;
+    nb_pack = (unsigned)((P + 1 + 63) / 64);
+    const size_t pl = split_pack_lds(pack->k);
+    lds = pl > lds ? pl : lds;
+  }
+  if (lds > kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
+  char* base = (char*)tile_lists;
+  tp.hdr = (int4*)(base + L.hdr); tp.uidx = (int32_t*)(base + L.idx); tp.D = (f4w*)(base + L.D);
+  tp.stats = stats; tp.g0 = g0; tp.ng = ng; tp.ut = ut; tp.P = P;
+  if (L.ntile + nb_pack > 2147483647LL) return MIA_ERR_UNSUPPORTED;
+  if (L.ntile + nb_pack == 0) return MIA_OK;
+  if (P == 0) {     // no observations at all: every tile is empty (-> prior weights downstream); no index exists
+    MIA_HIP_TRY(hipMemsetAsync(base + L.hdr, 0, (size_t)L.ntile * 16, stream));
+    MIA_HIP_TRY(hipMemsetAsync(base + L.idx, 0xff, (size_t)L.ntile * 16 * ut * sizeof(int32_t), stream));
+    MIA_HIP_TRY(hipMemsetAsync(base + L.D, 0, (size_t)L.ntile * ut * 1024, stream));
+    if (nb_pack) return split_pack_launch(pack->Yb, pack->d, pack->k, P, pack->rec, stream);
+    return MIA_OK;
+  }
+  if (!grid_xyz || !index_ws) return MIA_ERR_NULL;
+  int rc = make_scan_params(&tp.scan, grid_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, index_ws, taper);
+  if (rc != MIA_OK) return rc;
+  tp.nb_main = (unsigned)L.ntile;
+  if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)localize_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  localize_tiles_kernel<<<dim3((unsigned)(L.ntile + nb_pack)), dim3(64), lds, stream>>>(tp);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+}  // namespace mia
+
+using namespace mia;
+
+extern "C" int mia_letkf_split_record_bytes(int k, size_t* bytes) {
+  if (!bytes) return MIA_ERR_NULL;
+  if (k < 1 || k > 1024) return MIA_ERR_SIZE;
+  *bytes = (size_t)split_rec_bytes(k);
+  return MIA_OK;
+}
+
+extern "C" int mia_letkf_pack_split_f32(const float* Yb, const float* d, int k, int64_t P, void* rec, void* stream) {
+  (void)hipGetLastError();
+  return split_pack_launch(Yb, d, k, P, rec, (hipStream_t)stream);
+}
+
+extern "C" int mia_letkf_tile_lists_bytes(int64_t n_points, int p_max, int extra_blocks, size_t* bytes) {
+  if (!bytes) return MIA_ERR_NULL;
+  if (n_points < 0 || p_max < 0 || extra_blocks < 0) return MIA_ERR_SIZE;
+  if (tile_ut_for(p_max) + extra_blocks > 6) return MIA_ERR_UNSUPPORTED;
+  *bytes = tile_list_layout(n_points, tile_ut_for(p_max) + extra_blocks).bytes;
+  return MIA_OK;
+}
+
+extern "C" int mia_letkf_localize_tiles_f64(int taper, const double* grid_xyz, int64_t g0, int64_t g1,
+                                            const double* obs_xyz, int64_t P, int n_coord, const int32_t* coord_group,
+                                            const double* gc_c, int n_r, double gc_eps, int p_max, int extra_blocks,
+                                            void* tile_lists, size_t tile_lists_bytes, int32_t* stats, void* ws, size_t ws_bytes,
+                                            void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (taper != MIA_TAPER_GC && taper != MIA_TAPER_GC_INF) return MIA_ERR_SIZE;
+  if (g1 < g0 || g0 < 0 || P < 0 || p_max < 0 || extra_blocks < 0) return MIA_ERR_SIZE;
+  if (n_coord < 1 || n_coord > MIA_MAX_COORD || n_r < 1 || n_r > MIA_MAX_RADII) return MIA_ERR_SIZE;
+  if (!coord_group || !gc_c || !stats || !tile_lists) return MIA_ERR_NULL;
+  const int ut = tile_ut_for(p_max) + extra_blocks;
+  if (ut > 6) return MIA_ERR_UNSUPPORTED;
+  if (tile_lists_bytes < tile_list_layout(g1 - g0, ut).bytes) return MIA_ERR_WORKSPACE;
+  MIA_HIP_TRY(hipMemsetAsync(stats, 0, 2 * sizeof(int32_t), stream));
+  if (P > 0) {
+    int rc = index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, ws, ws_bytes, stream, nullptr, nullptr, false, false);
+    if (rc != MIA_OK) return rc;
+  }
+  return tile_lists_launch(grid_xyz, g0, g1 - g0, P, n_coord, coord_group, gc_c, n_r, gc_eps, taper, ut, tile_lists, stats, ws,
+                           stream, nullptr);
+}

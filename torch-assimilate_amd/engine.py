@@ -46,6 +46,33 @@ class NeighbourLists:
 
 
 @dataclass
+class TileLists:
+    """Tile-shaped lists of grid points [g0, g1) (csrc/mia_tiles.h): device buffer + the bound they were sized for."""
+
+    def __init__(self, lists, p_max, g0, g1, stats, extra_blocks=0):
+        self.lists, self.p_max, self.g0, self.g1, self.stats, self.extra_blocks = lists, p_max, g0, g1, stats, extra_blocks
+
+    @property
+    def ut(self):
+        return max(1, (self.p_max + 8 + 15) // 16) + self.extra_blocks
+
+    def unpack(self):
+        """host view for tests: (hdr [ntile, 4], uidx [ntile, 16 ut], D [ntile, ut, 64, 4])"""
+        import numpy as np
+        n = self.g1 - self.g0
+        ntile, ut = (n + 15) // 16, self.ut
+        raw = self.lists.cpu().numpy()
+
+        def up(x):
+            return (x + 255) // 256 * 256
+        o_idx = up(max(ntile, 1) * 16)
+        o_d = o_idx + up(max(ntile, 1) * 16 * ut * 4)
+        hdr = raw[:ntile * 16].view(np.int32).reshape(ntile, 4)
+        uidx = raw[o_idx:o_idx + ntile * 16 * ut * 4].view(np.int32).reshape(ntile, 16 * ut)
+        D = raw[o_d:o_d + ntile * ut * 1024].view(np.float32).reshape(ntile, ut, 64, 4)
+        return hdr, uidx, D
+
+
 class ObsIndex:
     """Cell index of one observation set for one localisation (built by mia_letkf_index_build_f64)."""
     ws: torch.Tensor
@@ -151,6 +178,71 @@ class LetkfEngine:
             cap = (p_max + 7) // 8 * 8          # lists were truncated: retry with room for all
         self._p_cap_hint = max(8, (p_max + 7) // 8 * 8)
         return NeighbourLists(cnt, idx, w, cap, p_max, g0, g1)
+
+    # ------------------------------------------------------------ tile route (round 3)
+    def localize_tiles(self, grid_xyz, obs_xyz, radii: Sequence[float], p_max: int,
+                       coord_group: Optional[Sequence[int]] = None, eps: float = 1e-5, g0: int = 0,
+                       g1: Optional[int] = None, taper: int = 0, extra_blocks: int = 0) -> "TileLists":
+        """Tile lists of grid points [g0, g1) (mia_letkf_localize_tiles_f64): per tile of sixteen points the union of
+        their Gaspari-Cohn lists and the sqrt(weight) matrix, in the analysis kernel's register layout.  ``p_max`` bounds
+        the local observations of a point (e.g. ``NeighbourLists.p_max`` of an earlier call on the geometry),
+        ``extra_blocks`` adds sixteen slots each to what a tile's union may hold; the returned object's ``stats`` holds
+        [longest list, tiles whose union did not fit] on the device."""
+        grid = self._dev(grid_xyz, torch.float64)
+        obs = self._dev(obs_xyz, torch.float64)
+        if grid.dim() == 1:
+            grid = grid[:, None].contiguous()
+        if obs.dim() == 1:
+            obs = obs[:, None].contiguous()
+        G, nc = grid.shape
+        P = obs.shape[0]
+        if P and obs.shape[1] != nc:
+            raise ValueError("grid and observation coordinates differ in dimensionality")
+        g1 = G if g1 is None else g1
+        radii = [float(r) for r in (radii if hasattr(radii, "__len__") else [radii])]
+        coord_group = [0] * nc if coord_group is None else [int(c) for c in coord_group]
+        cg = (C.c_int32 * nc)(*coord_group)
+        rc = (C.c_double * len(radii))(*radii)
+        nbytes = C.c_size_t(0)
+        _cabi.check(self.lib.mia_letkf_localize_workspace_bytes(P, nc, C.byref(nbytes)), "localize_workspace_bytes")
+        ws = self._workspace("loc", nbytes.value)
+        tb = C.c_size_t(0)
+        _cabi.check(self.lib.mia_letkf_tile_lists_bytes(g1 - g0, int(p_max), int(extra_blocks), C.byref(tb)),
+                    "mia_letkf_tile_lists_bytes")
+        lists = torch.empty(max(tb.value, 256), dtype=torch.uint8, device=self.device)
+        stats = torch.zeros(2, dtype=torch.int32, device=self.device)
+        _cabi.check(self.lib.mia_letkf_localize_tiles_f64(
+            int(taper), _ptr(grid), g0, g1, _ptr(obs), P, nc, cg, rc, len(radii), float(eps), int(p_max), int(extra_blocks),
+            _ptr(lists), lists.numel(), _ptr(stats), _ptr(ws), ws.numel(), self._stream()), "mia_letkf_localize_tiles_f64")
+        return TileLists(lists, int(p_max), g0, g1, stats, int(extra_blocks))
+
+    def pack_split(self, Yb: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
+        """[k][P] perturbations + d[P] -> (P + 1) split records (uint8 tensor; mia_letkf_pack_split_f32)."""
+        Yb = Yb.to(device=self.device, dtype=torch.float32).contiguous()
+        d = d.to(device=self.device, dtype=torch.float32).contiguous().reshape(-1)
+        k, P = Yb.shape
+        rb = C.c_size_t(0)
+        _cabi.check(self.lib.mia_letkf_split_record_bytes(k, C.byref(rb)), "mia_letkf_split_record_bytes")
+        rec = torch.empty(((P + 1) * rb.value,), dtype=torch.uint8, device=self.device)
+        _cabi.check(self.lib.mia_letkf_pack_split_f32(_ptr(Yb), _ptr(d), k, P, _ptr(rec), self._stream()),
+                    "mia_letkf_pack_split_f32")
+        return rec
+
+    def analysis_tiles(self, X: torch.Tensor, split_rec: torch.Tensor, P: int, tiles: "TileLists", inf_factor: float = 1.0,
+                       out: Optional[torch.Tensor] = None):
+        """Analysis of the tile lists' grid points from split records (mia_letkf_analysis_tiles_f32).  Returns
+        (Xa [m, k, g1 - g0], flags int32 [g1 - g0], retry_count int32 [1]); declined points carry MIA_FLAG_RETRY."""
+        X = X.to(device=self.device, dtype=torch.float32).contiguous()
+        m, k, G = X.shape
+        n = tiles.g1 - tiles.g0
+        xa = out if out is not None else torch.empty((m, k, n), dtype=torch.float32, device=self.device)
+        flags = torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)
+        retry = torch.zeros(1, dtype=torch.int32, device=self.device)
+        _cabi.check(self.lib.mia_letkf_analysis_tiles_f32(
+            _ptr(X), G, m, k, tiles.g0, tiles.g1, _ptr(split_rec), int(P), _ptr(tiles.lists), tiles.p_max, tiles.extra_blocks,
+            float(inf_factor), _ptr(xa), xa.shape[-1], 0, _ptr(flags), _ptr(retry), self._stream()),
+            "mia_letkf_analysis_tiles_f32")
+        return xa, flags[:n], retry
 
     def build_index(self, obs_xyz, radii: Sequence[float], coord_group: Optional[Sequence[int]] = None) -> ObsIndex:
         """Bin the observations into the uniform cell grid used by the fused-localisation analysis."""

@@ -73,6 +73,10 @@ class ShardedLetkf:
         v, sp = C.c_int(1), C.c_int(1)
         self.engine.lib.mia_get_option(b"tile", C.byref(v))
         self.engine.lib.mia_get_option(b"tile_split", C.byref(sp))
+        tl = C.c_int(1)
+        self.engine.lib.mia_get_option(b"tile_lists", C.byref(tl))
+        if v.value and sp.value and tl.value and not self._no_tile_lists and self.native_step:
+            return "letkf_tile2_kernel<2, 3, false>"
         return ("letkf_tile_kernel<2, 3, false, %s>" % ("true" if sp.value else "false")) if v.value else "letkf_cheb_kernel<20, 1, false>"
 
     @property
@@ -194,6 +198,10 @@ class ShardedLetkf:
         self.last_p_max = 0
         self._p_max_hint = None
         self._last_flags = None
+        # tile route of the native step driver (tile-shaped lists + split records, csrc/letkf_tile2.hip): switched off for this
+        # object once a step reports tiles whose union does not fit their slots (scattered grids) -- per-point lists then
+        self._no_tile_lists = False
+        self._tile_extra = 0          # row blocks of sixteen slots added to the tiles' unions (MIA_STEP_TILE_EXTRA)
 
     @property
     def engine(self):
@@ -466,7 +474,7 @@ class ShardedLetkf:
                  slot["ws"].numel(), comp.cuda_stream, side, prep.cuda_stream if prep is not None else None,
                  # MIA_STEP_NO_JOIN for steps in flight; MIA_STEP_WS_CLEAN: this slot's workspace was last used by a step that
                  # ran to completion (its index kernels leave the header zeroed)
-                 (1 if pipelined else 0) | (4 if slot.get("ws_clean") else 0)]
+                 (1 if pipelined else 0) | (4 if slot.get("ws_clean") else 0) | (8 if self._no_tile_lists else 0) | (self._tile_extra << 4)]
         slot["ws_clean"] = False            # (until this step has been collected without an error)
         step_fn = lib.mia_letkf_sharded_step_streams_f32
 
@@ -551,6 +559,15 @@ class ShardedLetkf:
                 raise _cabi.MiaError("native step driver: exchange error bits %d" % cnt[7])
             warnings.warn("segmented launch timed out waiting for a segment; falling back to per-piece launches",
                           RuntimeWarning)
+            redo = "same"
+        elif n_over and p_seen <= p["hint"] and not self._no_tile_lists:
+            # tile route: the union of some tile's lists does not fit its slots (the bound on the lists themselves held): sixteen
+            # more slots per tile, and once the format has no more to give this geometry goes back to per-point lists -- on
+            # every rank alike (the counters are the maximum over the ranks)
+            if self._tile_extra < 5:
+                self._tile_extra += 1
+            else:
+                self._no_tile_lists = True
             redo = "same"
         elif n_over or p_seen > p["hint"]:
             self._p_max_hint = None                            # bound broken on some rank: all ranks redo
