@@ -15,15 +15,24 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="c2")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--grid", type=int, default=100000)
+ap.add_argument("--route", default="tiles", choices=["tiles", "lists"],
+                help="tiles: tile lists + split records + letkf_tile2_kernel (configs 2, 4); lists: per-point lists + round-2 kernels")
 a = ap.parse_args()
 k, stride, c, gamma = {"c2": (40, 2, 10.0, None), "c4": (80, 1, 16.5, None), "c5": (40, 2, 10.0, 0.5)}[a.config]
 dev = torch.device("cuda:0")
 eng = mia.LetkfEngine(dev)
 X, gx, ox, Yb, d = bench.make_case(a.grid, k, stride, dev)
 nb = eng.localize(gx, ox, [c])
-rec = eng.pack_obs(Yb, d, torch.float32)
-for _ in range(a.reps):
-    xa, fl = eng.analysis(X, None, None, nb, 1.1, rec=rec, return_flags=True, rbf_gamma=gamma)
+if a.route == "tiles" and gamma is None:
+    for _ in range(a.reps):
+        tiles = eng.localize_tiles(gx, ox, [c], nb.p_max)
+        srec = eng.pack_split(Yb, d)
+        xa, fl, retry = eng.analysis_tiles(X, srec, Yb.shape[1], tiles, 1.1)
+    print("tile stats", tiles.stats.tolist(), "declined", int(retry.item()))
+else:
+    rec = eng.pack_obs(Yb, d, torch.float32)
+    for _ in range(a.reps):
+        xa, fl = eng.analysis(X, None, None, nb, 1.1, rec=rec, return_flags=True, rbf_gamma=gamma)
 torch.cuda.synchronize()
 f = fl.cpu().numpy()
 import numpy as np

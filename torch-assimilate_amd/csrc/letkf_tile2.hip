@@ -86,6 +86,22 @@ __device__ __forceinline__ s4v t2_tr_read(const unsigned char* lds_addr) {     /
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)lds_addr);
 }
 
+// In-kernel phase stamps (diagnostic builds only, tools/tile2_stamps.py): -DMIA_TILE_STAMPS compiles them in; the stamp values
+// go to a buffer of their own that nothing else reads.  Slots 0 .. 8: s_memtime at the phase boundaries; 9: where the wave ran
+// (HW_ID low word, XCC_ID high word); 10, 11: the constant 100 MHz counter at start and end (comparable across CUs).
+#ifdef MIA_TILE_STAMPS
+constexpr int kT2StampN = 12, kT2StampTiles = 8192;
+__device__ long long g_tile2_stamps[kT2StampTiles * kT2StampN];
+#define T2_STAMP(i) do { if (lane == 0 && bid < kT2StampTiles) g_tile2_stamps[bid * kT2StampN + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define T2_STAMP_HWID() do { if (lane == 0 && bid < kT2StampTiles) g_tile2_stamps[bid * kT2StampN + 9] = \
+    (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } while (0)
+#define T2_STAMP_REAL(i) do { if (lane == 0 && bid < kT2StampTiles) g_tile2_stamps[bid * kT2StampN + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define T2_STAMP(i) do { } while (0)
+#define T2_STAMP_HWID() do { } while (0)
+#define T2_STAMP_REAL(i) do { } while (0)
+#endif
+
 #ifndef MIA_TILE2_WAVES_UT2
 #define MIA_TILE2_WAVES_UT2 4
 #endif
@@ -94,8 +110,8 @@ __device__ __forceinline__ s4v t2_tr_read(const unsigned char* lds_addr) {     /
 // KT = 3, four wavefronts per SIMD.  MROWS = true: any number of rows in a loop that shares the union, the Gram matrix and the
 // coefficients; the compiler hoists the loop's invariant addresses and predicates in front of it (227 registers at the same
 // shape), so these instantiations run at two wavefronts per SIMD.
-template <int UT, int KT, bool MROWS>
-__global__ __launch_bounds__(64, (UT <= 2 && KT <= 4 ? (MROWS ? 2 : MIA_TILE2_WAVES_UT2) : (UT <= 3 && KT <= 4 && !MROWS ? 2 : 1)))
+template <int UT, int KT, bool MROWS, int WAVES>
+__global__ __launch_bounds__(64, WAVES)
 void letkf_tile2_kernel(Tile2Params P) {
   constexpr int UMAX = 16 * UT, NB = (KT + 1) / 2, NKB = (UT + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -121,6 +137,9 @@ void letkf_tile2_kernel(Tile2Params P) {
   const int lrc = lr < npts ? lr : npts - 1;
   const bool colok = lr < npts;
 
+  T2_STAMP(0);
+  T2_STAMP_HWID();
+  T2_STAMP_REAL(10);
   const int4 hd = P.thdr[tile];
   const int U = __builtin_amdgcn_readfirstlane(hd.x);
   if (U < 0) {                     // the union of this tile did not fit its slots: loud failure, never a truncated analysis
@@ -157,6 +176,7 @@ void letkf_tile2_kernel(Tile2Params P) {
   }
   for (int i = lane; i < 32; i += 64) reinterpret_cast<f4w*>(zline)[i] = f4w{0.f, 0.f, 0.f, 0.f};
   MIA_T2_SYNC();
+  T2_STAMP(1);        // header, slot table, tails have arrived
   // ---- the union's records, straight into the LDS image: load u, lane l = piece line 4 u + (l >> 4), column l & 15
   {
     const int g = lane >> 4, hl = g & 1;
@@ -220,8 +240,10 @@ void letkf_tile2_kernel(Tile2Params P) {
     const f4w e4 = *reinterpret_cast<const f4w*>(El + 16 * t + 4 * h);
     dreg[t] *= e4;
   }
+  T2_STAMP(2);        // gather and x requested
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // records in LDS (and x, D in registers)
   __builtin_amdgcn_wave_barrier();
+  T2_STAMP(3);        // ... and landed
 
   // byte offset of this lane's A / B fragment of row block t, member block b: row 16 t + lr, chunk sigma(b, h)
   auto frag_off = [&](int t, int b) -> unsigned {
@@ -298,6 +320,7 @@ void letkf_tile2_kernel(Tile2Params P) {
 #pragma unroll
         for (int t = 0; t < UT; ++t) Z[t] = t2_mfma3(Z[t], ah[t], al[t], xh[b], xl[b]);
       }
+      T2_STAMP(4);    // x' split, Gram + Z issued
       // A fragments of G for the 32-deep products: lane group h supplies slots 16 (2 kb + tt) + 4 h + q, i.e. the values
       // this lane holds of the tiles (2 kb, t) and (2 kb + 1, t) -- no data moves
 #pragma unroll
@@ -378,6 +401,7 @@ void letkf_tile2_kernel(Tile2Params P) {
     //      u_{j+1} = 2 (alpha D^2 o (G u_j) - u_j) - u_{j-1}, u_0 = D^2 o Z; the two weight functions accumulate c_j u_j.
     //      Vectors are carried times a power of two per column (|u_0| -> 2^8; |u_j| <= sqrt(U) |u_0| stays far inside the
     //      half-precision range); the universal coefficients are used unscaled, the route's constants multiply the results.
+    T2_STAMP(5);      // Gershgorin, table header requested and used
     const unsigned cbase = (unsigned)tab_idx * (unsigned)(kTabDeg * 8);
     auto coef = [&](int j) -> float2 {                              // (zero beyond a point's own degree)
       return t2_ld<float2>(P.tab_c, cbase + (unsigned)(j < kTabDeg ? j : kTabDeg - 1) * 8u);
@@ -417,12 +441,18 @@ void letkf_tile2_kernel(Tile2Params P) {
         }
       split8(bv, bh, bl);
     };
+    // (kb = 0 runs unconditionally -- a tile without any observation left above -- so that the accumulators start from the
+    //  MFMA's zero operand instead of eight register moves per step)
     f4w y[UT];
     auto product = [&](const f4w (&tv)[UT]) {
+      {
+        h8v bh, bl;
+        rhs_split(tv, 0, bh, bl);
 #pragma unroll
-      for (int t = 0; t < UT; ++t) y[t] = f4w{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < UT; ++t) y[t] = t2_mfma3(f4w{0.f, 0.f, 0.f, 0.f}, GAh[t][0], GAl[t][0], bh, bl);
+      }
 #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
+      for (int kb = 1; kb < NKB; ++kb)
         if (32 * kb < U) {
           h8v bh, bl;
           rhs_split(tv, kb, bh, bl);
@@ -430,22 +460,32 @@ void letkf_tile2_kernel(Tile2Params P) {
           for (int t = 0; t < UT; ++t) y[t] = t2_mfma3(y[t], GAh[t][kb], GAl[t][kb], bh, bl);
         }
     };
+    // u_new = 2 (alpha D^2 o y - u_cur) - u_old, written over u_old; the two weight functions accumulate c_j u_new.  Scalar
+    // fused multiply-adds on purpose (this file is compiled without the SLP vectoriser): v_pk_fma_f32 costs more than two
+    // v_fma_f32 beside MFMAs, and the packed form needs separate negations
     auto advance = [&](f4w (&vold)[UT], const f4w (&vcur)[UT], const float2 cj) {
       product(vcur);
 #pragma unroll
-      for (int t = 0; t < UT; ++t) {
-        vold[t] = 2.0f * (ad2[t] * y[t] - vcur[t]) - vold[t];
-        aphi[t] = cj.x * vold[t] + aphi[t];
-        apsi[t] = cj.y * vold[t] + apsi[t];
-      }
+      for (int t = 0; t < UT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float tq = __builtin_fmaf(ad2[t][q], y[t][q], -vcur[t][q]);
+          const float vn = __builtin_fmaf(2.0f, tq, -vold[t][q]);
+          vold[t][q] = vn;
+          aphi[t][q] = __builtin_fmaf(cj.x, vn, aphi[t][q]);
+          apsi[t][q] = __builtin_fmaf(cj.y, vn, apsi[t][q]);
+        }
     };
     product(va);
 #pragma unroll
-    for (int t = 0; t < UT; ++t) {
-      vb[t] = ad2[t] * y[t] - va[t];
-      aphi[t] = c0.x * va[t] + c1.x * vb[t];
-      apsi[t] = c0.y * va[t] + c1.y * vb[t];
-    }
+    for (int t = 0; t < UT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float vq = __builtin_fmaf(ad2[t][q], y[t][q], -va[t][q]);
+        vb[t][q] = vq;
+        aphi[t][q] = __builtin_fmaf(c1.x, vq, c0.x * va[t][q]);
+        apsi[t][q] = __builtin_fmaf(c1.y, vq, c0.y * va[t][q]);
+      }
     int j = 2;
     for (; j + 1 <= degmax; j += 2) {
       const float2 cj = cn0, cj1 = cn1;
@@ -458,18 +498,22 @@ void letkf_tile2_kernel(Tile2Params P) {
     //      recurrence run on u_hat = E u:   x' w_mean = sum_b d_b (D psi(S) z)_b = sum_b (d_b / E_b) apsi_hat_b, and
     //      Xa' = sum_b y_b (D phi(S) z)_b = sum_b yhat_b aphi_hat_b: no per-slot factor is left.  The results carry
     //      (scale of x') x (scale of the vectors); the route's constants, left out of the coefficients, come in here.
+    T2_STAMP(6);      // recurrence
     const float funs = inv_s2 * inv_sx;
     // (x of this row once more, in the RESULT layout -- member 16 tj + 4 h + q -- for f0 x': L2-hot, requested before the
     //  last products, which cover its latency)
     f4w xre[KT];
     {
       const float* xbase = P.X + (int64_t)mi * k * P.ldx + P.g0 + p0;
+      const unsigned xo0 = (unsigned)(4 * h) * ldxb + (unsigned)lrc * 4u;            // member 4 h, this lane's column
+      const unsigned xolast = (unsigned)(k - 1) * ldxb + (unsigned)lrc * 4u;       // (clamp for the ragged last block)
 #pragma unroll
       for (int tj = 0; tj < KT; ++tj)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int mem = 16 * tj + 4 * h + q;
-          xre[tj][q] = t2_ld<float>(xbase, (unsigned)(mem < k ? mem : k - 1) * ldxb + (unsigned)lrc * 4u);
+          unsigned o = xo0 + (unsigned)(16 * tj + q) * ldxb;
+          if (tj == KT - 1) o = o < xolast ? o : xolast;
+          xre[tj][q] = t2_ld<float>(xbase, o);
         }
     }
     float zu = 0.0f;
@@ -514,7 +558,7 @@ void letkf_tile2_kernel(Tile2Params P) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         acc[tj][q] = acc[tj][q] * fo + (mterm + P.f0 * (xre[tj][q] - xm));
-        if (!(fabsf(acc[tj][q]) <= 1e30f) && 16 * tj + 4 * h + q < k) pflag |= MIA_FLAG_NONFINITE;
+        if (!(fabsf(acc[tj][q]) <= 1e30f) && (tj < KT - 1 || 16 * tj + 4 * h + q < k)) pflag |= MIA_FLAG_NONFINITE;
       }
     }
     if (colok && !decl) {
@@ -524,28 +568,42 @@ void letkf_tile2_kernel(Tile2Params P) {
       for (int tj = 0; tj < KT; ++tj)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          if (16 * tj + 4 * h + q < k)
+          if (tj < KT - 1 || 16 * tj + 4 * h + q < k)
             *reinterpret_cast<float*>(reinterpret_cast<char*>(obase) + (olane + (unsigned)(16 * tj + q) * ldob)) = acc[tj][q];
     } else {
       pflag = 0;          // (columns that are not written do not report)
     }
   }
+  T2_STAMP(7);        // output products and stores issued
   {
     const unsigned long long fb = __ballot(pflag != 0);
     const bool anyf = ((fb >> lr) & 0x0001000100010001ull) != 0ull;
     if (h == 0 && colok && !decl) P.flags[p0 + lr] = (anyf ? MIA_FLAG_NONFINITE : 0) | (deg << 8);
   }
+  T2_STAMP(8);
+  T2_STAMP_REAL(11);
 }
+
+#ifdef MIA_TILE_STAMPS
+extern "C" int mia_debug_tile2_stamps(long long* host, int n_tiles) {
+  if (n_tiles > kT2StampTiles) n_tiles = kT2StampTiles;
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tile2_stamps), sizeof(long long) * kT2StampN * (size_t)n_tiles);
+}
+#endif
 
 static size_t tile2_lds_bytes(int ut, int k) {
   return (size_t)ut * split_nc8(k) * 512 + 512 + (size_t)16 * ut * 12;
 }
 
+// wavefronts per SIMD the instantiations are compiled for (register budget 512 / WAVES)
 template <int UT, int KT, bool MROWS>
+constexpr int tile2_waves() { return UT <= 2 && KT <= 4 ? (MROWS ? 2 : MIA_TILE2_WAVES_UT2) : (UT <= 3 && KT <= 4 && !MROWS ? 2 : 1); }
+
+template <int UT, int KT, bool MROWS, int WAVES = tile2_waves<UT, KT, MROWS>()>
 static int tile2_launch_m(const Tile2Params& tp, hipStream_t stream) {
   const size_t lds = tile2_lds_bytes(UT, tp.k);
   if (lds > kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
-  auto kern = letkf_tile2_kernel<UT, KT, MROWS>;
+  auto kern = letkf_tile2_kernel<UT, KT, MROWS, WAVES>;
   if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t ntile = (tp.ng + 15) >> 4;
   const int64_t gx = ntile < 65536 ? ntile : 65536;
@@ -566,6 +624,15 @@ static int tile2_launch_m(const Tile2Params& tp, hipStream_t stream) {
 
 template <int UT, int KT>
 static int tile2_launch_s(const Tile2Params& tp, hipStream_t stream) {
+#ifdef MIA_EXPERIMENTS
+  if constexpr (UT == 2 && KT == 3) {       // (A/B of the occupancy target, tools/ builds only: MIA_TILE2_WAVES=3|5|6)
+    int w = 0;
+    MIA_EXP_SET(w, "MIA_TILE2_WAVES", atoi);
+    if (tp.m == 1 && w == 5) return tile2_launch_m<UT, KT, false, 5>(tp, stream);
+    if (tp.m == 1 && w == 6) return tile2_launch_m<UT, KT, false, 6>(tp, stream);
+    if (tp.m == 1 && w == 3) return tile2_launch_m<UT, KT, false, 3>(tp, stream);
+  }
+#endif
   return tp.m == 1 ? tile2_launch_m<UT, KT, false>(tp, stream) : tile2_launch_m<UT, KT, true>(tp, stream);
 }
 

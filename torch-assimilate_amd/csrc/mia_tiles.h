@@ -69,22 +69,26 @@ using f2w = __attribute__((ext_vector_type(2))) float;
 using f4w = __attribute__((ext_vector_type(4))) float;
 using u4w = __attribute__((ext_vector_type(4))) unsigned;
 
-// x (8 values) -> hi = f16(x), lo = f16(x - hi), both rounded to nearest.  The remainders come straight from the packed
-// halves (v_fma_mix_f32 reads an f16 operand in place; the compiler's own form is two conversions + a packed subtraction,
-// and packed f32 instructions are slow beside MFMAs).
+// x (8 values) -> hi = f16(x), lo = f16(x - hi), both rounded to nearest: three instructions per pair of values (the
+// compiler's own form is two conversions, a packed subtraction and a conversion, and packed f32 instructions are slow beside
+// MFMAs).
 __device__ __forceinline__ void split8(const float (&x)[8], h8v& hi, h8v& lo) {
+  u4w hu, lu;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const f2w v = {x[2 * i], x[2 * i + 1]};
     const h2v a = __builtin_convertvector(v, h2v);                  // v_cvt_pk_f16_f32, round to nearest
     const unsigned au = __builtin_bit_cast(unsigned, a);
-    f2w r;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(au), "v"(v[0]));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(au), "v"(v[1]));
-    const h2v b = __builtin_convertvector(r, h2v);
-    hi[2 * i] = a[0]; hi[2 * i + 1] = a[1];
-    lo[2 * i] = b[0]; lo[2 * i + 1] = b[1];
+    // lo = f16(x - hi), straight into the two halves of one register: v_fma_mixlo / mixhi read the f16 operand in place and
+    // round the (exact) f32 difference once
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(au), "v"(v[0]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(au), "v"(v[1]));
+    hu[i] = au;
+    lu[i] = l;
   }
+  hi = __builtin_bit_cast(h8v, hu);
+  lo = __builtin_bit_cast(h8v, lu);
 }
 __device__ __forceinline__ h8v hi8(const float (&x)[8]) {
   h8v hi;

@@ -45,7 +45,6 @@ class NeighbourLists:
         return ok
 
 
-@dataclass
 class TileLists:
     """Tile-shaped lists of grid points [g0, g1) (csrc/mia_tiles.h): device buffer + the bound they were sized for."""
 
@@ -73,6 +72,7 @@ class TileLists:
         return hdr, uidx, D
 
 
+@dataclass
 class ObsIndex:
     """Cell index of one observation set for one localisation (built by mia_letkf_index_build_f64)."""
     ws: torch.Tensor
@@ -243,6 +243,33 @@ class LetkfEngine:
             float(inf_factor), _ptr(xa), xa.shape[-1], 0, _ptr(flags), _ptr(retry), self._stream()),
             "mia_letkf_analysis_tiles_f32")
         return xa, flags[:n], retry
+
+    def tile_route_applies(self, X: torch.Tensor, p_max: int, extra_blocks: int = 0, rbf_gamma=None, method: str = "auto") -> bool:
+        """Whether the tile route (tile lists + split records + csrc/letkf_tile2.hip) takes this analysis: float32, plain ETKF
+        core, dual route p_max <= k <= 96, the union's row blocks within what the ensemble size allows, route options on."""
+        if X.dtype != torch.float32 or rbf_gamma is not None or method == "eig" or X.dim() != 3:
+            return False
+        k = X.shape[1]
+        ut = max(1, (int(p_max) + 8 + 15) // 16) + int(extra_blocks)
+        if not (2 <= k <= 96 and p_max <= k and ut <= min(6, (k + 15) // 16 + 1)):
+            return False
+        v = C.c_int(0)
+        for name in (b"tile", b"tile_split", b"tile_lists"):
+            self.lib.mia_get_option(name, C.byref(v))
+            if not v.value:
+                return False
+        return True
+
+    def retry_points(self, X: torch.Tensor, Yb: torch.Tensor, d: torch.Tensor, nbrs: NeighbourLists, inf_factor: float,
+                     out: torch.Tensor, flags: torch.Tensor, out_offset: int = 0):
+        """Eigensolver redo of the grid points flagged MIA_FLAG_RETRY (mia_letkf_analysis_retry_f32) from per-point lists."""
+        X = X.contiguous()
+        m, k, G = X.shape
+        rec = self.pack_obs(Yb, d, torch.float32)
+        _cabi.check(self.lib.mia_letkf_analysis_retry_f32(
+            _ptr(X), G, m, k, nbrs.g0, nbrs.g1, _ptr(rec), rec.shape[0], _ptr(nbrs.cnt), _ptr(nbrs.idx), _ptr(nbrs.w),
+            nbrs.p_cap, nbrs.p_max, float(inf_factor), 0.0, _ptr(out), out.shape[-1], out_offset, _ptr(flags), self._stream()),
+            "mia_letkf_analysis_retry_f32")
 
     def build_index(self, obs_xyz, radii: Sequence[float], coord_group: Optional[Sequence[int]] = None) -> ObsIndex:
         """Bin the observations into the uniform cell grid used by the fused-localisation analysis."""

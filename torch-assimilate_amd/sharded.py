@@ -166,7 +166,7 @@ class ShardedLetkf:
                  rbf_gamma: Optional[float] = None, compute_shard: Optional[Callable] = None, group=None,
                  method: str = "auto", fused_localization: bool = False,
                  comm_chunks: int = 4, chunk_compute: Optional[Callable] = None, native_step: bool = True,
-                 max_in_flight: int = 3, peer_exchange: str = "auto", copy_results: bool = True):
+                 max_in_flight: int = 3, peer_exchange: str = "auto", copy_results: bool = True, prep_streams: int = 2):
         self.device, self.rank, self.world = device, rank, world
         self.radii, self.inf_factor, self.coord_group, self.eps = list(radii), inf_factor, coord_group, eps
         self.rbf_gamma = rbf_gamma
@@ -182,6 +182,7 @@ class ShardedLetkf:
         self._time_next = False        # time_next_step(): the next native step brackets its analysis kernel with events
         self.kernel_timings = []       # [(start, stop)] torch events recorded on the analysis stream by the library
         self.max_in_flight = max(1, min(int(max_in_flight), 8))
+        self.prep_streams = max(1, min(int(prep_streams), 8))      # steps in flight: preparation streams taken in turn
         # exchange of the analysis blocks at world > 1: "auto" = direct peer writes into library-owned, IPC-mapped result
         # buffers when the node allows it and a self-test of the mapping passes, RCCL all-gather otherwise; "off" = RCCL.
         # With the direct route a result lives in its pipeline slot's buffer: copy_results (default) hands out a copy,
@@ -234,6 +235,12 @@ class ShardedLetkf:
         #  the path is gone, see DESIGN.md.)
         nb = eng.localize(grid_xyz, obs_xyz, self.radii, self.coord_group, self.eps, g0, g1,
                           assume_p_max=self._p_max_hint)
+        if len(obs_xyz) > 0 and not self._no_tile_lists and torch.is_tensor(X):
+            # the route the native step driver takes on this geometry (tile lists + split records): the entry-by-entry calls
+            # take it too, so that a step's result does not depend on which call of a run it is
+            xa = self._engine_shard_tiles(X, grid_xyz, obs_xyz, Yb, d, g0, g1, nb)
+            if xa is not None:
+                return xa
         xa, flags, finish = eng.analysis(X, Yb, d, nb, self.inf_factor, rbf_gamma=self.rbf_gamma,
                                          return_flags=True, method=self.method, defer_retry=True)
         if not nb.confirm():
@@ -242,6 +249,35 @@ class ShardedLetkf:
                                              return_flags=True, method=self.method, defer_retry=True)
         self.last_retries = finish()
         self._p_max_hint = nb.observed_p_max if nb.observed_p_max is not None else nb.p_max
+        self.last_p_max = nb.p_max
+        self._last_flags = flags
+        return xa
+
+    def _engine_shard_tiles(self, X, grid_xyz, obs_xyz, Yb, d, g0, g1, nb):
+        """Exact-list call on the tile route: the lists' true maximum sizes the tiles; a union that does not fit gets sixteen
+        more slots per tile until the format has no more (then None: per-point lists).  Declined points are redone by the
+        eigensolver kernel from the per-point lists ``nb``."""
+        eng = self.engine
+        while eng.tile_route_applies(X, nb.p_max, self._tile_extra, self.rbf_gamma, self.method):
+            tiles = eng.localize_tiles(grid_xyz, obs_xyz, self.radii, nb.p_max, self.coord_group, self.eps, g0, g1,
+                                       extra_blocks=self._tile_extra)
+            if int(tiles.stats[1].item()) == 0:                 # host sync (first call on a geometry only)
+                break
+            self._tile_extra += 1
+        else:
+            if self._tile_extra:
+                self._no_tile_lists, self._tile_extra = True, 0
+            return None
+        Xc = X.contiguous()
+        rec = eng.pack_split(Yb, d)
+        xa, flags, retry = eng.analysis_tiles(Xc, rec, Yb.shape[1], tiles, self.inf_factor)
+        n_retry = int(retry.item())
+        if n_retry:
+            if not nb.confirm():                                # (lists built on an assumed bound that did not hold)
+                nb = eng.localize(grid_xyz, obs_xyz, self.radii, self.coord_group, self.eps, g0, g1)
+            eng.retry_points(Xc, Yb, d, nb, self.inf_factor, xa, flags)
+        self.last_retries = n_retry
+        self._p_max_hint = max(int(tiles.stats[0].item()), 0)
         self.last_p_max = nb.p_max
         self._last_flags = flags
         return xa
@@ -384,9 +420,10 @@ class ShardedLetkf:
                 h.result()
             shard = self._engine_shard(X, grid_xyz, obs_xyz, Yb, d, g0, g1)
             if self.world > 1:
-                t = torch.tensor([self._p_max_hint], dtype=torch.int32, device=X.device)
+                t = torch.tensor([self._p_max_hint, self._tile_extra, int(self._no_tile_lists)], dtype=torch.int32, device=X.device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-                self._p_max_hint = int(t.item())                  # one bound for all ranks
+                # one bound (and one tile format) for all ranks
+                self._p_max_hint, self._tile_extra, self._no_tile_lists = int(t[0].item()), int(t[1].item()), bool(t[2].item())
             return PendingStep(self, None, out=gather_blocks(shard, G, self.world, self.group))
         if not self._native_available():
             return PendingStep(self, None, out=self.assimilate(X, grid_xyz, obs_xyz, Yb, d))
@@ -458,7 +495,7 @@ class ShardedLetkf:
                 # TWO preparation streams taken in turn: with the sixteen-point analysis kernel (~75 us) the chain of small,
                 # latency-bound index / list launches of ONE stream (~100 us per step) had become what bounds the pipeline
                 # (0.127 -> 0.107 ms per step at depth 4; a third stream: 0.117 with the split-precision kernel, a fourth 0.167)
-                st["pstreams"] = [torch.cuda.Stream(device=X.device, priority=-1) for _ in range(2)]
+                st["pstreams"] = [torch.cuda.Stream(device=X.device, priority=-1) for _ in range(self.prep_streams)]
             comp, prep = st["astream"], st["pstreams"][self._submitted % len(st["pstreams"])]
             prep.wait_stream(cur)                                 # inputs (and `out`'s memory) are ready
             # where the step's last work is enqueued: the placement stream when there is one, else the exchange stream
