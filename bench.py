@@ -11,8 +11,8 @@ grid points of a G = N * 1e5 problem (config 3 at N = 8, weak scaling) and the a
 ensemble is all-gathered over RCCL.
 
 One step = one full pass of the hot path with inputs resident in HBM: pack obs records,
-build the observation cell index, Gaspari-Cohn neighbour lists, fused local analysis
-(Gram, matrix functions / eigensolve, weights, transform) [, all-gather], enqueued by ONE call
+build the observation cell index, tile-shaped Gaspari-Cohn lists, fused local analysis
+(Gram, matrix functions, transform) [, all-gather], enqueued by ONE call
 into the C-ABI library (mia_letkf_sharded_step_f32) and ended by the one host read-back that
 validates it.  Prints ONE JSON line on rank 0.
 """
@@ -54,6 +54,19 @@ def executed_flops(k, p, m, deg, kernel="tile"):
     point (letkf_cheb_kernel): Gram on 16x16x4 tiles over the padded order, z / output products, recurrence."""
     if not deg:
         return None
+    if kernel == "tile2":
+        # letkf_tile2_kernel (tile lists + split records): THREE v_mfma_f32_16x16x32_f16 (hi hi, hi lo, lo hi; 16384 flop each)
+        # per f32 product block of 16 x 16 x 32 -- Gram UT^2 NB + per state row Z UT NB, deg products UT NKB (the tile runs to the
+        # largest degree of its 16 points), output KT NKB -- and one for the Gershgorin product (UT NKB).  Returned: the f32
+        # products these implement, padding included, + the vector-unit update (4 fused multiply-adds per union slot, step and
+        # point), per analysis; second value = what the matrix cores execute
+        ut, kt = (p + 8 + 15) // 16, (k + 15) // 16
+        nb, nkb = (kt + 1) // 2, (ut + 1) // 2
+        dmax = int(deg + 0.999)
+        triples = ut * ut * nb + m * (ut * nb + dmax * ut * nkb + kt * nkb)
+        singles = ut * nkb
+        valu = m * dmax * 16 * ut * 16 * 8
+        return ((triples + singles) * 16384 + valu) / 16.0, (3 * triples + singles) * 16384 / 16.0
     if kernel == "tile_split":
         # split-precision instantiations: every product is THREE v_mfma_f32_16x16x32_f16 (hi hi, hi lo, lo hi; 16384 flop
         # each) per pair of 16-row blocks and 32 summation indices; the Gershgorin product takes one.  Returned: the f32
@@ -317,7 +330,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-4 / config-5 kernel timings")
     ap.add_argument("--grid-per-gpu", type=int, default=G_PER_GPU)
     ap.add_argument("--pipeline-depth", type=int, default=int(os.environ.get("MIA_PIPELINE_DEPTH", "6")), choices=[1, 2, 3, 4, 5, 6, 7, 8],
-                    help="steps in flight (ShardedLetkf.submit): 4 (default) = steps i+1 .. i+3 are enqueued before step i "
+                    help="steps in flight (ShardedLetkf.submit): d (default 6) = steps i+1 .. i+d-1 are enqueued before step i "
                          "is collected; 1 = serial steps")
     ap.add_argument("--method", default="auto", choices=["auto", "eig", "matfun"],
                     help="analysis route: auto = eigensolver-free matfun kernel (default), eig = fused Jacobi")
@@ -418,10 +431,20 @@ def main():
     gc.freeze()
     # warm-up LAST, straight into the timed loop: the collection above leaves the GPU idle for ~0.1 s and the clocks
     # take a few milliseconds of work to come back (20 timed steps right after it ran 25 % slower than steady state)
-    warm = max(args.warmup, 50)
+    # Untimed conditioning of clocks and caches; then EXACTLY --warmup steps straight into the timed region.  A timed region of
+    # fewer than 200 steps lasts a few milliseconds (20 steps: 1.5 ms), less than the host's scheduling noise: such a region is
+    # timed `repeats` times back to back (each bracketed by barrier + synchronize as the contract asks) and the MEDIAN
+    # region is reported -- `steps` stays what was asked, `repeats` says how many regions were measured.
+    run(max(50, args.warmup), depth)
+    repeats = 1 if args.steps >= 200 else max(25, min(200, 4000 // max(args.steps, 1)))
+    warm = args.warmup
     run(warm, depth)
     runner.kernel_timings.clear()
-    elapsed, out = timed(args.steps, depth)
+    regions = []
+    for _ in range(repeats):
+        el_i, out = timed(args.steps, depth)
+        regions.append(el_i)
+    elapsed = float(np.median(regions))
     loop_kernel_ms = runner.kernel_ms()      # the dominant kernel inside the timed loop (every 4th step)
     n_timed = len(runner.kernel_timings)
     serial_ms = None
@@ -438,7 +461,7 @@ def main():
     p_max = runner.last_p_max
     deg = runner.mean_degree()
     kname = runner.dominant_kernel_name
-    kkind = ("tile_split" if "true>" in kname else "tile") if "tile" in kname else "point"
+    kkind = "tile2" if "tile2" in kname else (("tile_split" if "true>" in kname else "tile") if "tile" in kname else "point")
 
     def rates(k, p, m, dg, n_pts, ms, kind):
         """executed / useful / reference-credit flop rates of one launch of n_pts analyses in `ms`"""
@@ -504,15 +527,23 @@ def main():
                    "rel_frobenius_error_64_points_vs_oracle": float(np.linalg.norm(got - ref) / np.linalg.norm(ref)),
                    "reference_algorithm_credit_TFLOPs": algorithmic_flops(k2, pm2, 1) * gpg / (ms2 * 1e-3) / 1e12}
             if gamma2 is None and deg2:
-                kk = (kkind if kkind != "point" else "tile") if (k2 <= 96 and pm2 + 8 <= 96) else "point"
+                tiles2 = r3.engine.tile_route_applies(X2, pm2, r3._tile_extra) and not r3._no_tile_lists
+                kk = "tile2" if tiles2 else ((kkind if kkind not in ("point", "tile2") else "tile_split") if (k2 <= 96 and pm2 + 8 <= 96) else "point")
                 exf = executed_flops(k2, pm2, 1, deg2, kk)
+                usf = useful_flops(k2, pm2, 1, deg2)
                 if isinstance(exf, tuple):
                     rec.update(f16_mfma_flops_per_analysis=exf[1],
                                matrix_core_frac=exf[1] * gpg / (ms2 * 1e-3) / 1e12 / PEAK_F16_TFLOPS)
                     exf = exf[0]
-                rec.update(executed_flops_per_analysis=exf, executed_frac=exf * gpg / (ms2 * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
-                           kernel="letkf_tile_kernel (%s)" % ("split half-precision products" if kk == "tile_split" else "f32 products")
-                                  if kk != "point" else "letkf_cheb_kernel (one grid point per wavefront)")
+                rec.update(useful_flops_per_analysis=usf, useful_frac=usf * gpg / (ms2 * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                           executed_f32_equivalent_flops_per_analysis=exf,
+                           executed_f32_equivalent_ratio_to_fp32_peak=exf * gpg / (ms2 * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                           executed_note="f32-equivalent of the half-precision MFMA triples, padding included: runs on the "
+                                         "half-precision matrix pipe, not bounded by 1, not a utilisation (useful_frac is)",
+                           kernel={"tile2": "letkf_tile2_kernel (tile lists + split records)",
+                                   "tile_split": "letkf_tile_kernel (split half-precision products)",
+                                   "tile": "letkf_tile_kernel (f32 products)",
+                                   "point": "letkf_cheb_kernel (one grid point per wavefront)"}[kk])
             secondary[name] = rec
 
     if rank == 0:
@@ -521,35 +552,46 @@ def main():
         line = {
             "metric": "local analyses/sec (LETKF, 40-member)", "value": value, "unit": "analyses/s",
             "n_gpus": world, "steps": args.steps, "warmup": warm,
+            "repeats": repeats,
+            "repeats_note": ("the timed region of --steps steps was measured %d times back to back (each bracketed by barrier + "
+                             "synchronize); value / ms_per_step are the median region's, spread (min .. max) %.4f .. %.4f ms per step"
+                             % (repeats, 1e3 * min(regions) / args.steps, 1e3 * max(regions) / args.steps)) if repeats > 1 else None,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "dtype_detail": ("inputs, outputs, accumulation and every vector operation float32; the matrix products run as "
                              "three half-precision MFMAs per f32 product on operands carried as pairs of halves (22-23 "
                              "significant bits; measured error equal to f32 products', DESIGN.md 3.0)")
-                            if kkind == "tile_split" else "float32 throughout",
+                            if kkind in ("tile_split", "tile2") else "float32 throughout",
             "config": {"workload": "LETKF config %s: G=%d grid points (%d per GPU), k=%d members, P=%d obs, "
                                    "Gaspari-Cohn radius %g (<=%d local obs), inf %.1f, m=1"
                                    % ("2" if world == 1 else "3-style", G, gpg, K_ENS, P, GC_RADIUS, p_max, INF),
                        "parallelism": "grid-point block shard x%d%s" % (world, " + all-gather of the analysis ensemble over xGMI "
                                                                         "(%s)" % runner.exchange_route if world > 1 else ""),
                        "ranks": world},
-            # frac <= 1 by construction: flops the kernel EXECUTES (MFMA tiles incl. padding + the vector-unit update),
-            # per launch, over the measured launch duration, against the fp32 peak (vector = f32-MFMA = 157.3 TFLOP/s)
-            "roofline": {"bound": "mfma" if kkind != "point" else "valu_issue",
-                         "achieved": ex_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": None if ex_tf is None else ex_tf / PEAK_FP32_TFLOPS,
-                         "frac_basis": ("f32-equivalent: the f32 products (padding included) that the kernel's split half-precision "
-                                        "MFMA triples implement + its vector-unit update, against the f32 peak -- the rate an "
-                                        "ideal f32-MFMA kernel of the same products could reach; the matrix cores themselves: "
-                                        "matrix_core") if kkind == "tile_split" else
-                                       "flops the kernel executes (f32 MFMA tiles incl. padding + vector-unit update) against the f32 peak",
+            # frac = USEFUL f32 flops of one launch / its measured duration / FP32 peak: <= 1 by construction (no padding, no
+            # credit for the Gram matrix sixteen points share, no credit for the eigensolve the route does not execute).
+            # What the kernel executes (padded, on the half-precision matrix pipe) is reported beside it under its own keys.
+            "roofline": {"bound": ("vector_issue+latency" if kkind != "point" else "valu_issue"),
+                         "bound_evidence": ("profiles/r03_v2_pmc.json (rocprofv3 --pmc, kernel alone): vector unit 47 % busy, matrix "
+                                            "pipe 15 %, HBM 0.13 of peak; a wave's cycles: 29 % issuing, 38 % issue-stalled, 33 % "
+                                            "parked on s_waitcnt; tools/tile2_stamps.py: all resident waves start together, so "
+                                            "their memory phases coincide, and the last 1.2 tiles per SIMD run at low occupancy"),
+                         "achieved": us_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": None if us_tf is None else us_tf / PEAK_FP32_TFLOPS,
+                         "frac_basis": ("useful f32 flops per analysis (symmetric Gram k p (p+1), per state row 4 k p + 2 deg p^2, "
+                                        "taper 25 p: no padding, nothing shared) x analyses per launch / launch duration inside the "
+                                        "timed loop / FP32 peak"),
+                         "useful_flops_per_analysis": us_f,
+                         "frac_alone": None if (us_f is None or not alone_ms) else us_f * gpg / (alone_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                         "executed_f32_equivalent": None if ex_tf is None else {
+                             "flops_per_analysis": ex_f, "TFLOPs": ex_tf, "ratio_to_fp32_peak": ex_tf / PEAK_FP32_TFLOPS,
+                             "note": "the f32 products (padding to 16 x 16 x 32 blocks and the shared Gram matrix included) that the "
+                                     "kernel's half-precision MFMA triples implement + its vector-unit update; they run on the "
+                                     "half-precision matrix pipe, so this ratio is NOT bounded by 1 and is not a utilisation"},
                          "matrix_core": None if f16_tf is None else {
                              "executed_f16_mfma_flops_per_analysis": f16_f, "achieved": f16_tf, "peak": PEAK_F16_TFLOPS,
                              "unit": "TFLOP/s", "frac": f16_tf / PEAK_F16_TFLOPS,
-                             "note": "v_mfma_f32_16x16x32_f16, three per f32 product; no longer what bounds the kernel"},
-                         "executed_flops_per_analysis": ex_f,
-                         "useful_flops_per_analysis": us_f, "useful_TFLOPs": us_tf,
-                         "useful_frac": None if us_tf is None else us_tf / PEAK_FP32_TFLOPS,
+                             "note": "v_mfma_f32_16x16x32_f16, three per f32 product"},
                          "reference_algorithm_credit": {"flops_per_analysis": algorithmic_flops(K_ENS, 20, 1), "TFLOPs": credit_tf,
                                                         "ratio_to_peak": credit_tf / PEAK_FP32_TFLOPS,
                                                         "note": "SURVEY 8(d) count of the reference's algorithm (9k^3 symmetric-QR "
@@ -565,11 +607,11 @@ def main():
                                              if loop_kernel_ms else "burst of 5 launches after the timed loop",
                          "kernel_ms_alone": alone_ms,
                          "hbm_algorithmic_GBs": hbm_alg, "hbm_frac": hbm_alg / PEAK_HBM_GBS,
-                         "note": "the matrix cores do every contraction (16 grid points per wavefront share one Gram matrix).  f32 "
-                                 "MFMAs share the FP32 pipe with the vector instructions (never overlap: tools/mfma_rate.hip), so "
-                                 "the products run as split half-precision MFMAs (16 cycles per 16x16x32, beside the vector unit) "
-                                 "at f32 accuracy; what bounds the kernel now is vector issue + the latency of its prologue "
-                                 "(lists, union, gather) at 3 wavefronts per SIMD: profiles/r02_v5_*"},
+                         "note": "sixteen grid points per wavefront share one Gram matrix; every contraction is a triple of "
+                                 "half-precision MFMAs on operands carried as pairs of halves (f32 accuracy; f32 MFMAs share the FP32 "
+                                 "pipe with the vector instructions, tools/mfma_rate.hip).  The wave starts at the gather: union, ranks "
+                                 "and sqrt(rho) matrix come tile-shaped from the localisation kernel, the records arrive split and "
+                                 "per-record scaled, straight into LDS (LDS-DMA)."},
             "route": {"method": args.method, "mean_chebyshev_degree": deg, "declined_points_last_step": runner.last_retries,
                       "eigensolver_route_kernel_ms": eig_ms,
                       "eigensolver_route_kernel_analyses_per_s": (gpg / (eig_ms * 1e-3)) if eig_ms else None},

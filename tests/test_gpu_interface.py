@@ -183,7 +183,7 @@ def _emulated_peer_comm(mia, runner, rank, ref_full, G, chunks):
     world = 2
     m, k = ref_full.shape[0], ref_full.shape[1]
     n = (G + world - 1) // world
-    nc = ((n + chunks - 1) // chunks + 7) // 8 * 8
+    nc = ((n + chunks - 1) // chunks + 15) // 16 * 16
     peer = 1 - rank
     pieces = []
     for c in range(chunks):

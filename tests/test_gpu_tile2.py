@@ -73,7 +73,7 @@ GEOMS = {
     "stride3_inf": lambda rs: (np.arange(120.0) * 0.7, np.arange(0, 84, 3.0), [6.0], None, 1),
     "edge_outside": lambda rs: (np.arange(-30.0, 90.0), np.arange(0, 50, 2.0), [5.0], None, 0),
     "2d_rows": lambda rs: (np.stack(np.meshgrid(np.arange(4.0), np.arange(24.0), indexing="ij"), -1).reshape(-1, 2),
-                           rs.uniform(-1, 24, size=(150, 2)) * [0.2, 1.0], [1.6], None, 0),
+                           rs.uniform(-1, 24, size=(60, 2)) * [0.2, 1.0], [1.6], None, 0),
     "3d_two_radii": lambda rs: (np.stack(np.meshgrid(np.arange(2.0), np.arange(3.0), np.arange(16.0), indexing="ij"), -1).reshape(-1, 3),
                                 rs.uniform(0, 1, size=(80, 3)) * [2, 3, 16], [1.5, 2.5], [0, 0, 1], 0),
 }

@@ -45,6 +45,9 @@ struct Tile2Params {
   float* Xa; int64_t ldo, o0; int32_t* flags; int32_t* retry_count;
   int dmax;
   const int2* tab_hdr; const float2* tab_c;
+  // pieces (step driver with an exchange in several pieces): the ng points are seg_len-sized pieces (a multiple of 16: tiles
+  // never straddle one), piece s writes its own (m k, seg_len) buffer at Xa + s * seg_stride.  0: one result array
+  int seg_len; int64_t seg_stride;
 };
 
 __device__ __forceinline__ float t2_add_h(float v) {       // sum over the four lanes (lr, h = 0..3), in every one of them
@@ -132,7 +135,12 @@ void letkf_tile2_kernel(Tile2Params P) {
   const int64_t tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int64_t p0 = tile << 4;
   const int npts = P.ng - p0 < 16 ? (int)(P.ng - p0) : 16;
-  const int64_t oc0 = P.o0 + p0;
+  int64_t oc0 = P.o0 + p0;
+  if (P.seg_len > 0) {
+    const unsigned sgi = (unsigned)p0 / (unsigned)P.seg_len;
+    oc0 = p0 - (int64_t)sgi * P.seg_len;
+    P.Xa += (int64_t)sgi * P.seg_stride;
+  }
   const unsigned ldxb = (unsigned)P.ldx * 4u, ldob = (unsigned)P.ldo * 4u;       // (k ld 4 < 2^31: checked on the host)
   const int lrc = lr < npts ? lr : npts - 1;
   const bool colok = lr < npts;
@@ -633,7 +641,9 @@ static int tile2_launch_s(const Tile2Params& tp, hipStream_t stream) {
     if (tp.m == 1 && w == 3) return tile2_launch_m<UT, KT, false, 3>(tp, stream);
   }
 #endif
-  return tp.m == 1 ? tile2_launch_m<UT, KT, false>(tp, stream) : tile2_launch_m<UT, KT, true>(tp, stream);
+  bool force_rows = false;      // (experiment builds: the many-rows instantiation also for m = 1)
+  MIA_EXP_SET(force_rows, "MIA_TILE2_FORCE_MROWS", (bool)atoi);
+  return tp.m == 1 && !force_rows ? tile2_launch_m<UT, KT, false>(tp, stream) : tile2_launch_m<UT, KT, true>(tp, stream);
 }
 
 template <int UT>
@@ -663,7 +673,8 @@ bool tile2_covers(int m, int k, int p_max, int extra_blocks, int64_t ldx, int64_
 int tile2_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const void* rec, int64_t P,
                           const void* tile_lists, int ut, float inf_factor, float* Xa, int64_t ldo, int64_t o0,
                           int32_t* flags, int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c,
-                          hipStream_t stream) {
+                          hipStream_t stream, int seg_len, int64_t seg_stride) {
+  if (seg_len < 0 || (seg_len & 15) || (seg_len > 0 && ng >= ((int64_t)1 << 31))) return MIA_ERR_UNSUPPORTED;
   if (!flags || !retry_count || !tab_hdr || !tab_c || !tile_lists || !rec) return MIA_ERR_UNSUPPORTED;
   const int kt = (k + 15) >> 4;
   if (ut < 1 || ut > 6 || ut > kt + 1 || !tile2_covers(m, k, 0, ut - 1, ldx, ldo, ng)) return MIA_ERR_UNSUPPORTED;
@@ -681,6 +692,7 @@ int tile2_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0,
   tp.cs_psi = (float)(1.0 / rg);
   tp.Xa = Xa; tp.ldo = ldo; tp.o0 = o0; tp.flags = flags; tp.retry_count = retry_count; tp.dmax = dmax;
   tp.tab_hdr = tab_hdr; tp.tab_c = tab_c;
+  tp.seg_len = seg_len; tp.seg_stride = seg_stride;
 #ifdef MIA_TILE2_SINGLE        // (development builds: one instantiation, for register / ISA inspection)
   if (ut == 2 && kt == 3) return tile2_launch_s<2, 3>(tp, stream);
   return MIA_ERR_UNSUPPORTED;
@@ -715,5 +727,5 @@ extern "C" int mia_letkf_analysis_tiles_f32(const float* X, int64_t ldx, int m, 
   const float2* tc = nullptr;
   if (!cheb_dual_table(stream, &th, &tc)) return MIA_ERR_UNSUPPORTED;
   return tile2_analysis_launch(X, ldx, m, k, g0, g1 - g0, split_rec, P, tile_lists, tile_ut_for(p_max) + extra_blocks, inf_factor, Xa,
-                               ldo, o0, flags, retry_count, option(MIA_OPT_CHEB_DMAX), th, tc, stream);
+                               ldo, o0, flags, retry_count, option(MIA_OPT_CHEB_DMAX), th, tc, stream, 0, 0);
 }

@@ -78,15 +78,24 @@ __device__ __forceinline__ void split8(const float (&x)[8], h8v& hi, h8v& lo) {
   for (int i = 0; i < 4; ++i) {
     const f2w v = {x[2 * i], x[2 * i + 1]};
     const h2v a = __builtin_convertvector(v, h2v);                  // v_cvt_pk_f16_f32, round to nearest
-    const unsigned au = __builtin_bit_cast(unsigned, a);
-    // lo = f16(x - hi), straight into the two halves of one register: v_fma_mixlo / mixhi read the f16 operand in place and
-    // round the (exact) f32 difference once
-    unsigned l;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(au), "v"(v[0]));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(au), "v"(v[1]));
-    hu[i] = au;
-    lu[i] = l;
+    hu[i] = __builtin_bit_cast(unsigned, a);
   }
+  // lo = f16(x - hi), straight into the two halves of a register: v_fma_mixlo / mixhi read the f16 operand in place and round
+  // the (exact) f32 difference once.  ONE statement for the eight values, closed by the two wait states a matrix instruction
+  // needs after a vector instruction wrote one of its operands: the compiler pads nothing around inline assembly (without
+  // them an MFMA scheduled right behind read a stale operand -- found on the UT = 1 many-rows instantiation).
+  asm("v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %4, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %1, %5, -1.0, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %1, %5, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %2, %6, -1.0, %12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %2, %6, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %3, %7, -1.0, %14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %3, %7, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "s_nop 1"
+      : "=&v"(lu[0]), "=&v"(lu[1]), "=&v"(lu[2]), "=&v"(lu[3])
+      : "v"(hu[0]), "v"(hu[1]), "v"(hu[2]), "v"(hu[3]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]),
+        "v"(x[6]), "v"(x[7]));
   hi = __builtin_bit_cast(h8v, hu);
   lo = __builtin_bit_cast(h8v, lu);
 }
@@ -117,6 +126,6 @@ bool tile2_covers(int m, int k, int p_max, int extra_blocks, int64_t ldx, int64_
 int tile2_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const void* rec, int64_t P,
                           const void* tile_lists, int ut, float inf_factor, float* Xa, int64_t ldo, int64_t o0,
                           int32_t* flags, int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c,
-                          hipStream_t stream);
+                          hipStream_t stream, int seg_len = 0, int64_t seg_stride = 0);
 
 }  // namespace mia

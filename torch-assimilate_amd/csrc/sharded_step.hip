@@ -292,7 +292,7 @@ int step_layout(int64_t G, int m, int k, int64_t P, int n_coord, int world, int 
     return MIA_ERR_SIZE;
   const int kp = (k + 1 + 3) / 4 * 4;
   L->n = (G + world - 1) / world;
-  L->nc = ((L->n + n_chunks - 1) / n_chunks + 7) / 8 * 8;   // (segmented launches want whole groups of 8)
+  L->nc = ((L->n + n_chunks - 1) / n_chunks + 15) / 16 * 16;   // (whole tiles of sixteen points per piece)
   L->cap = p_max_assumed < 8 ? 8 : (p_max_assumed + 7) / 8 * 8;
   size_t o = 0;
   L->rec = o; o = mia::align_up(o + (size_t)(P > 0 ? P : 1) * kp * sizeof(float), 256);
@@ -674,7 +674,7 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
   const int pm_tl = p_max_assumed < L.cap ? p_max_assumed : L.cap;
   const int2* tl_th = nullptr;
   const float2* tl_tc = nullptr;
-  const bool tl_route = mia::option(MIA_OPT_TILE_LISTS) != 0 && !(step_flags & MIA_STEP_NO_TILE_LISTS) && n_chunks == 1 &&
+  const bool tl_route = mia::option(MIA_OPT_TILE_LISTS) != 0 && !(step_flags & MIA_STEP_NO_TILE_LISTS) && (n_chunks == 1 || exch) &&
                         method != 1 && !(gamma > 0.0f) && blk > 0 && P > 0 && L.ut <= 6 && mia::option(MIA_OPT_TILE) != 0 &&
                         mia::option(MIA_OPT_TILE_SPLIT) != 0 && mia::tile2_covers(m, k, pm_tl, (step_flags >> 4) & 7, G, exch ? L.nc : G, blk) &&
                         mia::cheb_dual_table((hipStream_t)(prep_stream ? prep_stream : stream), &tl_th, &tl_tc);
@@ -708,7 +708,7 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
     *seq_io = seq;
   }
 
-  bool segmented = false;
+  bool segmented = false, tl_block = false;
   if (phase == 0) {
     // counters[0..3] = {longest list, truncated lists, declined points, error bits} of this rank; [4..7] = max over ranks.
     // They, the trailer copy and the segment slots are cleared by the first index kernel when it runs
@@ -755,9 +755,18 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
     // the side stream starts once the lists exist (and the slots it polls have been cleared)
     if (exch) MIA_HIP_TRY(hipStreamWaitEvent(cs, comm->ev[kMaxChunks], 0));
     if (t_start && !carried) MIA_HIP_TRY(hipEventRecord(t_start, s));   // (after the wait for the lists: kernel time only)
+    // tile route with several pieces: ONE launch over the block, every tile writes into its piece's buffer; the pieces are
+    // exchanged once it has finished (the kernel is a fraction of one piece's all-gather: nothing to overlap inside it)
+    if (tl_route && n_chunks > 1 && b1 > b0) {
+      rc = mia::tile2_analysis_launch(X, G, m, k, b0, b1 - b0, base + L.hrec, P, base + L.tl, L.ut, inf_factor,
+                                      (float*)(base + L.bufs), L.nc, 0, flags, ctr + 2, mia::option(MIA_OPT_CHEB_DMAX), tl_th, tl_tc, s,
+                                      (int)L.nc, (int64_t)(L.chunk_bytes / sizeof(float)));
+      if (rc != MIA_OK) return rc;
+      tl_block = true;
+    }
     // one launch over the whole block whose segments are exchanged as they complete (no kernel boundary, no
     // event between the pieces: a 1e5-point block in 4 launches costs 292 us instead of 245 us on MI355X)
-    if (exch && n_chunks > 1 && !eig_only && b1 > b0 && signal_mode) {
+    if (!tl_block && exch && n_chunks > 1 && !eig_only && b1 > b0 && signal_mode) {
       rc = mia::cheb_analysis_launch(X, G, m, k, b0, b1 - b0, rec, cnt, idx, w, L.cap, p_max_assumed < L.cap ? p_max_assumed : L.cap,
                                      inf_factor, gamma > 0.0f ? 1 : 0, gamma, (float*)(base + L.bufs), L.nc, 0, flags,
                                      ctr + 2, nullptr, nullptr, s, (int)L.nc, (int64_t)(L.chunk_bytes / sizeof(float)), done);
@@ -773,7 +782,7 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
     float* dst = exch ? (float*)(base + L.bufs + L.chunk_bytes * c) : Xa;
     const int64_t ldo = exch ? L.nc : G;
     const int64_t o0 = exch ? 0 : c0;
-    if (c1 > c0 && !segmented) {
+    if (c1 > c0 && !segmented && !tl_block) {
       const int32_t* ccnt = cnt + (c0 - b0);
       const int32_t* cidx = idx + (size_t)(c0 - b0) * L.cap;
       const double* cw = w + (size_t)(c0 - b0) * L.cap;
@@ -781,8 +790,10 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
       if (phase == 1 && tl_route) {
         // declined points of the tile route: float32 records and per-point lists are built now (the step's index is still in
         // its workspace, unsorted: the flagged points' lists are put into sorted-index order as on the lazy route)
-        rc = mia_letkf_pack_obs_f32(Yb, d, k, P, rec, stream);
-        if (rc != MIA_OK) return rc;
+        if (c == 0) {
+          rc = mia_letkf_pack_obs_f32(Yb, d, k, P, rec, stream);
+          if (rc != MIA_OK) return rc;
+        }
         rc = mia::localize_lists_impl(grid_xyz, c0, c1, P, n_coord, coord_group, gc_c, n_r, gc_eps, L.cap, const_cast<int32_t*>(ccnt),
                                       const_cast<int32_t*>(cidx), const_cast<double*>(cw), (int32_t*)(base + L.scratch),
                                       base + L.loc, (hipStream_t)stream, nullptr, MIA_TAPER_GC);
@@ -853,7 +864,7 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
           rc = mia::segment_wait_launch(done + (size_t)c * 64 * mia::kSlotStride, (int)(c1 - c0), ctr + 3, cs);
           if (rc != MIA_OK) return rc;
         }
-      } else {
+      } else if (!tl_block || c == 0) {      // (the tile route's one launch: the first piece's wait covers all of them)
         MIA_HIP_TRY(hipEventRecord(comm->ev[c], s));
         MIA_HIP_TRY(hipStreamWaitEvent(cs, comm->ev[c], 0));
       }

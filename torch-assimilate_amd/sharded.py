@@ -797,20 +797,34 @@ class ShardedLetkf:
         ev = lambda: torch.cuda.Event(enable_timing=True)
         fused = (self.fused_localization and self.method != "eig" and self._p_max_hint is not None
                  and X.dtype == torch.float32)
-        names = ["pack_obs", "obs_index_build" if fused else "localize(index+lists, incl. host sync)", "analysis_kernel"]
+        tiles_route = (not fused and not self._no_tile_lists and len(obs_xyz) > 0 and self._p_max_hint is not None
+                       and eng.tile_route_applies(X, self._p_max_hint, self._tile_extra, self.rbf_gamma, self.method))
+        names = ["pack_split" if tiles_route else "pack_obs",
+                 "obs_index_build" if fused else ("localize_tiles(index + tile lists)" if tiles_route
+                                                  else "localize(index+lists, incl. host sync)"), "analysis_kernel"]
         acc = dict.fromkeys(names, 0.0)
         burst = 5
         for _ in range(reps):
             nk = 1
             e = [ev() for _ in range(4)]
             e[0].record()
-            rec = eng.pack_obs(Yb, d, X.dtype)
+            rec = eng.pack_split(Yb, d) if tiles_route else eng.pack_obs(Yb, d, X.dtype)
             e[1].record()
             if fused:
                 index = eng.build_index(obs_xyz, self.radii, self.coord_group)
                 e[2].record()
                 _, _, fin = eng.analysis_fused(X, rec, grid_xyz, index, self._p_max_hint, self.inf_factor, self.eps,
                                                self.rbf_gamma, g0, g1)
+            elif tiles_route:
+                tiles = eng.localize_tiles(grid_xyz, obs_xyz, self.radii, self._p_max_hint, self.coord_group, self.eps, g0, g1,
+                                           extra_blocks=self._tile_extra)
+                torch.cuda.synchronize()          # (idle GPU in front of the burst, as on the list route)
+                out = torch.empty((X.shape[0], X.shape[1], g1 - g0), dtype=torch.float32, device=X.device)
+                e[2].record()
+                for _ in range(burst):
+                    eng.analysis_tiles(X, rec, Yb.shape[1], tiles, self.inf_factor, out=out)
+                nk = burst
+                fin = lambda: 0
             else:
                 nb = eng.localize(grid_xyz, obs_xyz, self.radii, self.coord_group, self.eps, g0, g1)
                 # the list step ends in a host read-back, so the GPU is idle here: launch the analysis kernel
