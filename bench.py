@@ -100,6 +100,16 @@ def useful_flops(k, p, m, deg):
     return k * p * (p + 1) + m * (4 * k * p + 2 * deg * p * p) + 25 * p
 
 
+def useful_flops_shared(k, p, m, deg, u=None):
+    """As useful_flops, but with the Gram matrix counted ONCE per tile of sixteen points over the tile's union of U ~ p + 8
+    observations (what a tile-shaped algorithm needs at least): k U (U + 1) / 16 per analysis.  This count is a subset of what
+    the tile kernels execute, so its rate over the FP32 peak cannot exceed the executed one."""
+    if not deg:
+        return None
+    u = p + 8 if u is None else u
+    return k * u * (u + 1) / 16.0 + m * (4 * k * p + 2 * deg * p * p) + 25 * p
+
+
 def algorithmic_bytes(k, m, P_over_G, n_coord=1):
     return 4.0 * (2 * k * m + (k + 1) * P_over_G + 2 * n_coord * (1 + P_over_G))
 
@@ -535,7 +545,12 @@ def main():
                     rec.update(f16_mfma_flops_per_analysis=exf[1],
                                matrix_core_frac=exf[1] * gpg / (ms2 * 1e-3) / 1e12 / PEAK_F16_TFLOPS)
                     exf = exf[0]
-                rec.update(useful_flops_per_analysis=usf, useful_frac=usf * gpg / (ms2 * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                uss = useful_flops_shared(k2, pm2, 1, deg2, u=min(pm2 + 15, 16 * ((pm2 + 8 + 15) // 16)))
+                rec.update(useful_flops_per_analysis=uss, useful_frac=uss * gpg / (ms2 * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                           useful_basis="useful f32 flops with the Gram matrix counted once per tile of sixteen points (no padding); "
+                                        "a per-point algorithm's count (unshared_*) credits the shared Gram sixteen times and can exceed "
+                                        "what any kernel executes",
+                           unshared_flops_per_analysis=usf, unshared_credit_ratio_to_fp32_peak=usf * gpg / (ms2 * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
                            executed_f32_equivalent_flops_per_analysis=exf,
                            executed_f32_equivalent_ratio_to_fp32_peak=exf * gpg / (ms2 * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
                            executed_note="f32-equivalent of the half-precision MFMA triples, padding included: runs on the "
@@ -582,6 +597,9 @@ def main():
                                         "taper 25 p: no padding, nothing shared) x analyses per launch / launch duration inside the "
                                         "timed loop / FP32 peak"),
                          "useful_flops_per_analysis": us_f,
+                         "frac_shared_gram_basis": None if not deg else useful_flops_shared(K_ENS, 20, 1, deg) * gpg / (kern_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                         "frac_shared_gram_note": "the same with the Gram matrix counted once per tile of sixteen points (k U (U+1) / 16 "
+                                                  "per analysis, U = 28): what a tile-shaped algorithm needs at least",
                          "frac_alone": None if (us_f is None or not alone_ms) else us_f * gpg / (alone_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
                          "executed_f32_equivalent": None if ex_tf is None else {
                              "flops_per_analysis": ex_f, "TFLOPs": ex_tf, "ratio_to_fp32_peak": ex_tf / PEAK_FP32_TFLOPS,
