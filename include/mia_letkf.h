@@ -83,6 +83,9 @@ const char* mia_status_string(int status);
  *   "segment_signal"   1  step driver with several pieces: one segmented launch / 0: one launch + event per piece
  *   "tile_lists"       1  step driver: tile-shaped lists + split records + the analysis kernel of csrc/letkf_tile2.hip where the
  *                         shape allows (needs "tile" and "tile_split") / 0: per-point lists and csrc/letkf_tile.hip
+ *   "bucket_index"     1  step driver, tile route: the observations are binned by ONE kernel into fixed-capacity buckets of the cell
+ *                         grid the step's workspace already holds (bounding box validated per observation, rebuilt when it no
+ *                         longer holds) / 0: bounding box + count + scan + scatter kernels every step
  * Returns MIA_ERR_UNSUPPORTED for an unknown name, MIA_ERR_SIZE for a value out of range. */
 int mia_set_option(const char* name, int value);
 int mia_get_option(const char* name, int* value);
@@ -562,6 +565,10 @@ int mia_letkf_sharded_step_f32(const float* X /* [m][k][G] */, int64_t G, int m,
 #define MIA_STEP_TILE_EXTRA(n) (((n) & 7) << 4) /* tile route: n more row blocks of sixteen union slots per tile (after a step
                                                    reported unions that did not fit; beyond what the ensemble size allows the
                                                    step takes the per-point lists) */
+#define MIA_STEP_FRESH_BOX 0x400  /* tile route: recompute the observations' bounding box this step (a step reported error bit 8:
+                                    an observation outside the box its workspace held, or other radii) */
+#define MIA_STEP_SCAN_INDEX 0x800 /* tile route: scan-based observation index instead of fixed-capacity buckets (a step reported
+                                    error bit 16: a cell with more observations than a bucket holds) */
 #define MIA_STEP_NO_TILE_LISTS 8 /* per-point lists even where the tile route would apply (after a step reported tiles whose
                                    union did not fit: counters[1] != 0 with counters[0] <= p_max_assumed) */
 int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int m, int k,

@@ -1,0 +1,134 @@
+"""GPU tests of the native step driver on the tile route (csrc/sharded_step.hip: bucket index -> tile lists + split records ->
+letkf_tile2_kernel): same result as the entry-by-entry engine calls, with the bucket index and with the scan-based one, when
+observations leave the bounding box a workspace held (box rebuilt, step repeated), when a cell overflows its bucket (scan-based
+index from then on), when tiles need more slots, and with steps in flight."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_fro, set_option
+from oracle import letkf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mia():
+    import torch_assimilate_amd as m
+    m.build()
+    return m
+
+
+def args_of(case, dev, shift=0.0, scale=1.0):
+    return (torch.as_tensor(case["state"], dtype=torch.float32, device=dev), torch.as_tensor(case["grid_x"] + shift, device=dev),
+            torch.as_tensor(case["obs_x"] + shift, device=dev), torch.as_tensor(case["yb"] * scale, dtype=torch.float32, device=dev),
+            torch.as_tensor(case["d"] * scale, dtype=torch.float32, device=dev))
+
+
+def test_bucket_index_equals_scan_index_and_engine_calls(mia):
+    """Tile lists do not depend on how the observations were binned (slots follow the rank of the observation index): the step
+    driver with the one-kernel bucket index, with the four-kernel scan index and the entry-by-entry engine route agree bit for
+    bit, serial steps and steps in flight."""
+    dev = torch.device("cuda:0")
+    case = O.synthetic_case(3000, 40, 2, seed=5)
+    a = args_of(case, dev)
+    ref = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1, native_step=False).assimilate(*a)
+    oracle = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], case["yb"], case["d"], 10.0, 1.1)[0]
+    assert rel_fro(ref.cpu().numpy(), oracle) < 1e-5
+    for bucket in (1, 0):
+        set_option("bucket_index", bucket)
+        r = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1, max_in_flight=3)
+        for _ in range(4):
+            out = r.assimilate(*a)
+        assert r.native_steps == 3 and torch.equal(out, ref) and r.last_flags_ok()
+        assert r.dominant_kernel_name.startswith("letkf_tile2_kernel")
+        pend = []
+        for _ in range(7):
+            pend.append(r.submit(*a))
+            if len(pend) == 3:
+                assert torch.equal(pend.pop(0).result(), ref)
+        while pend:
+            assert torch.equal(pend.pop(0).result(), ref)
+        assert r.native_steps == 10 and not r._scan_index and not r._no_tile_lists
+
+
+def test_observations_leaving_the_stored_box_rebuild_it(mia):
+    """The bucket index reuses the bounding box a workspace holds and checks every observation against it: a network that
+    moved (here by 500 grid steps, same sizes) is reported (error bit 8), the box rebuilt and the step repeated -- same result
+    as a fresh object; small drifts stay inside the box's one-cell margin and cost nothing."""
+    dev = torch.device("cuda:0")
+    case = O.synthetic_case(2000, 40, 2, seed=6)
+    r = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1)
+    for _ in range(3):
+        r.assimilate(*args_of(case, dev))
+    n0 = r.native_steps
+    for shift in (3.0, 500.0, -40.0):
+        a = args_of(case, dev, shift=shift)
+        out = r.assimilate(*a)
+        fresh = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1, native_step=False).assimilate(*a)
+        assert torch.equal(out, fresh) and r.last_flags_ok()
+    assert r.native_steps >= n0 + 3 and not r._scan_index
+    # other radii on the same workspace: the cell grid no longer fits them
+    r.radii = [6.0]
+    r._p_max_hint = None
+    a = args_of(case, dev)
+    for _ in range(3):
+        out = r.assimilate(*a)
+    fresh = mia.ShardedLetkf(dev, 0, 1, radii=[6.0], inf_factor=1.1, native_step=False).assimilate(*a)
+    assert torch.equal(out, fresh)
+
+
+def test_overfull_cell_falls_back_to_the_scan_index(mia):
+    """A cluster of 150 observations inside one cell (buckets hold at most 64): error bit 16, the object switches to the
+    scan-based index and repeats the step; points near the cluster see more than the tile route's 88 local observations and the
+    step takes whatever route covers that -- the result must equal the engine route's."""
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(3)
+    G, k = 1500, 40
+    grid = np.arange(G, dtype=np.float64)
+    obs = np.concatenate([np.arange(0, G, 4.0), 700.0 + rs.uniform(0, 3.0, size=150)])
+    state = rs.normal(size=(1, k, G))
+    hx = rs.normal(size=(k, len(obs)))
+    yb, d = hx - hx.mean(axis=0), rs.normal(size=len(obs))
+    a = (torch.as_tensor(state, dtype=torch.float32, device=dev), torch.as_tensor(grid, device=dev), torch.as_tensor(obs, device=dev),
+         torch.as_tensor(yb, dtype=torch.float32, device=dev), torch.as_tensor(d, dtype=torch.float32, device=dev))
+    ref = mia.ShardedLetkf(dev, 0, 1, radii=[1.5], inf_factor=1.1, native_step=False).assimilate(*a)
+    r = mia.ShardedLetkf(dev, 0, 1, radii=[1.5], inf_factor=1.1)
+    for _ in range(4):
+        out = r.assimilate(*a)
+    assert torch.equal(out, ref) and r.last_flags_ok()
+
+
+def test_dense_network_gets_more_slots(mia):
+    """One observation per grid step: sixteen consecutive points see p_max + 15 observations, more than the default slots of a
+    short list -- the step reports the tiles, the object adds a row block (MIA_STEP_TILE_EXTRA) and repeats; afterwards the
+    steps run on the tile route."""
+    dev = torch.device("cuda:0")
+    case = O.synthetic_case(1000, 24, 1, seed=9)
+    a = args_of(case, dev)
+    ref = mia.ShardedLetkf(dev, 0, 1, radii=[1.6], inf_factor=1.1, native_step=False).assimilate(*a)
+    oracle = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], case["yb"], case["d"], 1.6, 1.1)[0]
+    assert rel_fro(ref.cpu().numpy(), oracle) < 1e-5
+    r = mia.ShardedLetkf(dev, 0, 1, radii=[1.6], inf_factor=1.1)
+    for _ in range(4):
+        out = r.assimilate(*a)
+    assert torch.equal(out, ref) and r._tile_extra == 1 and not r._no_tile_lists
+    assert r.dominant_kernel_name.startswith("letkf_tile2_kernel")
+
+
+def test_declined_points_are_redone_from_lists_built_then(mia):
+    """Strong observations: the tile kernel declines points (MIA_FLAG_RETRY); phase 1 of the step builds float32 records and
+    per-point lists over a scan-based index and the eigensolver kernel redoes exactly those points -- same result as the engine
+    route, whose retry uses the exact lists."""
+    dev = torch.device("cuda:0")
+    case = O.synthetic_case(1200, 40, 2, seed=11)
+    a = args_of(case, dev, scale=12.0)
+    plain = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1, native_step=False)
+    ref = plain.assimilate(*a)
+    assert plain.last_retries > 0
+    oracle = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], case["yb"] * 12.0, case["d"] * 12.0, 10.0, 1.1)[0]
+    assert rel_fro(ref.cpu().numpy(), oracle) < 1e-5
+    r = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1)
+    for _ in range(4):
+        out = r.assimilate(*a)
+    assert torch.equal(out, ref) and r.last_retries == plain.last_retries and r.last_flags_ok()

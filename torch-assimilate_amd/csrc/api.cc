@@ -24,14 +24,14 @@ extern "C" const char* mia_status_string(int status) {
 #include "mia_options.h"
 
 namespace mia {
-static std::atomic<int> g_opt[MIA_OPT_COUNT_] = {62, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+static std::atomic<int> g_opt[MIA_OPT_COUNT_] = {62, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
 int option(int id) { return (id >= 0 && id < MIA_OPT_COUNT_) ? g_opt[id].load(std::memory_order_relaxed) : 0; }
 }  // namespace mia
 
 static const char* const kOptNames[MIA_OPT_COUNT_] = {"cheb_dmax", "cheb_table", "cheb_rowbatch", "cheb_big", "tile",
                                                       "tile_split", "localize_quad", "step_hostwait", "step_lazy_sort",
-                                                      "segment_signal", "tile_lists"};
-static const int kOptDefault[MIA_OPT_COUNT_] = {62, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+                                                      "segment_signal", "tile_lists", "bucket_index"};
+static const int kOptDefault[MIA_OPT_COUNT_] = {62, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
 
 extern "C" int mia_set_option(const char* name, int value) {
   if (!name) return MIA_ERR_NULL;

@@ -44,6 +44,8 @@ struct IndexParams {
   PackJob pack;          // ... the others (if any) pack observation records (pack.rec != nullptr)
   ZeroJob zero;          // small caller buffers cleared by the first kernel (saves their fill launches)
   int scatter_xyz;       // the cell sort is skipped (see index_build_impl): the scatter lays the coordinates out itself
+  long long bucket_total;   // entries of the bucket arrays
+  int* bidx; double* bxyz;
 };
 
 __device__ inline unsigned long long dkey(double x) {     // total order of doubles as unsigned integers
@@ -70,9 +72,12 @@ __device__ inline void index_dims(const IndexParams& p) {
     //  starts from -- the chain leaves the header as it found it and needs no fill launch per step)
     __hip_atomic_store(&p.hdr->kmax[c], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&p.hdr->kmin_inv[c], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    h[c] = p.cutoff[c] > 0.0 ? p.cutoff[c] : 1.0;
+    // (one cell of margin on either side: observations that drift a little between two builds stay inside a box that the
+    //  bucket index of the step driver keeps from one step to the next)
+    mn -= h[c]; mx += h[c];
     p.hdr->mn[c] = mn;
     ext[c] = mx - mn;
-    h[c] = p.cutoff[c] > 0.0 ? p.cutoff[c] : 1.0;
     double nn = floor(ext[c] / h[c]) + 1.0;
     n[c] = nn > 1048576.0 ? 1048576 : (long long)nn;
   }
@@ -91,6 +96,14 @@ __device__ inline void index_dims(const IndexParams& p) {
   }
   for (int c = p.nc; c < MIA_MAX_COORD; ++c) { p.hdr->invh[c] = 1.0; p.hdr->n[c] = 1; }
   p.hdr->ncell = int(n[0] * n[1] * n[2]);
+  for (int c = 0; c < MIA_MAX_COORD; ++c) p.hdr->cutoff[c] = c < p.nc ? p.cutoff[c] : 0.0;
+  {   // bucket capacity: the largest power of two <= (bucket entries) / cells, at most 64; below 8 the buckets are not used
+    long long per = (long long)p.bucket_total / (n[0] * n[1] * n[2]);
+    int cap = 64;
+    while (cap > per) cap >>= 1;
+    p.hdr->bucket_cap = cap >= 8 ? cap : 0;
+  }
+  p.hdr->magic = kIndexMagic;
   __hip_atomic_store(&p.hdr->done_bbox, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -592,6 +605,7 @@ int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_
   for (int c = 0; c < MIA_MAX_COORD; ++c) ip.cutoff[c] = c < n_coord ? 2.0 * gc_c[coord_group[c]] : 1.0;
   ip.hdr = L.hdr; ip.start = L.start; ip.cursor = L.cursor; ip.sorted = L.sorted; ip.cell_of = L.cell_of; ip.rank_of = L.rank_of;
   ip.sxyz = L.sxyz;
+  ip.bucket_total = (long long)L.bucket_total; ip.bidx = L.bidx; ip.bxyz = L.bxyz;
   // SINGLE-WAVE workgroups throughout the chain: when steps are pipelined these kernels run beside the previous step's
   // analysis kernel, which fills every SIMD's register file (7 waves x 72 VGPRs at C2).  A lone wave takes the slot of
   // the next analysis wave that retires; a 4-wave workgroup needs one to retire on each SIMD of one CU at the same
@@ -637,14 +651,91 @@ int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_
   return MIA_OK;
 }
 
+// Bucket index (step driver, tile route): the cell grid -- origin, cell edges, dimensions -- is the one the workspace's header
+// already holds (from an earlier build on this workspace: the bounding box with its one-cell margin changes slowly or not at
+// all between two assimilation steps), and every cell owns bucket_cap entries, so ONE kernel bins the observations: the cell's
+// atomic count is the observation's place in its bucket.  No bounding-box pass, no scan, no scatter pass.  Everything the box
+// is reused FOR is recomputed from this call's coordinates; that it still holds is checked here per observation (and the
+// radii against the ones the grid was derived for): kIndexErrBox sends the step back through the bounding-box kernel,
+// kIndexErrFull (a cell with more observations than a bucket holds) to the scan-based index.  The per-cell counts are zero on
+// entry: the tile-list kernel's last workgroup puts them back (localize_tiles_kernel).
+__global__ __launch_bounds__(64) void index_bucket_kernel(IndexParams p) {
+  MIA_PREP_PRIORITY();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int q = 0; q < 3; ++q)
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < p.zero.n[q]; i += stride) p.zero.ptr[q][i] = 0;
+  const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (j >= p.P) return;
+  IndexHeader* h = p.hdr;
+  const bool grid_ok = h->magic == kIndexMagic;
+  bool ok = grid_ok && h->bucket_cap > 0;
+  for (int c = 0; c < p.nc; ++c) ok = ok && h->cutoff[c] == p.cutoff[c];
+  const int cap = h->bucket_cap;
+  int id = 0;
+  bool skip = false;
+  double x[MIA_MAX_COORD] = {0.0, 0.0, 0.0};
+  for (int c = 0; c < p.nc; ++c) {
+    x[c] = p.obs[j * p.nc + c];
+    const double f = floor((x[c] - h->mn[c]) * h->invh[c]);
+    if (!(x[c] == x[c])) { skip = true; continue; }         // NaN coordinate: no cell (its weight is 0 everywhere)
+    if (!(f >= 0.0 && f < double(h->n[c]))) { ok = false; continue; }
+    id = id * h->n[c] + int(f);
+  }
+  if (!ok) {
+    atomicOr(&h->err, (grid_ok && cap == 0) ? kIndexErrFull : kIndexErrBox);
+    return;
+  }
+  if (skip) return;
+  const int pos = atomicAdd(&p.cursor[id], 1);
+  if (pos >= cap) { atomicOr(&h->err, kIndexErrFull); return; }
+  const int64_t e = (int64_t)id * cap + pos;
+  p.bidx[e] = int(j);
+  for (int c = 0; c < p.nc; ++c) p.bxyz[e * p.nc + c] = x[c];
+}
+
+int index_bucket_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_t* coord_group, const double* gc_c, int n_r,
+                            void* ws, size_t ws_bytes, hipStream_t stream, const ZeroJob* zero, bool fresh_box) {
+  if (P <= 0 || n_coord < 1 || n_coord > MIA_MAX_COORD || n_r < 1 || n_r > MIA_MAX_RADII) return MIA_ERR_SIZE;
+  if (P > 500000000LL) return MIA_ERR_UNSUPPORTED;
+  if (!coord_group || !gc_c || !obs_xyz || !ws) return MIA_ERR_NULL;
+  const IndexLayout L = index_layout(ws, P, n_coord);
+  if (ws_bytes < L.bytes) return MIA_ERR_WORKSPACE;
+  IndexParams ip;
+  ip.obs = obs_xyz; ip.P = P; ip.nc = n_coord; ip.cell_cap = (int)L.cap;
+  for (int c = 0; c < MIA_MAX_COORD; ++c) ip.cutoff[c] = c < n_coord ? 2.0 * gc_c[coord_group[c]] : 1.0;
+  ip.hdr = L.hdr; ip.start = L.start; ip.cursor = L.cursor; ip.sorted = L.sorted; ip.cell_of = L.cell_of; ip.rank_of = L.rank_of;
+  ip.sxyz = L.sxyz;
+  ip.bucket_total = (long long)L.bucket_total; ip.bidx = L.bidx; ip.bxyz = L.bxyz;
+  ip.pack = PackJob{nullptr, nullptr, nullptr, 0, 0};
+  ip.zero = ZeroJob{{nullptr, nullptr, nullptr}, {0, 0, 0}};
+  ip.scatter_xyz = 0;
+  constexpr unsigned kPrepThreads = 64;
+  const unsigned nbP = (unsigned)((P + kPrepThreads - 1) / kPrepThreads);
+  ip.nb_bbox = nbP < 256 ? nbP : 256;
+  if (fresh_box) {
+    // header + per-cell tables back to zero (a workspace of unknown history), then the bounding box and the cell grid
+    const size_t words = ((char*)ip.sorted - (char*)ip.hdr) / sizeof(uint32_t);
+    const unsigned nb = (unsigned)((words + kPrepThreads * 16 - 1) / (kPrepThreads * 16));
+    index_clear_kernel<<<dim3(nb < 1024 ? (nb ? nb : 1) : 1024), dim3(kPrepThreads), 0, stream>>>(reinterpret_cast<uint32_t*>(ip.hdr), words);
+    MIA_LAUNCH_CHECK();
+    index_bbox_dims_kernel<<<dim3(ip.nb_bbox), dim3(kPrepThreads), 0, stream>>>(ip);
+    MIA_LAUNCH_CHECK();
+  }
+  ip.zero = zero ? *zero : ZeroJob{{nullptr, nullptr, nullptr}, {0, 0, 0}};
+  index_bucket_kernel<<<dim3(nbP), dim3(kPrepThreads), 0, stream>>>(ip);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
 // scan parameters over an already built index
 int make_scan_params(ScanParams* sp, const double* grid_xyz, int64_t P, int n_coord, const int32_t* coord_group,
-                     const double* gc_c, int n_r, double gc_eps, void* ws, int taper) {
+                     const double* gc_c, int n_r, double gc_eps, void* ws, int taper, bool bucket) {
   if (taper != MIA_TAPER_GC && taper != MIA_TAPER_GC_INF) return MIA_ERR_SIZE;
   if (n_coord < 1 || n_coord > MIA_MAX_COORD || n_r < 1 || n_r > MIA_MAX_RADII) return MIA_ERR_SIZE;
   if (!coord_group || !gc_c || !grid_xyz || !ws) return MIA_ERR_NULL;
   const IndexLayout L = index_layout(ws, P, n_coord);
   sp->grid = grid_xyz; sp->sxyz = L.sxyz; sp->hdr = L.hdr; sp->start = L.start; sp->sorted = L.sorted;
+  if (bucket) { sp->sxyz = L.bxyz; sp->start = L.cursor; sp->sorted = L.bidx; }
   sp->nc = n_coord; sp->n_r = n_r;
   for (int c = 0; c < MIA_MAX_COORD; ++c) sp->group[c] = c < n_coord ? coord_group[c] : 0;
   for (int r = 0; r < MIA_MAX_RADII; ++r) { sp->inv_c[r] = r < n_r ? 1.0 / gc_c[r] : 1.0; sp->cc[r] = r < n_r ? gc_c[r] : 1.0; }

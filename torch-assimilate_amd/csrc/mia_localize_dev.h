@@ -16,7 +16,16 @@ struct IndexHeader {        // lives at the start of the workspace, written on d
   int n[MIA_MAX_COORD];
   int ncell;
   unsigned done_bbox, done_count;   // workgroups finished (the last one runs the serial follow-up stage)
+  // ---- what survives from one build to the next on the same workspace (bucket index of the step driver, see index_bucket_kernel)
+  double cutoff[MIA_MAX_COORD];     // minimal cell edge (2 c per coordinate) the cell grid was derived for
+  int bucket_cap;                   // entries per cell of the bucket arrays (a power of two), 0 = none
+  unsigned magic;                   // kIndexMagic: mn / invh / n / ncell describe a cell grid
+  unsigned err;                     // bucket build: kIndexErrBox / kIndexErrFull (cleared by the tile-list kernel's last workgroup)
+  unsigned done_tiles;              // tile-list workgroups finished (the last one cleans the per-cell counts and err)
 };
+constexpr unsigned kIndexMagic = 0x6d696131u;
+constexpr unsigned kIndexErrBox = 1u;      // an observation lies outside the stored box, or the radii changed: the box must be rebuilt
+constexpr unsigned kIndexErrFull = 2u;     // a cell holds more observations than a bucket has entries: scan-based index instead
 
 __device__ inline int cell_coord(double x, double mn, double invh, int n) {
   double f = floor((x - mn) * invh);
@@ -58,10 +67,10 @@ __device__ inline double taper_d2(int taper, double d2, double inv_c, double c) 
 // what a wavefront needs to find the local observations of one grid point
 struct ScanParams {
   const double* grid;   // [G][nc]
-  const double* sxyz;   // [P][nc] observation coordinates in cell order
+  const double* sxyz;   // [P][nc] observation coordinates in cell order (bucket index: [bucket_total][nc], cell c at c * bucket_cap)
   const IndexHeader* hdr;
-  const int* start;     // [ncell + 1]
-  const int* sorted;    // [P] observation index in cell order
+  const int* start;     // [ncell + 1] (bucket index: the per-cell counts)
+  const int* sorted;    // [P] observation index in cell order (bucket index: [bucket_total])
   int nc, n_r;
   int group[MIA_MAX_COORD];
   double inv_c[MIA_MAX_RADII];
@@ -138,6 +147,7 @@ __device__ inline int scan_neighbours(const ScanParams& p, int64_t g, int lane, 
 // layout of the index workspace (built by mia_letkf_index_build_f64)
 struct IndexLayout {
   IndexHeader* hdr; int* start; int* cursor; int* sorted; int* cell_of; int* rank_of; double* sxyz; size_t bytes; size_t cap;
+  int* bidx; double* bxyz; size_t bucket_total;      // bucket index: [bucket_total] observation index / [bucket_total][nc] coordinates
 };
 static inline size_t index_cell_cap(int64_t P) {
   int64_t cap = 2 * P;
@@ -156,6 +166,9 @@ static inline IndexLayout index_layout(void* ws, int64_t P, int nc) {
   L.cell_of = (int*)base; base += align_up((size_t)P * sizeof(int) + 4, 256);
   L.rank_of = (int*)base; base += align_up((size_t)P * sizeof(int) + 4, 256);
   L.sxyz = (double*)base; base += align_up((size_t)P * (size_t)nc * sizeof(double) + 8, 256);
+  L.bucket_total = (size_t)(P > 0 ? 4 * P : 0) + 64;
+  L.bidx = (int*)base; base += align_up(L.bucket_total * sizeof(int), 256);
+  L.bxyz = (double*)base; base += align_up(L.bucket_total * (size_t)nc * sizeof(double), 256);
   L.bytes = (size_t)(base - (char*)ws);
   return L;
 }
@@ -183,6 +196,10 @@ int localize_lists_impl(const double* grid_xyz, int64_t g0, int64_t g1, int64_t 
 int sort_flagged_lists(const int32_t* flags, const int32_t* nbr_cnt, int32_t* nbr_idx, double* nbr_w, int64_t ng, int p_cap,
                        void* ws, int64_t P, int n_coord, hipStream_t stream);
 int make_scan_params(ScanParams* sp, const double* grid_xyz, int64_t P, int n_coord, const int32_t* coord_group,
-                     const double* gc_c, int n_r, double gc_eps, void* ws, int taper = MIA_TAPER_GC);
+                     const double* gc_c, int n_r, double gc_eps, void* ws, int taper = MIA_TAPER_GC, bool bucket = false);
+// bucket index (step driver): ONE kernel bins the observations into fixed-capacity cells of the cell grid the workspace's header
+// describes (fresh_box: the bounding-box kernel runs first and rewrites the header); errors go to the header (IndexHeader::err)
+int index_bucket_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_t* coord_group, const double* gc_c, int n_r,
+                            void* ws, size_t ws_bytes, hipStream_t stream, const ZeroJob* zero, bool fresh_box);
 
 }  // namespace mia

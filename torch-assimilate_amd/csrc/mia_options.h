@@ -13,6 +13,8 @@ enum {
   MIA_OPT_STEP_LAZY_SORT,    // step driver: observation index without its per-cell sort when the tile kernel takes the analysis (1) / always sorted (0)
   MIA_OPT_SEGMENT_SIGNAL,    // step driver with several pieces: one segmented launch (1) or one launch + event per piece (0)
   MIA_OPT_TILE_LISTS,        // step driver: tile-shaped lists + split records + letkf_tile2_kernel where the shape allows (1) or the per-point lists (0)
+  MIA_OPT_BUCKET_INDEX,      // step driver, tile route: observations binned into fixed-capacity cell buckets by ONE kernel over the cell grid the
+                             // workspace holds (1) or bounding box + count + scan + scatter every step (0)
   MIA_OPT_COUNT_
 };
 

@@ -116,11 +116,12 @@ struct SplitPackJob { const float* Yb; const float* d; unsigned char* rec; int k
 // host side (tile_lists.hip)
 struct ScanParams;
 int split_pack_launch(const float* Yb, const float* d, int k, int64_t P, void* rec, hipStream_t stream);
-// tile lists of grid points [g0, g0 + ng) over the index already built in `index_ws`; optional packing passenger.
+// tile lists of grid points [g0, g0 + ng) over the index already built in `index_ws` (bucket: by index_bucket_build_impl,
+// whose error bits the kernel folds into stats[3] as bits 8 / 16; stats then has four entries); optional packing passenger.
 // stats: [0] longest list (running maximum), [1] tiles whose union did not fit (added)
 int tile_lists_launch(const double* grid_xyz, int64_t g0, int64_t ng, int64_t P, int n_coord, const int32_t* coord_group,
                       const double* gc_c, int n_r, double gc_eps, int taper, int ut, void* tile_lists, int32_t* stats,
-                      void* index_ws, hipStream_t stream, const SplitPackJob* pack);
+                      void* index_ws, hipStream_t stream, const SplitPackJob* pack, bool bucket = false);
 // letkf_tile2.hip
 bool tile2_covers(int m, int k, int p_max, int extra_blocks, int64_t ldx, int64_t ldo, int64_t ng);
 int tile2_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const void* rec, int64_t P,

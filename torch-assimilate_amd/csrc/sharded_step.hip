@@ -678,6 +678,7 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
                         method != 1 && !(gamma > 0.0f) && blk > 0 && P > 0 && L.ut <= 6 && mia::option(MIA_OPT_TILE) != 0 &&
                         mia::option(MIA_OPT_TILE_SPLIT) != 0 && mia::tile2_covers(m, k, pm_tl, (step_flags >> 4) & 7, G, exch ? L.nc : G, blk) &&
                         mia::cheb_dual_table((hipStream_t)(prep_stream ? prep_stream : stream), &tl_th, &tl_tc);
+  const bool tl_bucket = tl_route && mia::option(MIA_OPT_BUCKET_INDEX) != 0 && !(step_flags & MIA_STEP_SCAN_INDEX);
   // a step in flight whose analysis is ONE plain launch (stage 2 after the host-side wait): the launch carries its completion
   // (and timing) events in its own dispatch packet
   const bool carried = kdone_out && phase == 0 && !exch && !peer && n_chunks == 1 && method != 1 && (step_flags & kStepPrepDone) &&
@@ -726,12 +727,19 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
     if (b1 > b0 && tl_route) {
       const mia::ZeroJob zj{{counters, exch ? ctr : nullptr, exch ? done : nullptr},
                             {8, exch ? 4 : 0, exch ? (int64_t)done_ints : 0}};
-      rc = mia::index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, base + L.loc, L.loc_bytes, ps, nullptr,
-                                 zero_in_kernel ? &zj : nullptr, (step_flags & MIA_STEP_WS_CLEAN) != 0, false);
+      // bucket index: one kernel over the cell grid this workspace already holds (validated per observation); the first step on a
+      // workspace, or one sent back by error bit 8, runs the bounding-box kernel first
+      if (tl_bucket)
+        rc = mia::index_bucket_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, base + L.loc, L.loc_bytes, ps,
+                                          zero_in_kernel ? &zj : nullptr,
+                                          !(step_flags & MIA_STEP_WS_CLEAN) || (step_flags & MIA_STEP_FRESH_BOX));
+      else
+        rc = mia::index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, base + L.loc, L.loc_bytes, ps, nullptr,
+                                   zero_in_kernel ? &zj : nullptr, (step_flags & MIA_STEP_WS_CLEAN) != 0, false);
       if (rc != MIA_OK) return rc;
       const mia::SplitPackJob sj{Yb, d, (unsigned char*)(base + L.hrec), k};
       rc = mia::tile_lists_launch(grid_xyz, b0, b1 - b0, P, n_coord, coord_group, gc_c, n_r, gc_eps, MIA_TAPER_GC, L.ut,
-                                  base + L.tl, ctr, base + L.loc, ps, &sj);
+                                  base + L.tl, ctr, base + L.loc, ps, &sj, tl_bucket);
       if (rc != MIA_OK) return rc;
     } else if (b1 > b0) {
       // the record packing rides inside the first index kernel too (independent work, no launch of its own)
@@ -793,6 +801,11 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
         if (c == 0) {
           rc = mia_letkf_pack_obs_f32(Yb, d, k, P, rec, stream);
           if (rc != MIA_OK) return rc;
+          if (tl_bucket) {      // (the buckets are no scan-based index: build one, unsorted like the lazy route's)
+            rc = mia::index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, base + L.loc, L.loc_bytes, (hipStream_t)stream,
+                                       nullptr, nullptr, false, false);
+            if (rc != MIA_OK) return rc;
+          }
         }
         rc = mia::localize_lists_impl(grid_xyz, c0, c1, P, n_coord, coord_group, gc_c, n_r, gc_eps, L.cap, const_cast<int32_t*>(ccnt),
                                       const_cast<int32_t*>(cidx), const_cast<double*>(cw), (int32_t*)(base + L.scratch),

@@ -118,6 +118,12 @@ struct TileLocParams {
   int64_t P;
 };
 
+// BUCKET: the observations sit in fixed-capacity buckets per cell (index_bucket_kernel, localize.hip) instead of the scan-based
+// layout: scan.start = per-cell counts, scan.sorted / scan.sxyz = bucket entries, cell c at c * bucket_cap.  The candidates of a
+// tile are then the entries of the cells of its box taken as ONE flat sequence (a prefix sum over the box's <= 64 cells).  The
+// last workgroup to finish zeroes the per-cell counts and folds / clears the build's error bits: the workspace is left as the next
+// build needs to find it, without a clearing launch.
+template <bool BUCKET>
 __global__ __launch_bounds__(64) void localize_tiles_kernel(TileLocParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tl_lds[];
   if (blockIdx.x >= p.nb_main) {
@@ -173,46 +179,101 @@ __global__ __launch_bounds__(64) void localize_tiles_kernel(TileLocParams p) {
   bool overflow = nrows > kTlMaxRows;
   int ubase = 0;
   int cnt4[4] = {0, 0, 0, 0};          // local observations of points 4 pg + i so far (the same in every lane of a group)
-  for (int row = 0; row < (overflow ? 0 : (int)nrows); ++row) {
-    int base_cell = 0;
-    if (nc == 2) base_cell = (lo[0] + row) * hd->n[1];
-    else if (nc == 3) base_cell = ((lo[0] + row / n1) * hd->n[1] + (lo[1] + row % n1)) * hd->n[2];
-    const int beg = __builtin_amdgcn_readfirstlane(q.start[base_cell + lo[last]]);
-    const int end = __builtin_amdgcn_readfirstlane(q.start[base_cell + hi[last] + 1]);
-    for (int pos0 = beg; pos0 < end; pos0 += 16) {
-      const bool have = pos0 + cl < end;
-      const int pos = have ? pos0 + cl : end - 1;
-      const int oj = q.sorted[pos];
-      double ox[MIA_MAX_COORD] = {0.0, 0.0, 0.0};
-      for (int c = 0; c < nc; ++c) ox[c] = q.sxyz[(int64_t)pos * nc + c];
-      f4w wq = {0.f, 0.f, 0.f, 0.f};
-      bool anyu = false;
+  // sixteen candidates (one per lane cl, position `pos` of the index arrays, valid where `have`) against the tile's points
+  auto weigh = [&](bool have, int64_t pos) {
+    const int oj = q.sorted[pos];
+    double ox[MIA_MAX_COORD] = {0.0, 0.0, 0.0};
+    for (int c = 0; c < nc; ++c) ox[c] = q.sxyz[pos * nc + c];
+    f4w wq = {0.f, 0.f, 0.f, 0.f};
+    bool anyu = false;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int pt = 4 * pg + i;
-        double d2[MIA_MAX_RADII] = {0.0, 0.0, 0.0};
-        for (int c = 0; c < nc; ++c) {
-          const double dx = ox[c] - gxs[pt * MIA_MAX_COORD + c];
-          d2[q.group[c]] += dx * dx;
-        }
-        double wgt = 1.0;
-        for (int r = 0; r < q.n_r; ++r) wgt *= taper_d2(q.taper, d2[r], q.inv_c[r], q.cc[r]);
-        const bool use = have && pt < npts && wgt > q.eps;
-        wq[i] = use ? (float)(wgt * rsqrt_f64(wgt)) : 0.0f;
-        anyu = anyu || use;
-        const unsigned long long bal = __ballot(use);
-        cnt4[i] += __popc((unsigned)(bal >> (16 * pg)) & 0xffffu);
+    for (int i = 0; i < 4; ++i) {
+      const int pt = 4 * pg + i;
+      double d2[MIA_MAX_RADII] = {0.0, 0.0, 0.0};
+      for (int c = 0; c < nc; ++c) {
+        const double dx = ox[c] - gxs[pt * MIA_MAX_COORD + c];
+        d2[q.group[c]] += dx * dx;
       }
-      // a candidate is a member of the union when any of its four lanes (one per point group) uses it
-      const unsigned long long anyb = __ballot(anyu);
-      const unsigned memb = (unsigned)((anyb | (anyb >> 16) | (anyb >> 32) | (anyb >> 48)) & 0xffffull);
-      const bool member = (memb >> cl) & 1u;
-      const int u = ubase + __popc(memb & ((1u << cl) - 1u));
-      if (member && u < kTlUmax) {
-        if (pg == 0) ukey[u] = oj;
-        *reinterpret_cast<f4w*>(Wt + u * 16 + 4 * pg) = wq;
+      double wgt = 1.0;
+      for (int r = 0; r < q.n_r; ++r) wgt *= taper_d2(q.taper, d2[r], q.inv_c[r], q.cc[r]);
+      const bool use = have && pt < npts && wgt > q.eps;
+      wq[i] = use ? (float)(wgt * rsqrt_f64(wgt)) : 0.0f;
+      anyu = anyu || use;
+      const unsigned long long bal = __ballot(use);
+      cnt4[i] += __popc((unsigned)(bal >> (16 * pg)) & 0xffffu);
+    }
+    // a candidate is a member of the union when any of its four lanes (one per point group) uses it
+    const unsigned long long anyb = __ballot(anyu);
+    const unsigned memb = (unsigned)((anyb | (anyb >> 16) | (anyb >> 32) | (anyb >> 48)) & 0xffffull);
+    const bool member = (memb >> cl) & 1u;
+    const int u = ubase + __popc(memb & ((1u << cl) - 1u));
+    if (member && u < kTlUmax) {
+      if (pg == 0) ukey[u] = oj;
+      *reinterpret_cast<f4w*>(Wt + u * 16 + 4 * pg) = wq;
+    }
+    ubase += __popc(memb);
+  };
+  if constexpr (BUCKET) {
+    const int cap = hd->bucket_cap;
+    const int nlast = empty ? 0 : hi[last] - lo[last] + 1;
+    const long long ncb = nrows * nlast;                     // cells of the box
+    overflow = overflow || ncb > 64;
+    int mycid = 0, mycnt = 0;
+    if (!overflow && lane < (int)ncb) {
+      const int row = lane / nlast, cc = lane - row * nlast;
+      int base_cell = 0;
+      if (nc == 2) base_cell = (lo[0] + row) * hd->n[1];
+      else if (nc == 3) base_cell = ((lo[0] + row / n1) * hd->n[1] + (lo[1] + row % n1)) * hd->n[2];
+      mycid = base_cell + lo[last] + cc;
+      mycnt = q.start[mycid];
+      mycnt = mycnt > cap ? cap : mycnt;
+    }
+    int incl = mycnt;                                        // inclusive prefix over the box's cells (lane = cell)
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+    const int total = overflow ? 0 : __builtin_amdgcn_readfirstlane(__shfl(incl, 63, 64));
+    int* pref = uinv;                                        // (scratch until the ranks are formed: [<= 64] exclusive prefix | cell id)
+    pref[lane] = incl - mycnt;
+    MIA_TL_SYNC();
+    const int ncbi = (int)(ncb > 64 ? 64 : ncb);
+    for (int q0 = 0; q0 < total; q0 += 16) {
+      const int qi = q0 + cl;
+      const bool have = qi < total;
+      const int qc = have ? qi : total - 1;
+      int sel = 0;                                           // the cell of candidate qc: last cell whose prefix is <= qc
+      for (int i = 1; i < ncbi; ++i) sel += pref[i] <= qc ? 1 : 0;
+      const int cid = __shfl(mycid, sel, 64), pf = pref[sel];
+      weigh(have, (int64_t)cid * cap + (qc - pf));
+    }
+    MIA_TL_SYNC();
+    for (int s_ = lane; s_ < kTlUmax; s_ += 64) uinv[s_] = -1;
+  } else {
+    for (int row = 0; row < (overflow ? 0 : (int)nrows); ++row) {
+      int base_cell = 0;
+      if (nc == 2) base_cell = (lo[0] + row) * hd->n[1];
+      else if (nc == 3) base_cell = ((lo[0] + row / n1) * hd->n[1] + (lo[1] + row % n1)) * hd->n[2];
+      const int beg = __builtin_amdgcn_readfirstlane(q.start[base_cell + lo[last]]);
+      const int end = __builtin_amdgcn_readfirstlane(q.start[base_cell + hi[last] + 1]);
+      for (int pos0 = beg; pos0 < end; pos0 += 16) {
+        const bool have = pos0 + cl < end;
+        weigh(have, have ? pos0 + cl : end - 1);
       }
-      ubase += __popc(memb);
+    }
+  }
+  if constexpr (BUCKET) {
+    // every read of the index by this workgroup is done: the last workgroup to say so zeroes the per-cell counts and the error
+    // word (after folding it into the step's error bits) -- what the next build on this workspace expects to find
+    IndexHeader* hw = const_cast<IndexHeader*>(hd);
+    unsigned last_wg = 0;
+    if (lane == 0) last_wg = __hip_atomic_fetch_add(&hw->done_tiles, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.nb_main - 1 ? 1u : 0u;
+    if (__builtin_amdgcn_readfirstlane(last_wg)) {
+      int* counts = const_cast<int*>(q.start);
+      for (int i = lane; i < hd->ncell; i += 64) counts[i] = 0;
+      if (lane == 0) {
+        const unsigned e = __hip_atomic_load(&hw->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e) atomicOr(&p.stats[3], (int)(e << 3));
+        __hip_atomic_store(&hw->err, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&hw->done_tiles, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
   const int U = ubase;
@@ -262,7 +323,7 @@ static size_t tile_loc_lds() {
 
 int tile_lists_launch(const double* grid_xyz, int64_t g0, int64_t ng, int64_t P, int n_coord, const int32_t* coord_group,
                       const double* gc_c, int n_r, double gc_eps, int taper, int ut, void* tile_lists, int32_t* stats,
-                      void* index_ws, hipStream_t stream, const SplitPackJob* pack) {
+                      void* index_ws, hipStream_t stream, const SplitPackJob* pack, bool bucket) {
   if (ng < 0 || P < 0 || ut < 1 || ut > 6) return MIA_ERR_SIZE;
   if (!tile_lists || !stats) return MIA_ERR_NULL;
   const TileListLayout L = tile_list_layout(ng, ut);
@@ -291,11 +352,12 @@ int tile_lists_launch(const double* grid_xyz, int64_t g0, int64_t ng, int64_t P,
     return MIA_OK;
   }
   if (!grid_xyz || !index_ws) return MIA_ERR_NULL;
-  int rc = make_scan_params(&tp.scan, grid_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, index_ws, taper);
+  int rc = make_scan_params(&tp.scan, grid_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, index_ws, taper, bucket);
   if (rc != MIA_OK) return rc;
   tp.nb_main = (unsigned)L.ntile;
-  if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)localize_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  localize_tiles_kernel<<<dim3((unsigned)(L.ntile + nb_pack)), dim3(64), lds, stream>>>(tp);
+  auto kern = bucket ? localize_tiles_kernel<true> : localize_tiles_kernel<false>;
+  if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  kern<<<dim3((unsigned)(L.ntile + nb_pack)), dim3(64), lds, stream>>>(tp);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
@@ -344,5 +406,5 @@ extern "C" int mia_letkf_localize_tiles_f64(int taper, const double* grid_xyz, i
     if (rc != MIA_OK) return rc;
   }
   return tile_lists_launch(grid_xyz, g0, g1 - g0, P, n_coord, coord_group, gc_c, n_r, gc_eps, taper, ut, tile_lists, stats, ws,
-                           stream, nullptr);
+                           stream, nullptr, false);
 }

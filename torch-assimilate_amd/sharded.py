@@ -203,6 +203,8 @@ class ShardedLetkf:
         # object once a step reports tiles whose union does not fit their slots (scattered grids) -- per-point lists then
         self._no_tile_lists = False
         self._tile_extra = 0          # row blocks of sixteen slots added to the tiles' unions (MIA_STEP_TILE_EXTRA)
+        self._fresh_box_once = False  # the next step recomputes the observations' bounding box (MIA_STEP_FRESH_BOX)
+        self._scan_index = False      # scan-based observation index from now on (a cell overflowed its bucket: MIA_STEP_SCAN_INDEX)
 
     @property
     def engine(self):
@@ -511,7 +513,9 @@ class ShardedLetkf:
                  slot["ws"].numel(), comp.cuda_stream, side, prep.cuda_stream if prep is not None else None,
                  # MIA_STEP_NO_JOIN for steps in flight; MIA_STEP_WS_CLEAN: this slot's workspace was last used by a step that
                  # ran to completion (its index kernels leave the header zeroed)
-                 (1 if pipelined else 0) | (4 if slot.get("ws_clean") else 0) | (8 if self._no_tile_lists else 0) | (self._tile_extra << 4)]
+                 (1 if pipelined else 0) | (4 if slot.get("ws_clean") else 0) | (8 if self._no_tile_lists else 0) | (self._tile_extra << 4) |
+                 (0x400 if self._fresh_box_once else 0) | (0x800 if self._scan_index else 0)]
+        self._fresh_box_once = False
         slot["ws_clean"] = False            # (until this step has been collected without an error)
         step_fn = lib.mia_letkf_sharded_step_streams_f32
 
@@ -585,9 +589,19 @@ class ShardedLetkf:
             cnt[4:8] = cnt[0:4]                                # no exchange route: the rank's own counters
         p_seen, n_over, n_retry = cnt[4], cnt[5], cnt[6]
         redo = None
-        if cnt[7] & 2:
+        if cnt[7] & 24:
+            # bucket index of the tile route: an observation outside the bounding box this slot's workspace held (or other
+            # radii) -> this step again with a fresh box; a cell with more observations than a bucket holds -> the scan-based
+            # index from now on.  Identical on every rank (the error bits are OR-ed over the ranks).
+            if cnt[7] & 16:
+                self._scan_index = True
+            else:
+                self._fresh_box_once = True
+            slot["ws_clean"] = False                           # (this slot's box is stale: its next step rebuilds it)
+            redo = "same"
+        elif cnt[7] & 2:
             raise _cabi.MiaError("direct exchange: a peer did not deliver within the waiter's bound (error bits %d)" % cnt[7])
-        if cnt[7]:
+        elif cnt[7]:
             # a segment waiter gave up (the analysis launch and the exchange stream must be able to run
             # concurrently: e.g. more HIP streams than hardware queues): all ranks switch to one launch + one
             # event per piece and repeat the step
