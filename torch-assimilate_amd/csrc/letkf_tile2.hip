@@ -48,6 +48,10 @@ struct Tile2Params {
   // pieces (step driver with an exchange in several pieces): the ng points are seg_len-sized pieces (a multiple of 16: tiles
   // never straddle one), piece s writes its own (m k, seg_len) buffer at Xa + s * seg_stride.  0: one result array
   int seg_len; int64_t seg_stride;
+  // housekeeping for the step driver's bucket index (null: none): the launch's first workgroups zero the per-cell counts
+  // clr_counts[0 .. *clr_n) -- their only readers, the tile-list kernel, ran before this launch -- and workgroup 0 folds the build's
+  // error word into *err_out (bits 8, 16) and clears it
+  int* clr_counts; const int* clr_n; unsigned* clr_err; int32_t* err_out;
 };
 
 __device__ __forceinline__ float t2_add_h(float v) {       // sum over the four lanes (lr, h = 0..3), in every one of them
@@ -131,6 +135,14 @@ void letkf_tile2_kernel(Tile2Params P) {
   const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
   const int64_t ntile = (P.ng + 15) >> 4;
   if (bid >= ntile) return;
+  if (P.clr_counts) {
+    const int ncl = *P.clr_n;
+    for (int64_t i = bid * 64 + lane; i < ncl; i += ntile * 64) P.clr_counts[i] = 0;
+    if (bid == 0 && lane == 0) {
+      const unsigned e = *P.clr_err;
+      if (e) { atomicOr(P.err_out, (int)(e << 3)); *P.clr_err = 0u; }
+    }
+  }
   const int64_t q8 = ntile >> 3, r8 = ntile & 7, xcd = bid & 7;
   const int64_t tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int64_t p0 = tile << 4;
@@ -148,7 +160,47 @@ void letkf_tile2_kernel(Tile2Params P) {
   T2_STAMP(0);
   T2_STAMP_HWID();
   T2_STAMP_REAL(10);
+  // ---- first round trip: everything that does not depend on the slot table is requested together with it -- header, slot
+  //      table (first: the only thing the second round trip waits for), sqrt(rho) matrix, the state row
   const int4 hd = P.thdr[tile];
+  int myidx[(UMAX + 63) / 64];
+#pragma unroll
+  for (int r = 0; r < (UMAX + 63) / 64; ++r) {
+    const int s = lane + 64 * r;
+    myidx[r] = s < UMAX ? t2_ld<int32_t>(P.tidx + tile * UMAX, (unsigned)s * 4u) : -1;
+  }
+  f4w dreg[UT];
+#pragma unroll
+  for (int t = 0; t < UT; ++t) dreg[t] = t2_ld<f4w>(P.tD + (tile * UT + t) * 64, (unsigned)lane * 16u);
+  // member (b, i) of lane group h = 8 sigma(b, h) + i, sigma = 4 b + 2 (h & 1) + (h >> 1): column lr of the state row
+  const int sg = 2 * (h & 1) + (h >> 1);
+  auto load_xs = [&](int mi, float (&xr)[NB][8]) {
+    const float* xbase = P.X + (int64_t)mi * k * P.ldx + P.g0 + p0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int m0 = 8 * (4 * b + sg);
+      if (b < NB - 1 || (k & 7) == 0) {
+        const unsigned vo = (unsigned)(m0 < k ? m0 : 0) * ldxb + (unsigned)lrc * 4u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xr[b][i] = t2_ld<float>(xbase, vo + (unsigned)i * ldxb);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int mem = m0 + i;
+          xr[b][i] = t2_ld<float>(xbase, (unsigned)(mem < k ? mem : k - 1) * ldxb + (unsigned)lrc * 4u);
+        }
+      }
+    }
+  };
+  float xsb[NB][8];
+  load_xs(0, xsb);
+#pragma unroll
+  for (int r = 0; r < (UMAX + 63) / 64; ++r) {
+    const int s = lane + 64 * r;
+    if (s < UMAX) ukey[s] = myidx[r];
+  }
+  for (int i = lane; i < 32; i += 64) reinterpret_cast<f4w*>(zline)[i] = f4w{0.f, 0.f, 0.f, 0.f};
+  MIA_T2_SYNC();
   const int U = __builtin_amdgcn_readfirstlane(hd.x);
   if (U < 0) {                     // the union of this tile did not fit its slots: loud failure, never a truncated analysis
     if (colok && h == 0) P.flags[p0 + lr] = MIA_FLAG_OVERFLOW;
@@ -157,35 +209,9 @@ void letkf_tile2_kernel(Tile2Params P) {
       for (int it = h; it < P.m * k; it += 4) P.Xa[(int64_t)it * P.ldo + oc0 + lr] = nanv;
     return;
   }
-  // ---- slot table and the records' tails; the sqrt(rho) matrix
-  int myidx[(UMAX + 63) / 64];
-#pragma unroll
-  for (int r = 0; r < (UMAX + 63) / 64; ++r) {
-    const int s = lane + 64 * r;
-    int v = -1;
-    if (s < UMAX) v = t2_ld<int32_t>(P.tidx + tile * UMAX, (unsigned)s * 4u);
-    myidx[r] = v < 0 ? -1 : v;
-    if (s < UMAX) ukey[s] = v;
-  }
-  f4w dreg[UT];
-#pragma unroll
-  for (int t = 0; t < UT; ++t) dreg[t] = t2_ld<f4w>(P.tD + (tile * UT + t) * 64, (unsigned)lane * 16u);
-  bool badrec = false;
-#pragma unroll
-  for (int r = 0; r < (UMAX + 63) / 64; ++r) {
-    const int s = lane + 64 * r;
-    if (s < UMAX) {
-      const int64_t j = myidx[r] < 0 ? P.zero_rec : (int64_t)myidx[r];
-      const f2w tl = *reinterpret_cast<const f2w*>(P.rec + j * P.rb + 32 * nc8);
-      wdl[s] = tl[0];
-      El[s] = tl[1];
-      badrec = badrec || !(tl[1] == tl[1]);
-    }
-  }
-  for (int i = lane; i < 32; i += 64) reinterpret_cast<f4w*>(zline)[i] = f4w{0.f, 0.f, 0.f, 0.f};
-  MIA_T2_SYNC();
-  T2_STAMP(1);        // header, slot table, tails have arrived
-  // ---- the union's records, straight into the LDS image: load u, lane l = piece line 4 u + (l >> 4), column l & 15
+  T2_STAMP(1);        // header and slot table have arrived
+  // ---- second round trip: the union's records, straight into the LDS image (load u, lane l = piece line 4 u + (l >> 4), column
+  //      l & 15), and their tails (innovation, scale) -- consumed only after the Gram product
   {
     const int g = lane >> 4, hl = g & 1;
     int tc = g >> 1;                                     // (row block, chunk) index of this lane's piece line, load 0
@@ -209,49 +235,13 @@ void letkf_tile2_kernel(Tile2Params P) {
       tc += 2;
     }
   }
-  // Tiles with a non-finite record: through the shared Gram matrix it would reach all 16 columns (NaN * 0 = NaN), also the
-  // points that do not see that observation.  Every point of such a tile is handed to the eigensolver kernel (MIA_FLAG_RETRY),
-  // which works point by point and leaves the damage where the reference has it.
-  const bool tilebad = __any(badrec);
-  if (tilebad) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the LDS-DMA of this wave must have landed before the wave ends)
-    if (colok && h == 0) { P.flags[p0 + lr] = MIA_FLAG_RETRY; atomicAdd(P.retry_count, 1); }
-    return;
+  f2w tails[(UMAX + 63) / 64];
+#pragma unroll
+  for (int r = 0; r < (UMAX + 63) / 64; ++r) {
+    const int64_t j = myidx[r] < 0 ? P.zero_rec : (int64_t)myidx[r];
+    tails[r] = *reinterpret_cast<const f2w*>(P.rec + j * P.rb + 32 * nc8);
   }
-
-  // member (b, i) of lane group h = 8 sigma(b, h) + i, sigma = 4 b + 2 (h & 1) + (h >> 1): column lr of the state row
-  const int sg = 2 * (h & 1) + (h >> 1);
-  auto load_xs = [&](int mi, float (&xr)[NB][8]) {
-    const float* xbase = P.X + (int64_t)mi * k * P.ldx + P.g0 + p0;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int m0 = 8 * (4 * b + sg);
-      if (b < NB - 1 || (k & 7) == 0) {
-        const unsigned vo = (unsigned)(m0 < k ? m0 : 0) * ldxb + (unsigned)lrc * 4u;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) xr[b][i] = t2_ld<float>(xbase, vo + (unsigned)i * ldxb);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int mem = m0 + i;
-          xr[b][i] = t2_ld<float>(xbase, (unsigned)(mem < k ? mem : k - 1) * ldxb + (unsigned)lrc * 4u);
-        }
-      }
-    }
-  };
-  float xsb[NB][8];
-  load_xs(0, xsb);
-
-  // D_hat = D E: the records' own scales enter through the sqrt(rho) matrix
-#pragma unroll
-  for (int t = 0; t < UT; ++t) {
-    const f4w e4 = *reinterpret_cast<const f4w*>(El + 16 * t + 4 * h);
-    dreg[t] *= e4;
-  }
-  T2_STAMP(2);        // gather and x requested
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // records in LDS (and x, D in registers)
-  __builtin_amdgcn_wave_barrier();
-  T2_STAMP(3);        // ... and landed
+  T2_STAMP(2);        // gather requested
 
   // byte offset of this lane's A / B fragment of row block t, member block b: row 16 t + lr, chunk sigma(b, h)
   auto frag_off = [&](int t, int b) -> unsigned {
@@ -264,12 +254,8 @@ void letkf_tile2_kernel(Tile2Params P) {
   float alpha = 0.0f;
   int deg = 0, tab_idx = 0, degmax = 0, pflag = 0;
   bool decl = false;
-  for (int mi = 0; mi < (MROWS ? P.m : 1); ++mi) {
-    if (mi > 0) load_xs(mi, xsb);
-    // ---- x' = x - mean as scaled half pairs (one power of two per column)
-    float xm, inv_sx;
-    h8v xh[NB], xl[NB];
-    {
+  // ---- x' = x - mean as scaled half pairs (one power of two per column)
+  auto split_x = [&](float (&xsb)[NB][8], float& xm, float& inv_sx, h8v (&xh)[NB], h8v (&xl)[NB]) {
       float xs = 0.0f;
 #pragma unroll
       for (int b = 0; b < NB; ++b)
@@ -301,110 +287,136 @@ void letkf_tile2_kernel(Tile2Params P) {
         for (int i = 0; i < 8; ++i) t8[i] = xsb[b][i] * sx;
         split8(t8, xh[b], xl[b]);
       }
+    };
+  // ---- first state row: Gram matrix, interval and degree of every point (shared by all rows), its own Z
+  float xm0, inv_sx0;
+  f4w Z0[UT];
+  {
+    h8v xh[NB], xl[NB];
+    split_x(xsb, xm0, inv_sx0, xh, xl);
+#pragma unroll
+    for (int t = 0; t < UT; ++t) Z0[t] = f4w{0.f, 0.f, 0.f, 0.f};
+    f4w (&Z)[UT] = Z0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // records in LDS (x, D, tails in registers)
+    __builtin_amdgcn_wave_barrier();
+    T2_STAMP(3);        // ... and landed
+    f4w G[UT][UT];          // G[t1][t2][q] = Gram[16 t1 + 4 h + q][16 t2 + lr]
+#pragma unroll
+    for (int t1 = 0; t1 < UT; ++t1)
+#pragma unroll
+      for (int t2 = 0; t2 < UT; ++t2) G[t1][t2] = f4w{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      h8v ah[UT], al[UT];
+#pragma unroll
+      for (int t = 0; t < UT; ++t) {
+        const unsigned o = frag_off(t, b);
+        ah[t] = *reinterpret_cast<const h8v*>(smem + o);
+        al[t] = *reinterpret_cast<const h8v*>(smem + o + 256);
+      }
+#pragma unroll
+      for (int t2 = 0; t2 < UT; ++t2)
+#pragma unroll
+        for (int t1 = 0; t1 < UT; ++t1) G[t1][t2] = t2_mfma3(G[t1][t2], ah[t1], al[t1], ah[t2], al[t2]);
+#pragma unroll
+      for (int t = 0; t < UT; ++t) Z[t] = t2_mfma3(Z[t], ah[t], al[t], xh[b], xl[b]);
     }
-    // ---- G = Yw Yw^T (first row only) and Z = Yw X'
-    f4w Z[UT];
+    T2_STAMP(4);    // x' split, Gram + Z issued
+    // the records' tails: innovation (in the record's scale) and scale per slot.  A tile with a non-finite record: through
+    // the shared Gram matrix it would reach all 16 columns (NaN * 0 = NaN), also the points that do not see that observation --
+    // every point of such a tile is handed to the eigensolver kernel (MIA_FLAG_RETRY), which works point by point and leaves
+    // the damage where the reference has it.
+    {
+      bool badrec = false;
 #pragma unroll
-    for (int t = 0; t < UT; ++t) Z[t] = f4w{0.f, 0.f, 0.f, 0.f};
-    if (mi == 0) {
-      f4w G[UT][UT];          // G[t1][t2][q] = Gram[16 t1 + 4 h + q][16 t2 + lr]
-#pragma unroll
-      for (int t1 = 0; t1 < UT; ++t1)
-#pragma unroll
-        for (int t2 = 0; t2 < UT; ++t2) G[t1][t2] = f4w{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        h8v ah[UT], al[UT];
-#pragma unroll
-        for (int t = 0; t < UT; ++t) {
-          const unsigned o = frag_off(t, b);
-          ah[t] = *reinterpret_cast<const h8v*>(smem + o);
-          al[t] = *reinterpret_cast<const h8v*>(smem + o + 256);
+      for (int r = 0; r < (UMAX + 63) / 64; ++r) {
+        const int s = lane + 64 * r;
+        if (s < UMAX) {
+          wdl[s] = tails[r][0];
+          El[s] = tails[r][1];
+          badrec = badrec || !(tails[r][1] == tails[r][1]);
         }
-#pragma unroll
-        for (int t2 = 0; t2 < UT; ++t2)
-#pragma unroll
-          for (int t1 = 0; t1 < UT; ++t1) G[t1][t2] = t2_mfma3(G[t1][t2], ah[t1], al[t1], ah[t2], al[t2]);
-#pragma unroll
-        for (int t = 0; t < UT; ++t) Z[t] = t2_mfma3(Z[t], ah[t], al[t], xh[b], xl[b]);
       }
-      T2_STAMP(4);    // x' split, Gram + Z issued
-      // A fragments of G for the 32-deep products: lane group h supplies slots 16 (2 kb + tt) + 4 h + q, i.e. the values
-      // this lane holds of the tiles (2 kb, t) and (2 kb + 1, t) -- no data moves
-#pragma unroll
-      for (int t = 0; t < UT; ++t)
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-          float gv[8];
-#pragma unroll
-          for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) gv[4 * tt + q] = 2 * kb + tt < UT ? G[2 * kb + tt < UT ? 2 * kb + tt : 0][t][q] * 0x1p-16f : 0.0f;
-          split8(gv, GAh[t][kb], GAl[t][kb]);
-        }
-      // ---- Gershgorin bound of every point: L_g = max_a w_a sum_b |G_ab| w_b (hi halves only: a bound, margin below),
-      //      then degree / interval from the table.  D_hat spans the records' scales: one power of two for the wave
-      f4w R[UT];
-#pragma unroll
-      for (int t = 0; t < UT; ++t) R[t] = f4w{0.f, 0.f, 0.f, 0.f};
-      unsigned dmx = 0u;
-#pragma unroll
-      for (int t = 0; t < UT; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const unsigned a = __float_as_uint(dreg[t][q]); dmx = a > dmx ? a : dmx; }
-      dmx = t2_wave_max_u32(dmx);
-      int esd;
-      const float sd = pow2_scale(dmx, 0, &esd);
-      const float inv_sd = __uint_as_float((unsigned)(127 - esd) << 23);
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-        if (32 * kb < U) {
-          float dv[8];
-#pragma unroll
-          for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dv[4 * tt + q] = 2 * kb + tt < UT ? dreg[2 * kb + tt < UT ? 2 * kb + tt : 0][q] * sd : 0.0f;
-          const h8v dh = hi8(dv);
-#pragma unroll
-          for (int t = 0; t < UT; ++t) {
-            u4w ag = __builtin_bit_cast(u4w, GAh[t][kb]);
-            ag &= 0x7fff7fffu;
-            R[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, ag), dh, R[t], 0, 0, 0);
-          }
-        }
-      float L = 0.0f;
-#pragma unroll
-      for (int t = 0; t < UT; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float v = dreg[t][q] * R[t][q];
-          L = (v > L || v != v) ? v : L;
-        }
-      L = __uint_as_float(t2_max_h(__float_as_uint(L))) * inv_sd;
-      L = fmaxf(L, 1e-37f) * 1.002f;       // (in units of 2^-16; half-precision operands: 2 x 2^-11)
-      if (!(L == L) || !(fabsf(L) < 1e30f)) { pflag |= MIA_FLAG_NONFINITE; L = 1.0f; }
-      tab_idx = (int)ceilf(float(kTabPerOctave) * (__builtin_amdgcn_logf(L * P.inv_reg) + 16.0f)) + kTabIdx0;
-      tab_idx = tab_idx < 0 ? 0 : (tab_idx > kTabN - 1 ? kTabN - 1 : tab_idx);
-      const int2 th = t2_ld<int2>(P.tab_hdr, (unsigned)tab_idx * 8u);
-      deg = th.x;
-      alpha = __builtin_ldexpf(__int_as_float(th.y) * P.inv_reg, 16);
-      decl = colok && (deg > P.dmax || deg > kTabDeg - 1);
-      if (decl && h == 0) {
-        P.flags[p0 + lr] = MIA_FLAG_RETRY;
-        atomicAdd(P.retry_count, 1);
+      if (__any(badrec)) {
+        if (colok && h == 0) { P.flags[p0 + lr] = MIA_FLAG_RETRY; atomicAdd(P.retry_count, 1); }
+        return;
       }
-      degmax = (int)wave_max_nonneg_dpp((colok && !decl) ? float(deg) : 0.0f);
-    } else {
+      MIA_T2_SYNC();
+      // D_hat = D E: the records' own scales enter through the sqrt(rho) matrix
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-#pragma unroll
-        for (int t = 0; t < UT; ++t) {
-          const unsigned o = frag_off(t, b);
-          const h8v ah = *reinterpret_cast<const h8v*>(smem + o), al = *reinterpret_cast<const h8v*>(smem + o + 256);
-          Z[t] = t2_mfma3(Z[t], ah, al, xh[b], xl[b]);
-        }
+      for (int t = 0; t < UT; ++t) {
+        const f4w e4 = *reinterpret_cast<const f4w*>(El + 16 * t + 4 * h);
+        dreg[t] *= e4;
       }
     }
+    // A fragments of G for the 32-deep products: lane group h supplies slots 16 (2 kb + tt) + 4 h + q, i.e. the values
+    // this lane holds of the tiles (2 kb, t) and (2 kb + 1, t) -- no data moves
+#pragma unroll
+    for (int t = 0; t < UT; ++t)
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        float gv[8];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gv[4 * tt + q] = 2 * kb + tt < UT ? G[2 * kb + tt < UT ? 2 * kb + tt : 0][t][q] * 0x1p-16f : 0.0f;
+        split8(gv, GAh[t][kb], GAl[t][kb]);
+      }
+    // ---- Gershgorin bound of every point: L_g = max_a w_a sum_b |G_ab| w_b (hi halves only: a bound, margin below),
+    //      then degree / interval from the table.  D_hat spans the records' scales: one power of two for the wave
+    f4w R[UT];
+#pragma unroll
+    for (int t = 0; t < UT; ++t) R[t] = f4w{0.f, 0.f, 0.f, 0.f};
+    unsigned dmx = 0u;
+#pragma unroll
+    for (int t = 0; t < UT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const unsigned a = __float_as_uint(dreg[t][q]); dmx = a > dmx ? a : dmx; }
+    dmx = t2_wave_max_u32(dmx);
+    int esd;
+    const float sd = pow2_scale(dmx, 0, &esd);
+    const float inv_sd = __uint_as_float((unsigned)(127 - esd) << 23);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+      if (32 * kb < U) {
+        float dv[8];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dv[4 * tt + q] = 2 * kb + tt < UT ? dreg[2 * kb + tt < UT ? 2 * kb + tt : 0][q] * sd : 0.0f;
+        const h8v dh = hi8(dv);
+#pragma unroll
+        for (int t = 0; t < UT; ++t) {
+          u4w ag = __builtin_bit_cast(u4w, GAh[t][kb]);
+          ag &= 0x7fff7fffu;
+          R[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, ag), dh, R[t], 0, 0, 0);
+        }
+      }
+    float L = 0.0f;
+#pragma unroll
+    for (int t = 0; t < UT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float v = dreg[t][q] * R[t][q];
+        L = (v > L || v != v) ? v : L;
+      }
+    L = __uint_as_float(t2_max_h(__float_as_uint(L))) * inv_sd;
+    L = fmaxf(L, 1e-37f) * 1.002f;       // (in units of 2^-16; half-precision operands: 2 x 2^-11)
+    if (!(L == L) || !(fabsf(L) < 1e30f)) { pflag |= MIA_FLAG_NONFINITE; L = 1.0f; }
+    tab_idx = (int)ceilf(float(kTabPerOctave) * (__builtin_amdgcn_logf(L * P.inv_reg) + 16.0f)) + kTabIdx0;
+    tab_idx = tab_idx < 0 ? 0 : (tab_idx > kTabN - 1 ? kTabN - 1 : tab_idx);
+    const int2 th = t2_ld<int2>(P.tab_hdr, (unsigned)tab_idx * 8u);
+    deg = th.x;
+    alpha = __builtin_ldexpf(__int_as_float(th.y) * P.inv_reg, 16);
+    decl = colok && (deg > P.dmax || deg > kTabDeg - 1);
+    if (decl && h == 0) {
+      P.flags[p0 + lr] = MIA_FLAG_RETRY;
+      atomicAdd(P.retry_count, 1);
+    }
+    degmax = (int)wave_max_nonneg_dpp((colok && !decl) ? float(deg) : 0.0f);
+  }
+  // ---- per state row: recurrence, x' w_mean, output product, stores
+  auto row_tail = [&](const int mi, f4w (&Z)[UT], const float xm, const float inv_sx) {
     // ---- the recurrence on the 16 columns at once, on u = D^2 o v (the vectors ARE the right-hand sides of the products):
     //      u_{j+1} = 2 (alpha D^2 o (G u_j) - u_j) - u_{j-1}, u_0 = D^2 o Z; the two weight functions accumulate c_j u_j.
     //      Vectors are carried times a power of two per column (|u_0| -> 2^8; |u_j| <= sqrt(U) |u_0| stays far inside the
@@ -581,6 +593,28 @@ void letkf_tile2_kernel(Tile2Params P) {
     } else {
       pflag = 0;          // (columns that are not written do not report)
     }
+  };
+  row_tail(0, Z0, xm0, inv_sx0);
+  if constexpr (MROWS) {
+    for (int mi = 1; mi < P.m; ++mi) {
+      load_xs(mi, xsb);
+      float xm, inv_sx;
+      h8v xh[NB], xl[NB];
+      split_x(xsb, xm, inv_sx, xh, xl);
+      f4w Z[UT];
+#pragma unroll
+      for (int t = 0; t < UT; ++t) Z[t] = f4w{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int t = 0; t < UT; ++t) {
+          const unsigned o = frag_off(t, b);
+          const h8v ah = *reinterpret_cast<const h8v*>(smem + o), al = *reinterpret_cast<const h8v*>(smem + o + 256);
+          Z[t] = t2_mfma3(Z[t], ah, al, xh[b], xl[b]);
+        }
+      }
+      row_tail(mi, Z, xm, inv_sx);
+    }
   }
   T2_STAMP(7);        // output products and stores issued
   {
@@ -673,7 +707,7 @@ bool tile2_covers(int m, int k, int p_max, int extra_blocks, int64_t ldx, int64_
 int tile2_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const void* rec, int64_t P,
                           const void* tile_lists, int ut, float inf_factor, float* Xa, int64_t ldo, int64_t o0,
                           int32_t* flags, int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c,
-                          hipStream_t stream, int seg_len, int64_t seg_stride) {
+                          hipStream_t stream, int seg_len, int64_t seg_stride, const Tile2Housekeeping* hk) {
   if (seg_len < 0 || (seg_len & 15) || (seg_len > 0 && ng >= ((int64_t)1 << 31))) return MIA_ERR_UNSUPPORTED;
   if (!flags || !retry_count || !tab_hdr || !tab_c || !tile_lists || !rec) return MIA_ERR_UNSUPPORTED;
   const int kt = (k + 15) >> 4;
@@ -693,6 +727,8 @@ int tile2_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0,
   tp.Xa = Xa; tp.ldo = ldo; tp.o0 = o0; tp.flags = flags; tp.retry_count = retry_count; tp.dmax = dmax;
   tp.tab_hdr = tab_hdr; tp.tab_c = tab_c;
   tp.seg_len = seg_len; tp.seg_stride = seg_stride;
+  tp.clr_counts = hk ? hk->counts : nullptr; tp.clr_n = hk ? hk->n : nullptr; tp.clr_err = hk ? hk->err : nullptr;
+  tp.err_out = hk ? hk->err_out : nullptr;
 #ifdef MIA_TILE2_SINGLE        // (development builds: one instantiation, for register / ISA inspection)
   if (ut == 2 && kt == 3) return tile2_launch_s<2, 3>(tp, stream);
   return MIA_ERR_UNSUPPORTED;
@@ -727,5 +763,5 @@ extern "C" int mia_letkf_analysis_tiles_f32(const float* X, int64_t ldx, int m, 
   const float2* tc = nullptr;
   if (!cheb_dual_table(stream, &th, &tc)) return MIA_ERR_UNSUPPORTED;
   return tile2_analysis_launch(X, ldx, m, k, g0, g1 - g0, split_rec, P, tile_lists, tile_ut_for(p_max) + extra_blocks, inf_factor, Xa,
-                               ldo, o0, flags, retry_count, option(MIA_OPT_CHEB_DMAX), th, tc, stream, 0, 0);
+                               ldo, o0, flags, retry_count, option(MIA_OPT_CHEB_DMAX), th, tc, stream, 0, 0, nullptr);
 }

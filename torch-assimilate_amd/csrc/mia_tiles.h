@@ -123,10 +123,12 @@ int tile_lists_launch(const double* grid_xyz, int64_t g0, int64_t ng, int64_t P,
                       const double* gc_c, int n_r, double gc_eps, int taper, int ut, void* tile_lists, int32_t* stats,
                       void* index_ws, hipStream_t stream, const SplitPackJob* pack, bool bucket = false);
 // letkf_tile2.hip
+// housekeeping the analysis launch does for the bucket index (see Tile2Params)
+struct Tile2Housekeeping { int* counts; const int* n; unsigned* err; int32_t* err_out; };
 bool tile2_covers(int m, int k, int p_max, int extra_blocks, int64_t ldx, int64_t ldo, int64_t ng);
 int tile2_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const void* rec, int64_t P,
                           const void* tile_lists, int ut, float inf_factor, float* Xa, int64_t ldo, int64_t o0,
                           int32_t* flags, int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c,
-                          hipStream_t stream, int seg_len = 0, int64_t seg_stride = 0);
+                          hipStream_t stream, int seg_len = 0, int64_t seg_stride = 0, const Tile2Housekeeping* hk = nullptr);
 
 }  // namespace mia

@@ -624,6 +624,8 @@ extern "C" int mia_letkf_step_timing_events(void* start_event, void* stop_event)
 // stage 2 = everything from that wait on (analysis, exchange), with *pe_io / *seq_io as stage 1 left them.
 constexpr int kStepPrepDone = 0x100;      // internal step flag: the launch thread has waited for the preparation on the host
 
+static inline char* base_of(void* ws) { return (char*)ws; }
+
 static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, const float* d, int64_t P,
                      const double* grid_xyz, const double* obs_xyz, int n_coord, const int32_t* coord_group,
                      const double* gc_c, int n_r, double gc_eps, float inf_factor, float gamma, int method, int p_max_assumed,
@@ -679,6 +681,12 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
                         mia::option(MIA_OPT_TILE_SPLIT) != 0 && mia::tile2_covers(m, k, pm_tl, (step_flags >> 4) & 7, G, exch ? L.nc : G, blk) &&
                         mia::cheb_dual_table((hipStream_t)(prep_stream ? prep_stream : stream), &tl_th, &tl_tc);
   const bool tl_bucket = tl_route && mia::option(MIA_OPT_BUCKET_INDEX) != 0 && !(step_flags & MIA_STEP_SCAN_INDEX);
+  // (the analysis launch puts the bucket index's per-cell counts and error word back to zero, see Tile2Params)
+  mia::Tile2Housekeeping tl_hk{nullptr, nullptr, nullptr, nullptr};
+  if (tl_bucket) {
+    const mia::IndexLayout IL = mia::index_layout(base_of(ws) + L.loc, P, n_coord);
+    tl_hk = mia::Tile2Housekeeping{IL.cursor, &IL.hdr->ncell, &IL.hdr->err, nullptr};      // (err_out: below, once ctr is known)
+  }
   // a step in flight whose analysis is ONE plain launch (stage 2 after the host-side wait): the launch carries its completion
   // (and timing) events in its own dispatch packet
   const bool carried = kdone_out && phase == 0 && !exch && !peer && n_chunks == 1 && method != 1 && (step_flags & kStepPrepDone) &&
@@ -697,6 +705,7 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
   // exchange route: the redo counters live in the trailer of the last piece and travel with its all-gather
   int32_t* ctr = exch ? (int32_t*)(base + L.bufs + L.chunk_bytes * (n_chunks - 1) + (size_t)rows * L.nc * sizeof(float))
                       : counters;
+  tl_hk.err_out = ctr + 3;
   (void)hipGetLastError();
   if (exch || peer) {
     rc = comm_events(comm);
@@ -768,7 +777,7 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
     if (tl_route && n_chunks > 1 && b1 > b0) {
       rc = mia::tile2_analysis_launch(X, G, m, k, b0, b1 - b0, base + L.hrec, P, base + L.tl, L.ut, inf_factor,
                                       (float*)(base + L.bufs), L.nc, 0, flags, ctr + 2, mia::option(MIA_OPT_CHEB_DMAX), tl_th, tl_tc, s,
-                                      (int)L.nc, (int64_t)(L.chunk_bytes / sizeof(float)));
+                                      (int)L.nc, (int64_t)(L.chunk_bytes / sizeof(float)), tl_bucket ? &tl_hk : nullptr);
       if (rc != MIA_OK) return rc;
       tl_block = true;
     }
@@ -843,7 +852,8 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
           const unsigned long long tiles_before = mia::tile_launch_count();
           if (tl_route)
             rc = mia::tile2_analysis_launch(X, G, m, k, c0, c1 - c0, base + L.hrec, P, base + L.tl, L.ut, inf_factor, dst, ldo, o0,
-                                            cfl, ctr + 2, mia::option(MIA_OPT_CHEB_DMAX), tl_th, tl_tc, (hipStream_t)stream);
+                                            cfl, ctr + 2, mia::option(MIA_OPT_CHEB_DMAX), tl_th, tl_tc, (hipStream_t)stream, 0, 0,
+                                            tl_bucket ? &tl_hk : nullptr);
           else
             rc = mia_letkf_analysis_matfun_f32(X, G, m, k, c0, c1, rec, P, ccnt, cidx, cw, L.cap, p_max_assumed,
                                                inf_factor, gamma, dst, ldo, o0, cfl, ctr + 2, stream);

@@ -120,10 +120,13 @@ struct TileLocParams {
 
 // BUCKET: the observations sit in fixed-capacity buckets per cell (index_bucket_kernel, localize.hip) instead of the scan-based
 // layout: scan.start = per-cell counts, scan.sorted / scan.sxyz = bucket entries, cell c at c * bucket_cap.  The candidates of a
-// tile are then the entries of the cells of its box taken as ONE flat sequence (a prefix sum over the box's <= 64 cells).  The
-// last workgroup to finish zeroes the per-cell counts and folds / clears the build's error bits: the workspace is left as the next
-// build needs to find it, without a clearing launch.
-template <bool BUCKET>
+// tile are then the entries of the cells of its box taken as ONE flat sequence (a prefix sum over the box's <= 64 cells).  (The
+// per-cell counts and the build's error word are put back to zero by the analysis kernel that follows -- letkf_tile2_kernel's
+// first workgroups -- so the workspace is left as the next build needs to find it, without a clearing launch and without a
+// completion counter: 6250 atomics on one address cost 75 us.)
+// NC = number of coordinates, TAPER = MIA_TAPER_*: compile-time, so that the distance loops unroll and the taper is one
+// straight-line polynomial (the generic form spent more scalar instructions on its loops than vector ones on the weights).
+template <bool BUCKET, int NC, int TAPER>
 __global__ __launch_bounds__(64) void localize_tiles_kernel(TileLocParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tl_lds[];
   if (blockIdx.x >= p.nb_main) {
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(64) void localize_tiles_kernel(TileLocParams p) {
   float* Wt = reinterpret_cast<float*>(uinv + kTlUmax);               // [kTlUmax][16] sqrt(rho) of (member, point), 0 = not local
   const ScanParams& q = p.scan;
   const IndexHeader* hd = q.hdr;
-  const int nc = q.nc;
+  constexpr int nc = NC;
   const int64_t tile = blockIdx.x;
   const int64_t p0 = tile << 4;
   const int npts = p.ng - p0 < 16 ? (int)(p.ng - p0) : 16;
@@ -180,22 +183,38 @@ __global__ __launch_bounds__(64) void localize_tiles_kernel(TileLocParams p) {
   int ubase = 0;
   int cnt4[4] = {0, 0, 0, 0};          // local observations of points 4 pg + i so far (the same in every lane of a group)
   // sixteen candidates (one per lane cl, position `pos` of the index arrays, valid where `have`) against the tile's points
+  // (the coordinates of this lane's four points -- point group pg -- and the radius groups, in registers)
+  double gxr[4][NC];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) gxr[i][c] = gxs[(4 * pg + i) * MIA_MAX_COORD + c];
+  int grp[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) grp[c] = NC == 1 ? 0 : q.group[c];
+  const int n_r = NC == 1 ? 1 : q.n_r;
   auto weigh = [&](bool have, int64_t pos) {
     const int oj = q.sorted[pos];
-    double ox[MIA_MAX_COORD] = {0.0, 0.0, 0.0};
-    for (int c = 0; c < nc; ++c) ox[c] = q.sxyz[pos * nc + c];
+    double ox[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) ox[c] = q.sxyz[pos * NC + c];
     f4w wq = {0.f, 0.f, 0.f, 0.f};
     bool anyu = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int pt = 4 * pg + i;
       double d2[MIA_MAX_RADII] = {0.0, 0.0, 0.0};
-      for (int c = 0; c < nc; ++c) {
-        const double dx = ox[c] - gxs[pt * MIA_MAX_COORD + c];
-        d2[q.group[c]] += dx * dx;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const double dx = ox[c] - gxr[i][c];
+#pragma unroll
+        for (int r = 0; r < (NC == 1 ? 1 : MIA_MAX_RADII); ++r)
+          if (grp[c] == r) d2[r] += dx * dx;
       }
       double wgt = 1.0;
-      for (int r = 0; r < q.n_r; ++r) wgt *= taper_d2(q.taper, d2[r], q.inv_c[r], q.cc[r]);
+#pragma unroll
+      for (int r = 0; r < (NC == 1 ? 1 : MIA_MAX_RADII); ++r)
+        if (r < n_r) wgt *= TAPER == MIA_TAPER_GC_INF ? gc_inf_taper_d2(d2[r], q.inv_c[r], q.cc[r]) : gc_taper_d2(d2[r], q.inv_c[r], q.cc[r]);
       const bool use = have && pt < npts && wgt > q.eps;
       wq[i] = use ? (float)(wgt * rsqrt_f64(wgt)) : 0.0f;
       anyu = anyu || use;
@@ -256,23 +275,6 @@ __global__ __launch_bounds__(64) void localize_tiles_kernel(TileLocParams p) {
       for (int pos0 = beg; pos0 < end; pos0 += 16) {
         const bool have = pos0 + cl < end;
         weigh(have, have ? pos0 + cl : end - 1);
-      }
-    }
-  }
-  if constexpr (BUCKET) {
-    // every read of the index by this workgroup is done: the last workgroup to say so zeroes the per-cell counts and the error
-    // word (after folding it into the step's error bits) -- what the next build on this workspace expects to find
-    IndexHeader* hw = const_cast<IndexHeader*>(hd);
-    unsigned last_wg = 0;
-    if (lane == 0) last_wg = __hip_atomic_fetch_add(&hw->done_tiles, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.nb_main - 1 ? 1u : 0u;
-    if (__builtin_amdgcn_readfirstlane(last_wg)) {
-      int* counts = const_cast<int*>(q.start);
-      for (int i = lane; i < hd->ncell; i += 64) counts[i] = 0;
-      if (lane == 0) {
-        const unsigned e = __hip_atomic_load(&hw->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (e) atomicOr(&p.stats[3], (int)(e << 3));
-        __hip_atomic_store(&hw->err, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&hw->done_tiles, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
@@ -355,7 +357,12 @@ int tile_lists_launch(const double* grid_xyz, int64_t g0, int64_t ng, int64_t P,
   int rc = make_scan_params(&tp.scan, grid_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, index_ws, taper, bucket);
   if (rc != MIA_OK) return rc;
   tp.nb_main = (unsigned)L.ntile;
-  auto kern = bucket ? localize_tiles_kernel<true> : localize_tiles_kernel<false>;
+  void (*kern)(TileLocParams) = nullptr;
+#define MIA_TL_PICK(B, T)                                                                                                  \
+  kern = n_coord == 1 ? localize_tiles_kernel<B, 1, T> : (n_coord == 2 ? localize_tiles_kernel<B, 2, T> : localize_tiles_kernel<B, 3, T>)
+  if (bucket) { if (taper == MIA_TAPER_GC_INF) MIA_TL_PICK(true, MIA_TAPER_GC_INF); else MIA_TL_PICK(true, MIA_TAPER_GC); }
+  else { if (taper == MIA_TAPER_GC_INF) MIA_TL_PICK(false, MIA_TAPER_GC_INF); else MIA_TL_PICK(false, MIA_TAPER_GC); }
+#undef MIA_TL_PICK
   if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   kern<<<dim3((unsigned)(L.ntile + nb_pack)), dim3(64), lds, stream>>>(tp);
   MIA_LAUNCH_CHECK();
