@@ -339,8 +339,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-4 / config-5 kernel timings")
     ap.add_argument("--grid-per-gpu", type=int, default=G_PER_GPU)
-    ap.add_argument("--pipeline-depth", type=int, default=int(os.environ.get("MIA_PIPELINE_DEPTH", "6")), choices=[1, 2, 3, 4, 5, 6, 7, 8],
-                    help="steps in flight (ShardedLetkf.submit): d (default 6) = steps i+1 .. i+d-1 are enqueued before step i "
+    ap.add_argument("--pipeline-depth", type=int, default=int(os.environ.get("MIA_PIPELINE_DEPTH", "8")), choices=[1, 2, 3, 4, 5, 6, 7, 8],
+                    help="steps in flight (ShardedLetkf.submit): d (default 8) = steps i+1 .. i+d-1 are enqueued before step i "
                          "is collected; 1 = serial steps")
     ap.add_argument("--method", default="auto", choices=["auto", "eig", "matfun"],
                     help="analysis route: auto = eigensolver-free matfun kernel (default), eig = fused Jacobi")
@@ -388,7 +388,7 @@ def main():
                           comm_chunks=int(os.environ.get("MIA_COMM_CHUNKS", "4" if args.pipeline_depth == 1 else "1")),
                           native_step=os.environ.get("MIA_NATIVE_STEP", "1") != "0",
                           max_in_flight=max(2, args.pipeline_depth),
-                          prep_streams=int(os.environ.get("MIA_PREP_STREAMS", "2")),
+                          prep_streams=int(os.environ.get("MIA_PREP_STREAMS", "3")),
                           # N > 1: direct peer writes into IPC-mapped result buffers when the node allows it (self-tested
                           # at set-up, RCCL all-gather otherwise); the result is consumed from the slot buffer, no copy
                           peer_exchange=os.environ.get("MIA_PEER_EXCHANGE", "auto"), copy_results=False)
@@ -491,6 +491,43 @@ def main():
         r2 = ShardedLetkf(device, rank, world, radii=[GC_RADIUS], inf_factor=INF, method="eig")
         r2._engine = runner.engine
         eig_ms, _ = r2.time_stages(X, grid_x, obs_x, Yb, d, reps=5)
+
+    # ---- N > 1: exchange and compute apart, so that a scaling figure can be read: this rank's exchange alone
+    #      (HIP events on the exchange stream), its compute alone (serial step of its block without exchange = a one-rank
+    #      runner on the block's grid points), the bytes it puts on its xGMI links per step and the time those bytes take at the
+    #      link rate of MI355X_MICROARCH.md / DESIGN.md section 5 (153 GB/s per link taken as bidirectional: ~77 GB/s each way)
+    multi = None
+    if world > 1:
+        try:
+            ex_ms, ex_route, ex_bytes = runner.time_exchange(1, K_ENS, G, reps=10)
+            g0b, g1b = rank * gpg, min(G, (rank + 1) * gpg)
+            solo = ShardedLetkf(device, 0, 1, radii=[GC_RADIUS], inf_factor=INF, method=args.method)
+            solo._engine = runner.engine
+            Xb = X[:, :, g0b:g1b].contiguous()
+            gb = grid_x[g0b:g1b].contiguous()
+            for _ in range(5):
+                solo.assimilate(Xb, gb, obs_x, Yb, d)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                solo.assimilate(Xb, gb, obs_x, Yb, d)
+            torch.cuda.synchronize()
+            comp_ms = 1e3 * (time.perf_counter() - t0) / 50
+            vals = torch.tensor([ex_ms, comp_ms], device=device, dtype=torch.float64)
+            allv = [torch.zeros_like(vals) for _ in range(world)]
+            dist.all_gather(allv, vals)
+            per_link = ex_bytes / max(world - 1, 1)
+            multi = {"exchange_route": runner.exchange_route, "exchange_ms_per_rank": [float(v[0]) for v in allv],
+                     "compute_ms_per_rank_serial_block": [float(v[1]) for v in allv],
+                     "bytes_sent_per_rank_per_step": ex_bytes, "bytes_per_link_per_step": per_link,
+                     "xgmi_budget_ms": {"at_77_GBs_per_direction": 1e3 * per_link / 77e9, "at_153_GBs_per_direction": 1e3 * per_link / 153e9,
+                                        "note": "direct route: every rank writes its block to each of its world - 1 peers over its own link "
+                                                "to that peer, all links at once; the RCCL ring forwards world - 1 blocks over one link pair"},
+                     "note": "exchange alone (no analysis in front of it) and a serial step of this rank's block without any exchange; the "
+                             "pipelined step overlaps step i's exchange with step i+1's compute, so ms_per_step ~ max(exchange, compute "
+                             "pipelined) -- with the exchange the larger one at N = 8 by the budget above (>= 6x is xGMI-bound)"}
+        except Exception as exc:      # (diagnostics only: never let them take the headline down)
+            multi = {"error": repr(exc)}
 
     # ---- one step END TO END from pinned host buffers: H2D of state / obs-space inputs / coordinates,
     #      the step, D2H of the analysis ensemble (never part of `value`)
@@ -639,6 +676,7 @@ def main():
                                  "streams; every step is fully computed, exchanged and validated inside the timed "
                                  "region.  serial_*: the same step run one at a time (what a cycled filter, whose step i+1 "
                                  "depends on step i, gets)"},
+            "multi_gpu": multi,
             "e2e_ms_incl_h2d_d2h": e2e_ms,
             "stages_ms": stage_ms,
             "secondary": secondary,

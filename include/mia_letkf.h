@@ -531,6 +531,9 @@ int mia_comm_set_place_stream(mia_comm_t* comm, void* stream);
 int mia_comm_peer_alloc(mia_comm_t* comm, size_t result_bytes, int n_slots, void* ipc_handles_out);
 int mia_comm_peer_open(mia_comm_t* comm, const void* all_handles);
 int mia_comm_peer_attach(mia_comm_t* comm, int peer, void* const* result_bufs, void* sync_area);
+/* bound of the direct exchange's device-side waits: 2^log2_polls polls of ~1-2 us each (10 .. 30; default 25, about a minute).
+ * A waiter that gives up raises error bit 2 of counters[3] / [7] -- the grid always drains. */
+int mia_comm_peer_wait_bound(mia_comm_t* comm, int log2_polls);
 void* mia_comm_peer_buffer(mia_comm_t* comm, int slot);
 void* mia_comm_peer_sync_area(mia_comm_t* comm);
 int mia_comm_peer_exchange(mia_comm_t* comm, int slot, int rows, int64_t G, int64_t b0, int64_t b1, int32_t* counters,

@@ -32,6 +32,21 @@ def test_kernel_descriptors():
     assert str(mia.LinearKernel()) == "LinearKernel" and repr(mia.RBFKernel()) == "RBFKernel"
 
 
+def test_vector_lengthscale_is_refused_inside_compositions():
+    """rbf.py:75-78 divides both arguments by a per-feature lengthscale.  Only a GaussKernel used on its own in the global KETKF
+    gets that treatment here; inside a composition (or under localisation) the vector must not be dropped silently."""
+    import numpy as np
+    from torch_assimilate_amd import kernels as K
+    vec = K.GaussKernel(np.array([1.0, 2.0, 0.5]))
+    assert K.kernel_route(vec, allow_feature_scale=True) == (0.5, None)
+    with pytest.raises(NotImplementedError):
+        K.kernel_route(vec)
+    for comp in (vec * K.ScaleKernel(0.3), K.LinearKernel() + vec, vec ** K.ScaleKernel(0.0)):
+        with pytest.raises(NotImplementedError):
+            K.kernel_route(comp, allow_feature_scale=True)
+    assert K.kernel_route(K.GaussKernel(2.0) * K.ScaleKernel(0.3))[1] is not None
+
+
 def test_metric_descriptor_matches_oracle_distance():
     rs = np.random.RandomState(3)
     g, o = rs.normal(size=3), rs.normal(size=(50, 3))

@@ -108,6 +108,7 @@ _PROTOS = {
     "mia_comm_peer_alloc": ([vp, sz, i32, vp], i32),
     "mia_comm_peer_open": ([vp, vp], i32),
     "mia_comm_peer_attach": ([vp, i32, C.POINTER(vp), vp], i32),
+    "mia_comm_peer_wait_bound": ([vp, i32], i32),
     "mia_comm_peer_buffer": ([vp, i32], vp),
     "mia_comm_peer_sync_area": ([vp], vp),
     "mia_comm_peer_exchange": ([vp, i32, i32, i64, i64, i64, vp, vp], i32),

@@ -1633,9 +1633,13 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
     }
   }
   // sixteen grid points per wavefront (letkf_tile.hip): dual route, few state rows, no weights output
-  if (ap.dual && ap.tab_hdr && !W_out && !ienks && !ap.fused && tile_route_covers(m, k, p_max) && option(MIA_OPT_TILE))
-    return tile_analysis_launch(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, 0, p_cap, p_max, inf_factor, Xa, ldo, o0,
-                                flags, retry_count, ap.dmax, ap.tab_hdr, ap.tab_c, stream, seg_len, seg_stride, done);
+  // (a launch the tile kernel refuses for its sizes -- offsets beyond 32 bits, LDS, a segmented launch of a large shape -- falls
+  //  through to the one-point-per-wavefront kernels below instead of to the eigensolver)
+  if (ap.dual && ap.tab_hdr && !W_out && !ienks && !ap.fused && tile_route_covers(m, k, p_max) && option(MIA_OPT_TILE)) {
+    const int trc = tile_analysis_launch(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, 0, p_cap, p_max, inf_factor, Xa, ldo, o0,
+                                         flags, retry_count, ap.dmax, ap.tab_hdr, ap.tab_c, stream, seg_len, seg_stride, done);
+    if (trc != MIA_ERR_UNSUPPORTED) return trc;
+  }
   const size_t lds = cheb_lds_bytes(ap.kp, p_max, nmax, ap.rows, ap.dual != 0, false, 0, ap.fused != 0);
   if (lds > (long long)kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
   ap.lds_per_wave = (int)lds;

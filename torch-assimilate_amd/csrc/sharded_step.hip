@@ -85,6 +85,10 @@ struct mia_comm {
   bool peer_opened[kMaxRanks] = {};      // mapped through hipIpcOpenMemHandle (closed on destroy)
   int peer_ready = 0;                    // every rank attached
   uint32_t peer_seq[kMaxSlots] = {};     // exchanges done per slot (the sequence number the flags carry)
+  // bound of the device-side waits for the peers' flags, in polls of ~1-2 us (mia_comm_peer_wait_bound).  Ranks of a real run
+  // drift apart by seconds (I/O of one rank between steps, a first-step table build, a debugger): the default is ~1 minute --
+  // an RCCL collective would simply wait; a waiter that gives up raises error bit 2, it never hangs the grid
+  int peer_wait_polls = 1 << 25;
 };
 
 namespace {
@@ -261,7 +265,7 @@ int peer_finish(mia_comm* c, int slot, uint32_t seq, int64_t G, int64_t b0, int6
   const int world = c->world, rank = c->rank, sw0 = slot * kSyncSlotWords;
   const PeerPtrs pp = peer_ptrs(c, slot);
   const uint32_t* my = c->peer_sync[rank] + sw0;
-  peer_wait_kernel<<<1, 64, 0, cs>>>(my + kMaxRanks, world, rank, seq, counters + 3, 1 << 21, nullptr, nullptr);
+  peer_wait_kernel<<<1, 64, 0, cs>>>(my + kMaxRanks, world, rank, seq, counters + 3, c->peer_wait_polls, nullptr, nullptr);
   MIA_LAUNCH_CHECK();
   const int64_t nb = b1 > b0 ? b1 - b0 : 0;
   unsigned gx = (unsigned)((nb / 4 + 255) / 256);
@@ -271,7 +275,7 @@ int peer_finish(mia_comm* c, int slot, uint32_t seq, int64_t G, int64_t b0, int6
   MIA_LAUNCH_CHECK();
   peer_flag_kernel<<<1, 64, 0, cs>>>(pp, world, sw0 + rank, seq);
   MIA_LAUNCH_CHECK();
-  peer_wait_kernel<<<1, 64, 0, cs>>>(my, world, rank, seq, counters + 3, 1 << 21,
+  peer_wait_kernel<<<1, 64, 0, cs>>>(my, world, rank, seq, counters + 3, c->peer_wait_polls,
                                      reinterpret_cast<const int32_t*>(my + 2 * kMaxRanks), counters);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
@@ -470,6 +474,13 @@ extern "C" int mia_comm_peer_attach(mia_comm_t* c, int peer, void* const* result
   return MIA_OK;
 }
 
+extern "C" int mia_comm_peer_wait_bound(mia_comm_t* c, int log2_polls) {
+  if (!c) return MIA_ERR_NULL;
+  if (log2_polls < 10 || log2_polls > 30) return MIA_ERR_SIZE;
+  c->peer_wait_polls = 1 << log2_polls;
+  return MIA_OK;
+}
+
 extern "C" void* mia_comm_peer_buffer(mia_comm_t* c, int slot) {
   return (c && slot >= 0 && slot < c->peer_slots) ? (void*)c->peer_buf[c->rank][slot] : nullptr;
 }
@@ -593,19 +604,25 @@ thread_local hipEvent_t t_time_start = nullptr, t_time_stop = nullptr;
 
 // events that order the preparation stream before the analysis stream (no communicator, hence no event storage of
 // its own, on the single-rank route): a small ring, created on first use
-hipEvent_t g_prep_ev[64];
-std::atomic<unsigned> g_prep_next{0};
+// (one ring per device: an event belongs to the device that was current when it was created, and the launch threads serve
+//  jobs of several devices)
+constexpr int kPrepDevices = 16;
+hipEvent_t g_prep_ev[kPrepDevices][64];
+std::atomic<unsigned> g_prep_next[kPrepDevices];
 std::mutex g_prep_mutex;
-bool g_prep_init = false;
+bool g_prep_init[kPrepDevices] = {};
 int prep_event(hipEvent_t* ev) {
+  int dev = 0;
+  MIA_HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kPrepDevices) return MIA_ERR_UNSUPPORTED;
   {
     std::lock_guard<std::mutex> lock(g_prep_mutex);
-    if (!g_prep_init) {
-      for (int i = 0; i < 64; ++i) MIA_HIP_TRY(hipEventCreateWithFlags(&g_prep_ev[i], hipEventDisableTiming));
-      g_prep_init = true;
+    if (!g_prep_init[dev]) {
+      for (int i = 0; i < 64; ++i) MIA_HIP_TRY(hipEventCreateWithFlags(&g_prep_ev[dev][i], hipEventDisableTiming));
+      g_prep_init[dev] = true;
     }
   }
-  *ev = g_prep_ev[g_prep_next.fetch_add(1) & 63];
+  *ev = g_prep_ev[dev][g_prep_next[dev].fetch_add(1) & 63];
   return MIA_OK;
 }
 }  // namespace

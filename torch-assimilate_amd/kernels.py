@@ -144,6 +144,11 @@ class GaussKernel(BaseKernel):
         return 0.5 / self.lengthscale ** 2
 
     def program(self) -> Program:
+        if self.feature_scale is not None:
+            # (only the top-level kernel of the global KETKF gets its inputs divided by the vector, kernel_route / KETKFModule;
+            #  inside a composition the expression route would silently run the unit-lengthscale kernel instead of rbf.py:75-78)
+            raise NotImplementedError("a per-observation (vector) lengthscale is supported for a GaussKernel / RBFKernel used on its "
+                                      "own in the global KETKF, not inside a kernel composition")
         return [(KOP_SQDIST, 0.0), (KOP_CONST, -self.gamma), (KOP_MUL, 0.0), (KOP_EXP, 0.0)]
 
     def __str__(self):

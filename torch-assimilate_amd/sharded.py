@@ -166,7 +166,7 @@ class ShardedLetkf:
                  rbf_gamma: Optional[float] = None, compute_shard: Optional[Callable] = None, group=None,
                  method: str = "auto", fused_localization: bool = False,
                  comm_chunks: int = 4, chunk_compute: Optional[Callable] = None, native_step: bool = True,
-                 max_in_flight: int = 3, peer_exchange: str = "auto", copy_results: bool = True, prep_streams: int = 2):
+                 max_in_flight: int = 3, peer_exchange: str = "auto", copy_results: bool = True, prep_streams: int = 3):
         self.device, self.rank, self.world = device, rank, world
         self.radii, self.inf_factor, self.coord_group, self.eps = list(radii), inf_factor, coord_group, eps
         self.rbf_gamma = rbf_gamma
@@ -780,6 +780,44 @@ class ShardedLetkf:
             out = out[:, :, :, :n]
         out = out.reshape(m, k, world * n)
         return out if world * n == G else out[:, :, :G].contiguous()
+
+    def time_exchange(self, m: int, k: int, G: int, reps: int = 10):
+        """The exchange of one step ALONE (no analysis in front of it), HIP events on the exchange stream, mean over ``reps``:
+        the direct peer exchange when that route is up (mia_comm_peer_exchange on slot 0: free flags, push of this rank's block to
+        every peer, ready flags, waits), otherwise one all-gather of the blocks through torch.distributed (RCCL).  Collective:
+        every rank calls it at the same point.  Returns (ms, route, bytes this rank sends per step)."""
+        import ctypes as C
+        import torch.distributed as dist
+        from . import _cabi
+        g0, g1 = block_partition(G, self.world)[self.rank]
+        n = (G + self.world - 1) // self.world
+        st = self._native if self._native is not None else {}
+        peer = st.get("peer") if st.get("peer_shape") == (m, k, G) else None
+        stream = st.get("stream") or torch.cuda.current_stream(self.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if peer:
+            ctr = torch.zeros(8, dtype=torch.int32, device=self.device)
+            lib = self.engine.lib
+            torch.cuda.synchronize(self.device)
+            dist.barrier(group=self.group)
+            with torch.cuda.stream(stream):
+                e0.record()
+                for _ in range(reps):
+                    _cabi.check(lib.mia_comm_peer_exchange(st["comm"], 0, m * k, G, g0, g1, ctr.data_ptr(), C.c_void_p(stream.cuda_stream)),
+                                "mia_comm_peer_exchange")
+                e1.record()
+            torch.cuda.synchronize(self.device)
+            return e0.elapsed_time(e1) / reps, "direct", m * k * (g1 - g0) * 4 * (self.world - 1)
+        send = torch.zeros((m, k, n), dtype=torch.float32, device=self.device)
+        recv = torch.empty((self.world, m, k, n), dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.group)
+        e0.record()
+        for _ in range(reps):
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+        e1.record()
+        torch.cuda.synchronize(self.device)
+        return e0.elapsed_time(e1) / reps, "rccl", m * k * n * 4 * (self.world - 1)
 
     def time_next_step(self):
         """Arm the library's profiling hook for the next native step (mia_letkf_step_timing_events): its analysis
