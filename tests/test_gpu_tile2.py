@@ -319,3 +319,30 @@ def test_declined_points_are_flagged(eng):
     ref = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], case["yb"], case["d"], 10.0, 1.1)[0]
     if (~decl).any():
         assert rel_fro(xa.cpu().numpy()[:, :, ~decl], ref[:, :, ~decl]) < TOL32
+
+
+@pytest.mark.parametrize("k,c,sy,sx", [(27, 6.25, 2e2, 4e-3), (40, 5.0, 5e2, 1.0), (20, 4.0, 50.0, 1e3)])
+def test_strong_observations_are_redone_in_float64(eng, k, c, sy, sx):
+    """Observations 50 .. 500 times more accurate than the ensemble spread (lambda_max / reg ~ 1e4 .. 1e6): the matrix-function
+    kernel declines every point and the eigensolver redoes them -- in float64 arithmetic on the float32 data, because a spectrum
+    that wide is also what a float32 eigensolver resolves worst (the float32 redo left 1.4e-5 on the k = 27 case of
+    tools/stress_tile.py).  Against the float64 analysis of the same inputs: north-star tolerance."""
+    rs = np.random.RandomState(k)
+    G = 203
+    grid, obs = np.arange(G, dtype=np.float64), np.arange(0, G, 1.0) + 0.13
+    state = rs.normal(size=(2, k, G)) * sx
+    hx = rs.normal(size=(k, len(obs))) * 0.7 * sy
+    yb, d = hx - hx.mean(axis=0), rs.normal(size=len(obs)) * 0.7 * sy
+    X, Yb, D = dev(state), dev(yb), dev(d)
+    nb = eng.localize(grid, obs, [c])
+    assert nb.p_max <= k
+    ref = eng.analysis(X.double(), Yb.double(), D.double(), nb, 1.1, method="eig").cpu().numpy()
+    tiles = eng.localize_tiles(grid, obs, [c], nb.p_max, extra_blocks=1)
+    assert tiles.stats.tolist()[1] == 0
+    xa, fl, retry = eng.analysis_tiles(X, eng.pack_split(Yb, D), len(obs), tiles, 1.1)
+    assert int(retry.item()) > G // 2                         # (declined: the spectrum needs a degree beyond the cap)
+    eng.retry_points(X, Yb, D, nb, 1.1, xa, fl)
+    assert rel_fro(xa.cpu().numpy(), ref) < TOL32
+    # the same through the round-2 kernel on per-point lists (same redo)
+    xo = eng.analysis(X, Yb, D, nb, 1.1, method="matfun")
+    assert rel_fro(xo.cpu().numpy(), ref) < TOL32

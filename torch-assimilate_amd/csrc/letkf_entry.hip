@@ -30,6 +30,11 @@ int wave_analysis_launch(const T* X, int64_t ldx, int m, int k, int64_t g0, int6
                          T* W_opt, int32_t* flags_opt, int only_flagged, hipStream_t stream,
                          const mia_kernel_op_t* prog = nullptr, int n_ops = 0);
 
+int wave_analysis_launch_f32_in_f64(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
+                                    const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
+                                    float inf_factor, int kernel_mode, float gamma, float* Xa, int64_t ldo, int64_t o0,
+                                    float* W_opt, int32_t* flags_opt, int only_flagged, hipStream_t stream);
+
 int sys_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
                         const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
                         float inf_factor, int kernel_mode, float gamma, float* Xa, int64_t ldo, int64_t o0,
@@ -74,7 +79,15 @@ static int analysis_packed_impl(const T* X, int64_t ldx, int m, int k, int64_t g
   if (kernel_mode == 2)   // kernel expression: runtime-order kernel only
     return wave_analysis_launch<T>(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
                                    kernel_mode, gamma, Xa, ldo, o0, W_opt, flags_opt, only_flagged, stream, prog, n_ops);
-  if constexpr (sizeof(T) == 4) {     // float32, order <= 64: the systolic-Jacobi kernel (letkf_sys.hip)
+  if constexpr (sizeof(T) == 4) {
+    // redo of declined points (only_flagged): float64 arithmetic on the float32 data where the block fits the LDS -- a spectrum
+    // too wide for the matrix-function route is also what a float32 eigensolver resolves worst (tools/stress_tile.py)
+    if (only_flagged && kernel_mode != 2) {
+      const int rc = wave_analysis_launch_f32_in_f64(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
+                                                     kernel_mode, gamma, Xa, ldo, o0, W_opt, flags_opt, only_flagged, stream);
+      if (rc != MIA_ERR_UNSUPPORTED) return rc;
+    }
+    // float32, order <= 64: the systolic-Jacobi kernel (letkf_sys.hip)
     const int rc = sys_analysis_launch(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor,
                                        kernel_mode, gamma, Xa, ldo, o0, W_opt, flags_opt, only_flagged, stream);
     if (rc != MIA_ERR_UNSUPPORTED) return rc;

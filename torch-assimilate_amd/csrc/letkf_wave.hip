@@ -28,13 +28,17 @@
 
 namespace mia {
 
-template <typename T>
+// T = type of the arithmetic, TI = type of the arrays (state, records, analysis, weights).  TI = float with T = double is the
+// redo of declined points (mia_letkf_analysis_retry_f32): float32 data, float64 eigensolve -- points whose spectrum is too wide
+// for the matrix-function route are also the ones a float32 eigensolver resolves worst (lambda_max / reg ~ 1e4: 1.4e-5 on the
+// analysis in tools/stress_tile.py with the float32 kernel).
+template <typename T, typename TI = T>
 struct WaveParams {
-  const T* X; int64_t ldx; int m; int k;
+  const TI* X; int64_t ldx; int m; int k;
   int64_t g0, ng;
-  const T* rec; int kp;
+  const TI* rec; int kp;
   const int32_t* cnt; const int32_t* idx; const double* w; int p_cap; int p_max;
-  T reg; T* Xa; int64_t ldo, o0; T* W; int32_t* flags;
+  T reg; TI* Xa; int64_t ldo, o0; TI* W; int32_t* flags;
   int dual; int nmax; int lda; int rows; int pts_per_block; int max_sweeps; T rot_tol2, stop_tol2;
   int kernel_mode; T gamma;   // 0 linear (ETKF), 1 RBF(gamma), 2 kernel expression `prog`
   int only_flagged;
@@ -63,8 +67,8 @@ __device__ inline T kprog_pair(const KernelProgram<T>& kp, const T* Yt, int kpad
   return kprog_eval(kp, dt, sq, l1, same);
 }
 
-template <typename T, int NT>
-__global__ __launch_bounds__(NT) void letkf_wave_kernel(WaveParams<T> P) {
+template <typename T, int NT, typename TI = T>
+__global__ __launch_bounds__(NT) void letkf_wave_kernel(WaveParams<T, TI> P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int k = P.k, kp = P.kp, pm = P.p_max, nmax = P.nmax, lda = P.lda, rows = P.rows;
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(NT) void letkf_wave_kernel(WaveParams<T> P) {
     if (P.only_flagged && !(P.flags[pt] & MIA_FLAG_RETRY)) continue;
     if (cnt > pm || cnt > P.p_cap) {   // loud failure: never analyse with a truncated list
       if (P.flags && tid == 0) P.flags[pt] = MIA_FLAG_OVERFLOW;
-      const T nanv = T(__builtin_nanf(""));
+      const TI nanv = TI(__builtin_nanf(""));
       for (int it = tid; it < P.m * k; it += NT) P.Xa[(int64_t)it * P.ldo + P.o0 + pt] = nanv;
       if (P.W) for (int it = tid; it < k * k; it += NT) P.W[pt * (int64_t)k * k + it] = nanv;
       continue;
@@ -129,7 +133,16 @@ __global__ __launch_bounds__(NT) void letkf_wave_kernel(WaveParams<T> P) {
     // observations is not bounded by it.  (A kernel expression may need |x - y|_1, which is no product: it keeps the block.)
     const bool streamp = !P.dual && P.kernel_mode != 2;
     // ---- gather + sqrt(rho) scale: records are 16-byte aligned rows of kp elements
-    {
+    if constexpr (!std::is_same<T, TI>::value) {      // float32 records into a float64 block
+      const int kpv = kp / 4;
+      for (int it = tid; it < (streamp ? 0 : cnt * kpv); it += NT) {
+        const int j = it / kpv, c = it - j * kpv;
+        const float4 v = reinterpret_cast<const float4*>(P.rec + (int64_t)lidx[j] * kp)[c];
+        const T wj = lw[j];
+        T* o = Yt + (size_t)j * kp + 4 * c;
+        o[0] = T(v.x) * wj; o[1] = T(v.y) * wj; o[2] = T(v.z) * wj; o[3] = T(v.w) * wj;
+      }
+    } else {
       constexpr int VW = 16 / sizeof(T);
       const int kpv = kp / VW;
       using VT = typename std::conditional<sizeof(T) == 4, float4, double2>::type;
@@ -189,9 +202,9 @@ __global__ __launch_bounds__(NT) void letkf_wave_kernel(WaveParams<T> P) {
           T av = T(0), bv = T(0);
           if (j < cnt) {
             const T wj = lw[j];
-            const T* rj = P.rec + (int64_t)lidx[j] * kp;
-            av = ra <= k ? rj[ra] * wj : T(0);
-            bv = rb <= k ? rj[rb] * wj : T(0);
+            const TI* rj = P.rec + (int64_t)lidx[j] * kp;
+            av = ra <= k ? T(rj[ra]) * wj : T(0);
+            bv = rb <= k ? T(rj[rb]) * wj : T(0);
           }
           acc = mfma16(av, bv, acc);
         }
@@ -317,8 +330,8 @@ __global__ __launch_bounds__(NT) void letkf_wave_kernel(WaveParams<T> P) {
     }
     // ---- ensemble transform, one state row at a time
     for (int mi = 0; mi < P.m; ++mi) {
-      const T* xrow = P.X + (int64_t)mi * k * P.ldx + g;
-      for (int i = tid; i < k; i += NT) xp[i] = xrow[(int64_t)i * P.ldx];
+      const TI* xrow = P.X + (int64_t)mi * k * P.ldx + g;
+      for (int i = tid; i < k; i += NT) xp[i] = T(xrow[(int64_t)i * P.ldx]);
       __syncthreads();
       // every lane sums the k members itself (LDS broadcast reads): no serial section, no barrier
       T xm = T(0);
@@ -354,14 +367,14 @@ __global__ __launch_bounds__(NT) void letkf_wave_kernel(WaveParams<T> P) {
       }
       __syncthreads();
       const T mterm = xm + zu;
-      T* orow = P.Xa + (int64_t)mi * k * P.ldo + P.o0 + pt;
+      TI* orow = P.Xa + (int64_t)mi * k * P.ldo + P.o0 + pt;
       for (int j = tid; j < k; j += NT) {
         T acc;
         if (P.dual) { acc = f0 * (xp[j] - xm); for (int b = 0; b < cnt; ++b) acc += sb[b] * Yt[(size_t)b * kp + j]; }
         else acc = sb[j];
         const T out = mterm + acc;
         if (!(t_abs(out) <= T(1e30))) flag |= MIA_FLAG_NONFINITE;
-        orow[(int64_t)j * P.ldo] = out;
+        orow[(int64_t)j * P.ldo] = TI(out);
       }
       __syncthreads();
     }
@@ -378,12 +391,12 @@ __global__ __launch_bounds__(NT) void letkf_wave_kernel(WaveParams<T> P) {
         Mm = Mq;
         __syncthreads();
       }
-      T* wout = P.W + pt * (int64_t)k * k;
+      TI* wout = P.W + pt * (int64_t)k * k;
       for (int it = tid; it < k * k; it += NT) {
         const int i = it / k, j = it - i * k;
         T acc = wbar[i] + (i == j ? f0 : T(0));
         for (int r = 0; r < n; ++r) acc += gW[r] * Mm[i * lda + r] * Mm[j * lda + r];
-        wout[it] = acc;
+        wout[it] = TI(acc);
       }
     }
     if (P.flags) {
@@ -407,13 +420,13 @@ static size_t wave_lds_bytes(int k, int kp, int p_max, int nmax, int lda, int ro
   return align_up(b, 16);
 }
 
-template <typename T>
-int wave_analysis_launch(const T* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const T* rec,
-                         const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap,
-                         int p_max, T inf_factor, int kernel_mode, T gamma, T* Xa, int64_t ldo, int64_t o0,
-                         T* W_opt, int32_t* flags_opt, int only_flagged, hipStream_t stream,
-                         const mia_kernel_op_t* prog, int n_ops) {
-  WaveParams<T> ap;
+template <typename T, typename TI>
+static int wave_analysis_launch_io(const TI* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const TI* rec,
+                                   const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap,
+                                   int p_max, T inf_factor, int kernel_mode, T gamma, TI* Xa, int64_t ldo, int64_t o0,
+                                   TI* W_opt, int32_t* flags_opt, int only_flagged, hipStream_t stream,
+                                   const mia_kernel_op_t* prog, int n_ops) {
+  WaveParams<T, TI> ap;
   ap.prog.n = 0;
   if (kernel_mode == 2) {
     const int rc = kernel_program_check(prog, n_ops);
@@ -455,16 +468,37 @@ int wave_analysis_launch(const T* X, int64_t ldx, int m, int k, int64_t g0, int6
   const int64_t nblk = (ng + ppb - 1) / ppb;
   if (nblk > 2147483647LL) return MIA_ERR_UNSUPPORTED;
   if (big) {
-    auto kern = letkf_wave_kernel<T, 256>;
+    auto kern = letkf_wave_kernel<T, 256, TI>;
     if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kern<<<dim3((unsigned)nblk), dim3(256), lds, stream>>>(ap);
   } else {
-    auto kern = letkf_wave_kernel<T, 64>;
+    auto kern = letkf_wave_kernel<T, 64, TI>;
     if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kern<<<dim3((unsigned)nblk), dim3(64), lds, stream>>>(ap);
   }
   MIA_LAUNCH_CHECK();
   return MIA_OK;
+}
+
+template <typename T>
+int wave_analysis_launch(const T* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const T* rec,
+                         const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap,
+                         int p_max, T inf_factor, int kernel_mode, T gamma, T* Xa, int64_t ldo, int64_t o0,
+                         T* W_opt, int32_t* flags_opt, int only_flagged, hipStream_t stream,
+                         const mia_kernel_op_t* prog, int n_ops) {
+  return wave_analysis_launch_io<T, T>(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max, inf_factor, kernel_mode,
+                                       gamma, Xa, ldo, o0, W_opt, flags_opt, only_flagged, stream, prog, n_ops);
+}
+
+// float32 arrays, float64 arithmetic (ETKF / RBF cores; the redo of declined points).  MIA_ERR_UNSUPPORTED when the float64
+// block does not fit the LDS: the caller keeps the float32 kernels then.
+int wave_analysis_launch_f32_in_f64(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
+                                    const int32_t* nbr_cnt, const int32_t* nbr_idx, const double* nbr_w, int p_cap, int p_max,
+                                    float inf_factor, int kernel_mode, float gamma, float* Xa, int64_t ldo, int64_t o0,
+                                    float* W_opt, int32_t* flags_opt, int only_flagged, hipStream_t stream) {
+  return wave_analysis_launch_io<double, float>(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, p_cap, p_max,
+                                                (double)inf_factor, kernel_mode, (double)gamma, Xa, ldo, o0, W_opt, flags_opt,
+                                                only_flagged, stream, nullptr, 0);
 }
 
 template int wave_analysis_launch<float>(const float*, int64_t, int, int, int64_t, int64_t, const float*,
