@@ -1,0 +1,120 @@
+"""Full-size GPU tests (BASELINE.json configurations 2 - 5 at their stated sizes): properties that need no oracle at scale
+(determinism, shard invariance, agreement of independent routes) plus the float64 oracle on 64 randomly chosen grid points.
+Inputs are generated on the device (bench.make_case: the distribution of oracle.synthetic_case)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_fro
+from oracle import letkf_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL32 = 1e-5
+
+
+@pytest.fixture(scope="module")
+def mia():
+    import torch_assimilate_amd as m
+    m.build()
+    return m
+
+
+@pytest.fixture(scope="module")
+def eng(mia):
+    return mia.LetkfEngine("cuda:0")
+
+
+def oracle_points(X, gx, ox, Yb, d, c, inf, pts, gamma=None):
+    st, yb_h, d_h = X.double().cpu().numpy(), Yb.double().cpu().numpy(), d.double().cpu().numpy()
+    gxh, oxh = gx.cpu().numpy(), ox.cpu().numpy()
+    core = O.etkf_weights if gamma is None else (lambda a, b, i, g_=gamma: O.ketkf_weights(a, b, lambda x, y: O.rbf_kernel(x, y, g_), i))
+    out = []
+    for g in pts:
+        lo, hi = max(0, int(g) - 200), min(len(gxh), int(g) + 200)       # (the taper's support is a few dozen grid steps)
+        sel = (oxh >= gxh[lo]) & (oxh <= gxh[hi - 1])
+        w = O.localized_weights(O.abs_distance_1d(gxh[g], oxh[sel]), yb_h[:, sel], d_h[sel], [c], inf, core=core)
+        out.append(O.apply_weights(st[:, :, [g]], w[None])[:, :, 0])
+    return np.stack(out, axis=-1)
+
+
+@pytest.mark.parametrize("name,k,stride,c", [("c2", 40, 2, 10.0), ("c4", 80, 1, 16.5)])
+def test_tile_route_at_full_size(eng, name, k, stride, c):
+    """Configs 2 and 4 at 1e5 grid points on the tile route: 64 oracle points, bit-for-bit determinism, a shard that cuts the
+    grid anywhere reproduces the full run per point to rounding, the round-2 kernel on per-point lists agrees."""
+    import bench
+    dev = torch.device("cuda:0")
+    G = 100000
+    X, gx, ox, Yb, d = bench.make_case(G, k, stride, dev)
+    nb = eng.localize(gx, ox, [c])
+    assert nb.p_max == (20 if name == "c2" else 63)
+    tiles = eng.localize_tiles(gx, ox, [c], nb.p_max)
+    assert tiles.stats.tolist() == [nb.p_max, 0]
+    rec = eng.pack_split(Yb, d)
+    xa, fl, retry = eng.analysis_tiles(X, rec, Yb.shape[1], tiles, 1.1)
+    assert int(retry.item()) == 0 and int((fl & 0xff).max().item()) == 0 and bool(torch.isfinite(xa).all())
+    xa2 = eng.analysis_tiles(X, rec, Yb.shape[1], eng.localize_tiles(gx, ox, [c], nb.p_max), 1.1)[0]
+    assert torch.equal(xa, xa2)
+    g0, g1 = 30005, 30117
+    part = eng.analysis_tiles(X, rec, Yb.shape[1], eng.localize_tiles(gx, ox, [c], nb.p_max, g0=g0, g1=g1), 1.1)[0]
+    ref_part = xa[:, :, g0:g1]
+    assert float(((part - ref_part).norm(dim=(0, 1)) / ref_part.norm(dim=(0, 1))).max()) < 2e-6
+    xo = eng.analysis(X, Yb, d, nb, 1.1, method="matfun")
+    assert float(torch.linalg.norm(xa - xo) / torch.linalg.norm(xo)) < 1e-6
+    pts = np.random.RandomState(1).choice(G, 64, replace=False)
+    ref = oracle_points(X, gx, ox, Yb, d, c, 1.1, pts)
+    got = xa[:, :, torch.as_tensor(pts, device=dev)].double().cpu().numpy()
+    assert rel_fro(got, ref) < TOL32
+    mean = X.double().mean(dim=1, keepdim=True)[:, :, torch.as_tensor(pts, device=dev)].cpu().numpy()
+    assert rel_fro(got - mean, ref - mean) < 5e-5
+
+
+def test_config5_at_full_size(eng):
+    """Config 5 (RBF-kernelised filter, gamma 0.5, k = 40) at 1e5 grid points: 64 oracle points, determinism, the eigensolver
+    route on a 2000-point shard agrees with the matrix-function route."""
+    import bench
+    dev = torch.device("cuda:0")
+    G = 100000
+    X, gx, ox, Yb, d = bench.make_case(G, 40, 2, dev, seed=43)
+    nb = eng.localize(gx, ox, [10.0])
+    rec = eng.pack_obs(Yb, d, torch.float32)
+    xa, fl = eng.analysis(X, None, None, nb, 1.1, rec=rec, rbf_gamma=0.5, return_flags=True, method="matfun")
+    assert int((fl & 0xff).max().item()) == 0 and bool(torch.isfinite(xa).all())
+    assert torch.equal(xa, eng.analysis(X, None, None, nb, 1.1, rec=rec, rbf_gamma=0.5, method="matfun"))
+    nb_s = eng.localize(gx, ox, [10.0], g0=50000, g1=52000)
+    xe = eng.analysis(X, None, None, nb_s, 1.1, rec=rec, rbf_gamma=0.5, method="eig")
+    part = xa[:, :, 50000:52000]
+    assert float(torch.linalg.norm(part - xe) / torch.linalg.norm(xe)) < TOL32
+    pts = np.random.RandomState(2).choice(G, 64, replace=False)
+    ref = oracle_points(X, gx, ox, Yb, d, 10.0, 1.1, pts, gamma=0.5)
+    got = xa[:, :, torch.as_tensor(pts, device=dev)].double().cpu().numpy()
+    assert rel_fro(got, ref) < TOL32
+
+
+def test_config3_problem_on_one_gpu(mia):
+    """Config 3's problem (G = 1e6 grid points, P = 5e5 observations, k = 40) through the native step driver on ONE GPU: steps in
+    flight, 64 oracle points, determinism across steps, and rank 3's block of an 8-rank partition computed alone (what that
+    rank of the 8-GPU run computes) equals the same columns of the full run per point to rounding."""
+    import bench
+    dev = torch.device("cuda:0")
+    G = 1000000
+    X, gx, ox, Yb, d = bench.make_case(G, 40, 2, dev)
+    r = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1, max_in_flight=3)
+    out = None
+    for _ in range(3):
+        out = r.assimilate(X, gx, ox, Yb, d)
+    assert r.native_steps == 2 and r.last_flags_ok() and bool(torch.isfinite(out).all())
+    assert r.dominant_kernel_name.startswith("letkf_tile2_kernel")
+    pend = [r.submit(X, gx, ox, Yb, d) for _ in range(3)]
+    for h in pend:
+        assert torch.equal(h.result(), out)
+    pts = np.random.RandomState(3).choice(G, 64, replace=False)
+    ref = oracle_points(X, gx, ox, Yb, d, 10.0, 1.1, pts)
+    got = out[:, :, torch.as_tensor(pts, device=dev)].double().cpu().numpy()
+    assert rel_fro(got, ref) < TOL32
+    from torch_assimilate_amd.sharded import block_partition
+    g0, g1 = block_partition(G, 8)[3]
+    eng = r.engine
+    tiles = eng.localize_tiles(gx, ox, [10.0], 20, g0=g0, g1=g1)
+    blk = eng.analysis_tiles(X, eng.pack_split(Yb, d), Yb.shape[1], tiles, 1.1)[0]
+    full = out[:, :, g0:g1]
+    assert float(((blk - full).norm(dim=(0, 1)) / full.norm(dim=(0, 1))).max()) < 2e-6
