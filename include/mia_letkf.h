@@ -86,6 +86,10 @@ const char* mia_status_string(int status);
  *   "bucket_index"     1  step driver, tile route: the observations are binned by ONE kernel into fixed-capacity buckets of the cell
  *                         grid the step's workspace already holds (bounding box validated per observation, rebuilt when it no
  *                         longer holds) / 0: bounding box + count + scan + scatter kernels every step
+ * Scope: process-wide defaults, read when a call ENQUEUES its work -- for steps handed to the launch threads
+ * (mia_letkf_step_submit) at submission: a step runs with the routes that were in force when it was submitted, whatever is
+ * set afterwards.  What differs per runner of one process travels in the call's own arguments (method, step_flags:
+ * MIA_STEP_NO_TILE_LISTS, MIA_STEP_SCAN_INDEX, MIA_STEP_TILE_EXTRA).
  * Returns MIA_ERR_UNSUPPORTED for an unknown name, MIA_ERR_SIZE for a value out of range. */
 int mia_set_option(const char* name, int value);
 int mia_get_option(const char* name, int* value);

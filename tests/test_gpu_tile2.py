@@ -81,8 +81,9 @@ GEOMS = {
 
 @pytest.mark.parametrize("name", sorted(GEOMS))
 def test_tile_lists_equal_the_per_point_lists(eng, name):
-    """Same masks (float64 `w > eps` decision) and same float32 sqrt(weight) as mia_letkf_localize_f64, for 1-D / 2-D / 3-D
-    networks, two radii, the form-factor-infinity taper, grid points outside the observations' bounding box, ragged tiles."""
+    """Same masks (float64 `w > eps` decision) as mia_letkf_localize_f64 and the same sqrt(weight) -- to 2e-6 for the
+    Gaspari-Cohn taper, which the tile kernel evaluates in float32 (cancellation-free form), bit for bit for the other taper --
+    for 1-D / 2-D / 3-D networks, two radii, grid points outside the observations' bounding box, ragged tiles."""
     grid, obs, radii, cg, taper = GEOMS[name](np.random.RandomState(5))
     nb = eng.localize(grid, obs, radii, cg, taper=taper)
     for g0, g1 in ((0, len(grid)), (7, min(len(grid), 59))):
@@ -97,7 +98,37 @@ def test_tile_lists_equal_the_per_point_lists(eng, name):
             pytest.skip("union of %d tiles exceeds the slots of this bound (scattered points): list route" % n_over)
         assert longest == part.p_max
         got, ref = lists_from_tiles(tiles), lists_from_points(part)
-        assert got == ref
+        assert [sorted(a) for a in got] == [sorted(b) for b in ref]                     # the masks: exact
+        if taper:
+            assert got == ref
+        else:
+            for a, b in zip(got, ref):
+                np.testing.assert_allclose([a[j] for j in sorted(a)], [b[j] for j in sorted(b)], rtol=2e-6 * len(radii), atol=0)
+
+
+def test_decisions_at_the_edge_of_the_support_are_the_float64_ones(eng):
+    """Pairs whose weight is within a few 1e-7 (relative) of eps on either side: float32 cannot tell them apart, the kernel takes
+    those decisions again in float64, and the masks equal the per-point lists'."""
+    from scipy.optimize import brentq
+    eps, c = 1e-5, 10.0
+
+    def gc(r):
+        return r ** 5 / 12 - 0.5 * r ** 4 + 0.625 * r ** 3 + 5 / 3 * r ** 2 - 5 * r + 4 - 2 / (3 * r)
+    r_eps = brentq(lambda r: gc(r) - eps, 1.5, 1.999)
+    grid = np.arange(64.0)
+    # observations at distance c r_eps (1 +- delta) from grid points 8, 24, 40, 56 on either side, delta from 1e-9 to 1e-6
+    deltas = np.array([-1e-6, -1e-7, -1e-8, -1e-9, 1e-9, 1e-8, 1e-7, 1e-6])
+    obs = np.concatenate([g + s * c * r_eps * (1 + deltas) for g in (8.0, 24.0, 40.0, 56.0) for s in (-1, 1)])
+    obs = np.concatenate([obs, np.arange(0, 64, 2.0)])
+    nb = eng.localize(grid, obs, [c])
+    tiles = eng.localize_tiles(grid, obs, [c], nb.p_max, extra_blocks=2)
+    assert tiles.stats.tolist()[1] == 0
+    got, ref = lists_from_tiles(tiles), lists_from_points(nb)
+    assert [sorted(a) for a in got] == [sorted(b) for b in ref]
+    for gi, g in enumerate((8, 24, 40, 56)):                    # the probes fall on both sides of the decision
+        for si in range(2):
+            base = (2 * gi + si) * 8
+            assert [j - base for j in sorted(got[g]) if base <= j < base + 8] == [0, 1, 2, 3]
 
 
 def test_pack_split_records(eng):

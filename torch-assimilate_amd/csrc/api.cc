@@ -25,7 +25,15 @@ extern "C" const char* mia_status_string(int status) {
 
 namespace mia {
 static std::atomic<int> g_opt[MIA_OPT_COUNT_] = {62, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
-int option(int id) { return (id >= 0 && id < MIA_OPT_COUNT_) ? g_opt[id].load(std::memory_order_relaxed) : 0; }
+// A thread may run under a SNAPSHOT of the options (the step driver's launch threads: a job is enqueued with the routes that
+// were in force when the caller submitted it, whatever mia_set_option does in the meantime)
+static thread_local const int* t_override = nullptr;
+int option(int id) {
+  if (id < 0 || id >= MIA_OPT_COUNT_) return 0;
+  return t_override ? t_override[id] : g_opt[id].load(std::memory_order_relaxed);
+}
+void option_snapshot(int* out) { for (int i = 0; i < MIA_OPT_COUNT_; ++i) out[i] = g_opt[i].load(std::memory_order_relaxed); }
+void option_override(const int* snapshot) { t_override = snapshot; }
 }  // namespace mia
 
 static const char* const kOptNames[MIA_OPT_COUNT_] = {"cheb_dmax", "cheb_table", "cheb_rowbatch", "cheb_big", "tile",

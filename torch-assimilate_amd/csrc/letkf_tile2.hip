@@ -52,6 +52,7 @@ struct Tile2Params {
   // clr_counts[0 .. *clr_n) -- their only readers, the tile-list kernel, ran before this launch -- and workgroup 0 folds the build's
   // error word into *err_out (bits 8, 16) and clears it
   int* clr_counts; const int* clr_n; unsigned* clr_err; int32_t* err_out;
+  int stagger;      // (experiment builds) start delay per wave slot of a SIMD, in units of 64 cycles
 };
 
 __device__ __forceinline__ float t2_add_h(float v) {       // sum over the four lanes (lr, h = 0..3), in every one of them
@@ -157,6 +158,12 @@ void letkf_tile2_kernel(Tile2Params P) {
   const int lrc = lr < npts ? lr : npts - 1;
   const bool colok = lr < npts;
 
+#ifdef MIA_EXPERIMENTS
+  if (P.stagger > 0) {      // waves of one SIMD start their memory phases apart
+    const int slot = (int)(__builtin_amdgcn_s_getreg((4 << 11) | 4) & 0xf);      // HW_ID wave id
+    for (int i = 0; i < slot * P.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+  }
+#endif
   T2_STAMP(0);
   T2_STAMP_HWID();
   T2_STAMP_REAL(10);
@@ -643,7 +650,12 @@ constexpr int tile2_waves() { return UT <= 2 && KT <= 4 ? (MROWS ? 2 : MIA_TILE2
 
 template <int UT, int KT, bool MROWS, int WAVES = tile2_waves<UT, KT, MROWS>()>
 static int tile2_launch_m(const Tile2Params& tp, hipStream_t stream) {
-  const size_t lds = tile2_lds_bytes(UT, tp.k);
+  size_t lds = tile2_lds_bytes(UT, tp.k);
+  {   // (experiment builds: a larger LDS request caps the wavefronts per CU -- occupancy A/B without touching the registers)
+    int per_cu = 0;
+    MIA_EXP_SET(per_cu, "MIA_TILE2_WAVES_PER_CU", atoi);
+    if (per_cu > 0 && (size_t)(160 * 1024) / per_cu > lds) lds = ((size_t)(160 * 1024) / per_cu) & ~(size_t)255;
+  }
   if (lds > kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
   auto kern = letkf_tile2_kernel<UT, KT, MROWS, WAVES>;
   if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -729,6 +741,8 @@ int tile2_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0,
   tp.seg_len = seg_len; tp.seg_stride = seg_stride;
   tp.clr_counts = hk ? hk->counts : nullptr; tp.clr_n = hk ? hk->n : nullptr; tp.clr_err = hk ? hk->err : nullptr;
   tp.err_out = hk ? hk->err_out : nullptr;
+  tp.stagger = 0;
+  MIA_EXP_SET(tp.stagger, "MIA_TILE2_STAGGER", atoi);
 #ifdef MIA_TILE2_SINGLE        // (development builds: one instantiation, for register / ISA inspection)
   if (ut == 2 && kt == 3) return tile2_launch_s<2, 3>(tp, stream);
   return MIA_ERR_UNSUPPORTED;

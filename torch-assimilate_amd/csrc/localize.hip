@@ -13,6 +13,7 @@
 #include "mia_options.h"
 #include "mia_localize_dev.h"
 #include "mia_pack_dev.h"
+#include "mia_tiles.h"
 
 namespace mia {
 
@@ -46,6 +47,8 @@ struct IndexParams {
   int scatter_xyz;       // the cell sort is skipped (see index_build_impl): the scatter lays the coordinates out itself
   long long bucket_total;   // entries of the bucket arrays
   int* bidx; double* bxyz;
+  unsigned nb_main;         // index_bucket_kernel: workgroups nb_main, nb_main + 1, ... pack split records (independent passenger)
+  SplitPackJob spack;
 };
 
 __device__ inline unsigned long long dkey(double x) {     // total order of doubles as unsigned integers
@@ -661,7 +664,12 @@ int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_
 // entry: the tile-list kernel's last workgroup puts them back (localize_tiles_kernel).
 __global__ __launch_bounds__(64) void index_bucket_kernel(IndexParams p) {
   MIA_PREP_PRIORITY();
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (blockIdx.x >= p.nb_main) {      // independent passenger: the split records of the analysis kernel (only it needs them)
+    extern __shared__ __attribute__((aligned(16))) float bk_lds[];
+    pack_split_wave(p.spack, p.P, (int64_t)(blockIdx.x - p.nb_main), bk_lds);
+    return;
+  }
+  const int64_t stride = (int64_t)p.nb_main * blockDim.x;
   for (int q = 0; q < 3; ++q)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < p.zero.n[q]; i += stride) p.zero.ptr[q][i] = 0;
   const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -694,7 +702,8 @@ __global__ __launch_bounds__(64) void index_bucket_kernel(IndexParams p) {
 }
 
 int index_bucket_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_t* coord_group, const double* gc_c, int n_r,
-                            void* ws, size_t ws_bytes, hipStream_t stream, const ZeroJob* zero, bool fresh_box) {
+                            void* ws, size_t ws_bytes, hipStream_t stream, const ZeroJob* zero, bool fresh_box,
+                            const SplitPackJob* spack) {
   if (P <= 0 || n_coord < 1 || n_coord > MIA_MAX_COORD || n_r < 1 || n_r > MIA_MAX_RADII) return MIA_ERR_SIZE;
   if (P > 500000000LL) return MIA_ERR_UNSUPPORTED;
   if (!coord_group || !gc_c || !obs_xyz || !ws) return MIA_ERR_NULL;
@@ -722,7 +731,18 @@ int index_bucket_build_impl(const double* obs_xyz, int64_t P, int n_coord, const
     MIA_LAUNCH_CHECK();
   }
   ip.zero = zero ? *zero : ZeroJob{{nullptr, nullptr, nullptr}, {0, 0, 0}};
-  index_bucket_kernel<<<dim3(nbP), dim3(kPrepThreads), 0, stream>>>(ip);
+  ip.nb_main = nbP;
+  ip.spack = SplitPackJob{nullptr, nullptr, nullptr, 0};
+  unsigned nb_pack = 0;
+  size_t lds = 0;
+  if (spack && spack->rec) {
+    ip.spack = *spack;
+    nb_pack = (unsigned)((P + 1 + 63) / 64);
+    lds = split_pack_lds(spack->k);
+    if (lds > kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
+    if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)index_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  index_bucket_kernel<<<dim3(nbP + nb_pack), dim3(kPrepThreads), lds, stream>>>(ip);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

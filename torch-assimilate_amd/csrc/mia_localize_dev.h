@@ -199,7 +199,9 @@ int make_scan_params(ScanParams* sp, const double* grid_xyz, int64_t P, int n_co
                      const double* gc_c, int n_r, double gc_eps, void* ws, int taper = MIA_TAPER_GC, bool bucket = false);
 // bucket index (step driver): ONE kernel bins the observations into fixed-capacity cells of the cell grid the workspace's header
 // describes (fresh_box: the bounding-box kernel runs first and rewrites the header); errors go to the header (IndexHeader::err)
+struct SplitPackJob;
 int index_bucket_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_t* coord_group, const double* gc_c, int n_r,
-                            void* ws, size_t ws_bytes, hipStream_t stream, const ZeroJob* zero, bool fresh_box);
+                            void* ws, size_t ws_bytes, hipStream_t stream, const ZeroJob* zero, bool fresh_box,
+                            const SplitPackJob* spack = nullptr);
 
 }  // namespace mia

@@ -20,6 +20,9 @@ enum {
 
 namespace mia {
 int option(int id);
+// snapshot of all options (MIA_OPT_COUNT_ ints) / run this thread under a snapshot (nullptr: the process-wide values again)
+void option_snapshot(int* out);
+void option_override(const int* snapshot);
 }
 
 // Timing / accuracy experiments of tools/ (phase skipping, tolerances, alternative launch shapes) read the environment --

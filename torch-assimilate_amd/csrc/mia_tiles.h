@@ -113,6 +113,70 @@ __device__ __forceinline__ h8v hi8(const float (&x)[8]) {
 // split-record packing job (rides in the tile-list kernel as extra single-wave workgroups, or runs as a launch of its own)
 struct SplitPackJob { const float* Yb; const float* d; unsigned char* rec; int k; };
 
+// ---- split records ---------------------------------------------------------------------------------------------------
+// One wavefront packs records j0 .. j0 + 63 (indices up to P: record P is the all-zero record).  Lane j reads entry j of
+// every row of Yb (256-byte row segments, sixteen rows requested before any is consumed) into an LDS image [64][ls], ls odd;
+// every lane then finds its record's largest member magnitude (-> power of two), writes the tail, and the chunks of the
+// 64 records are converted by all lanes, one chunk of eight members (32 bytes out) per lane and trip.
+// lds: 64 * ls floats + 64 floats, ls = (k + 1) | 1.
+__device__ inline void pack_split_wave(const SplitPackJob& J, int64_t P, int64_t block, float* lds) {
+  const int lane = threadIdx.x & 63;
+  const int k = J.k, nc8 = (k + 7) >> 3, rb = 32 * nc8 + 16;
+  const int ls = (k + 1) | 1;
+  float* scl = lds + 64 * ls;
+  const int64_t j0 = block * 64;
+  const int64_t j = j0 + lane;
+  const bool real = j < P;                    // (j == P: the zero record; j > P: nothing)
+  const int64_t jc = real ? j : (P > 0 ? P - 1 : 0);
+  for (int i0 = 0; i0 < k; i0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = i0 + u < k ? i0 + u : k - 1;
+      v[u] = (P > 0) ? J.Yb[(int64_t)i * P + jc] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (i0 + u < k) lds[lane * ls + i0 + u] = real ? v[u] : 0.0f;
+  }
+  const float dj = (real && P > 0) ? J.d[jc] : 0.0f;
+  do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0);
+  unsigned mx = 0u;
+  for (int i = 0; i < k; ++i) {
+    const unsigned a = __float_as_uint(lds[lane * ls + i]) & 0x7fffffffu;
+    mx = a > mx ? a : mx;
+  }
+  int es;
+  const float sc = pow2_scale(mx, 9, &es);
+  const float wd = dj * sc;
+  const bool bad = mx >= 0x7f800000u || !(fabsf(wd) < 3.0e38f);
+  scl[lane] = sc;
+  if (j <= P) {
+    const float E = bad ? __builtin_nanf("") : __uint_as_float((unsigned)(127 - es) << 23);
+    *reinterpret_cast<f4w*>(J.rec + j * rb + 32 * nc8) = f4w{wd, E, 0.0f, 0.0f};
+  }
+  do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0);
+  const int nvalid = P + 1 - j0 < 64 ? (int)(P + 1 - j0) : 64;
+  const int nq = nvalid * nc8;
+  int r = lane / nc8, c = lane - r * nc8;
+  const int dr = 64 / nc8, dc = 64 - dr * nc8;
+  for (int q = lane; q < nq; q += 64) {
+    const float s = scl[r];
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = 8 * c + i < k ? lds[r * ls + 8 * c + i] * s : 0.0f;
+    h8v hi, lo;
+    split8(x, hi, lo);
+    unsigned char* o = J.rec + (j0 + r) * rb + 32 * c;
+    *reinterpret_cast<h8v*>(o) = hi;
+    *reinterpret_cast<h8v*>(o + 16) = lo;
+    r += dr; c += dc;
+    if (c >= nc8) { c -= nc8; ++r; }
+  }
+}
+
+static inline size_t split_pack_lds(int k) { return ((size_t)64 * ((k + 1) | 1) + 64) * sizeof(float); }
+
 // host side (tile_lists.hip)
 struct ScanParams;
 int split_pack_launch(const float* Yb, const float* d, int k, int64_t P, void* rec, hipStream_t stream);

@@ -755,17 +755,19 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
                             {8, exch ? 4 : 0, exch ? (int64_t)done_ints : 0}};
       // bucket index: one kernel over the cell grid this workspace already holds (validated per observation); the first step on a
       // workspace, or one sent back by error bit 8, runs the bounding-box kernel first
+      // (the split records ride in the bucket kernel -- small, and no LDS of its own -- rather than in the tile-list kernel, whose
+      //  occupancy the packing's 10 KB of LDS per workgroup would cap)
+      const mia::SplitPackJob sj{Yb, d, (unsigned char*)(base + L.hrec), k};
       if (tl_bucket)
         rc = mia::index_bucket_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, base + L.loc, L.loc_bytes, ps,
                                           zero_in_kernel ? &zj : nullptr,
-                                          !(step_flags & MIA_STEP_WS_CLEAN) || (step_flags & MIA_STEP_FRESH_BOX));
+                                          !(step_flags & MIA_STEP_WS_CLEAN) || (step_flags & MIA_STEP_FRESH_BOX), &sj);
       else
         rc = mia::index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, base + L.loc, L.loc_bytes, ps, nullptr,
                                    zero_in_kernel ? &zj : nullptr, (step_flags & MIA_STEP_WS_CLEAN) != 0, false);
       if (rc != MIA_OK) return rc;
-      const mia::SplitPackJob sj{Yb, d, (unsigned char*)(base + L.hrec), k};
       rc = mia::tile_lists_launch(grid_xyz, b0, b1 - b0, P, n_coord, coord_group, gc_c, n_r, gc_eps, MIA_TAPER_GC, L.ut,
-                                  base + L.tl, ctr, base + L.loc, ps, &sj, tl_bucket);
+                                  base + L.tl, ctr, base + L.loc, ps, tl_bucket ? nullptr : &sj, tl_bucket);
       if (rc != MIA_OK) return rc;
     } else if (b1 > b0) {
       // the record packing rides inside the first index kernel too (independent work, no launch of its own)
@@ -988,10 +990,12 @@ struct StepJob {
   int32_t* host8; void *after, *on; void** done_event; void *t0, *t1;
   hipEvent_t pe = nullptr; uint32_t seq = 0;
   hipEvent_t kdone = nullptr;      // completion event carried by the analysis launch itself (stage 2), if any
+  int opts[MIA_OPT_COUNT_];        // the route options as they stood when the caller submitted the step
   int device = 0;
   int rc = 0;
   bool done = false;
   int run(int stage) {
+    struct Scope { Scope(const int* o) { mia::option_override(o); } ~Scope() { mia::option_override(nullptr); } } scope(opts);
     return step_impl(X, G, m, k, Yb, d, P, grid, obs, n_coord, cg, rc_, n_r, eps, inf, gamma, method, hint, comm, n_chunks, phase,
                      Xa, flags, counters, ws, ws_bytes, stream, comm_stream, prep_stream, step_flags, stage, &pe, &seq,
                      (hipEvent_t)t0, (hipEvent_t)t1, stage == 2 ? &kdone : nullptr);
@@ -1102,6 +1106,7 @@ extern "C" int mia_letkf_step_submit(const float* X, int64_t G, int m, int k, co
   j->counters = counters; j->ws = ws; j->ws_bytes = ws_bytes; j->stream = stream; j->comm_stream = comm_stream;
   j->prep_stream = prep_stream; j->step_flags = step_flags; j->host8 = host8; j->after = after_stream; j->on = on_stream;
   j->done_event = done_event; j->t0 = time_start_event; j->t1 = time_stop_event;
+  mia::option_snapshot(j->opts);
   if (hipGetDevice(&j->device) != hipSuccess) { (void)hipGetLastError(); delete j; return MIA_ERR_UNSUPPORTED; }
   {
     std::lock_guard<std::mutex> lk(g_launcher.mu);

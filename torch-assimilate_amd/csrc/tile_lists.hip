@@ -19,75 +19,12 @@ namespace mia {
 
 #define MIA_TL_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-// ---- split records ---------------------------------------------------------------------------------------------------
-// One wavefront packs records j0 .. j0 + 63 (indices up to P: record P is the all-zero record).  Lane j reads entry j of
-// every row of Yb (256-byte row segments, sixteen rows requested before any is consumed) into an LDS image [64][ls], ls odd;
-// every lane then finds its record's largest member magnitude (-> power of two), writes the tail, and the chunks of the
-// 64 records are converted by all lanes, one chunk of eight members (32 bytes out) per lane and trip.
-// lds: 64 * ls floats + 64 floats, ls = (k + 1) | 1.
-__device__ inline void pack_split_wave(const SplitPackJob& J, int64_t P, int64_t block, float* lds) {
-  const int lane = threadIdx.x & 63;
-  const int k = J.k, nc8 = (k + 7) >> 3, rb = 32 * nc8 + 16;
-  const int ls = (k + 1) | 1;
-  float* scl = lds + 64 * ls;
-  const int64_t j0 = block * 64;
-  const int64_t j = j0 + lane;
-  const bool real = j < P;                    // (j == P: the zero record; j > P: nothing)
-  const int64_t jc = real ? j : (P > 0 ? P - 1 : 0);
-  for (int i0 = 0; i0 < k; i0 += 16) {
-    float v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int i = i0 + u < k ? i0 + u : k - 1;
-      v[u] = (P > 0) ? J.Yb[(int64_t)i * P + jc] : 0.0f;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u)
-      if (i0 + u < k) lds[lane * ls + i0 + u] = real ? v[u] : 0.0f;
-  }
-  const float dj = (real && P > 0) ? J.d[jc] : 0.0f;
-  MIA_TL_SYNC();
-  unsigned mx = 0u;
-  for (int i = 0; i < k; ++i) {
-    const unsigned a = __float_as_uint(lds[lane * ls + i]) & 0x7fffffffu;
-    mx = a > mx ? a : mx;
-  }
-  int es;
-  const float sc = pow2_scale(mx, 9, &es);
-  const float wd = dj * sc;
-  const bool bad = mx >= 0x7f800000u || !(fabsf(wd) < 3.0e38f);
-  scl[lane] = sc;
-  if (j <= P) {
-    const float E = bad ? __builtin_nanf("") : __uint_as_float((unsigned)(127 - es) << 23);
-    *reinterpret_cast<f4w*>(J.rec + j * rb + 32 * nc8) = f4w{wd, E, 0.0f, 0.0f};
-  }
-  MIA_TL_SYNC();
-  const int nvalid = P + 1 - j0 < 64 ? (int)(P + 1 - j0) : 64;
-  const int nq = nvalid * nc8;
-  int r = lane / nc8, c = lane - r * nc8;
-  const int dr = 64 / nc8, dc = 64 - dr * nc8;
-  for (int q = lane; q < nq; q += 64) {
-    const float s = scl[r];
-    float x[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = 8 * c + i < k ? lds[r * ls + 8 * c + i] * s : 0.0f;
-    h8v hi, lo;
-    split8(x, hi, lo);
-    unsigned char* o = J.rec + (j0 + r) * rb + 32 * c;
-    *reinterpret_cast<h8v*>(o) = hi;
-    *reinterpret_cast<h8v*>(o + 16) = lo;
-    r += dr; c += dc;
-    if (c >= nc8) { c -= nc8; ++r; }
-  }
-}
-
 struct SplitPackParams { SplitPackJob job; int64_t P; };
 __global__ __launch_bounds__(64) void pack_split_kernel(SplitPackParams p) {
   extern __shared__ __attribute__((aligned(16))) float pk_lds[];
   pack_split_wave(p.job, p.P, (int64_t)blockIdx.x, pk_lds);
 }
 
-static size_t split_pack_lds(int k) { return ((size_t)64 * ((k + 1) | 1) + 64) * sizeof(float); }
 
 int split_pack_launch(const float* Yb, const float* d, int k, int64_t P, void* rec, hipStream_t stream) {
   if (k < 1 || k > 1024 || P < 0) return MIA_ERR_SIZE;
@@ -104,6 +41,25 @@ int split_pack_launch(const float* Yb, const float* d, int k, int64_t P, void* r
 }
 
 // ---- tile lists ------------------------------------------------------------------------------------------------------
+// Gaspari-Cohn taper in float32 from the float64 squared distance -- the weights enter a float32 analysis, so float32
+// accuracy is what they need; what must stay the reference's is the DECISION `w > eps`, and that is re-taken in float64 for the
+// (rare) pairs whose float32 weight lies within 1e-4 of eps (localize_tiles_kernel).  Written so that nothing cancels:
+//   outer branch  f2(r) = (2 - r)^4 (r^2 / 12 + r / 6 - 1 / 24) / r      (the polynomial of gaspari_cohn.py:87-95 has a fourth-
+//   order zero at r = 2; its Horner form loses all digits there in float32), and 2 - r = (4 c^2 - d^2) / (c^2 (2 + r)) with the
+//   numerator formed in float64 -- relative error of the weight ~6e-7 up to the edge of the support.
+__device__ __forceinline__ float gc_taper_fast(double d2, double four_c2, float inv_c, float c, float inv_c2) {
+  const float d2f = (float)d2;
+  if (!(d2f > 0.0f)) return d2 == 0.0 ? 1.0f : 0.0f;             // r = 0 -> 1; NaN -> 0
+  const float y = __builtin_amdgcn_rsqf(d2f);
+  const float r = d2f * y * inv_c, rinv = c * y;
+  const float f1 = (((-0.25f * r + 0.5f) * r + 0.625f) * r - 5.0f / 3.0f) * r * r + 1.0f;
+  const float t = (float)(four_c2 - d2) * inv_c2 * __builtin_amdgcn_rcpf(2.0f + r);      // 2 - r
+  const float t2 = t * t;
+  const float f2 = t2 * t2 * ((r * (1.0f / 12.0f) + 1.0f / 6.0f) * r - 1.0f / 24.0f) * rinv;
+  return r < 1.0f ? f1 : (r < 2.0f ? f2 : 0.0f);
+}
+
+
 constexpr int kTlUmax = 96;           // largest union (UT = 6)
 constexpr int kTlMaxRows = 64;        // cell rows of a tile's box (outer coordinates); more = scattered points: no tile list
 
@@ -139,7 +95,7 @@ __global__ __launch_bounds__(64) void localize_tiles_kernel(TileLocParams p) {
   int* cgs = reinterpret_cast<int*>(gxs + 16 * MIA_MAX_COORD);        // [16][3] their cells
   int* ukey = cgs + 16 * MIA_MAX_COORD;                               // [kTlUmax] observation index of union member u
   int* uinv = ukey + kTlUmax;                                         // [kTlUmax] member of slot s, -1 = unused
-  float* Wt = reinterpret_cast<float*>(uinv + kTlUmax);               // [kTlUmax][16] sqrt(rho) of (member, point), 0 = not local
+  float* Wt = reinterpret_cast<float*>(uinv + kTlUmax);               // [16 ut][16] sqrt(rho) of (member, point), 0 = not local
   const ScanParams& q = p.scan;
   const IndexHeader* hd = q.hdr;
   constexpr int nc = NC;
@@ -193,6 +149,15 @@ __global__ __launch_bounds__(64) void localize_tiles_kernel(TileLocParams p) {
 #pragma unroll
   for (int c = 0; c < NC; ++c) grp[c] = NC == 1 ? 0 : q.group[c];
   const int n_r = NC == 1 ? 1 : q.n_r;
+  // (float32 copies of the taper's constants, float64 4 c^2)
+  const float epsf = (float)q.eps;
+  double fc2[MIA_MAX_RADII];
+  float icf[MIA_MAX_RADII], ccf[MIA_MAX_RADII], ic2f[MIA_MAX_RADII];
+#pragma unroll
+  for (int r = 0; r < MIA_MAX_RADII; ++r) {
+    fc2[r] = 4.0 * q.cc[r] * q.cc[r];
+    icf[r] = (float)q.inv_c[r]; ccf[r] = (float)q.cc[r]; ic2f[r] = (float)(q.inv_c[r] * q.inv_c[r]);
+  }
   auto weigh = [&](bool have, int64_t pos) {
     const int oj = q.sorted[pos];
     double ox[NC];
@@ -211,12 +176,32 @@ __global__ __launch_bounds__(64) void localize_tiles_kernel(TileLocParams p) {
         for (int r = 0; r < (NC == 1 ? 1 : MIA_MAX_RADII); ++r)
           if (grp[c] == r) d2[r] += dx * dx;
       }
-      double wgt = 1.0;
+      bool use;
+      if constexpr (TAPER == MIA_TAPER_GC) {
+        float wf = 1.0f;
 #pragma unroll
-      for (int r = 0; r < (NC == 1 ? 1 : MIA_MAX_RADII); ++r)
-        if (r < n_r) wgt *= TAPER == MIA_TAPER_GC_INF ? gc_inf_taper_d2(d2[r], q.inv_c[r], q.cc[r]) : gc_taper_d2(d2[r], q.inv_c[r], q.cc[r]);
-      const bool use = have && pt < npts && wgt > q.eps;
-      wq[i] = use ? (float)(wgt * rsqrt_f64(wgt)) : 0.0f;
+        for (int r = 0; r < (NC == 1 ? 1 : MIA_MAX_RADII); ++r)
+          if (r < n_r) wf *= gc_taper_fast(d2[r], fc2[r], icf[r], ccf[r], ic2f[r]);
+        use = wf > epsf;
+        // the decision is the float64 one: pairs whose float32 weight is within 1e-4 of eps are weighed again in float64
+        const bool amb = have && pt < npts && fabsf(wf - epsf) < 1e-4f * epsf;
+        if (__any(amb)) {
+          if (amb) {
+            double wgt = 1.0;
+            for (int r = 0; r < n_r; ++r) wgt *= gc_taper_d2(d2[r], q.inv_c[r], q.cc[r]);
+            use = wgt > q.eps;
+          }
+        }
+        use = use && have && pt < npts;
+        wq[i] = use ? wf * __builtin_amdgcn_rsqf(wf) : 0.0f;
+      } else {
+        double wgt = 1.0;
+#pragma unroll
+        for (int r = 0; r < (NC == 1 ? 1 : MIA_MAX_RADII); ++r)
+          if (r < n_r) wgt *= gc_inf_taper_d2(d2[r], q.inv_c[r], q.cc[r]);
+        use = have && pt < npts && wgt > q.eps;
+        wq[i] = use ? (float)(wgt * rsqrt_f64(wgt)) : 0.0f;
+      }
       anyu = anyu || use;
       const unsigned long long bal = __ballot(use);
       cnt4[i] += __popc((unsigned)(bal >> (16 * pg)) & 0xffffu);
@@ -226,7 +211,7 @@ __global__ __launch_bounds__(64) void localize_tiles_kernel(TileLocParams p) {
     const unsigned memb = (unsigned)((anyb | (anyb >> 16) | (anyb >> 32) | (anyb >> 48)) & 0xffffull);
     const bool member = (memb >> cl) & 1u;
     const int u = ubase + __popc(memb & ((1u << cl) - 1u));
-    if (member && u < kTlUmax) {
+    if (member && u < UMAX) {
       if (pg == 0) ukey[u] = oj;
       *reinterpret_cast<f4w*>(Wt + u * 16 + 4 * pg) = wq;
     }
@@ -319,8 +304,8 @@ __global__ __launch_bounds__(64) void localize_tiles_kernel(TileLocParams p) {
   }
 }
 
-static size_t tile_loc_lds() {
-  return 16 * MIA_MAX_COORD * (sizeof(double) + sizeof(int)) + 2 * kTlUmax * sizeof(int) + (size_t)kTlUmax * 16 * sizeof(float);
+static size_t tile_loc_lds(int ut) {
+  return 16 * MIA_MAX_COORD * (sizeof(double) + sizeof(int)) + 2 * kTlUmax * sizeof(int) + (size_t)16 * ut * 16 * sizeof(float);
 }
 
 int tile_lists_launch(const double* grid_xyz, int64_t g0, int64_t ng, int64_t P, int n_coord, const int32_t* coord_group,
@@ -330,7 +315,7 @@ int tile_lists_launch(const double* grid_xyz, int64_t g0, int64_t ng, int64_t P,
   if (!tile_lists || !stats) return MIA_ERR_NULL;
   const TileListLayout L = tile_list_layout(ng, ut);
   unsigned nb_pack = 0;
-  size_t lds = tile_loc_lds();
+  size_t lds = tile_loc_lds(ut);
   TileLocParams tp;
   tp.pack = SplitPackJob{nullptr, nullptr, nullptr, 0};
   if (pack && pack->rec) {
