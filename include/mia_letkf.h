@@ -265,6 +265,12 @@ int mia_letkf_weights_retry_f32(const float* X, int64_t ldx, int m, int k, int64
  *     records; dual route (p_max <= k <= 96, p_max <= 88), any number m of state rows.  flags / retry_count as
  *     mia_letkf_analysis_matfun_f32: declined points (and every point of a tile that holds a non-finite record) get
  *     MIA_FLAG_RETRY and are redone by mia_letkf_analysis_retry_f32 from per-point lists.
+ * mia_letkf_weights_tiles_f32  the same analysis AND the weights W [g1-g0][k][k], W[g][i][j] = w_mean_i + W_pert_ij (what
+ *     LETKF.estimate_weights returns, interface/letkf.py:127-146): the Chebyshev recurrence on a matrix block per grid point,
+ *     four points of a tile per wavefront (csrc/letkf_tile2w.hip).  Unions of at most 32 slots
+ *     (ceil((p_max + 8) / 16) + extra_blocks <= 2), otherwise MIA_ERR_UNSUPPORTED (use
+ *     mia_letkf_weights_matfun_f32).  Declined points: MIA_FLAG_RETRY, counted, left untouched in Xa and W;
+ *     mia_letkf_weights_retry_f32 redoes them from per-point lists.
  * ---------------------------------------------------------------------------------- */
 int mia_letkf_tile_lists_bytes(int64_t n_points, int p_max, int extra_blocks, size_t* bytes);
 int mia_letkf_localize_tiles_f64(int taper, const double* grid_xyz, int64_t g0, int64_t g1,
@@ -279,6 +285,10 @@ int mia_letkf_analysis_tiles_f32(const float* X, int64_t ldx, int m, int k, int6
                                  const void* split_rec, int64_t P, const void* tile_lists, int p_max, int extra_blocks,
                                  float inf_factor, float* Xa, int64_t ldo, int64_t o0, int32_t* flags,
                                  int32_t* retry_count, void* stream);
+int mia_letkf_weights_tiles_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                const void* split_rec, int64_t P, const void* tile_lists, int p_max, int extra_blocks,
+                                float inf_factor, float* Xa, int64_t ldo, int64_t o0, float* W /* [g1-g0][k][k] */,
+                                int32_t* flags, int32_t* retry_count, void* stream);
 
 /* matfun route with the Gaspari-Cohn localisation fused in: every wavefront scans the observation index
  * (mia_letkf_index_build_f64) for its grid point itself, so no neighbour lists are written or read.

@@ -377,3 +377,67 @@ def test_strong_observations_are_redone_in_float64(eng, k, c, sy, sx):
     # the same through the round-2 kernel on per-point lists (same redo)
     xo = eng.analysis(X, Yb, D, nb, 1.1, method="matfun")
     assert rel_fro(xo.cpu().numpy(), ref) < TOL32
+
+
+WCASES = [(40, 2, 10.0, 1), (10, 1, 1.6, 1), (24, 2, 6.5, 2), (64, 2, 12.0, 1), (33, 2, 3.0, 1), (20, 4, 18.0, 1), (96, 3, 16.0, 1),
+          (16, 2, 7.0, 1)]
+
+
+@pytest.mark.parametrize("k,stride,c,m", WCASES)
+def test_weights_on_the_tile_route_vs_oracle(eng, k, stride, c, m):
+    """LETKF.estimate_weights semantics (letkf.py:127-146: W[g, i, j] = w_mean_i + W_pert_ij) from tile lists and split
+    records (mia_letkf_weights_tiles_f32, csrc/letkf_tile2w.hip): unions of one and two sixteen-row blocks, one to six member
+    blocks, ensemble sizes that are not multiples of 8 or 16, ragged last tile.  Weights and analysis against the oracle; the
+    analysis equals the plain tile launch bit for bit; applying the weights reproduces the analysis."""
+    case = O.synthetic_case(203, k, stride, seed=3 * k + m, m=m)
+    nb = eng.localize(case["grid_x"], case["obs_x"], [c])
+    tiles = eng.localize_tiles(case["grid_x"], case["obs_x"], [c], nb.p_max)
+    if tiles.stats.tolist()[1]:
+        tiles = eng.localize_tiles(case["grid_x"], case["obs_x"], [c], nb.p_max, extra_blocks=1)
+    assert tiles.stats.tolist() == [nb.p_max, 0] and tiles.ut <= 2
+    rec = eng.pack_split(dev(case["yb"]), dev(case["d"]))
+    P = case["yb"].shape[1]
+    X = dev(case["state"])
+    for inf in (1.0, 1.1):
+        xa, W, fl, retry = eng.weights_tiles(X, rec, P, tiles, inf)
+        assert int(retry.item()) == 0 and int((fl & 0xff).max().item()) == 0
+        ref_xa, ref_w = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], case["yb"], case["d"], c, inf)
+        Wn = W.cpu().numpy()
+        assert rel_fro(Wn, ref_w) < TOL32
+        assert rel_fro(Wn - np.eye(k), ref_w - np.eye(k)) < 5e-5
+        assert rel_fro(xa.cpu().numpy(), ref_xa) < TOL32
+        xa2 = eng.analysis_tiles(X, rec, P, tiles, inf)[0]
+        assert torch.equal(xa, xa2)
+        mean = X.mean(dim=1, keepdim=True)
+        applied = mean + torch.einsum("mig,gij->mjg", X - mean, W)
+        assert rel_fro(applied.cpu().numpy(), ref_xa) < TOL32
+
+
+def test_weights_on_tiles_declined_points_and_mixed_magnitudes(eng):
+    """Declined points keep MIA_FLAG_RETRY and are redone with weights by the eigensolver kernel (mia_letkf_weights_retry_f32);
+    observation types of very different magnitudes inside one tile keep the weights within the tolerance."""
+    case = O.synthetic_case(203, 40, 2, seed=77)
+    c = 10.0
+    nb = eng.localize(case["grid_x"], case["obs_x"], [c])
+    tiles = eng.localize_tiles(case["grid_x"], case["obs_x"], [c], nb.p_max)
+    P = case["yb"].shape[1]
+    X = dev(case["state"])
+    # (a) strong observations on part of the domain: those points are declined
+    sc = np.where(case["obs_x"] < 80, 14.0, 1.0)
+    yb, d = case["yb"] * sc, case["d"] * sc
+    rec = eng.pack_split(dev(yb), dev(d))
+    xa, W, fl, retry = eng.weights_tiles(X, rec, P, tiles, 1.1)
+    n_retry = int(retry.item())
+    f = fl.cpu().numpy()
+    assert 0 < n_retry < 203 and ((f & 8) != 0).sum() == n_retry
+    eng.weights_retry(X, dev(yb), dev(d), nb, 1.1, xa, W, fl)
+    ref_xa, ref_w = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], yb, d, c, 1.1)
+    assert rel_fro(W.cpu().numpy(), ref_w) < 5e-5 and rel_fro(xa.cpu().numpy(), ref_xa) < TOL32
+    # (b) two observation types, normalised magnitudes 1e-4 and 2
+    s = np.where(np.arange(P) % 2 == 0, 1e-4, 2.0)
+    yb, d = case["yb"] * s, case["d"] * s
+    rec = eng.pack_split(dev(yb), dev(d))
+    xa, W, fl, retry = eng.weights_tiles(X, rec, P, tiles, 1.1)
+    assert int(retry.item()) == 0
+    ref_xa, ref_w = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], yb, d, c, 1.1)
+    assert rel_fro(W.cpu().numpy(), ref_w) < TOL32 and rel_fro(W.cpu().numpy() - np.eye(40), ref_w - np.eye(40)) < 5e-5

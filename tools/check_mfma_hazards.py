@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Static check of the compiled tile kernels for a hazard the compiler missed once (letkf_tile2w.hip, UT = 1): a vector
+or memory instruction reading (or overwriting) the result of a v_mfma fewer than 8 wait states after it, on ANY path -- the taken side of a branch
+included (the compiler had padded only the fall-through side).  Usage: python tools/check_mfma_hazards.py file.hip [flags]
+(compiles to assembly with hipcc -S --cuda-device-only and walks every kernel)."""
+import re, subprocess, sys, os, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NEED = 8
+
+
+def regs(tok):
+    tok = tok.strip().rstrip(",")
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def operands(line):
+    body = line.split(";")[0].strip()
+    parts = body.split(None, 1)
+    if len(parts) < 2:
+        return parts[0] if parts else "", []
+    return parts[0], [t for t in re.split(r",\s*", parts[1])]
+
+
+def check(asm):
+    lines = asm.splitlines()
+    labels = {l.split(":")[0]: i for i, l in enumerate(lines) if re.match(r"^[.\w$]+:", l)}
+    bad = []
+    kernel = None
+    for i, l in enumerate(lines):
+        if re.match(r"^_Z\w+:", l):
+            kernel = l.split(":")[0]
+        op, ops = operands(l)
+        if not op.startswith("v_mfma"):
+            continue
+        dst = regs(ops[0])
+        stack, seen = [(i + 1, 0)], set()
+        while stack:
+            j, ws = stack.pop()
+            while j < len(lines) and ws < NEED:
+                if (j, ws) in seen:
+                    break
+                seen.add((j, ws))
+                o, a = operands(lines[j])
+                if not o or o.endswith(":") or o.startswith(".") or o.startswith(";"):
+                    j += 1
+                    continue
+                if o == "s_endpgm":
+                    break
+                if o.startswith("v_mfma"):
+                    # a dependent MFMA (srcC or operand) is interlocked by other rules; an independent one does not read dst
+                    pass
+                elif o.startswith(("v_", "global_store", "ds_write", "buffer_store", "flat_store", "ds_bpermute", "ds_read", "global_load")):
+                    # any read of the result, and any write over it (the matrix instruction's own write would land later)
+                    if any(regs(t) & dst for t in a):
+                        bad.append((kernel, i + 1, j + 1, ws, lines[i].strip(), lines[j].strip()))
+                        break
+                if o == "s_nop":
+                    ws += int(a[0]) + 1
+                else:
+                    ws += 1
+                if o == "s_branch":
+                    j = labels.get(a[0], len(lines))
+                    continue
+                if o.startswith("s_cbranch"):
+                    stack.append((labels.get(a[0], len(lines)), ws))
+                j += 1
+    return bad
+
+
+if __name__ == "__main__":
+    src = sys.argv[1]
+    flags = sys.argv[2:]
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+               "-I" + os.path.join(ROOT, "torch-assimilate_amd", "csrc"), "--cuda-device-only", "-S", src, "-o", out] + flags
+        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+        bad = check(open(out).read())
+    for b in bad[:40]:
+        print("HAZARD kernel %s: mfma at line %d read at line %d after %d wait states\n   %s\n   %s" % b)
+    print("%s: %d hazard(s)" % (os.path.basename(src), len(bad)))
+    sys.exit(1 if bad else 0)

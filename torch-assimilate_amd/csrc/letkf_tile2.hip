@@ -34,8 +34,6 @@
 
 namespace mia {
 
-#define MIA_T2_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
-
 struct Tile2Params {
   const float* X; int64_t ldx; int m, k;
   int64_t g0, ng;
@@ -54,45 +52,6 @@ struct Tile2Params {
   int* clr_counts; const int* clr_n; unsigned* clr_err; int32_t* err_out;
   int stagger;      // (experiment builds) start delay per wave slot of a SIMD, in units of 64 cycles
 };
-
-__device__ __forceinline__ float t2_add_h(float v) {       // sum over the four lanes (lr, h = 0..3), in every one of them
-  typedef unsigned u2v __attribute__((ext_vector_type(2)));
-  u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = __uint_as_float(r.x) + __uint_as_float(r.y);
-  r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-__device__ __forceinline__ unsigned t2_max_h(unsigned u) {   // maximum of bit patterns over the same four lanes
-  typedef unsigned u2v __attribute__((ext_vector_type(2)));
-  u2v r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  u = r.x > r.y ? r.x : r.y;
-  r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  return r.x > r.y ? r.x : r.y;
-}
-__device__ __forceinline__ unsigned t2_wave_max_u32(unsigned u) {     // wave-uniform maximum (DPP)
-  unsigned t;
-  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0xB1, 0xf, 0xf, false); u = u > t ? u : t;
-  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x4E, 0xf, 0xf, false); u = u > t ? u : t;
-  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x124, 0xf, 0xf, false); u = u > t ? u : t;
-  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x128, 0xf, 0xf, false); u = u > t ? u : t;
-  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)u, 0), b = (unsigned)__builtin_amdgcn_readlane((int)u, 16);
-  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)u, 32), d = (unsigned)__builtin_amdgcn_readlane((int)u, 48);
-  const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
-  return ab > cd ? ab : cd;
-}
-__device__ __forceinline__ f4w t2_mfma3(f4w acc, const h8v ah, const h8v al, const h8v bh, const h8v bl) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
-}
-template <typename T>
-__device__ __forceinline__ T t2_ld(const void* base, unsigned byte_off) {     // wave-uniform base + 32-bit lane offset
-  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
-}
-typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
-__device__ __forceinline__ s4v t2_tr_read(const unsigned char* lds_addr) {     // ds_read_b64_tr_b16 (EXEC must be all ones)
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)lds_addr);
-}
 
 // In-kernel phase stamps (diagnostic builds only, tools/tile2_stamps.py): -DMIA_TILE_STAMPS compiles them in; the stamp values
 // go to a buffer of their own that nothing else reads.  Slots 0 .. 8: s_memtime at the phase boundaries; 9: where the wave ran
@@ -385,7 +344,7 @@ void letkf_tile2_kernel(Tile2Params P) {
     const float inv_sd = __uint_as_float((unsigned)(127 - esd) << 23);
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
-      if (32 * kb < U) {
+      if (kb == 0 || 32 * kb < U) {     // (kb = 0 unconditionally: no branch between this product and the use of its result)
         float dv[8];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)

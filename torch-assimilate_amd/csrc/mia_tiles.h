@@ -99,6 +99,33 @@ __device__ __forceinline__ void split8(const float (&x)[8], h8v& hi, h8v& lo) {
   hi = __builtin_bit_cast(h8v, hu);
   lo = __builtin_bit_cast(h8v, lu);
 }
+// The same with the lo halves written OVER A COPY of the hi halves (four register moves more): the outputs of split8 are fresh
+// registers of the allocator's choice, and it may choose one that a matrix instruction wrote a few cycles earlier -- the
+// compiler pads neither side of inline assembly, so the (later) write of the matrix instruction could land on top of the lo
+// halves.  tools/check_mfma_hazards.py finds such places in a build; code outside the hottest loops uses this form.
+__device__ __forceinline__ void split8_tied(const float (&x)[8], h8v& hi, h8v& lo) {
+  u4w hu, lu;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f2w v = {x[2 * i], x[2 * i + 1]};
+    const h2v a = __builtin_convertvector(v, h2v);
+    hu[i] = __builtin_bit_cast(unsigned, a);
+    lu[i] = hu[i];
+  }
+  asm("v_fma_mixlo_f16 %0, %0, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %1, %1, -1.0, %6 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %1, %1, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %2, %2, -1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %2, %2, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %3, %3, -1.0, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %3, %3, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "s_nop 1"
+      : "+v"(lu[0]), "+v"(lu[1]), "+v"(lu[2]), "+v"(lu[3])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+  hi = __builtin_bit_cast(h8v, hu);
+  lo = __builtin_bit_cast(h8v, lu);
+}
 __device__ __forceinline__ h8v hi8(const float (&x)[8]) {
   h8v hi;
 #pragma unroll
@@ -109,6 +136,48 @@ __device__ __forceinline__ h8v hi8(const float (&x)[8]) {
   }
   return hi;
 }
+
+// ---- wave helpers of the tile kernels (letkf_tile2.hip, letkf_tile2w.hip) ----------------------------------------------
+#define MIA_T2_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+__device__ __forceinline__ float t2_add_h(float v) {       // sum over the four lanes (lr, h = 0..3), in every one of them
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r.x) + __uint_as_float(r.y);
+  r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ unsigned t2_max_h(unsigned u) {   // maximum of bit patterns over the same four lanes
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  u2v r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  u = r.x > r.y ? r.x : r.y;
+  r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return r.x > r.y ? r.x : r.y;
+}
+__device__ __forceinline__ unsigned t2_wave_max_u32(unsigned u) {     // wave-uniform maximum (DPP)
+  unsigned t;
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0xB1, 0xf, 0xf, false); u = u > t ? u : t;
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x4E, 0xf, 0xf, false); u = u > t ? u : t;
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x124, 0xf, 0xf, false); u = u > t ? u : t;
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x128, 0xf, 0xf, false); u = u > t ? u : t;
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)u, 0), b = (unsigned)__builtin_amdgcn_readlane((int)u, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)u, 32), d = (unsigned)__builtin_amdgcn_readlane((int)u, 48);
+  const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
+}
+__device__ __forceinline__ f4w t2_mfma3(f4w acc, const h8v ah, const h8v al, const h8v bh, const h8v bl) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+}
+template <typename T>
+__device__ __forceinline__ T t2_ld(const void* base, unsigned byte_off) {     // wave-uniform base + 32-bit lane offset
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
+__device__ __forceinline__ s4v t2_tr_read(const unsigned char* lds_addr) {     // ds_read_b64_tr_b16 (EXEC must be all ones)
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)lds_addr);
+}
+
 
 // split-record packing job (rides in the tile-list kernel as extra single-wave workgroups, or runs as a launch of its own)
 struct SplitPackJob { const float* Yb; const float* d; unsigned char* rec; int k; };

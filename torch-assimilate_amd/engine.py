@@ -244,6 +244,35 @@ class LetkfEngine:
             "mia_letkf_analysis_tiles_f32")
         return xa, flags[:n], retry
 
+    def weights_tiles(self, X: torch.Tensor, split_rec: torch.Tensor, P: int, tiles: "TileLists", inf_factor: float = 1.0):
+        """Analysis + weights of the tile lists' grid points (mia_letkf_weights_tiles_f32).  Returns (Xa [m, k, n], W [n, k, k],
+        flags [n], retry_count [1]) or None when the shape is outside the kernel (unions of more than 32 slots)."""
+        X = X.to(device=self.device, dtype=torch.float32).contiguous()
+        m, k, G = X.shape
+        n = tiles.g1 - tiles.g0
+        xa = torch.empty((m, k, n), dtype=torch.float32, device=self.device)
+        W = torch.empty((n, k, k), dtype=torch.float32, device=self.device)
+        flags = torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)
+        retry = torch.zeros(1, dtype=torch.int32, device=self.device)
+        rc = self.lib.mia_letkf_weights_tiles_f32(
+            _ptr(X), G, m, k, tiles.g0, tiles.g1, _ptr(split_rec), int(P), _ptr(tiles.lists), tiles.p_max, tiles.extra_blocks,
+            float(inf_factor), _ptr(xa), xa.shape[-1], 0, _ptr(W), _ptr(flags), _ptr(retry), self._stream())
+        if rc == -3:
+            return None
+        _cabi.check(rc, "mia_letkf_weights_tiles_f32")
+        return xa, W, flags[:n], retry
+
+    def weights_retry(self, X: torch.Tensor, Yb: torch.Tensor, d: torch.Tensor, nbrs: NeighbourLists, inf_factor: float,
+                      out: torch.Tensor, W: torch.Tensor, flags: torch.Tensor):
+        """Eigensolver redo (analysis + weights) of the points flagged MIA_FLAG_RETRY (mia_letkf_weights_retry_f32)."""
+        X = X.contiguous()
+        m, k, G = X.shape
+        rec = self.pack_obs(Yb, d, torch.float32)
+        _cabi.check(self.lib.mia_letkf_weights_retry_f32(
+            _ptr(X), G, m, k, nbrs.g0, nbrs.g1, _ptr(rec), rec.shape[0], _ptr(nbrs.cnt), _ptr(nbrs.idx), _ptr(nbrs.w),
+            nbrs.p_cap, nbrs.p_max, float(inf_factor), 0.0, _ptr(out), out.shape[-1], 0, _ptr(W), _ptr(flags), self._stream()),
+            "mia_letkf_weights_retry_f32")
+
     def tile_route_applies(self, X: torch.Tensor, p_max: int, extra_blocks: int = 0, rbf_gamma=None, method: str = "auto") -> bool:
         """Whether the tile route (tile lists + split records + csrc/letkf_tile2.hip) takes this analysis: float32, plain ETKF
         core, dual route p_max <= k <= 96, the union's row blocks within what the ensemble size allows, route options on."""
