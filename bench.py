@@ -598,6 +598,40 @@ def main():
                                    "point": "letkf_cheb_kernel (one grid point per wavefront)"}[kk])
             secondary[name] = rec
 
+        # LETKF.estimate_weights (interface/letkf.py:127-146) on the tile route: analysis + the (G, k, k) weights
+        try:
+            eng = runner.engine
+            pmw = int(runner.last_p_max or 20)
+            tl = eng.localize_tiles(grid_x, obs_x, [GC_RADIUS], pmw)
+            srec = eng.pack_split(Yb, d)
+            res = eng.weights_tiles(X, srec, P, tl, INF)
+            if res is not None and int(tl.stats[1].item()) == 0:
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(7):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    res = eng.weights_tiles(X, srec, P, tl, INF)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                Wd = res[1]
+                pts = np.random.RandomState(3).choice(G, 64, replace=False)
+                st, yb_h, d_h = X.double().cpu().numpy(), Yb.double().cpu().numpy(), d.double().cpu().numpy()
+                gxh, oxh = grid_x.cpu().numpy(), obs_x.cpu().numpy()
+                refw = np.stack([O.localized_weights(O.abs_distance_1d(gxh[g], oxh), yb_h, d_h, [GC_RADIUS], INF) for g in pts])
+                gotw = Wd[torch.as_tensor(pts, device=device)].double().cpu().numpy()
+                wms = float(np.median(ts[1:]))
+                secondary["c2_weights"] = {
+                    "workload": "G=%d, k=%d: the analysis AND the (G, k, k) weights (estimate_weights), tile route "
+                                "(mia_letkf_weights_tiles_f32: letkf_tile2_kernel + letkf_tile2w_kernel)" % (G, K_ENS),
+                    "ms": wms, "analyses_per_s": G / (wms * 1e-3), "weights_bytes": int(Wd.numel() * 4),
+                    "hbm_floor_ms": Wd.numel() * 4 / 8e12 * 1e3, "declined_points": int(res[3].item()),
+                    "rel_frobenius_error_64_points_vs_oracle": float(np.linalg.norm(gotw - refw) / np.linalg.norm(refw))}
+                del Wd, res
+        except Exception as exc:        # (a secondary figure must not take the bench line down)
+            secondary["c2_weights"] = {"error": repr(exc)}
+
     if rank == 0:
         value = G * args.steps / elapsed
         traffic = traffic_from_profiles(world)

@@ -17,6 +17,7 @@ ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--grid", type=int, default=100000)
 ap.add_argument("--route", default="tiles", choices=["tiles", "lists"],
                 help="tiles: tile lists + split records + letkf_tile2_kernel (configs 2, 4); lists: per-point lists + round-2 kernels")
+ap.add_argument("--weights", action="store_true", help="tiles route: also the (G, k, k) weights (letkf_tile2w_kernel)")
 a = ap.parse_args()
 k, stride, c, gamma = {"c2": (40, 2, 10.0, None), "c4": (80, 1, 16.5, None), "c5": (40, 2, 10.0, 0.5)}[a.config]
 dev = torch.device("cuda:0")
@@ -27,7 +28,10 @@ if a.route == "tiles" and gamma is None:
     for _ in range(a.reps):
         tiles = eng.localize_tiles(gx, ox, [c], nb.p_max)
         srec = eng.pack_split(Yb, d)
-        xa, fl, retry = eng.analysis_tiles(X, srec, Yb.shape[1], tiles, 1.1)
+        if a.weights:
+            xa, W, fl, retry = eng.weights_tiles(X, srec, Yb.shape[1], tiles, 1.1)
+        else:
+            xa, fl, retry = eng.analysis_tiles(X, srec, Yb.shape[1], tiles, 1.1)
     print("tile stats", tiles.stats.tolist(), "declined", int(retry.item()))
 else:
     rec = eng.pack_obs(Yb, d, torch.float32)

@@ -15,7 +15,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU S
   timeout 300 rocprofv3 --pmc $set --output-format csv -d $out/pmc$i -- python3 tools/prof_kernel.py --reps 3 "$@" > $out/pmc$i.log 2>&1
   echo "pass $i done"
 done
-for kn in $kern localize_tiles_kernel; do
+for kn in $kern localize_tiles_kernel letkf_tile2w_kernel; do
   python3 tools/summarize_pmc.py $out $kn > $out/pmc_summary_$kn.json
   cat $out/pmc_summary_$kn.json
 done

@@ -209,7 +209,39 @@ class LETKF(ETKF):
         nb = self._lists(grid_coords, obs_coords, g0, g1, grid_info, obs_info)
         k = yb.shape[0]
         x = torch.zeros((1, k, nb.g1), dtype=self.dtype, device=self.engine.device)
+        W = self._weights_on_tiles(x, yb, d, nb, grid_coords, obs_coords)
+        if W is not None:
+            return W
         _, W = self.engine.analysis(x, yb, d, nb, self.inf_factor, return_weights=True, **self._kernel_args())
+        return W
+
+    def _weights_on_tiles(self, x, yb, d, nb, grid_coords, obs_coords):
+        """The tile route of the weights (engine.weights_tiles: tile lists + split records, csrc/letkf_tile2w.hip) where it
+        applies -- float32, plain ETKF core, a built-in distance, unions of at most 32 observations per tile; declined points are
+        redone with weights by the eigensolver kernel from the per-point lists.  None: the caller takes the per-point route."""
+        eng = self.engine
+        ka = self._kernel_args()
+        if (ka.get("rbf_gamma") is not None or ka.get("kernel_program") is not None
+                or not hasattr(self.localization, "tile_lists") or nb.g1 - nb.g0 <= 0):
+            return None
+        tiles = None
+        for extra in (0, 1):
+            if not eng.tile_route_applies(x, nb.p_max, extra) or max(1, (nb.p_max + 8 + 15) // 16) + extra > 2:
+                return None
+            tiles = self.localization.tile_lists(eng, grid_coords, obs_coords, nb.p_max, nb.g0, nb.g1, extra_blocks=extra)
+            if tiles is None:
+                return None
+            if int(tiles.stats[1].item()) == 0:
+                break
+        else:
+            return None
+        rec = eng.pack_split(yb, d)
+        res = eng.weights_tiles(x, rec, yb.shape[1], tiles, self.inf_factor)
+        if res is None:
+            return None
+        xa, W, flags, retry = res
+        if int(retry.item()):
+            eng.weights_retry(x, yb, d, nb, self.inf_factor, xa, W, flags)
         return W
 
     def analyse_arrays(self, state, yb, d, grid_coords=None, obs_coords=None, g0=0, g1=None,

@@ -118,6 +118,16 @@ class GaspariCohn:
         return engine.merge_neighbour_lists(parts)
 
 
+    def tile_lists(self, engine, grid_xyz, obs_xyz, p_max: int, g0: int = 0, g1: Optional[int] = None, extra_blocks: int = 0):
+        """Tile lists (engine.localize_tiles) of grid points [g0, g1) for the built-in metrics; None for a user callable."""
+        metric = self.builtin_metric
+        if metric is None:
+            return None
+        nc = 1 if np.ndim(grid_xyz) == 1 else np.shape(grid_xyz)[1]
+        return engine.localize_tiles(grid_xyz, obs_xyz, list(self.radius), p_max, metric.groups(nc, len(self.radius)),
+                                     self.epsilon, g0, g1, taper=self._taper, extra_blocks=extra_blocks)
+
+
 class GaspariCohnInf(GaspariCohn):
     """Gaspari-Cohn correlation function with form factor infinity, C_0(z, inf, c): mirror of
     pytassim.localization.GaspariCohnInf (gaspari_cohn.py:139-254).  One length scale (the reference divides the
