@@ -17,7 +17,6 @@ for spec in sys.argv[1:]:
     if tiles.stats.tolist()[1]:
         tiles = eng.localize_tiles(case["grid_x"], case["obs_x"], [c], nb.p_max, extra_blocks=1)
     rec = eng.pack_split(dev(case["yb"]), dev(case["d"]))
-    W0 = torch.full((203, k, k), 7.0, dtype=torch.float32, device="cuda:0")
     r = eng.weights_tiles(dev(case["state"]), rec, case["yb"].shape[1], tiles, 1.1)
     if r is None:
         print(spec, "unsupported"); continue
@@ -27,8 +26,5 @@ for spec in sys.argv[1:]:
     err = np.abs(W - ref_w).reshape(203, -1).max(axis=1)
     nanp = np.flatnonzero(~np.isfinite(err)); bad = np.flatnonzero(np.isfinite(err) & (err > 1e-4))
     zero = np.flatnonzero((W.reshape(203, -1) == 0).all(axis=1))
-    fh = (fl.cpu().numpy() >> 16)
-    print(" marks of all-zero points", sorted(set(fh[zero].tolist())), "of nan points", sorted(set(fh[nanp].tolist())), "of good points",
-          sorted(set(fh[np.flatnonzero(err < 1e-4)].tolist())))
     print(spec, "p_max", nb.p_max, "ut", tiles.ut, "| nan points", nanp.tolist()[:20], "| all-zero points", zero.tolist()[:40],
           "| other wrong", [g for g in bad.tolist() if g not in zero][:20], "| max err of the rest %.2e" % np.nanmax(np.where(err < 1e-4, err, 0)))
