@@ -1,6 +1,11 @@
 import os
 import sys
 
+# The oracle's per-point float64 linear algebra (k <= 96) runs on the host: on a box that shows hundreds of cores to a
+# process entitled to sixteen, every tiny eigh / matmul fanned out over all of them takes 100x longer than on one core.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "4")
+
 import numpy as np
 import pytest
 
@@ -12,6 +17,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    try:
+        import torch
+        torch.set_num_threads(4)
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

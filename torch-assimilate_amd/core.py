@@ -88,8 +88,8 @@ class KETKFModule(ETKFModule):
         gamma, prog = kernel_route(self.kernel, allow_feature_scale=True)
         if gamma is None and prog is None:
             return super().__call__(normed_perts, normed_obs)
-        if prog is None:
-            prog = self.kernel.program()
+        if prog is None:      # (a lone Gauss / RBF kernel: its inputs are divided by a lengthscale vector below, rbf.py:75-78)
+            prog = self.kernel.program(allow_vector=True)
         eng = self.engine
         perts = torch.as_tensor(normed_perts)
         obs = torch.as_tensor(normed_obs)

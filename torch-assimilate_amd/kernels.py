@@ -143,8 +143,8 @@ class GaussKernel(BaseKernel):
     def gamma(self) -> float:
         return 0.5 / self.lengthscale ** 2
 
-    def program(self) -> Program:
-        if self.feature_scale is not None:
+    def program(self, allow_vector: bool = False) -> Program:
+        if self.feature_scale is not None and not allow_vector:
             # (only the top-level kernel of the global KETKF gets its inputs divided by the vector, kernel_route / KETKFModule;
             #  inside a composition the expression route would silently run the unit-lengthscale kernel instead of rbf.py:75-78)
             raise NotImplementedError("a per-observation (vector) lengthscale is supported for a GaussKernel / RBFKernel used on its "
