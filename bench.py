@@ -389,6 +389,7 @@ def main():
                           native_step=os.environ.get("MIA_NATIVE_STEP", "1") != "0",
                           max_in_flight=max(2, args.pipeline_depth),
                           prep_streams=int(os.environ.get("MIA_PREP_STREAMS", "3")),
+                          analysis_streams=int(os.environ.get("MIA_ANALYSIS_STREAMS", "1")),
                           # N > 1: direct peer writes into IPC-mapped result buffers when the node allows it (self-tested
                           # at set-up, RCCL all-gather otherwise); the result is consumed from the slot buffer, no copy
                           peer_exchange=os.environ.get("MIA_PEER_EXCHANGE", "auto"), copy_results=False)
@@ -459,7 +460,8 @@ def main():
     n_timed = len(runner.kernel_timings)
     serial_ms = None
     if depth != 1:           # secondary figure: the unpipelined step (latency of one step incl. its read-back)
-        n_ser = max(10, args.steps // 8)
+        n_ser = max(100, args.steps // 8)
+        run(10, 1)               # (the switch from steps in flight to one at a time: other streams, first-use set-up)
         el1, _ = timed(n_ser, 1)
         serial_ms = 1e3 * el1 / n_ser
     assert out.shape == (1, K_ENS, G) and bool(torch.isfinite(out).all())
@@ -640,7 +642,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": warm,
             "repeats": repeats,
             "repeats_note": ("the timed region of --steps steps was measured %d times back to back (each bracketed by barrier + "
-                             "synchronize); value / ms_per_step are the median region's, spread (min .. max) %.4f .. %.4f ms per step"
+                             "synchronize); value / ms_per_step are the median region's, spread (min .. max) %.4f .. %.4f ms per step; every region fills "
+                             "and drains the pipeline of steps in flight (about one step's latency, 0.1 ms, per region: a 20-step region "
+                             "is 4-8 %% slower per step than the default 2000-step region)"
                              % (repeats, 1e3 * min(regions) / args.steps, 1e3 * max(regions) / args.steps)) if repeats > 1 else None,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

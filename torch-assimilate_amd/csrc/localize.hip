@@ -23,10 +23,6 @@ namespace mia {
 // critical path.  Raising the waves' issue priority (3) let them through; alone on the GPU it changes nothing.
 // With the split-precision analysis kernel at two waves per SIMD the preparation fits beside it and the boost costs the
 // analysis kernel more than it gains the chain: 0.0863 -> 0.0844 ms per step with priority 0 (1: 0.0875), now the default.
-#ifndef MIA_PREP_PRIO
-#define MIA_PREP_PRIO 0
-#endif
-#define MIA_PREP_PRIORITY() __builtin_amdgcn_s_setprio(MIA_PREP_PRIO)
 
 struct IndexParams {
   const double* obs;  // [P][nc]
@@ -663,6 +659,7 @@ int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_
 // kIndexErrFull (a cell with more observations than a bucket holds) to the scan-based index.  The per-cell counts are zero on
 // entry: the tile-list kernel's last workgroup puts them back (localize_tiles_kernel).
 __global__ __launch_bounds__(64) void index_bucket_kernel(IndexParams p) {
+  MIA_PREP_PRIORITY();
   MIA_PREP_PRIORITY();
   if (blockIdx.x >= p.nb_main) {      // independent passenger: the split records of the analysis kernel (only it needs them)
     extern __shared__ __attribute__((aligned(16))) float bk_lds[];

@@ -24,6 +24,12 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 
 // largest dynamic LDS request a launch may make: 160 KB per CU on gfx950, less what the kernels declare statically
 // (a request of 159.6 KB passed a plain 160 KB check and then failed at launch with hipErrorInvalidValue)
+// Wave priority of the preparation kernels (observation index, neighbour / tile lists): short chains of dependent memory round
+// trips that run BESIDE an earlier step's analysis kernel.  0 = leave the arbiter alone (A/B: tools/ab_prio.sh)
+#ifndef MIA_PREP_PRIO
+#define MIA_PREP_PRIO 0
+#endif
+#define MIA_PREP_PRIORITY() __builtin_amdgcn_s_setprio(MIA_PREP_PRIO)
 constexpr size_t kMaxDynamicLds = 160 * 1024 - 1024;
 
 // device copy of a kernel expression (mia_kernel_op_t program), passed by value in the launch parameters

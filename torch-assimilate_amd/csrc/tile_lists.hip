@@ -84,6 +84,7 @@ struct TileLocParams {
 // straight-line polynomial (the generic form spent more scalar instructions on its loops than vector ones on the weights).
 template <bool BUCKET, int NC, int TAPER>
 __global__ __launch_bounds__(64) void localize_tiles_kernel(TileLocParams p) {
+  MIA_PREP_PRIORITY();
   extern __shared__ __attribute__((aligned(16))) unsigned char tl_lds[];
   if (blockIdx.x >= p.nb_main) {
     pack_split_wave(p.pack, p.P, (int64_t)(blockIdx.x - p.nb_main), reinterpret_cast<float*>(tl_lds));

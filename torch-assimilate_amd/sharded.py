@@ -166,7 +166,8 @@ class ShardedLetkf:
                  rbf_gamma: Optional[float] = None, compute_shard: Optional[Callable] = None, group=None,
                  method: str = "auto", fused_localization: bool = False,
                  comm_chunks: int = 4, chunk_compute: Optional[Callable] = None, native_step: bool = True,
-                 max_in_flight: int = 3, peer_exchange: str = "auto", copy_results: bool = True, prep_streams: int = 3):
+                 max_in_flight: int = 3, peer_exchange: str = "auto", copy_results: bool = True, prep_streams: int = 3,
+                 analysis_streams: int = 1):
         self.device, self.rank, self.world = device, rank, world
         self.radii, self.inf_factor, self.coord_group, self.eps = list(radii), inf_factor, coord_group, eps
         self.rbf_gamma = rbf_gamma
@@ -183,6 +184,7 @@ class ShardedLetkf:
         self.kernel_timings = []       # [(start, stop)] torch events recorded on the analysis stream by the library
         self.max_in_flight = max(1, min(int(max_in_flight), 8))
         self.prep_streams = max(1, min(int(prep_streams), 8))      # steps in flight: preparation streams taken in turn
+        self.analysis_streams = max(1, min(int(analysis_streams), 4))
         # exchange of the analysis blocks at world > 1: "auto" = direct peer writes into library-owned, IPC-mapped result
         # buffers when the node allows it and a self-test of the mapping passes, RCCL all-gather otherwise; "off" = RCCL.
         # With the direct route a result lives in its pipeline slot's buffer: copy_results (default) hands out a copy,
@@ -494,11 +496,13 @@ class ShardedLetkf:
             # the CUs are slower than one after the other: re-measured with the tile kernel, 7.9e8 -> 7.5e8 /s), the exchange stream
             if st.get("astream") is None:
                 st["astream"] = torch.cuda.Stream(device=X.device)
+                st["astreams"] = [st["astream"]] + [torch.cuda.Stream(device=X.device) for _ in range(self.analysis_streams - 1)]
                 # TWO preparation streams taken in turn: with the sixteen-point analysis kernel (~75 us) the chain of small,
                 # latency-bound index / list launches of ONE stream (~100 us per step) had become what bounds the pipeline
                 # (0.127 -> 0.107 ms per step at depth 4; a third stream: 0.117 with the split-precision kernel, a fourth 0.167)
                 st["pstreams"] = [torch.cuda.Stream(device=X.device, priority=-1) for _ in range(self.prep_streams)]
-            comp, prep = st["astream"], st["pstreams"][self._submitted % len(st["pstreams"])]
+            comp = st["astreams"][self._submitted % len(st["astreams"])] if not exch else st["astream"]
+            prep = st["pstreams"][self._submitted % len(st["pstreams"])]
             prep.wait_stream(cur)                                 # inputs (and `out`'s memory) are ready
             # where the step's last work is enqueued: the placement stream when there is one, else the exchange stream
             last = ((st["stream"] if peer else (st.get("xstream") or st["stream"])) if exch else comp)
