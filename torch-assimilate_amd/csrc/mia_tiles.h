@@ -257,6 +257,24 @@ int tile_lists_launch(const double* grid_xyz, int64_t g0, int64_t ng, int64_t P,
                       void* index_ws, hipStream_t stream, const SplitPackJob* pack, bool bucket = false);
 // letkf_tile2.hip
 // housekeeping the analysis launch does for the bucket index (see Tile2Params)
+struct Tile2Params {
+  const float* X; int64_t ldx; int m, k;
+  int64_t g0, ng;
+  const unsigned char* rec; int rb, nc8; int64_t zero_rec;
+  const int4* thdr; const int32_t* tidx; const f4w* tD;
+  float inv_reg, f0, inv_k, cs_phi, cs_psi;
+  float* Xa; int64_t ldo, o0; int32_t* flags; int32_t* retry_count;
+  int dmax;
+  const int2* tab_hdr; const float2* tab_c;
+  // pieces (step driver with an exchange in several pieces): the ng points are seg_len-sized pieces (a multiple of 16: tiles
+  // never straddle one), piece s writes its own (m k, seg_len) buffer at Xa + s * seg_stride.  0: one result array
+  int seg_len; int64_t seg_stride;
+  // housekeeping for the step driver's bucket index (null: none): the launch's first workgroups zero the per-cell counts
+  // clr_counts[0 .. *clr_n) -- their only readers, the tile-list kernel, ran before this launch -- and workgroup 0 folds the build's
+  // error word into *err_out (bits 8, 16) and clears it
+  int* clr_counts; const int* clr_n; unsigned* clr_err; int32_t* err_out;
+  int stagger;      // (experiment builds) start delay per wave slot of a SIMD, in units of 64 cycles
+};
 struct Tile2Housekeeping { int* counts; const int* n; unsigned* err; int32_t* err_out; };
 bool tile2_covers(int m, int k, int p_max, int extra_blocks, int64_t ldx, int64_t ldo, int64_t ng);
 int tile2_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const void* rec, int64_t P,
