@@ -586,6 +586,11 @@ int mia_letkf_sharded_step_f32(const float* X /* [m][k][G] */, int64_t G, int m,
                                     an observation outside the box its workspace held, or other radii) */
 #define MIA_STEP_SCAN_INDEX 0x800 /* tile route: scan-based observation index instead of fixed-capacity buckets (a step reported
                                     error bit 16: a cell with more observations than a bucket holds) */
+#define MIA_STEP_REUSE_LISTS 0x1000 /* tile route, geometry epoch: use the tile lists `ws` already holds -- built by an earlier
+                                    * COMPLETED step on this workspace with the same grid / observation coordinates, radii, eps,
+                                    * block and tile format -- and rebuild only the split records.  The reference recomputes the
+                                    * localisation on every call (gaspari_cohn.py:97-136); results are identical when the
+                                    * geometry is.  counters[0], [1] stay 0 */
 #define MIA_STEP_NO_TILE_LISTS 8 /* per-point lists even where the tile route would apply (after a step reported tiles whose
                                    union did not fit: counters[1] != 0 with counters[0] <= p_max_assumed) */
 int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int m, int k,

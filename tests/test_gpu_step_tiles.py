@@ -132,3 +132,43 @@ def test_declined_points_are_redone_from_lists_built_then(mia):
     for _ in range(4):
         out = r.assimilate(*a)
     assert torch.equal(out, ref) and r.last_retries == plain.last_retries and r.last_flags_ok()
+
+
+def test_geometry_epoch_reuses_the_tile_lists(mia):
+    """``geometry_id``: steps of one geometry epoch rebuild only the split records (MIA_STEP_REUSE_LISTS) and reproduce the full
+    rebuild bit for bit -- serially and with steps in flight (every pipeline slot builds its lists once), with new perturbations
+    and innovations every step; a new id (moved observations) rebuilds; declined points are still redone."""
+    import bench
+    dev_ = torch.device("cuda:0")
+    G, k = 40000, 40
+    X, gx, ox, Yb, d = bench.make_case(G, k, 2, dev_, seed=9)
+    full = mia.ShardedLetkf(dev_, 0, 1, radii=[10.0], inf_factor=1.1, max_in_flight=4)
+    epoch = mia.ShardedLetkf(dev_, 0, 1, radii=[10.0], inf_factor=1.1, max_in_flight=4)
+    gen = torch.Generator(device=dev_)
+    gen.manual_seed(3)
+    steps = []
+    for i in range(10):
+        Yi = Yb * (1.0 + 0.1 * i) + 0.01 * torch.randn(Yb.shape, generator=gen, device=dev_)
+        di = d + 0.1 * torch.randn(d.shape, generator=gen, device=dev_)
+        if i == 7:
+            Yi[:, 100:140] *= 14.0                                    # strong observations: declined points in this step
+        steps.append((Yi.contiguous(), di.contiguous()))
+    ref = [full.assimilate(X, gx, ox, Yi, di).clone() for Yi, di in steps]
+    # serial
+    got = [epoch.assimilate(X, gx, ox, Yi, di, geometry_id="a").clone() for Yi, di in steps]
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    # in flight
+    pend = [epoch.submit(X, gx, ox, Yi, di, geometry_id="a") for Yi, di in steps[:4]]
+    out = [h.result().clone() for h in pend]
+    pend = [epoch.submit(X, gx, ox, Yi, di, geometry_id="a") for Yi, di in steps[4:]]
+    out += [h.result().clone() for h in pend]
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+    assert epoch.reused_steps >= 10
+    # moved observations under a new id: rebuilt, equal to the plain runner on the new geometry
+    ox2 = (ox + 0.25).contiguous()
+    r2 = full.assimilate(X, gx, ox2, *steps[0]).clone()
+    g2 = epoch.assimilate(X, gx, ox2, *steps[0], geometry_id="b").clone()
+    g3 = epoch.assimilate(X, gx, ox2, *steps[0], geometry_id="b").clone()
+    assert torch.equal(g2, r2) and torch.equal(g3, r2)

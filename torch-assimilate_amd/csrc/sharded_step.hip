@@ -698,9 +698,12 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
                         mia::option(MIA_OPT_TILE_SPLIT) != 0 && mia::tile2_covers(m, k, pm_tl, (step_flags >> 4) & 7, G, exch ? L.nc : G, blk) &&
                         mia::cheb_dual_table((hipStream_t)(prep_stream ? prep_stream : stream), &tl_th, &tl_tc);
   const bool tl_bucket = tl_route && mia::option(MIA_OPT_BUCKET_INDEX) != 0 && !(step_flags & MIA_STEP_SCAN_INDEX);
+  // geometry epoch: the tile lists this workspace holds are used again (the caller vouches for unchanged coordinates, radii,
+  // eps and block); only the split records are rebuilt.  Nothing to clear after the analysis: no index was built
+  const bool tl_reuse = tl_route && (step_flags & MIA_STEP_REUSE_LISTS) != 0;
   // (the analysis launch puts the bucket index's per-cell counts and error word back to zero, see Tile2Params)
   mia::Tile2Housekeeping tl_hk{nullptr, nullptr, nullptr, nullptr};
-  if (tl_bucket) {
+  if (tl_bucket && !tl_reuse) {
     const mia::IndexLayout IL = mia::index_layout(base_of(ws) + L.loc, P, n_coord);
     tl_hk = mia::Tile2Housekeeping{IL.cursor, &IL.hdr->ncell, &IL.hdr->err, nullptr};      // (err_out: below, once ctr is known)
   }
@@ -740,7 +743,7 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
     // counters[0..3] = {longest list, truncated lists, declined points, error bits} of this rank; [4..7] = max over ranks.
     // They, the trailer copy and the segment slots are cleared by the first index kernel when it runs
     // (every fill launch of its own costs ~5-8 us of the ~100 us this phase takes)
-    const bool zero_in_kernel = P > 0 && b1 > b0;
+    const bool zero_in_kernel = P > 0 && b1 > b0 && !tl_reuse;
     const size_t done_ints = (size_t)n_chunks * 64 * mia::kSlotStride;
     if (do1) {
     if (!zero_in_kernel) {
@@ -750,7 +753,10 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
         MIA_HIP_TRY(hipMemsetAsync(done, 0, done_ints * sizeof(int32_t), ps));
       }
     }
-    if (b1 > b0 && tl_route) {
+    if (b1 > b0 && tl_reuse) {
+      rc = mia::split_pack_launch(Yb, d, k, P, base + L.hrec, ps);
+      if (rc != MIA_OK) return rc;
+    } else if (b1 > b0 && tl_route) {
       const mia::ZeroJob zj{{counters, exch ? ctr : nullptr, exch ? done : nullptr},
                             {8, exch ? 4 : 0, exch ? (int64_t)done_ints : 0}};
       // bucket index: one kernel over the cell grid this workspace already holds (validated per observation); the first step on a
@@ -796,7 +802,7 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
     if (tl_route && n_chunks > 1 && b1 > b0) {
       rc = mia::tile2_analysis_launch(X, G, m, k, b0, b1 - b0, base + L.hrec, P, base + L.tl, L.ut, inf_factor,
                                       (float*)(base + L.bufs), L.nc, 0, flags, ctr + 2, mia::option(MIA_OPT_CHEB_DMAX), tl_th, tl_tc, s,
-                                      (int)L.nc, (int64_t)(L.chunk_bytes / sizeof(float)), tl_bucket ? &tl_hk : nullptr);
+                                      (int)L.nc, (int64_t)(L.chunk_bytes / sizeof(float)), (tl_bucket && !tl_reuse) ? &tl_hk : nullptr);
       if (rc != MIA_OK) return rc;
       tl_block = true;
     }
@@ -872,7 +878,7 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
           if (tl_route)
             rc = mia::tile2_analysis_launch(X, G, m, k, c0, c1 - c0, base + L.hrec, P, base + L.tl, L.ut, inf_factor, dst, ldo, o0,
                                             cfl, ctr + 2, mia::option(MIA_OPT_CHEB_DMAX), tl_th, tl_tc, (hipStream_t)stream, 0, 0,
-                                            tl_bucket ? &tl_hk : nullptr);
+                                            (tl_bucket && !tl_reuse) ? &tl_hk : nullptr);
           else
             rc = mia_letkf_analysis_matfun_f32(X, G, m, k, c0, c1, rec, P, ccnt, cidx, cw, L.cap, p_max_assumed,
                                                inf_factor, gamma, dst, ldo, o0, cfl, ctr + 2, stream);

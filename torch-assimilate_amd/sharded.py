@@ -192,6 +192,7 @@ class ShardedLetkf:
         self.peer_exchange = peer_exchange
         self.copy_results = copy_results
         self._submitted = 0
+        self.reused_steps = 0          # steps that ran on the tile lists of their geometry epoch (submit(..., geometry_id=))
         self._force_comm = False      # tests / tools: a one-rank RCCL communicator drives the exchange route
         self.native_steps = 0
         self.last_retries = 0
@@ -286,13 +287,13 @@ class ShardedLetkf:
         self._last_flags = flags
         return xa
 
-    def assimilate(self, X, grid_xyz, obs_xyz, Yb, d) -> torch.Tensor:
+    def assimilate(self, X, grid_xyz, obs_xyz, Yb, d, geometry_id=None) -> torch.Tensor:
         G = X.shape[-1]
         g0, g1 = block_partition(G, self.world)[self.rank]
         if (self.native_step and self._compute == self._engine_shard and self._chunk_compute is None
                 and torch.is_tensor(X) and X.is_cuda and X.dtype == torch.float32 and X.dim() == 3
                 and not self.fused_localization):
-            return self._assimilate_native(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1)
+            return self._assimilate_native(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, geometry_id)
         if self.world > 1 and self.comm_chunks > 1:
             return self._assimilate_overlapped(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1)
         shard = self._compute(X, grid_xyz, obs_xyz, Yb, d, g0, g1)
@@ -385,15 +386,16 @@ class ShardedLetkf:
             self.engine.lib.mia_comm_destroy(self._native["comm"])
         self._native = None
 
-    def _assimilate_native(self, X, grid_xyz, obs_xyz, Yb, d, G, g0, g1):
+    def _assimilate_native(self, X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, geometry_id=None):
         """Steady state: ONE library call enqueues the whole step (mia_letkf_sharded_step_f32: records,
         cell index, neighbour lists, analysis chunks, per-chunk RCCL all-gather + placement on a second
         stream, 16-byte max-reduce of the redo counters), then one 32-byte read-back decides -- identically
         on every rank -- whether anything has to be redone.  The first call on a geometry (no bound for the
         local observation count yet) takes the exact-list route through torch.distributed."""
-        return self._native_finish(self._native_submit(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, pipelined=False))
+        return self._native_finish(self._native_submit(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, pipelined=False,
+                                                       geometry_id=geometry_id))
 
-    def submit(self, X, grid_xyz, obs_xyz, Yb, d) -> "PendingStep":
+    def submit(self, X, grid_xyz, obs_xyz, Yb, d, geometry_id=None) -> "PendingStep":
         """Enqueue one assimilation step WITHOUT waiting for it: the returned handle's ``result()`` performs the
         step's one host read-back (validation + rare redo) and hands out the analysis.  Consecutive steps
         rotate through ``max_in_flight`` slots (own workspace and counters each) and share three streams -- a
@@ -404,16 +406,21 @@ class ShardedLetkf:
         yet is collected first; all ranks must submit and collect in the same order.
 
         The library reads X, Yb, d and the coordinates on ITS streams after this call has returned: the caller must not
-        modify those tensors (in place, on any stream) before ``result()`` of this step -- pass clones if it has to."""
+        modify those tensors (in place, on any stream) before ``result()`` of this step -- pass clones if it has to.
+
+        ``geometry_id`` (any hashable, default None): the caller's word that grid and observation COORDINATES are the ones of
+        every earlier step submitted with the same id (a fixed observing network in a cycled filter).  Steps on the tile
+        route then use the tile lists their pipeline slot already holds and rebuild only the split records
+        (MIA_STEP_REUSE_LISTS); results are identical to a full rebuild, which is what the reference does on every call."""
         G = X.shape[-1]
         g0, g1 = block_partition(G, self.world)[self.rank]
         if not (self.native_step and self._compute == self._engine_shard and self._chunk_compute is None
                 and torch.is_tensor(X) and X.is_cuda and X.dtype == torch.float32 and X.dim() == 3
                 and not self.fused_localization):
             return PendingStep(self, None, out=self.assimilate(X, grid_xyz, obs_xyz, Yb, d))
-        return self._native_submit(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, pipelined=True)
+        return self._native_submit(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, pipelined=True, geometry_id=geometry_id)
 
-    def _native_submit(self, X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, pipelined):
+    def _native_submit(self, X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, pipelined, geometry_id=None):
         import ctypes as C
         import torch.distributed as dist
         from . import _cabi
@@ -466,6 +473,7 @@ class ShardedLetkf:
         if slot.get("busy") is not None:                          # its previous step was never collected
             slot["busy"].result()
         if slot.get("key") != key:
+            slot["geom"] = None
             nbytes = C.c_size_t(0)
             _cabi.check(lib.mia_letkf_sharded_step_workspace_bytes(G, m, k, P, nc, self.world, C_chunks, hint,
                                                                    C.byref(nbytes)), "sharded_step_workspace_bytes")
@@ -483,6 +491,10 @@ class ShardedLetkf:
         # direct exchange: the result IS the slot's peer-mapped buffer (every rank uses the same slot for the same step)
         out = peer[slot_idx] if peer else torch.empty((m, k, G), dtype=torch.float32, device=X.device)
         flags = slot["flags"]          # (per slot: a step's flags are read when it is collected, before the slot is reused)
+        # geometry epoch: this slot's workspace holds the tile lists of an earlier, completed step of the same geometry and format
+        geom_key = None if geometry_id is None else (geometry_id, key, self._tile_extra, self._scan_index, g0, g1)
+        reuse = (geom_key is not None and slot.get("geom") == geom_key and not self._no_tile_lists and not self._fresh_box_once
+                 and C_chunks == 1 and st["comm"] is None)
         method = {"auto": 0, "eig": 1, "matfun": 2}[self.method]
         gamma = float(self.rbf_gamma) if self.rbf_gamma is not None else 0.0
         cur = torch.cuda.current_stream(X.device)
@@ -502,7 +514,9 @@ class ShardedLetkf:
                 # (0.127 -> 0.107 ms per step at depth 4; a third stream: 0.117 with the split-precision kernel, a fourth 0.167)
                 st["pstreams"] = [torch.cuda.Stream(device=X.device, priority=-1) for _ in range(self.prep_streams)]
             comp = st["astreams"][self._submitted % len(st["astreams"])] if not exch else st["astream"]
-            prep = st["pstreams"][self._submitted % len(st["pstreams"])]
+            # (a step on reused lists prepares with ONE short kernel: one preparation stream for all of them -- every further
+            #  queue in use costs the analysis queue dispatch time: 0.041 against 0.049 ms per step with three)
+            prep = st["pstreams"][0 if reuse else self._submitted % len(st["pstreams"])]
             prep.wait_stream(cur)                                 # inputs (and `out`'s memory) are ready
             # where the step's last work is enqueued: the placement stream when there is one, else the exchange stream
             last = ((st["stream"] if peer else (st.get("xstream") or st["stream"])) if exch else comp)
@@ -518,7 +532,7 @@ class ShardedLetkf:
                  # MIA_STEP_NO_JOIN for steps in flight; MIA_STEP_WS_CLEAN: this slot's workspace was last used by a step that
                  # ran to completion (its index kernels leave the header zeroed)
                  (1 if pipelined else 0) | (4 if slot.get("ws_clean") else 0) | (8 if self._no_tile_lists else 0) | (self._tile_extra << 4) |
-                 (0x400 if self._fresh_box_once else 0) | (0x800 if self._scan_index else 0)]
+                 (0x400 if self._fresh_box_once else 0) | (0x800 if self._scan_index else 0) | (0x1000 if reuse else 0)]
         self._fresh_box_once = False
         slot["ws_clean"] = False            # (until this step has been collected without an error)
         step_fn = lib.mia_letkf_sharded_step_streams_f32
@@ -565,7 +579,7 @@ class ShardedLetkf:
         h = PendingStep(self, dict(slot=slot, call=call, comp=comp, cur=cur, ev=ev, job=job, out=out, flags=flags, hint=hint,
                                    last=last, peer=bool(peer),
                                    C_chunks=C_chunks, args=(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1),
-                                   keep=(X, grid, obs, Yb, d)))
+                                   keep=(X, grid, obs, Yb, d), geom_key=geom_key, reused=reuse, geometry_id=geometry_id))
         slot["busy"] = h
         self._in_flight.append(h)
         self._submitted += 1
@@ -587,6 +601,7 @@ class ShardedLetkf:
             cnt = slot["counters"].tolist()                    # serial route: synchronous read-back
         slot["busy"] = None
         slot["ws_clean"] = True                                # the step's kernels have all run: its index header is zero again
+        slot["geom"] = None                                    # (set again below once this step is known to be good)
         self._in_flight.remove(h)
         X, grid_xyz, obs_xyz, Yb, d, G, g0, g1 = p["args"]
         if st["comm"] is None or (self.world == 1 and p["C_chunks"] == 1):
@@ -654,7 +669,11 @@ class ShardedLetkf:
                 self.engine.lib.mia_stream_wait_event(now.cuda_stream, p["ev"])
         self.native_steps += 1
         self.last_retries = cnt[2]
-        self._p_max_hint = p_seen if self.world > 1 else max(p_seen, 0)
+        self.reused_steps += 1 if p.get("reused") else 0
+        if not p.get("reused"):                                # (a step on reused lists reports no list lengths)
+            self._p_max_hint = p_seen if self.world > 1 else max(p_seen, 0)
+        if not self._no_tile_lists:
+            slot["geom"] = p.get("geom_key")                   # this slot's lists now belong to that geometry epoch
         self.last_p_max = p["hint"]
         self._last_flags = p["flags"][:g1 - g0]
         h._out, h._st = (p["out"].clone() if p.get("peer") and self.copy_results else p["out"]), None
