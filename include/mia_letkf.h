@@ -524,6 +524,9 @@ int mia_letkf_step_drain(void);
 int mia_letkf_step_readback(const int32_t* counters, int32_t* host8, void* after_stream, void* on_stream, void** done_event);
 int mia_event_synchronize(void* event);
 int mia_stream_wait_event(void* stream, void* event);
+/* dst_stream waits for what src_stream holds so far; *event_io: NULL on the first call (the event is created and handed back; free
+ * it with mia_event_destroy) */
+int mia_stream_wait_stream(void* dst_stream, void* src_stream, void** event_io);
 int mia_event_destroy(void* event);
 /* Host time the library's two launch threads have spent enqueueing since start-up (microseconds; preparation stage and
  * analysis / exchange / read-back stage) and the number of steps handed to them. */

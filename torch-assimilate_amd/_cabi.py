@@ -104,6 +104,7 @@ _PROTOS = {
     "mia_letkf_step_readback": ([vp, vp, vp, vp, C.POINTER(vp)], i32),
     "mia_event_synchronize": ([vp], i32),
     "mia_stream_wait_event": ([vp, vp], i32),
+    "mia_stream_wait_stream": ([vp, vp, C.POINTER(vp)], i32),
     "mia_event_destroy": ([vp], i32),
     "mia_letkf_step_launch_stats": ([C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)], i32),
     "mia_comm_peer_alloc": ([vp, sz, i32, vp], i32),

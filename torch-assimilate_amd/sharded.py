@@ -497,7 +497,11 @@ class ShardedLetkf:
                  and C_chunks == 1 and st["comm"] is None)
         method = {"auto": 0, "eig": 1, "matfun": 2}[self.method]
         gamma = float(self.rbf_gamma) if self.rbf_gamma is not None else 0.0
-        cur = torch.cuda.current_stream(X.device)
+        # (the caller's stream as a raw handle: torch.cuda.current_stream() + Stream.wait_stream() are ~15 us of Python objects
+        #  per step; the Stream object is built only on the paths that need one)
+        dev_index = X.device.index if X.device.index is not None else torch.cuda.current_device()
+        cur_raw = torch._C._cuda_getCurrentRawStream(dev_index)
+        cur = None if pipelined and not self._time_next else torch.cuda.current_stream(X.device)
         side = st["stream"].cuda_stream if st["stream"] is not None else None
         exch = st["comm"] is not None and (self.world > 1 or C_chunks > 1)
         if pipelined:
@@ -517,7 +521,10 @@ class ShardedLetkf:
             # (a step on reused lists prepares with ONE short kernel: one preparation stream for all of them -- every further
             #  queue in use costs the analysis queue dispatch time: 0.041 against 0.049 ms per step with three)
             prep = st["pstreams"][0 if reuse else self._submitted % len(st["pstreams"])]
-            prep.wait_stream(cur)                                 # inputs (and `out`'s memory) are ready
+            if "in_event" not in slot:
+                slot["in_event"] = C.c_void_p()
+            _cabi.check(lib.mia_stream_wait_stream(prep.cuda_stream, cur_raw, C.byref(slot["in_event"])),
+                        "mia_stream_wait_stream")                  # inputs (and `out`'s memory) are ready
             # where the step's last work is enqueued: the placement stream when there is one, else the exchange stream
             last = ((st["stream"] if peer else (st.get("xstream") or st["stream"])) if exch else comp)
         else:
@@ -576,7 +583,7 @@ class ShardedLetkf:
                 _cabi.check(lib.mia_letkf_step_timing_events(timing[0].cuda_event, timing[1].cuda_event),
                             "mia_letkf_step_timing_events")
             call(0)
-        h = PendingStep(self, dict(slot=slot, call=call, comp=comp, cur=cur, ev=ev, job=job, out=out, flags=flags, hint=hint,
+        h = PendingStep(self, dict(slot=slot, call=call, comp=comp, cur=cur, cur_raw=cur_raw, dev_index=dev_index, ev=ev, job=job, out=out, flags=flags, hint=hint,
                                    last=last, peer=bool(peer),
                                    C_chunks=C_chunks, args=(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1),
                                    keep=(X, grid, obs, Yb, d), geom_key=geom_key, reused=reuse, geometry_id=geometry_id))
@@ -647,26 +654,27 @@ class ShardedLetkf:
                 other.result()
             if redo == "exact":
                 self._p_max_hint = None                        # (draining may have set a hint again: exact lists now)
-            p["cur"].wait_stream(p["comp"])
-            p["cur"].wait_stream(p["last"])
+            cur_s = p["cur"] if p["cur"] is not None else torch.cuda.ExternalStream(p["cur_raw"], device=X.device)
+            cur_s.wait_stream(p["comp"])
+            cur_s.wait_stream(p["last"])
             h._out = self._assimilate_native(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1)
             h._st = None
             return h._out
         if n_retry:
             self.engine.lib.mia_letkf_step_drain()             # (after the steps already handed to the launch thread)
             p["call"](1)                                       # eigensolver redoes declined points; re-exchange
-        if p["comp"] is not p["cur"]:
+        if p["ev"] is not None or p["comp"] is not p["cur"]:
             # consumers on torch's stream see the result.  Wait for THIS step's completion event only: waiting for
             # the analysis stream as a whole would also wait for the later steps already enqueued on it, and the
             # next submit's preparation (which waits for torch's stream) would serialise behind them
-            now = torch.cuda.current_stream(X.device)
             if n_retry:
+                now = torch.cuda.current_stream(X.device)
                 for strm in {p["comp"], p["last"]}:
                     e2 = torch.cuda.Event()
                     e2.record(strm)
                     now.wait_event(e2)
             else:
-                self.engine.lib.mia_stream_wait_event(now.cuda_stream, p["ev"])
+                self.engine.lib.mia_stream_wait_event(torch._C._cuda_getCurrentRawStream(p["dev_index"]), p["ev"])
         self.native_steps += 1
         self.last_retries = cnt[2]
         self.reused_steps += 1 if p.get("reused") else 0
