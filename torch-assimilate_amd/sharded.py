@@ -883,7 +883,7 @@ class ShardedLetkf:
         tiles_route = (not fused and not self._no_tile_lists and len(obs_xyz) > 0 and self._p_max_hint is not None
                        and eng.tile_route_applies(X, self._p_max_hint, self._tile_extra, self.rbf_gamma, self.method))
         names = ["pack_split" if tiles_route else "pack_obs",
-                 "obs_index_build" if fused else ("localize_tiles(index + tile lists)" if tiles_route
+                 "obs_index_build" if fused else ("localize_tiles entry (scan index: 5 kernels, + tile lists; the step driver bins with ONE bucket kernel instead)" if tiles_route
                                                   else "localize(index+lists, incl. host sync)"), "analysis_kernel"]
         acc = dict.fromkeys(names, 0.0)
         burst = 5
