@@ -37,11 +37,6 @@ struct Tile2wParams {
   const int2* tab_hdr; const float2* tab_c;
 };
 
-#ifdef MIA_T2W_DEBUG
-#define T2W_MARK(b) do { if (lane == 0) atomicOr(P.flags + p0 + g, 1 << (b)); } while (0)
-#else
-#define T2W_MARK(b) do { } while (0)
-#endif
 constexpr int kWPts = 4;        // points of a tile per wavefront
 
 template <int UT, int KT>
@@ -393,9 +388,7 @@ void letkf_tile2w_kernel(Tile2wParams P) {
   for (int i = 0; i < kWPts; ++i) {
     const int g = kWPts * sub + i;                 // (wave-uniform)
     if (g >= npts) break;
-    T2W_MARK(16);
     if (__builtin_amdgcn_readlane((int)decl, g)) continue;
-    T2W_MARK(17);
     const int deg_g = __builtin_amdgcn_readlane(deg, g);
     const float alpha_g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha), g));
     const unsigned cbase = (unsigned)__builtin_amdgcn_readlane(tab_idx, g) * (unsigned)(kTabDeg * 8);
@@ -464,7 +457,6 @@ void letkf_tile2w_kernel(Tile2wParams P) {
       advance(vb, va, cj1);
     }
     if (j <= deg_g) advance(va, vb, cn0);
-    T2W_MARK(18);
     // ---- P = M Yhat^T: A fragments of M (row block rb) = the registers of its column block rb (M is symmetric)
     h8v mh[UT][NKB], ml[UT][NKB];
 #pragma unroll
@@ -521,7 +513,6 @@ void letkf_tile2w_kernel(Tile2wParams P) {
         }
       }
     }
-    T2W_MARK(19);
     if (__any(bad) && lane == 0) atomicOr(P.flags + p0 + g, MIA_FLAG_NONFINITE);
   }
 }
