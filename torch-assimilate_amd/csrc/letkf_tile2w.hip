@@ -465,7 +465,7 @@ void letkf_tile2w_kernel(Tile2wParams P) {
       for (int kb = 0; kb < NKB; ++kb) rhs_split1(am[rb], kb, mh[rb][kb], ml[rb][kb], tied_t{});
     const float wsc = P.cs_phi * inv_s * 0x1p15f;
     float* Wg = P.W + (p0 + g) * kk;
-    bool bad = false;
+    float chk = 0.0f;
 #pragma unroll
     for (int tj = 0; tj < KT; ++tj) {
       f4w p1[UT];
@@ -499,21 +499,19 @@ void letkf_tile2w_kernel(Tile2wParams P) {
         float vq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          vq[q] = __builtin_fmaf(acc[q], wsc, wm[q]) + (16 * ti + 4 * h + q == col ? P.f0 : 0.0f);
+          vq[q] = __builtin_fmaf(acc[q], wsc, wm[q]);
+          if (ti == tj) vq[q] += (4 * h + q == lr ? P.f0 : 0.0f);      // (the diagonal lives in the diagonal blocks)
+          chk = __builtin_fmaf(vq[q], 0.0f, chk);                      // NaN once any value is NaN or infinite: one test per point
           asm volatile("" : "+v"(vq[q]));
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int row = 16 * ti + 4 * h + q;
-          const float v = vq[q];
-          if (row < k && col < k) {
-            Wg[(unsigned)(row * k + col)] = v;
-            bad = bad || !(fabsf(v) <= 1e30f);
-          }
+          if (row < k && col < k) Wg[(unsigned)(row * k + col)] = vq[q];
         }
       }
     }
-    if (__any(bad) && lane == 0) atomicOr(P.flags + p0 + g, MIA_FLAG_NONFINITE);
+    if (__any(chk != chk) && lane == 0) atomicOr(P.flags + p0 + g, MIA_FLAG_NONFINITE);
   }
 }
 
