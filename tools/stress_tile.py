@@ -15,8 +15,8 @@ eng = mia.LetkfEngine(dev)
 rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 rel = lambda a, b: float(torch.linalg.norm(a.double() - b.double()) / max(float(torch.linalg.norm(b.double())), 1e-300))
-worst = {1: (0.0, ""), 0: (0.0, ""), 2: (0.0, "")}
-served2 = 0
+worst = {1: (0.0, ""), 0: (0.0, ""), 2: (0.0, ""), 3: (0.0, "")}
+served2 = servedw = 0
 served = 0
 for case in range(n_cases):
     k = int(rs.randint(2, 97))
@@ -80,9 +80,29 @@ for case in range(n_cases):
             sys.exit(2)
         if e > worst[2][0]:
             worst[2] = (e, tag)
+        # the weights on the same route (csrc/letkf_tile2w.hip: unions of at most 32 slots) against the float64 eigensolver's
+        if tiles.ut <= 2:
+            res = eng.weights_tiles(X, eng.pack_split(yb, d), P, tiles, inf)
+            if res is not None:
+                xw, W, flw, rw = res
+                if int(rw.item()):
+                    eng.weights_retry(X, yb, d, nb, inf, xw, W, flw)
+                try:
+                    _, Wref = eng.analysis(X.double(), yb.double(), d.double(), nb, inf, method="eig", return_weights=True)
+                except _cabi.MiaError:
+                    _, Wref = eng.analysis(X, yb, d, nb, inf, method="eig", return_weights=True)
+                bad = int((flw & 0xff & ~8).max().cpu())
+                ew, ex = rel(W, Wref), rel(xw, ref)
+                servedw += 1
+                if bad or not np.isfinite(ew) or not np.isfinite(ex):
+                    print("FLAGGED / non-finite (weights on tiles):", tag, "flags", bad, "err", ew, ex)
+                    sys.exit(2)
+                if max(ew, ex) > worst[3][0]:
+                    worst[3] = (max(ew, ex), tag)
 _cabi.set_option("tile_split", 1)
 print("%d of %d random cases on the round-2 tile kernel, %d of them also on the tile route" % (served, n_cases, served2))
 print("%-6s worst %.2e  at %s" % ("tile2", worst[2][0], worst[2][1]))
+print("%-6s worst %.2e  at %s  (%d cases: weights and analysis of mia_letkf_weights_tiles_f32)" % ("tile2w", worst[3][0], worst[3][1], servedw))
 for sp in (1, 0):
     print("%-6s worst %.2e  at %s" % ("split" if sp else "f32", worst[sp][0], worst[sp][1]))
-sys.exit(1 if max(worst[1][0], worst[0][0], worst[2][0]) > 1.0e-5 else 0)
+sys.exit(1 if max(worst[1][0], worst[0][0], worst[2][0], worst[3][0]) > 1.0e-5 else 0)
