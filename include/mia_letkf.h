@@ -269,7 +269,8 @@ int mia_letkf_weights_retry_f32(const float* X, int64_t ldx, int m, int k, int64
  *     LETKF.estimate_weights returns, interface/letkf.py:127-146): the Chebyshev recurrence on a matrix block per grid point,
  *     four points of a tile per wavefront (csrc/letkf_tile2w.hip).  Unions of at most 32 slots
  *     (ceil((p_max + 8) / 16) + extra_blocks <= 2), otherwise MIA_ERR_UNSUPPORTED (use
- *     mia_letkf_weights_matfun_f32).  Declined points: MIA_FLAG_RETRY, counted, left untouched in Xa and W;
+ *     mia_letkf_weights_matfun_f32).  Declined points (the analysis kernel's, and here also every point whose Chebyshev degree
+ *     exceeds 36: their analysis is written, their weights are not): MIA_FLAG_RETRY, counted, W left untouched;
  *     mia_letkf_weights_retry_f32 redoes them from per-point lists.
  * ---------------------------------------------------------------------------------- */
 int mia_letkf_tile_lists_bytes(int64_t n_points, int p_max, int extra_blocks, size_t* bytes);
