@@ -388,7 +388,7 @@ def main():
                           comm_chunks=int(os.environ.get("MIA_COMM_CHUNKS", "4" if args.pipeline_depth == 1 else "1")),
                           native_step=os.environ.get("MIA_NATIVE_STEP", "1") != "0",
                           max_in_flight=max(2, args.pipeline_depth),
-                          prep_streams=int(os.environ.get("MIA_PREP_STREAMS", "3")),
+                          prep_streams=int(os.environ.get("MIA_PREP_STREAMS", "5")),
                           analysis_streams=int(os.environ.get("MIA_ANALYSIS_STREAMS", "1")),
                           # N > 1: direct peer writes into IPC-mapped result buffers when the node allows it (self-tested
                           # at set-up, RCCL all-gather otherwise); the result is consumed from the slot buffer, no copy

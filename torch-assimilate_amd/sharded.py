@@ -166,7 +166,7 @@ class ShardedLetkf:
                  rbf_gamma: Optional[float] = None, compute_shard: Optional[Callable] = None, group=None,
                  method: str = "auto", fused_localization: bool = False,
                  comm_chunks: int = 4, chunk_compute: Optional[Callable] = None, native_step: bool = True,
-                 max_in_flight: int = 3, peer_exchange: str = "auto", copy_results: bool = True, prep_streams: int = 3,
+                 max_in_flight: int = 3, peer_exchange: str = "auto", copy_results: bool = True, prep_streams: int = 5,
                  analysis_streams: int = 1):
         self.device, self.rank, self.world = device, rank, world
         self.radii, self.inf_factor, self.coord_group, self.eps = list(radii), inf_factor, coord_group, eps
@@ -342,7 +342,9 @@ class ShardedLetkf:
                 st["comm"] = self._native_comm()
             # exchange stream at high priority: its (few, multi-wave) RCCL workgroups should be placed ahead of the
             # bulk analysis kernel's next workgroups when wave slots fall free, not queue behind 1e5 of them
-            st["stream"] = torch.cuda.Stream(device=self.device, priority=-1)
+            # (single GPU: this stream only carries the 32-byte counter read-back -- normal priority like every other stream of the
+            #  step: with high-priority preparation / read-back streams the loop ran 10 % slower, tools/ab_prio_streams.sh)
+            st["stream"] = torch.cuda.Stream(device=self.device, priority=-1 if (self.world > 1 or self._force_comm) else 0)
             if st["comm"] is not None:
                 # gathered pieces are copied into the result on a stream of their own, so that with steps in flight the
                 # next all-gather starts as soon as the previous one has landed
@@ -505,18 +507,15 @@ class ShardedLetkf:
         side = st["stream"].cuda_stream if st["stream"] is not None else None
         exch = st["comm"] is not None and (self.world > 1 or C_chunks > 1)
         if pipelined:
-            # three streams shared by all steps in flight: a HIGH-PRIORITY one for records / index / lists (a chain
-            # of small launches that runs beside an earlier step's analysis; the priority gives it a hardware queue
-            # of its own -- same-priority HIP streams share a small pool of queues and then serialise -- and lets its
-            # workgroups in first when the bulk kernel's drain), ONE analysis stream (two analysis kernels sharing
-            # the CUs are slower than one after the other: re-measured with the tile kernel, 7.9e8 -> 7.5e8 /s), the exchange stream
+            # streams shared by all steps in flight: ONE analysis stream (two analysis kernels sharing the CUs are slower than one
+            # after the other: 1.4-1.6e9 against 1.8e9 /s with the tile kernel), `prep_streams` preparation streams taken in turn,
+            # the exchange / read-back stream.  All at NORMAL priority: high-priority preparation streams (rounds 1-2, when one
+            # chain of small launches had to get past a kernel that filled the chip for 250 us) cost the round-3 loop 10 %
+            # (1.80e9 -> 2.00e9 /s with five streams at normal priority; three: 1.8e9, four: 1.95e9, six: 1.84e9)
             if st.get("astream") is None:
                 st["astream"] = torch.cuda.Stream(device=X.device)
                 st["astreams"] = [st["astream"]] + [torch.cuda.Stream(device=X.device) for _ in range(self.analysis_streams - 1)]
-                # TWO preparation streams taken in turn: with the sixteen-point analysis kernel (~75 us) the chain of small,
-                # latency-bound index / list launches of ONE stream (~100 us per step) had become what bounds the pipeline
-                # (0.127 -> 0.107 ms per step at depth 4; a third stream: 0.117 with the split-precision kernel, a fourth 0.167)
-                st["pstreams"] = [torch.cuda.Stream(device=X.device, priority=-1) for _ in range(self.prep_streams)]
+                st["pstreams"] = [torch.cuda.Stream(device=X.device) for _ in range(self.prep_streams)]
             comp = st["astreams"][self._submitted % len(st["astreams"])] if not exch else st["astream"]
             # (a step on reused lists prepares with ONE short kernel: one preparation stream for all of them -- every further
             #  queue in use costs the analysis queue dispatch time: 0.041 against 0.049 ms per step with three)
