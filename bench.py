@@ -679,7 +679,7 @@ def main():
             # credit for the Gram matrix sixteen points share, no credit for the eigensolve the route does not execute).
             # What the kernel executes (padded, on the half-precision matrix pipe) is reported beside it under its own keys.
             "roofline": {"bound": ("vector_issue+latency" if kkind != "point" else "valu_issue"),
-                         "bound_evidence": ("profiles/r03_v3_pmc.json (rocprofv3 --pmc, kernel alone): vector unit 51 % busy, matrix "
+                         "bound_evidence": ("profiles/r03_v4_pmc.json (rocprofv3 --pmc, kernel alone): vector unit 51 % busy, matrix "
                                             "pipe 16 %, HBM 0.13 of peak; a wave's cycles: 26 % issuing, 49 % issue-stalled, 25 % "
                                             "parked on s_waitcnt; tools/tile2_stamps.py: all resident waves start together, so "
                                             "their memory phases coincide, and the last 1.2 tiles per SIMD run at low occupancy"),
