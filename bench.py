@@ -339,7 +339,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-4 / config-5 kernel timings")
     ap.add_argument("--grid-per-gpu", type=int, default=G_PER_GPU)
-    ap.add_argument("--pipeline-depth", type=int, default=int(os.environ.get("MIA_PIPELINE_DEPTH", "8")), choices=[1, 2, 3, 4, 5, 6, 7, 8],
+    ap.add_argument("--pipeline-depth", type=int, default=int(os.environ.get("MIA_PIPELINE_DEPTH", "8")), choices=list(range(1, 17)),
                     help="steps in flight (ShardedLetkf.submit): d (default 8) = steps i+1 .. i+d-1 are enqueued before step i "
                          "is collected; 1 = serial steps")
     ap.add_argument("--method", default="auto", choices=["auto", "eig", "matfun"],
