@@ -660,8 +660,8 @@ def main():
             "repeats": repeats,
             "repeats_note": ("the timed region of --steps steps was measured %d times back to back (each bracketed by barrier + "
                              "synchronize); value / ms_per_step are the median region's, spread (min .. max) %.4f .. %.4f ms per step; every region fills "
-                             "and drains the pipeline of steps in flight (about one step's latency, 0.1 ms, per region: a 20-step region "
-                             "is 4-8 %% slower per step than the default 2000-step region)"
+                             "and drains the pipeline of steps in flight (1.5-2 step latencies, 0.15-0.2 ms, per region: a 20-step region "
+                             "is 12-15 %% slower per step than the default 2000-step region, profiles/r03_final_bench_steps20.json)"
                              % (repeats, 1e3 * min(regions) / args.steps, 1e3 * max(regions) / args.steps)) if repeats > 1 else None,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
