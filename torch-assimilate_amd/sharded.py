@@ -167,7 +167,7 @@ class ShardedLetkf:
                  method: str = "auto", fused_localization: bool = False,
                  comm_chunks: int = 4, chunk_compute: Optional[Callable] = None, native_step: bool = True,
                  max_in_flight: int = 3, peer_exchange: str = "auto", copy_results: bool = True, prep_streams: int = 5,
-                 analysis_streams: int = 1):
+                 analysis_streams: int = 1, prep_streams_shared: int = 2):
         self.device, self.rank, self.world = device, rank, world
         self.radii, self.inf_factor, self.coord_group, self.eps = list(radii), inf_factor, coord_group, eps
         self.rbf_gamma = rbf_gamma
@@ -185,6 +185,9 @@ class ShardedLetkf:
         self.max_in_flight = max(1, min(int(max_in_flight), 8))
         self.prep_streams = max(1, min(int(prep_streams), 8))      # steps in flight: preparation streams taken in turn
         self.analysis_streams = max(1, min(int(analysis_streams), 4))
+        # how many of the preparation streams may share the analysis stream's hardware queue (see _pick_prep_streams)
+        self.prep_streams_shared = max(0, min(int(prep_streams_shared), self.prep_streams))
+        self.prep_stream_pick = None
         # exchange of the analysis blocks at world > 1: "auto" = direct peer writes into library-owned, IPC-mapped result
         # buffers when the node allows it and a self-test of the mapping passes, RCCL all-gather otherwise; "off" = RCCL.
         # With the direct route a result lives in its pipeline slot's buffer: copy_results (default) hands out a copy,
@@ -422,6 +425,45 @@ class ShardedLetkf:
             return PendingStep(self, None, out=self.assimilate(X, grid_xyz, obs_xyz, Yb, d))
         return self._native_submit(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, pipelined=True, geometry_id=geometry_id)
 
+    @staticmethod
+    def _shares_queue(busy: "torch.cuda.Stream", other: "torch.cuda.Stream") -> bool:
+        """Whether work on ``other`` waits for work on ``busy``, i.e. the runtime mapped both HIP streams to one hardware queue
+        (ROCm multiplexes streams over GPU_MAX_HW_QUEUES = 4 queues): a ~1 ms spin kernel on ``busy``, a tiny kernel on ``other``."""
+        dev = busy.device
+        t = torch.zeros(1, device=dev)
+        torch.cuda.synchronize(dev)
+        e_busy, e_small = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(busy):
+            torch.cuda._sleep(2_000_000)
+            e_busy.record(busy)
+        with torch.cuda.stream(other):
+            t.add_(1.0)
+            e_small.record(other)
+        torch.cuda.synchronize(dev)
+        return e_busy.elapsed_time(e_small) > -0.2          # the tiny kernel finished after (or with) the spin kernel
+
+    def _pick_prep_streams(self, device, astream, n: int):
+        """``n`` preparation streams chosen by the hardware queue the runtime gave them.  ROCm multiplexes HIP streams over
+        GPU_MAX_HW_QUEUES (4) queues; which streams end up on the analysis stream's queue depends on creation order and differs
+        from process to process -- and decides the loop's speed: a preparation chain on the SHARED queue only runs between two
+        analysis kernels (its step's analysis starts ~35 us late instead of ~8), chains on other queues run beside the analysis
+        kernel and slow it down (35 -> 44 us when all of them do).  Measured on C2 (analyses/s, analysis kernel in the loop):
+        5 streams of which 0 / 1 / 2 shared: 2.0e9, 40 us / 2.15e9, 44 us / 2.0e9, 36 us; 4 of which 2: 1.98e9, 33 us; left to
+        chance: 1.8-2.02e9.  The default (5, 2 shared) keeps the kernel time of the unshared loop AND its rate."""
+        if os.environ.get("MIA_NO_STREAM_PICK"):
+            return [torch.cuda.Stream(device=device) for _ in range(n)]
+        n_shared = min(self.prep_streams_shared, n)
+        n_free = n - n_shared
+        free, shared = [], []
+        for _ in range(4 * n + 8):
+            s = torch.cuda.Stream(device=device)
+            (shared if self._shares_queue(astream, s) else free).append(s)
+            if len(free) >= n_free and len(shared) >= n_shared:
+                break
+        self.prep_stream_pick = (len(free), len(shared))
+        out = free[:n_free] + shared[:n_shared]
+        return out + (free[n_free:] + shared[n_shared:])[:n - len(out)]
+
     def _native_submit(self, X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, pipelined, geometry_id=None):
         import ctypes as C
         import torch.distributed as dist
@@ -515,7 +557,7 @@ class ShardedLetkf:
             if st.get("astream") is None:
                 st["astream"] = torch.cuda.Stream(device=X.device)
                 st["astreams"] = [st["astream"]] + [torch.cuda.Stream(device=X.device) for _ in range(self.analysis_streams - 1)]
-                st["pstreams"] = [torch.cuda.Stream(device=X.device) for _ in range(self.prep_streams)]
+                st["pstreams"] = self._pick_prep_streams(X.device, st["astream"], self.prep_streams)
             comp = st["astreams"][self._submitted % len(st["astreams"])] if not exch else st["astream"]
             # (a step on reused lists prepares with ONE short kernel: one preparation stream for all of them -- every further
             #  queue in use costs the analysis queue dispatch time: 0.041 against 0.049 ms per step with three)
