@@ -558,6 +558,15 @@ class ShardedLetkf:
                 st["astream"] = torch.cuda.Stream(device=X.device)
                 st["astreams"] = [st["astream"]] + [torch.cuda.Stream(device=X.device) for _ in range(self.analysis_streams - 1)]
                 st["pstreams"] = self._pick_prep_streams(X.device, st["astream"], self.prep_streams)
+                if st["comm"] is None and not os.environ.get("MIA_NO_STREAM_PICK"):
+                    # the read-back stream neither on the analysis stream's hardware queue (its 32-byte copy would sit between
+                    # two analysis kernels: 1.61e9 instead of 2.0e9 analyses/s) nor on the first preparation stream's (the one
+                    # that serves a geometry epoch)
+                    for _ in range(48):
+                        cand = torch.cuda.Stream(device=X.device)
+                        if not self._shares_queue(st["astream"], cand) and not self._shares_queue(st["pstreams"][0], cand):
+                            st["stream"] = cand
+                            break
             comp = st["astreams"][self._submitted % len(st["astreams"])] if not exch else st["astream"]
             # (a step on reused lists prepares with ONE short kernel: one preparation stream for all of them -- every further
             #  queue in use costs the analysis queue dispatch time: 0.041 against 0.049 ms per step with three)
