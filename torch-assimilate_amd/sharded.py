@@ -432,15 +432,17 @@ class ShardedLetkf:
         dev = busy.device
         t = torch.zeros(1, device=dev)
         torch.cuda.synchronize(dev)
-        e_busy, e_small = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e_start, e_busy, e_small = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         with torch.cuda.stream(busy):
+            e_start.record(busy)
             torch.cuda._sleep(2_000_000)
             e_busy.record(busy)
         with torch.cuda.stream(other):
             t.add_(1.0)
             e_small.record(other)
         torch.cuda.synchronize(dev)
-        return e_busy.elapsed_time(e_small) > -0.2          # the tiny kernel finished after (or with) the spin kernel
+        # the tiny kernel finished in the second half of the spin kernel's run or after it: it waited for it
+        return e_busy.elapsed_time(e_small) > -0.5 * e_start.elapsed_time(e_busy)
 
     def _pick_prep_streams(self, device, astream, n: int):
         """``n`` preparation streams chosen by the hardware queue the runtime gave them.  ROCm multiplexes HIP streams over
