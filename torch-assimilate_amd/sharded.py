@@ -456,9 +456,12 @@ class ShardedLetkf:
             return [torch.cuda.Stream(device=device) for _ in range(n)]
         n_shared = min(self.prep_streams_shared, n)
         n_free = n - n_shared
-        free, shared = [], []
+        free, shared, seen = [], [], {astream.cuda_stream}
         for _ in range(4 * n + 8):
             s = torch.cuda.Stream(device=device)
+            if s.cuda_stream in seen:                  # (torch hands streams out of a pool of 32 and wraps around)
+                continue
+            seen.add(s.cuda_stream)
             (shared if self._shares_queue(astream, s) else free).append(s)
             if len(free) >= n_free and len(shared) >= n_shared:
                 break
@@ -564,8 +567,11 @@ class ShardedLetkf:
                     # the read-back stream neither on the analysis stream's hardware queue (its 32-byte copy would sit between
                     # two analysis kernels: 1.61e9 instead of 2.0e9 analyses/s) nor on the first preparation stream's (the one
                     # that serves a geometry epoch)
-                    for _ in range(48):
+                    taken = {x.cuda_stream for x in [st["astream"]] + st["pstreams"]}
+                    for _ in range(24):
                         cand = torch.cuda.Stream(device=X.device)
+                        if cand.cuda_stream in taken:      # (torch hands streams out of a pool of 32 and wraps around)
+                            continue
                         if not self._shares_queue(st["astream"], cand) and not self._shares_queue(st["pstreams"][0], cand):
                             st["stream"] = cand
                             break
