@@ -291,6 +291,19 @@ int mia_letkf_weights_tiles_f32(const float* X, int64_t ldx, int m, int k, int64
                                 float inf_factor, float* Xa, int64_t ldo, int64_t o0, float* W /* [g1-g0][k][k] */,
                                 int32_t* flags, int32_t* retry_count, void* stream);
 
+/* The RBF-kernelised filter on tiles: KETKFModule._estimate_weights with RBFKernel(gamma) (core/ketkf.py:65-94,
+ * kernels/rbf.py:75-81,110-111) under wrapper_localization (interface/wrapper.py:86-98) + _apply_weights
+ * (interface/base.py:257-278), sixteen grid points per wavefront from the tile lists of mia_letkf_localize_tiles_f64 and
+ * the float32 perturbations Yb [k][P] / innovations d [P] themselves (no records of any kind).  The squared member
+ * distances of all sixteen points are one f32 matrix-core product per tile (pairs x union slots x points,
+ * csrc/lketkf_tile.hip).  2 <= k <= 40, a tile's union within 64 slots; MIA_ERR_UNSUPPORTED otherwise
+ * (mia_letkf_analysis_matfun_f32 with gamma > 0 takes every shape).  flags / retry_count as mia_letkf_analysis_tiles_f32;
+ * declined points are redone by mia_letkf_analysis_retry_f32 (gamma > 0) from per-point lists. */
+int mia_lketkf_rbf_analysis_tiles_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                      const float* Yb, const float* d, int64_t P, const void* tile_lists, int p_max,
+                                      int extra_blocks, float inf_factor, float gamma, float* Xa, int64_t ldo, int64_t o0,
+                                      int32_t* flags, int32_t* retry_count, void* stream);
+
 /* matfun route with the Gaspari-Cohn localisation fused in: every wavefront scans the observation index
  * (mia_letkf_index_build_f64) for its grid point itself, so no neighbour lists are written or read.
  * p_max_assumed sizes the launch (e.g. stats[0] of an earlier call on the same geometry); a grid point with

@@ -156,6 +156,14 @@ bool cheb_dual_table(hipStream_t stream, const int2** hdr, const float2** c) {
   return true;
 }
 
+// the primal-route table (1/sqrt(1+t), 1/(1+t)) at the default truncation target (lketkf_tile.hip)
+bool cheb_primal_table(hipStream_t stream, const int2** hdr, const float2** c) {
+  const CoefTable* t = cheb_coef_table(0, 12.0f, stream);
+  if (!t) return false;
+  *hdr = t->hdr; *c = t->c;
+  return true;
+}
+
 // v_rcp_f32 (1 ulp) where a correctly rounded quotient buys nothing: degree selection, interval scale, function samples
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 

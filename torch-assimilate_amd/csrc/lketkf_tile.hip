@@ -1,0 +1,487 @@
+// Localised kernel ETKF (RBF / Gauss kernel), sixteen grid points per wavefront FROM TILE LISTS (round 4; list format: mia_tiles.h).
+//
+// Reference: KETKFModule._estimate_weights (pytassim/core/ketkf.py:65-94) with RBFKernel / GaussKernel
+// (pytassim/kernels/rbf.py:75-81,110-111) under wrapper_localization (pytassim/interface/wrapper.py:86-98) and the
+// transform of interface/base.py:257-278.  Per grid point g, members a, b and the point's local observations j with
+// Gaspari-Cohn weights rho_gj:
+//     K_g[a][b] = exp(-gamma sum_j rho_gj (y_aj - y_bj)^2)            k x k, symmetric, ones on the diagonal
+//     ko_g[a]   = exp(-gamma sum_j rho_gj (y_aj - d_j)^2)
+//     Kc = C K C (double centring, C = I - 1 1^T / k),  koc = ko - mean(ko) - (rowmean(K) - mean(K))
+//     xa = mean + x'^T (Kc + reg)^-1 koc + sqrt(k-1) (Kc + reg)^-1/2 x'
+// The one-point-per-wavefront kernel (letkf_cheb.hip) builds a Gram matrix per point; here the PAIR STATISTIC is shared
+// by the sixteen points of a tile: in the index space of the union of their lists (U slots)
+//     Dist[(a, b), g] = sum_s L[(a, b), s] rho[s, g],      L[(a, b), s] = (y_as - y_bs)^2
+// is ONE matrix product whose left factor belongs to the tile -- exact f32 on the matrix cores (v_mfma_f32_16x16x4_f32:
+// rows = member pairs, columns = the 16 points, depth = slots; the sqrt(rho) matrix of the tile list, squared, is the
+// right-hand operand as it stands).  The 16 x 16 result layout hands lane (point = lane & 15, h = lane >> 4) four pairs
+// per product, so the pairs are ENUMERATED such that every lane receives exactly the part of ITS point's matrix it will
+// multiply with, in registers, and nothing is ever moved:
+//
+//   * a point's matrix lives in the four lanes h = 0..3 of its column; lane h owns rows a = R h + i, i < R (k' = 4 R >= k,
+//     rows / columns >= k are zero), and of every row the CIRCULANT HALF BAND b = a + delta (mod k'), delta = 0 .. H = k'/2
+//     -- every unordered pair once (delta = H twice), 820 of 1600 entries at k = 40;
+//   * registers hold them as pairs along anti-diagonals, KP[ip][n] = (K[2ip][n+1], K[2ip+1][n]), n < H, so that ONE packed
+//     multiply-add serves the forward product (both halves times the same vector entry w[2ip+n+1]) and one the transposed
+//     product (both halves into the same partial sum, times (w[2ip], w[2ip+1])); KP[ip][H] = (K[2ip][0], K[2ip+1][H]),
+//     KP[ip][H+1] = (ko[2ip], ko[2ip+1]);
+//   * a matrix-vector product K u is then R (H + 1) multiply-adds forward + R (H - 1) transposed per lane, the window of
+//     u (own rows + the next two lanes') and the transposed partial sums for the next two lanes travel through
+//     ds_bpermute_b32 (4 R - 1 per product), sums in a fixed order: a point's result does not depend on its tile mates.
+//
+// The matrix functions come from the same Chebyshev recurrence as everywhere else (primal table: 1/sqrt(1+t), 1/(1+t)) on
+// Kc, applied implicitly (x' is centred; every K u is centred again: 14 instructions instead of 2 per matrix entry);
+// the spectral bound is the largest row sum of K (K > 0 entrywise, ||C K C|| <= ||K||).  Degree ~5 at config 5.
+// One wavefront per tile, ~300 registers: one wave per SIMD (the matrix of 16 points is the register file).
+#include "mia_common.h"
+#include <hip/hip_ext.h>
+#include "mia_kernels.h"
+#include "mia_options.h"
+#include "mia_tiles.h"
+
+#ifndef LK_NV
+#define LK_NV 14
+#endif
+#ifndef LK_PAD_EXPR
+#define LK_PAD_EXPR (k != KP)
+#endif
+#ifndef LK_SB1
+#define LK_SB1
+#endif
+#ifndef LK_SB2
+#define LK_SB2
+#endif
+namespace mia {
+
+struct LkTileParams {
+  const float* X; int64_t ldx; int m, k;
+  int64_t g0, ng;
+  const float* Yb; const float* d; int64_t P;       // [k][P] perturbations, [P] innovations (R^-1/2-normalised)
+  const int4* thdr; const int32_t* tidx; const f4w* tD;
+  float inv_reg, inv_k, cs_phi, cs_psi, ng2;        // ng2 = -gamma log2(e)
+  float* Xa; int64_t ldo, o0; int32_t* flags; int32_t* retry_count;
+  int dmax;
+  const int2* tab_hdr; const float2* tab_c;
+  int seg_len; int64_t seg_stride;                  // pieces, as Tile2Params
+  int* clr_counts; const int* clr_n; unsigned* clr_err; int32_t* err_out;   // bucket-index housekeeping, as Tile2Params
+};
+
+__device__ __forceinline__ float lk_bperm(int byte_addr, float v) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
+}
+__device__ __forceinline__ f2w lk_fma2(f2w a, f2w b, f2w c) { return __builtin_elementwise_fma(a, b, c); }
+// a value parked in an accumulation register (the matrix of sixteen points is larger than the 256 architectural registers
+// of a lane: the tail of every row's band lives in AGPRs and is read into a temporary where it is used)
+__device__ __forceinline__ float lk_park(float v) { float a; asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v)); return a; }
+__device__ __forceinline__ float lk_fetch(float a) { float v; asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; }
+
+template <int R, int UT>
+__global__ __launch_bounds__(64, 1)
+void lketkf_tile_kernel(LkTileParams P) {
+  constexpr int KP = 4 * R, H = 2 * R, NP = H + 2, NS = 4 * UT, NSLOT = 16 * UT, S = NSLOT + 4;
+  constexpr int ROBS = KP + H, NROW = ROBS + 1;
+  constexpr int NV = R >= 10 ? LK_NV : H + 1;     // pairs n < NV of a row pair stay in architectural registers
+  static_assert(R % 2 == 0 && R >= 2 && R <= 10, "row pairs per lane");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* T = reinterpret_cast<float*>(smem);                    // [NROW][S]: member rows (wrapped copy of the first H), obs row
+  int* ukey = reinterpret_cast<int*>(smem + (size_t)NROW * S * 4);   // [NSLOT]
+  constexpr size_t LK_KL_OFF = ((size_t)NROW * S * 4 + NSLOT * 4 + 15) / 16 * 16;
+  const int lane = threadIdx.x, lr = lane & 15, h = lane >> 4;
+  const int k = P.k;
+
+  const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+  const int64_t ntile = (P.ng + 15) >> 4;
+  if (bid >= ntile) return;
+  if (P.clr_counts) {
+    const int ncl = *P.clr_n;
+    for (int64_t i = bid * 64 + lane; i < ncl; i += ntile * 64) P.clr_counts[i] = 0;
+    if (bid == 0 && lane == 0) {
+      const unsigned e = *P.clr_err;
+      if (e) { atomicOr(P.err_out, (int)(e << 3)); *P.clr_err = 0u; }
+    }
+  }
+  const int64_t q8 = ntile >> 3, r8 = ntile & 7, xcd = bid & 7;
+  const int64_t tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int64_t p0 = tile << 4;
+  const int npts = P.ng - p0 < 16 ? (int)(P.ng - p0) : 16;
+  int64_t oc0 = P.o0 + p0;
+  if (P.seg_len > 0) {
+    const unsigned sgi = (unsigned)p0 / (unsigned)P.seg_len;
+    oc0 = p0 - (int64_t)sgi * P.seg_len;
+    P.Xa += (int64_t)sgi * P.seg_stride;
+  }
+  const unsigned ldxb = (unsigned)P.ldx * 4u, ldob = (unsigned)P.ldo * 4u;
+  const int lrc = lr < npts ? lr : npts - 1;
+  const bool colok = lr < npts;
+  const bool pad = LK_PAD_EXPR;                                      // (wave-uniform)
+
+  // ---- first round trip: header, slot table, sqrt(rho) matrix
+  const int4 hd = P.thdr[tile];
+  for (int s = lane; s < NSLOT; s += 64) ukey[s] = t2_ld<int32_t>(P.tidx + tile * NSLOT, (unsigned)s * 4u);
+  f4w dreg[UT];
+#pragma unroll
+  for (int t = 0; t < UT; ++t) dreg[t] = t2_ld<f4w>(P.tD + (tile * UT + t) * 64, (unsigned)lane * 16u);
+  MIA_T2_SYNC();
+  const int U = __builtin_amdgcn_readfirstlane(hd.x);
+  if (U < 0) {                     // the union of this tile did not fit its slots: loud failure, never a truncated analysis
+    if (colok && h == 0) P.flags[p0 + lr] = MIA_FLAG_OVERFLOW;
+    const float nanv = __builtin_nanf("");
+    if (colok)
+      for (int it = h; it < P.m * k; it += 4) P.Xa[(int64_t)it * P.ldo + oc0 + lr] = nanv;
+    return;
+  }
+  // ---- second round trip: the union's columns of Yb (and d) as an f32 image T[member][slot]; slot 16 t + 4 kk + q sits at
+  //      position kk NS + 4 t + q of its row: the lane group kk of the A operand reads its NS values as UT 16-byte pieces
+  {
+    constexpr int NE = (KP + 1) * NSLOT, NLD = (NE + 63) / 64;
+    float v[NLD];
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+      const int e = lane + 64 * it;
+      const int a = e / NSLOT, sl = e - a * NSLOT;
+      const int j = e < NE ? ukey[sl] : -1;
+      const bool isobs = a == KP;
+      const bool ld = j >= 0 && (a < k || isobs);
+      const unsigned off = ((unsigned)(isobs ? 0 : a) * (unsigned)P.P + (unsigned)(j < 0 ? 0 : j)) * 4u;
+      const float* src = isobs ? P.d : P.Yb;
+      v[it] = ld ? t2_ld<float>(src, off) : 0.0f;
+    }
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+      const int e = lane + 64 * it;
+      const int a = e / NSLOT, sl = e - a * NSLOT;
+      const int pos = ((sl >> 2) & 3) * NS + 4 * (sl >> 4) + (sl & 3);
+      if (e < NE) {
+        const int row = a == KP ? ROBS : a;
+        T[row * S + pos] = v[it];
+        if (a < H) T[(KP + a) * S + pos] = v[it];
+      }
+    }
+  }
+  MIA_T2_SYNC();
+
+  // ---- pair statistic on the matrix cores.  A operand: lane (r = lane & 15, kk = lane >> 4) supplies row r = 4 h' + q' of a
+  //      row block: pair (ip, n = 2 nn + (q' >> 1), half = q' & 1).  Row a = R h' + 2 ip + half; partner b = a + delta with
+  //      delta = n + 1 - half (n < H), (0, H) for n = H, the observation row for n = H + 1.
+  f2w KPr[R / 2][NP];
+  float KA[R / 2][NP][2];       // the band's tail, parked in accumulation registers
+  {
+    float bsq[NS];
+#pragma unroll
+    for (int t = 0; t < UT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bsq[4 * t + q] = dreg[t][q] * dreg[t][q];
+    const int hp = lr >> 2, qp = lr & 3;
+    const unsigned aoff = (unsigned)((R * hp + (qp & 1)) * S + h * NS) * 4u;
+    const unsigned boff = aoff + (unsigned)(((qp >> 1) + 1 - (qp & 1)) * S) * 4u;
+    const unsigned char* Tb = reinterpret_cast<const unsigned char*>(T);
+#pragma unroll
+    for (int ip = 0; ip < R / 2; ++ip) {
+      // the special block (n = H, H + 1): q' = 0: delta 0; 1: delta H; 2, 3: observation row
+      const unsigned ospec = qp >= 2 ? (unsigned)(ROBS * S + h * NS) * 4u
+                                     : aoff + (unsigned)((2 * ip + (qp == 1 ? H : 0)) * S) * 4u;
+#pragma unroll
+      for (int nn = 0; nn < NP / 2; ++nn) {
+        const unsigned oa = aoff + (unsigned)(2 * ip * S) * 4u;
+        const unsigned ob = nn < H / 2 ? boff + (unsigned)((2 * ip + 2 * nn) * S) * 4u : ospec;
+        f4w acc = f4w{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < UT; ++t) {
+          const f4w ta = *reinterpret_cast<const f4w*>(Tb + oa + 16u * t);
+          const f4w tb = *reinterpret_cast<const f4w*>(Tb + ob + 16u * t);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float dl = ta[q] - tb[q];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dl * dl, bsq[4 * t + q], acc, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = 2 * nn + (q >> 1), hf = q & 1;
+          float kv = __builtin_amdgcn_exp2f(acc[q] * P.ng2);
+          if (pad) {          // rows / columns beyond the ensemble (k < 4 R): zero
+            const int dlt = n < H ? n + 1 - hf : (n == H ? (hf ? H : 0) : 0);
+            const int a = R * h + 2 * ip + hf;
+            int b = a + dlt;
+            b = b >= KP ? b - KP : b;
+            kv = (a < k && (n == H + 1 || b < k)) ? kv : 0.0f;
+          }
+          if (n >= NV && n <= H) KA[ip][n][hf] = lk_park(kv); else KPr[ip][n][hf] = kv;
+        }
+        LK_SB1;
+      }
+    }
+  }
+  auto getK = [&](int ip, int n) -> f2w {
+    if (n >= NV && n <= H) return f2w{lk_fetch(KA[ip][n][0]), lk_fetch(KA[ip][n][1])};
+    return KPr[ip][n];
+  };
+  const int adr_p1 = ((lane + 16) & 63) * 4, adr_p2 = ((lane + 32) & 63) * 4, adr_m1 = ((lane + 48) & 63) * 4;
+  // y = K w for the rows of this lane; w[0 .. R) own entries (the caller's), the window is fetched here
+  auto matvec = [&](const float (&u)[R], float (&yo)[R]) {
+    float w[3 * R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      w[i] = u[i];
+      w[R + i] = lk_bperm(adr_p1, u[i]);
+      w[2 * R + i] = lk_bperm(adr_p2, u[i]);
+    }
+    f2w yo2[R / 2];
+#pragma unroll
+    for (int ip = 0; ip < R / 2; ++ip) yo2[ip] = getK(ip, H) * f2w{w[2 * ip], w[2 * ip + 1 + H]};
+    float yw[3 * R - 1];
+#pragma unroll
+    for (int j = 1; j <= 3 * R - 2; ++j) {
+      f2w a2 = f2w{0.f, 0.f};
+#pragma unroll
+      for (int ip = 0; ip < R / 2; ++ip) {
+        const int n = j - 1 - 2 * ip;
+        if (n >= 0 && n < H) {
+          const f2w kp = getK(ip, n);
+          yo2[ip] = lk_fma2(kp, f2w{w[j], w[j]}, yo2[ip]);
+          const f2w mp = f2w{n <= H - 2 ? w[2 * ip] : 0.0f, n >= 1 ? w[2 * ip + 1] : 0.0f};
+          a2 = lk_fma2(kp, mp, a2);
+        }
+      }
+      yw[j] = a2[0] + a2[1];
+      LK_SB2;
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      float y = (i & 1) ? yo2[i >> 1][1] : yo2[i >> 1][0];
+      if (i >= 1) y += yw[i];
+      y += lk_bperm(adr_m1, yw[R + i]);
+      if (i <= R - 2) y += lk_bperm(adr_p2, yw[2 * R + i]);
+      yo[i] = y;
+    }
+  };
+
+  // ---- row sums r = K 1: spectral bound (largest row sum), the centring terms of the kernel vector
+  float alpha = 0.0f;
+  int deg = 0, tab_idx = 0, degmax = 0, pflag = 0;
+  bool decl = false;
+  {
+    float ones[R], r[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) ones[i] = (!pad || R * h + i < k) ? 1.0f : 0.0f;
+    matvec(ones, r);
+    float L = 0.0f, rs = 0.0f, kos = 0.0f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      L = (r[i] > L || r[i] != r[i]) ? r[i] : L;
+      rs += r[i];
+      kos += (i & 1) ? KPr[i >> 1][H + 1][1] : KPr[i >> 1][H + 1][0];
+    }
+    L = __uint_as_float(t2_max_h(__float_as_uint(L)));          // (non-negative or NaN: bit patterns order like the values)
+    rs = t2_add_h(rs) * P.inv_k * P.inv_k;                      // grand mean of K
+    kos = t2_add_h(kos) * P.inv_k;                              // mean of ko
+    // koc = ko - mean(ko) - (rowmean - grand mean), ketkf.py:77-88
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const float ko = (i & 1) ? KPr[i >> 1][H + 1][1] : KPr[i >> 1][H + 1][0];
+      float kc = ko - kos - (r[i] * P.inv_k - rs);
+      if (pad && R * h + i >= k) kc = 0.0f;
+      if (i & 1) KPr[i >> 1][H + 1][1] = kc; else KPr[i >> 1][H + 1][0] = kc;
+    }
+    L = fmaxf(L, 1e-30f) * 1.00001f;
+    if (!(L == L) || !(fabsf(L) < 1e30f)) { pflag |= MIA_FLAG_NONFINITE; L = 1.0f; }
+    tab_idx = (int)ceilf(float(kTabPerOctave) * __builtin_amdgcn_logf(L * P.inv_reg)) + kTabIdx0;
+    tab_idx = tab_idx < 0 ? 0 : (tab_idx > kTabN - 1 ? kTabN - 1 : tab_idx);
+    const int2 th = t2_ld<int2>(P.tab_hdr, (unsigned)tab_idx * 8u);
+    deg = th.x;
+    alpha = __int_as_float(th.y) * P.inv_reg;
+    decl = colok && (deg > P.dmax || deg > kTabDeg - 1);
+    if (decl && h == 0) {
+      P.flags[p0 + lr] = MIA_FLAG_RETRY;
+      atomicAdd(P.retry_count, 1);
+    }
+    degmax = (int)wave_max_nonneg_dpp((colok && !decl) ? float(deg) : 0.0f);
+  }
+
+  // ---- per state row: recurrence u_{j+1} = 2 (alpha Kc u_j - u_j) - u_{j-1} on x', accumulating phi(Kc) x' and koc . psi(Kc) x'
+  const unsigned cbase = (unsigned)tab_idx * (unsigned)(kTabDeg * 8);
+  auto coef = [&](int j) -> float2 { return t2_ld<float2>(P.tab_c, cbase + (unsigned)(j < kTabDeg ? j : kTabDeg - 1) * 8u); };
+  for (int mi = 0; mi < P.m; ++mi) {
+    const float* xbase = P.X + (int64_t)mi * k * P.ldx + P.g0 + p0;
+    float va[R], vb[R];
+    float xs = 0.0f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int a = R * h + i;
+      const bool live = !pad || a < k;
+      va[i] = t2_ld<float>(xbase, (unsigned)(live ? a : 0) * ldxb + (unsigned)lrc * 4u);
+      va[i] = live ? va[i] : 0.0f;
+      xs += va[i];
+    }
+    const float2 c0 = coef(0), c1 = coef(1);
+    float2 cn0 = coef(2), cn1 = coef(3);
+    const float xm = t2_add_h(xs) * P.inv_k;
+#pragma unroll
+    for (int i = 0; i < R; ++i) va[i] = (!pad || R * h + i < k) ? va[i] - xm : 0.0f;
+    float aphi[R], zacc = 0.0f;
+    float y[R];
+    auto centre = [&](float (&yy)[R]) -> float {       // alpha * mean of K u over the members
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < R; ++i) s += yy[i];
+      return t2_add_h(s) * P.inv_k * alpha;
+    };
+    auto kocdot = [&](const float (&vv)[R]) -> float {
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < R; ++i) s = fmaf((i & 1) ? KPr[i >> 1][H + 1][1] : KPr[i >> 1][H + 1][0], vv[i], s);
+      return s;
+    };
+    matvec(va, y);
+    {
+      const float am = centre(y);
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        float vq = fmaf(alpha, y[i], -(va[i] + am));
+        if (pad && R * h + i >= k) vq = 0.0f;
+        vb[i] = vq;
+        aphi[i] = fmaf(c1.x, vq, c0.x * va[i]);
+      }
+      zacc = fmaf(c1.y, kocdot(vb), c0.y * kocdot(va));
+    }
+    auto advance = [&](float (&vold)[R], const float (&vcur)[R], const float2 cj) {
+      matvec(vcur, y);
+      const float am = centre(y);
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const float tq = fmaf(alpha, y[i], -(vcur[i] + am));
+        float vn = fmaf(2.0f, tq, -vold[i]);
+        if (pad && R * h + i >= k) vn = 0.0f;
+        vold[i] = vn;
+        aphi[i] = fmaf(cj.x, vn, aphi[i]);
+      }
+      zacc = fmaf(cj.y, kocdot(vold), zacc);
+    };
+    int j = 2;
+    for (; j + 1 <= degmax; j += 2) {
+      const float2 cj = cn0, cj1 = cn1;
+      cn0 = coef(j + 2); cn1 = coef(j + 3);
+      advance(va, vb, cj);
+      advance(vb, va, cj1);
+    }
+    if (j <= degmax) advance(va, vb, cn0);
+    const float zu = t2_add_h(zacc) * P.cs_psi;
+    const float mterm = xm + zu;
+    int pf = 0;
+    if (colok && !decl) {
+      float* obase = P.Xa + (int64_t)mi * k * P.ldo + oc0;
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const int a = R * h + i;
+        const float o = fmaf(P.cs_phi, aphi[i], mterm);
+        if (!pad || a < k) {
+          if (!(fabsf(o) <= 1e30f)) pf = MIA_FLAG_NONFINITE;
+          *reinterpret_cast<float*>(reinterpret_cast<char*>(obase) + ((unsigned)a * ldob + (unsigned)lr * 4u)) = o;
+        }
+      }
+    }
+    pflag |= pf;
+  }
+  {
+    const unsigned long long fb = __ballot(pflag != 0);
+    const bool anyf = ((fb >> lr) & 0x0001000100010001ull) != 0ull;
+    if (h == 0 && colok && !decl) P.flags[p0 + lr] = (anyf ? MIA_FLAG_NONFINITE : 0) | (deg << 8);
+  }
+}
+
+static size_t lk_lds_bytes(int r, int ut) {
+  const size_t img = ((size_t)(6 * r + 1) * (16 * ut + 4) * 4 + (size_t)16 * ut * 4 + 15) / 16 * 16;
+  const int h = 2 * r, nv = r >= 10 ? LK_NV : h + 1;
+  return img + (size_t)(r / 2) * (h + 1 - nv) * 64 * 8;
+}
+
+template <int R, int UT>
+static int lk_launch(const LkTileParams& tp, hipStream_t stream) {
+  const size_t lds = lk_lds_bytes(R, UT);
+  auto kern = lketkf_tile_kernel<R, UT>;
+  const int64_t ntile = (tp.ng + 15) >> 4;
+  const int64_t gx = ntile < 65536 ? ntile : 65536;
+  const int64_t gy = (ntile + gx - 1) / gx;
+  if (gy > 65535) return MIA_ERR_UNSUPPORTED;
+  hipEvent_t& stop = launch_stop_event();
+  if (stop) {
+    hipExtLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(64), (unsigned)lds, stream, launch_start_event(), stop, 0, tp);
+    stop = nullptr;
+    launch_start_event() = nullptr;
+  } else {
+    kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64), lds, stream>>>(tp);
+  }
+  ++tile_launch_count();
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// RBF kernel, float32, 2 <= k <= 40 members, the tile's union within 64 slots, every global access base + 32-bit byte offset
+bool lketkf_tile_covers(int m, int k, int p_max, int extra_blocks, int64_t ldx, int64_t ldo, int64_t ng, int64_t P) {
+  if (!(m >= 1 && k >= 2 && k <= 40 && p_max >= 0 && extra_blocks >= 0)) return false;
+  if ((int64_t)k * ldx * 4 >= ((int64_t)1 << 31) || (int64_t)k * ldo * 4 >= ((int64_t)1 << 31)) return false;
+  if ((int64_t)k * (P > 0 ? P : 1) * 4 >= ((int64_t)1 << 31)) return false;
+  const int ut = tile_ut_for(p_max) + extra_blocks;
+  if (ut > 4) return false;
+  return ((ng + 15) >> 4) <= (int64_t)65536 * 65535;
+}
+
+int lketkf_tile_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* Yb, const float* d,
+                       int64_t P, const void* tile_lists, int ut, float inf_factor, float gamma, float* Xa, int64_t ldo,
+                       int64_t o0, int32_t* flags, int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c,
+                       hipStream_t stream, int seg_len, int64_t seg_stride, const Tile2Housekeeping* hk) {
+  if (seg_len < 0 || (seg_len & 15) || (seg_len > 0 && ng >= ((int64_t)1 << 31))) return MIA_ERR_UNSUPPORTED;
+  if (!flags || !retry_count || !tab_hdr || !tab_c || !tile_lists || (P > 0 && (!Yb || !d))) return MIA_ERR_UNSUPPORTED;
+  if (ut < 1 || ut > 4 || !(gamma > 0.0f) || !lketkf_tile_covers(m, k, 0, ut - 1, ldx, ldo, ng, P)) return MIA_ERR_UNSUPPORTED;
+  const TileListLayout L = tile_list_layout(ng, ut);
+  const char* base = (const char*)tile_lists;
+  LkTileParams tp;
+  tp.X = X; tp.ldx = ldx; tp.m = m; tp.k = k; tp.g0 = g0; tp.ng = ng;
+  tp.Yb = Yb; tp.d = d; tp.P = P;
+  tp.thdr = (const int4*)(base + L.hdr); tp.tidx = (const int32_t*)(base + L.idx); tp.tD = (const f4w*)(base + L.D);
+  const double rg = (double)(k - 1) / (double)inf_factor, km = (double)(k - 1);
+  tp.inv_reg = (float)(1.0 / rg);
+  tp.inv_k = (float)(1.0 / (double)k);
+  tp.cs_phi = (float)(sqrt(km) / sqrt(rg));
+  tp.cs_psi = (float)(1.0 / rg);
+  tp.ng2 = (float)(-(double)gamma * 1.4426950408889634);
+  tp.Xa = Xa; tp.ldo = ldo; tp.o0 = o0; tp.flags = flags; tp.retry_count = retry_count; tp.dmax = dmax;
+  tp.tab_hdr = tab_hdr; tp.tab_c = tab_c;
+  tp.seg_len = seg_len; tp.seg_stride = seg_stride;
+  tp.clr_counts = hk ? hk->counts : nullptr; tp.clr_n = hk ? hk->n : nullptr; tp.clr_err = hk ? hk->err : nullptr;
+  tp.err_out = hk ? hk->err_out : nullptr;
+  const int r = k <= 8 ? 2 : (k <= 16 ? 4 : (k <= 24 ? 6 : (k <= 32 ? 8 : 10)));
+#define MIA_LK_CASE(RR, UU) if (r == RR && ut == UU) return lk_launch<RR, UU>(tp, stream);
+#ifdef MIA_LK_SINGLE          // (development builds: one instantiation, for register / ISA inspection)
+  MIA_LK_CASE(10, 2)
+#else
+  MIA_LK_CASE(10, 1) MIA_LK_CASE(10, 2) MIA_LK_CASE(10, 3) MIA_LK_CASE(10, 4)
+  MIA_LK_CASE(8, 1) MIA_LK_CASE(8, 2) MIA_LK_CASE(8, 3) MIA_LK_CASE(8, 4)
+  MIA_LK_CASE(6, 1) MIA_LK_CASE(6, 2) MIA_LK_CASE(6, 3)
+  MIA_LK_CASE(4, 1) MIA_LK_CASE(4, 2)
+  MIA_LK_CASE(2, 1) MIA_LK_CASE(2, 2)
+#endif
+#undef MIA_LK_CASE
+  return MIA_ERR_UNSUPPORTED;
+}
+
+}  // namespace mia
+
+using namespace mia;
+
+extern "C" int mia_lketkf_rbf_analysis_tiles_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
+                                                 const float* Yb, const float* d, int64_t P, const void* tile_lists,
+                                                 int p_max, int extra_blocks, float inf_factor, float gamma, float* Xa,
+                                                 int64_t ldo, int64_t o0, int32_t* flags, int32_t* retry_count, void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (m < 1 || k < 2 || g1 < g0 || g0 < 0 || P < 0 || p_max < 0 || extra_blocks < 0 || !(inf_factor > 0.0f) || !(gamma > 0.0f))
+    return MIA_ERR_SIZE;
+  if (g1 == g0) return MIA_OK;
+  if (!X || !Xa || !tile_lists || !flags || !retry_count || (P > 0 && (!Yb || !d))) return MIA_ERR_NULL;
+  if (!lketkf_tile_covers(m, k, p_max, extra_blocks, ldx, ldo, g1 - g0, P)) return MIA_ERR_UNSUPPORTED;
+  const int2* th = nullptr;
+  const float2* tc = nullptr;
+  if (!cheb_primal_table(stream, &th, &tc)) return MIA_ERR_UNSUPPORTED;
+  return lketkf_tile_launch(X, ldx, m, k, g0, g1 - g0, Yb, d, P, tile_lists, tile_ut_for(p_max) + extra_blocks, inf_factor, gamma,
+                            Xa, ldo, o0, flags, retry_count, option(MIA_OPT_CHEB_DMAX), th, tc, stream, 0, 0, nullptr);
+}

@@ -61,6 +61,8 @@ bool cheb_tile_will_serve(int m, int k, int p_max, int p_cap, float gamma, int64
 
 // (letkf_cheb.hip) coefficient table of the dual route at the default truncation target (built on first use, per device)
 bool cheb_dual_table(hipStream_t stream, const int2** hdr, const float2** c);
+// ... and of the primal route (the RBF-kernelised tile kernel, lketkf_tile.hip)
+bool cheb_primal_table(hipStream_t stream, const int2** hdr, const float2** c);
 
 // one-wave kernel on `stream` that returns once the 64 slot counters at done64[j * kSlotStride] sum to `expected` (bounded
 // polling: after ~seconds it sets bit 0 of *err and returns, so the grid always drains)

@@ -244,6 +244,28 @@ class LetkfEngine:
             "mia_letkf_analysis_tiles_f32")
         return xa, flags[:n], retry
 
+    def analysis_tiles_rbf(self, X: torch.Tensor, Yb: torch.Tensor, d: torch.Tensor, tiles: "TileLists", inf_factor: float,
+                           rbf_gamma: float, out: Optional[torch.Tensor] = None):
+        """RBF-kernelised analysis (KETKFModule + RBFKernel(gamma), core/ketkf.py:65-94) of the tile lists' grid points from the
+        float32 perturbations themselves (mia_lketkf_rbf_analysis_tiles_f32).  Returns (Xa [m, k, n], flags [n], retry_count [1])
+        or None when the shape is outside the kernel (k > 40, unions of more than 64 slots)."""
+        X = X.to(device=self.device, dtype=torch.float32).contiguous()
+        Yb = Yb.to(device=self.device, dtype=torch.float32).contiguous()
+        d = d.to(device=self.device, dtype=torch.float32).contiguous().reshape(-1)
+        m, k, G = X.shape
+        n = tiles.g1 - tiles.g0
+        xa = out if out is not None else torch.empty((m, k, n), dtype=torch.float32, device=self.device)
+        flags = torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)
+        retry = torch.zeros(1, dtype=torch.int32, device=self.device)
+        rc = self.lib.mia_lketkf_rbf_analysis_tiles_f32(
+            _ptr(X), G, m, k, tiles.g0, tiles.g1, _ptr(Yb), _ptr(d), Yb.shape[1], _ptr(tiles.lists), tiles.p_max,
+            tiles.extra_blocks, float(inf_factor), float(rbf_gamma), _ptr(xa), xa.shape[-1], 0, _ptr(flags), _ptr(retry),
+            self._stream())
+        if rc == -3:
+            return None
+        _cabi.check(rc, "mia_lketkf_rbf_analysis_tiles_f32")
+        return xa, flags[:n], retry
+
     def weights_tiles(self, X: torch.Tensor, split_rec: torch.Tensor, P: int, tiles: "TileLists", inf_factor: float = 1.0):
         """Analysis + weights of the tile lists' grid points (mia_letkf_weights_tiles_f32).  Returns (Xa [m, k, n], W [n, k, k],
         flags [n], retry_count [1]) or None when the shape is outside the kernel (unions of more than 32 slots)."""
