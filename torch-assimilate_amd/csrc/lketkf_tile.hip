@@ -39,10 +39,13 @@
 #include "mia_tiles.h"
 
 #ifndef LK_NV
-#define LK_NV 14
+#define LK_NV 18
 #endif
-#ifndef LK_PAD_EXPR
-#define LK_PAD_EXPR (k != KP)
+#ifndef LK_MVSB
+#define LK_MVSB
+#endif
+#ifndef LK_ROT
+#define LK_ROT 1
 #endif
 #ifndef LK_SB1
 #define LK_SB1
@@ -51,6 +54,17 @@
 #define LK_SB2
 #endif
 namespace mia {
+
+// In-kernel phase stamps (diagnostic builds only, tools/lk_stamps.py; as letkf_tile2.hip): s_memtime at phase boundaries
+#ifdef MIA_LK_STAMPS
+constexpr int kLkStampN = 12, kLkStampTiles = 8192;
+__device__ long long g_lk_stamps[kLkStampTiles * kLkStampN];
+#define LK_STAMP(i) do { if (lane == 0 && bid < kLkStampTiles) g_lk_stamps[bid * kLkStampN + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define LK_STAMP_REAL(i) do { if (lane == 0 && bid < kLkStampTiles) g_lk_stamps[bid * kLkStampN + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define LK_STAMP(i) do { } while (0)
+#define LK_STAMP_REAL(i) do { } while (0)
+#endif
 
 struct LkTileParams {
   const float* X; int64_t ldx; int m, k;
@@ -71,10 +85,13 @@ __device__ __forceinline__ float lk_bperm(int byte_addr, float v) {
 __device__ __forceinline__ f2w lk_fma2(f2w a, f2w b, f2w c) { return __builtin_elementwise_fma(a, b, c); }
 // a value parked in an accumulation register (the matrix of sixteen points is larger than the 256 architectural registers
 // of a lane: the tail of every row's band lives in AGPRs and is read into a temporary where it is used)
-__device__ __forceinline__ float lk_park(float v) { float a; asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v)); return a; }
-__device__ __forceinline__ float lk_fetch(float a) { float v; asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; }
+// (the compiler pads nothing around inline assembly: the value parked is the result of a transcendental instruction, whose
+//  consumer needs a wait state -- without the s_nop the write picked up the register's previous content)
+__device__ __forceinline__ float lk_park(float v) { float a; asm("s_nop 1\n\tv_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v)); return a; }
+__device__ __forceinline__ float lk_fetch(float a) { float v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; }
 
-template <int R, int UT>
+// PAD: the ensemble is smaller than the 4 R rows the lanes of a point hold (k < 4 R): rows / columns beyond it are zeroed
+template <int R, int UT, bool PAD>
 __global__ __launch_bounds__(64, 1)
 void lketkf_tile_kernel(LkTileParams P) {
   constexpr int KP = 4 * R, H = 2 * R, NP = H + 2, NS = 4 * UT, NSLOT = 16 * UT, S = NSLOT + 4;
@@ -112,8 +129,10 @@ void lketkf_tile_kernel(LkTileParams P) {
   const unsigned ldxb = (unsigned)P.ldx * 4u, ldob = (unsigned)P.ldo * 4u;
   const int lrc = lr < npts ? lr : npts - 1;
   const bool colok = lr < npts;
-  const bool pad = LK_PAD_EXPR;                                      // (wave-uniform)
+  constexpr bool pad = PAD;
 
+  LK_STAMP(0);
+  LK_STAMP_REAL(10);
   // ---- first round trip: header, slot table, sqrt(rho) matrix
   const int4 hd = P.thdr[tile];
   for (int s = lane; s < NSLOT; s += 64) ukey[s] = t2_ld<int32_t>(P.tidx + tile * NSLOT, (unsigned)s * 4u);
@@ -129,6 +148,7 @@ void lketkf_tile_kernel(LkTileParams P) {
       for (int it = h; it < P.m * k; it += 4) P.Xa[(int64_t)it * P.ldo + oc0 + lr] = nanv;
     return;
   }
+  LK_STAMP(1);      // header, slot table
   // ---- second round trip: the union's columns of Yb (and d) as an f32 image T[member][slot]; slot 16 t + 4 kk + q sits at
   //      position kk NS + 4 t + q of its row: the lane group kk of the A operand reads its NS values as UT 16-byte pieces
   {
@@ -158,6 +178,7 @@ void lketkf_tile_kernel(LkTileParams P) {
     }
   }
   MIA_T2_SYNC();
+  LK_STAMP(2);      // image of the union's records in LDS
 
   // ---- pair statistic on the matrix cores.  A operand: lane (r = lane & 15, kk = lane >> 4) supplies row r = 4 h' + q' of a
   //      row block: pair (ip, n = 2 nn + (q' >> 1), half = q' & 1).  Row a = R h' + 2 ip + half; partner b = a + delta with
@@ -174,85 +195,120 @@ void lketkf_tile_kernel(LkTileParams P) {
     const unsigned aoff = (unsigned)((R * hp + (qp & 1)) * S + h * NS) * 4u;
     const unsigned boff = aoff + (unsigned)(((qp >> 1) + 1 - (qp & 1)) * S) * 4u;
     const unsigned char* Tb = reinterpret_cast<const unsigned char*>(T);
+    // the special block of a row pair (n = H, H + 1): q' = 0: delta 0; 1: delta H; 2, 3: observation row
+    const unsigned ospec0 = qp >= 2 ? (unsigned)(ROBS * S + h * NS) * 4u : aoff + (unsigned)((qp == 1 ? H : 0) * S) * 4u;
+    const unsigned ospec_step = qp >= 2 ? 0u : (unsigned)(2 * S) * 4u;
+    constexpr int NBP = NP / 2, NB = (R / 2) * NBP;
+    // software pipeline, one row block per stage (a scheduling barrier closes every stage): the operands of block b + 1 are
+    // read from LDS, block b's products are issued (a chain of NS dependent MFMAs: 32 cycles each, back to back), and block
+    // b - 1 -- its chain finished long ago -- goes through exp2, masking and into its home registers
+    auto ld_block = [&](int bb, f4w (&ta)[UT], f4w (&tb)[UT]) {
+      const int ip = bb / NBP, nn = bb % NBP;
+      const unsigned oa = aoff + (unsigned)(2 * ip * S) * 4u;
+      const unsigned ob = nn < H / 2 ? boff + (unsigned)((2 * ip + 2 * nn) * S) * 4u : ospec0 + (unsigned)ip * ospec_step;
 #pragma unroll
-    for (int ip = 0; ip < R / 2; ++ip) {
-      // the special block (n = H, H + 1): q' = 0: delta 0; 1: delta H; 2, 3: observation row
-      const unsigned ospec = qp >= 2 ? (unsigned)(ROBS * S + h * NS) * 4u
-                                     : aoff + (unsigned)((2 * ip + (qp == 1 ? H : 0)) * S) * 4u;
+      for (int t = 0; t < UT; ++t) {
+        ta[t] = *reinterpret_cast<const f4w*>(Tb + oa + 16u * t);
+        tb[t] = *reinterpret_cast<const f4w*>(Tb + ob + 16u * t);
+      }
+    };
+    auto fin_block = [&](int bb, const f4w acc) {
+      const int ip = bb / NBP, nn = bb % NBP;
 #pragma unroll
-      for (int nn = 0; nn < NP / 2; ++nn) {
-        const unsigned oa = aoff + (unsigned)(2 * ip * S) * 4u;
-        const unsigned ob = nn < H / 2 ? boff + (unsigned)((2 * ip + 2 * nn) * S) * 4u : ospec;
-        f4w acc = f4w{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < UT; ++t) {
-          const f4w ta = *reinterpret_cast<const f4w*>(Tb + oa + 16u * t);
-          const f4w tb = *reinterpret_cast<const f4w*>(Tb + ob + 16u * t);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float dl = ta[q] - tb[q];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dl * dl, bsq[4 * t + q], acc, 0, 0, 0);
-          }
+      for (int q = 0; q < 4; ++q) {
+        const int n = 2 * nn + (q >> 1), hf = q & 1;
+        float kv = __builtin_amdgcn_exp2f(acc[q] * P.ng2);
+        if (pad) {          // rows / columns beyond the ensemble (k < 4 R): zero
+          const int dlt = n < H ? n + 1 - hf : (n == H ? (hf ? H : 0) : 0);
+          const int a = R * h + 2 * ip + hf;
+          int b = a + dlt;
+          b = b >= KP ? b - KP : b;
+          kv = (a < k && (n == H + 1 || b < k)) ? kv : 0.0f;
         }
+        if (n >= NV && n <= H) KA[ip][n][hf] = lk_park(kv); else KPr[ip][n][hf] = kv;
+      }
+    };
+    f4w ta[2][UT], tb[2][UT], acc[2];
+    ld_block(0, ta[0], tb[0]);
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) {
+      if (bb + 1 < NB) ld_block(bb + 1, ta[(bb + 1) & 1], tb[(bb + 1) & 1]);
+      f4w ac = f4w{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < UT; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int n = 2 * nn + (q >> 1), hf = q & 1;
-          float kv = __builtin_amdgcn_exp2f(acc[q] * P.ng2);
-          if (pad) {          // rows / columns beyond the ensemble (k < 4 R): zero
-            const int dlt = n < H ? n + 1 - hf : (n == H ? (hf ? H : 0) : 0);
-            const int a = R * h + 2 * ip + hf;
-            int b = a + dlt;
-            b = b >= KP ? b - KP : b;
-            kv = (a < k && (n == H + 1 || b < k)) ? kv : 0.0f;
-          }
-          if (n >= NV && n <= H) KA[ip][n][hf] = lk_park(kv); else KPr[ip][n][hf] = kv;
+          const float dl = ta[bb & 1][t][q] - tb[bb & 1][t][q];
+          ac = __builtin_amdgcn_mfma_f32_16x16x4f32(dl * dl, bsq[4 * t + q], ac, 0, 0, 0);
         }
-        LK_SB1;
-      }
+      acc[bb & 1] = ac;
+      if (bb >= 1) fin_block(bb - 1, acc[(bb - 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    fin_block(NB - 1, acc[(NB - 1) & 1]);
   }
   auto getK = [&](int ip, int n) -> f2w {
     if (n >= NV && n <= H) return f2w{lk_fetch(KA[ip][n][0]), lk_fetch(KA[ip][n][1])};
     return KPr[ip][n];
   };
+  LK_STAMP(3);      // pair statistic, exp
   const int adr_p1 = ((lane + 16) & 63) * 4, adr_p2 = ((lane + 32) & 63) * 4, adr_m1 = ((lane + 48) & 63) * 4;
-  // y = K w for the rows of this lane; w[0 .. R) own entries (the caller's), the window is fetched here
+  // y = K u for the rows of this lane.  Anti-diagonal by anti-diagonal (j = row + delta, a scheduling barrier after each):
+  // the forward products of all row pairs with w[j], the transposed products into the partial sum of target row j, which
+  // leaves for its owner (this lane: j < R; the next lane: j < 2 R; the one after) as soon as it is complete and is added
+  // two anti-diagonals later -- the live set is the matrix, the window (2 R), R accumulators and a few values in flight
   auto matvec = [&](const float (&u)[R], float (&yo)[R]) {
-    float w[3 * R];
+    float n1[R], n2[R];
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-      w[i] = u[i];
-      w[R + i] = lk_bperm(adr_p1, u[i]);
-      w[2 * R + i] = lk_bperm(adr_p2, u[i]);
-    }
+    for (int i = 0; i < R; ++i) n1[i] = lk_bperm(adr_p1, u[i]);
+    auto wv = [&](int j) -> float { return j < R ? u[j] : (j < 2 * R ? n1[j - R] : n2[j - 2 * R]); };
     f2w yo2[R / 2];
 #pragma unroll
-    for (int ip = 0; ip < R / 2; ++ip) yo2[ip] = getK(ip, H) * f2w{w[2 * ip], w[2 * ip + 1 + H]};
-    float yw[3 * R - 1];
+    for (int ip = 0; ip < R / 2; ++ip) yo2[ip] = f2w{0.f, 0.f};
+    float pend[3 * R];
+    LK_MVSB;
 #pragma unroll
     for (int j = 1; j <= 3 * R - 2; ++j) {
-      f2w a2 = f2w{0.f, 0.f};
+      if (j == R) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) n2[i] = lk_bperm(adr_p2, u[i]);
+      }
+      f2w a2 = f2w{0.f, 0.f}, b2 = f2w{0.f, 0.f};
+      const float wj = wv(j);
 #pragma unroll
       for (int ip = 0; ip < R / 2; ++ip) {
         const int n = j - 1 - 2 * ip;
         if (n >= 0 && n < H) {
           const f2w kp = getK(ip, n);
-          yo2[ip] = lk_fma2(kp, f2w{w[j], w[j]}, yo2[ip]);
-          const f2w mp = f2w{n <= H - 2 ? w[2 * ip] : 0.0f, n >= 1 ? w[2 * ip + 1] : 0.0f};
-          a2 = lk_fma2(kp, mp, a2);
+          yo2[ip] = lk_fma2(kp, f2w{wj, wj}, yo2[ip]);
+          const f2w mp = f2w{n <= H - 2 ? u[2 * ip] : 0.0f, n >= 1 ? u[2 * ip + 1] : 0.0f};
+          if (ip & 1) b2 = lk_fma2(kp, mp, b2); else a2 = lk_fma2(kp, mp, a2);
         }
       }
-      yw[j] = a2[0] + a2[1];
-      LK_SB2;
+      const float ywj = (a2[0] + b2[0]) + (a2[1] + b2[1]);
+      if (j < R) pend[j] = ywj;
+      else if (j < 2 * R) pend[j] = lk_bperm(adr_m1, ywj);
+      else pend[j] = lk_bperm(adr_p2, ywj);
+      if (j >= 3) {          // the partial sum of two anti-diagonals ago has arrived: into its row's accumulator
+        const int jj = j - 2, i = jj < R ? jj : (jj < 2 * R ? jj - R : jj - 2 * R);
+        yo2[i >> 1][i & 1] += pend[jj];
+      }
+      LK_MVSB;
     }
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-      float y = (i & 1) ? yo2[i >> 1][1] : yo2[i >> 1][0];
-      if (i >= 1) y += yw[i];
-      y += lk_bperm(adr_m1, yw[R + i]);
-      if (i <= R - 2) y += lk_bperm(adr_p2, yw[2 * R + i]);
-      yo[i] = y;
+    for (int jj = 3 * R - 3; jj <= 3 * R - 2; ++jj) {
+      if (jj >= 1) {
+        const int i = jj < R ? jj : (jj < 2 * R ? jj - R : jj - 2 * R);
+        yo2[i >> 1][i & 1] += pend[jj];
+      }
     }
+#pragma unroll
+    for (int ip = 0; ip < R / 2; ++ip) {       // the pairs that have no partner: (K[2ip][0], K[2ip+1][H])
+      yo2[ip] = lk_fma2(getK(ip, H), f2w{u[2 * ip], wv(2 * ip + 1 + H)}, yo2[ip]);
+      yo[2 * ip] = yo2[ip][0];
+      yo[2 * ip + 1] = yo2[ip][1];
+    }
+    LK_MVSB;
   };
 
   // ---- row sums r = K 1: spectral bound (largest row sum), the centring terms of the kernel vector
@@ -297,6 +353,7 @@ void lketkf_tile_kernel(LkTileParams P) {
     degmax = (int)wave_max_nonneg_dpp((colok && !decl) ? float(deg) : 0.0f);
   }
 
+  LK_STAMP(4);      // row sums, bound, degree
   // ---- per state row: recurrence u_{j+1} = 2 (alpha Kc u_j - u_j) - u_{j-1} on x', accumulating phi(Kc) x' and koc . psi(Kc) x'
   const unsigned cbase = (unsigned)tab_idx * (unsigned)(kTabDeg * 8);
   auto coef = [&](int j) -> float2 { return t2_ld<float2>(P.tab_c, cbase + (unsigned)(j < kTabDeg ? j : kTabDeg - 1) * 8u); };
@@ -356,6 +413,15 @@ void lketkf_tile_kernel(LkTileParams P) {
       }
       zacc = fmaf(cj.y, kocdot(vold), zacc);
     };
+#if LK_ROT
+    for (int j = 2; j <= degmax; ++j) {
+      const float2 cj = cn0;
+      cn0 = cn1; cn1 = coef(j + 2);
+      advance(va, vb, cj);
+#pragma unroll
+      for (int i = 0; i < R; ++i) { const float t = va[i]; va[i] = vb[i]; vb[i] = t; }
+    }
+#else
     int j = 2;
     for (; j + 1 <= degmax; j += 2) {
       const float2 cj = cn0, cj1 = cn1;
@@ -364,6 +430,8 @@ void lketkf_tile_kernel(LkTileParams P) {
       advance(vb, va, cj1);
     }
     if (j <= degmax) advance(va, vb, cn0);
+#endif
+    if (mi == 0) LK_STAMP(5);      // recurrence of the first state row
     const float zu = t2_add_h(zacc) * P.cs_psi;
     const float mterm = xm + zu;
     int pf = 0;
@@ -386,7 +454,16 @@ void lketkf_tile_kernel(LkTileParams P) {
     const bool anyf = ((fb >> lr) & 0x0001000100010001ull) != 0ull;
     if (h == 0 && colok && !decl) P.flags[p0 + lr] = (anyf ? MIA_FLAG_NONFINITE : 0) | (deg << 8);
   }
+  LK_STAMP(6);
+  LK_STAMP_REAL(11);
 }
+
+#ifdef MIA_LK_STAMPS
+extern "C" int mia_debug_lk_stamps(long long* host, int n_tiles) {
+  if (n_tiles > kLkStampTiles) n_tiles = kLkStampTiles;
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lk_stamps), sizeof(long long) * kLkStampN * (size_t)n_tiles);
+}
+#endif
 
 static size_t lk_lds_bytes(int r, int ut) {
   const size_t img = ((size_t)(6 * r + 1) * (16 * ut + 4) * 4 + (size_t)16 * ut * 4 + 15) / 16 * 16;
@@ -394,10 +471,10 @@ static size_t lk_lds_bytes(int r, int ut) {
   return img + (size_t)(r / 2) * (h + 1 - nv) * 64 * 8;
 }
 
-template <int R, int UT>
-static int lk_launch(const LkTileParams& tp, hipStream_t stream) {
+template <int R, int UT, bool PAD>
+static int lk_launch_p(const LkTileParams& tp, hipStream_t stream) {
   const size_t lds = lk_lds_bytes(R, UT);
-  auto kern = lketkf_tile_kernel<R, UT>;
+  auto kern = lketkf_tile_kernel<R, UT, PAD>;
   const int64_t ntile = (tp.ng + 15) >> 4;
   const int64_t gx = ntile < 65536 ? ntile : 65536;
   const int64_t gy = (ntile + gx - 1) / gx;
@@ -413,6 +490,11 @@ static int lk_launch(const LkTileParams& tp, hipStream_t stream) {
   ++tile_launch_count();
   MIA_LAUNCH_CHECK();
   return MIA_OK;
+}
+
+template <int R, int UT>
+static int lk_launch(const LkTileParams& tp, hipStream_t stream) {
+  return tp.k == 4 * R ? lk_launch_p<R, UT, false>(tp, stream) : lk_launch_p<R, UT, true>(tp, stream);
 }
 
 // RBF kernel, float32, 2 <= k <= 40 members, the tile's union within 64 slots, every global access base + 32-bit byte offset
