@@ -100,8 +100,9 @@ void lketkf_tile_kernel(LkTileParams P) {
   static_assert(R % 2 == 0 && R >= 2 && R <= 10, "row pairs per lane");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* T = reinterpret_cast<float*>(smem);                    // [NROW][S]: member rows (wrapped copy of the first H), obs row
-  int* ukey = reinterpret_cast<int*>(smem + (size_t)NROW * S * 4);   // [NSLOT]
-  constexpr size_t LK_KL_OFF = ((size_t)NROW * S * 4 + NSLOT * 4 + 15) / 16 * 16;
+  int* ukey = reinterpret_cast<int*>(smem + (size_t)NROW * S * 4);   // [NSLOT] observation index of a slot
+  unsigned* smax = reinterpret_cast<unsigned*>(ukey + NSLOT);        // [NSLOT] largest magnitude of a slot's column (bit pattern)
+  float* esc2 = reinterpret_cast<float*>(smax + NSLOT);              // [NSLOT] 2^-2e of a slot, in operand order
   const int lane = threadIdx.x, lr = lane & 15, h = lane >> 4;
   const int k = P.k;
 
@@ -150,9 +151,12 @@ void lketkf_tile_kernel(LkTileParams P) {
   }
   LK_STAMP(1);      // header, slot table
   // ---- second round trip: the union's columns of Yb (and d) as an f32 image T[member][slot]; slot 16 t + 4 kk + q sits at
-  //      position kk NS + 4 t + q of its row: the lane group kk of the A operand reads its NS values as UT 16-byte pieces
+  //      position kk NS + 4 t + q of its row: the lane group kk of the A operand reads its NS values as UT 16-byte pieces.
+  //      Every slot's column is scaled by its own power of two 2^e (largest magnitude -> [2^5, 2^6): squared differences stay
+  //      below 2^14, inside half precision); the scale returns through the weights, rho_hat = rho 2^-2e.
   {
     constexpr int NE = (KP + 1) * NSLOT, NLD = (NE + 63) / 64;
+    for (int s_ = lane; s_ < NSLOT; s_ += 64) smax[s_] = 0u;
     float v[NLD];
 #pragma unroll
     for (int it = 0; it < NLD; ++it) {
@@ -165,32 +169,81 @@ void lketkf_tile_kernel(LkTileParams P) {
       const float* src = isobs ? P.d : P.Yb;
       v[it] = ld ? t2_ld<float>(src, off) : 0.0f;
     }
+    MIA_T2_SYNC();
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+      const int e = lane + 64 * it;
+      const int a = e / NSLOT, sl = e - a * NSLOT;
+      if (e < NE) atomicMax(&smax[sl], __float_as_uint(v[it]) & 0x7fffffffu);
+    }
+    MIA_T2_SYNC();
+    bool badrec = false;
 #pragma unroll
     for (int it = 0; it < NLD; ++it) {
       const int e = lane + 64 * it;
       const int a = e / NSLOT, sl = e - a * NSLOT;
       const int pos = ((sl >> 2) & 3) * NS + 4 * (sl >> 4) + (sl & 3);
       if (e < NE) {
+        const unsigned mx = smax[sl];
+        badrec = badrec || mx >= 0x7f800000u;
+        int es;
+        const float sc = pow2_scale(mx, 5, &es);
+        const float x = v[it] * sc;
         const int row = a == KP ? ROBS : a;
-        T[row * S + pos] = v[it];
-        if (a < H) T[(KP + a) * S + pos] = v[it];
+        T[row * S + pos] = x;
+        if (a < H) T[(KP + a) * S + pos] = x;
+        if (a == 0) esc2[pos] = __uint_as_float((unsigned)(127 - 2 * es) << 23);      // 2^-2e, in the operand's slot order
       }
+    }
+    // a non-finite record: through the shared product it would reach all 16 columns (NaN * 0), also the points that do not see
+    // that observation -- every point of such a tile goes to the eigensolver kernel, which works point by point
+    if (__any(badrec)) {
+      if (colok && h == 0) { P.flags[p0 + lr] = MIA_FLAG_RETRY; atomicAdd(P.retry_count, 1); }
+      return;
     }
   }
   MIA_T2_SYNC();
   LK_STAMP(2);      // image of the union's records in LDS
 
-  // ---- pair statistic on the matrix cores.  A operand: lane (r = lane & 15, kk = lane >> 4) supplies row r = 4 h' + q' of a
-  //      row block: pair (ip, n = 2 nn + (q' >> 1), half = q' & 1).  Row a = R h' + 2 ip + half; partner b = a + delta with
-  //      delta = n + 1 - half (n < H), (0, H) for n = H, the observation row for n = H + 1.
+  // ---- pair statistic on the matrix cores: Dist[(a, b), g] = sum_s (yhat_as - yhat_bs)^2 rho_hat_gs as split half-precision
+  //      products (v_mfma_f32_16x16x32_f16: hi = f16(x), lo = f16(x - hi); hi hi + hi lo + lo hi, 22 bits, f32 accumulation --
+  //      all terms are non-negative, nothing cancels).  The f32 matrix instruction shares the vector unit's issue (measured:
+  //      33 cycles each and NOT overlapped with the vector instructions that build its operand); the half-precision one
+  //      runs beside them.  A operand: lane (r = lane & 15, kg = lane >> 4) supplies row r = 4 h' + q' of a row block -- pair
+  //      (ip, n = 2 nn + (q' >> 1), half = q' & 1), row a = R h' + 2 ip + half, partner b = a + delta with delta = n + 1 - half
+  //      (n < H), (0, H) for n = H, the observation row for n = H + 1 -- over the slots 16 t + 4 kg + q, k index 8 kg + 4 t + q
+  //      of product t >> 1; B operand: this lane's own entries of the sqrt(rho) matrix, squared, times 2^-2e, scaled per point.
   f2w KPr[R / 2][NP];
   float KA[R / 2][NP][2];       // the band's tail, parked in accumulation registers
   {
-    float bsq[NS];
+    constexpr int NT2 = (UT + 1) / 2;
+    h8v bh[NT2], bl[NT2];
+    float exparg;
+    {
+      float bsq[2 * NT2][4];
+      unsigned bmx = 0u;
 #pragma unroll
-    for (int t = 0; t < UT; ++t)
+      for (int t = 0; t < 2 * NT2; ++t) {
+        const f4w e4 = t < UT ? *reinterpret_cast<const f4w*>(esc2 + h * NS + 4 * t) : f4w{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bsq[4 * t + q] = dreg[t][q] * dreg[t][q];
+        for (int q = 0; q < 4; ++q) {
+          bsq[t][q] = t < UT ? dreg[t < UT ? t : 0][q] * dreg[t < UT ? t : 0][q] * e4[q] : 0.0f;
+          const unsigned u_ = __float_as_uint(bsq[t][q]) & 0x7fffffffu;
+          bmx = u_ > bmx ? u_ : bmx;
+        }
+      }
+      bmx = t2_max_h(bmx);
+      int esb;
+      const float sb = pow2_scale(bmx, 9, &esb);
+      exparg = P.ng2 * __uint_as_float((unsigned)(127 - esb) << 23);
+#pragma unroll
+      for (int g = 0; g < NT2; ++g) {
+        float b8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b8[i] = bsq[2 * g + (i >> 2)][i & 3] * sb;
+        split8_tied(b8, bh[g], bl[g]);
+      }
+    }
     const int hp = lr >> 2, qp = lr & 3;
     const unsigned aoff = (unsigned)((R * hp + (qp & 1)) * S + h * NS) * 4u;
     const unsigned boff = aoff + (unsigned)(((qp >> 1) + 1 - (qp & 1)) * S) * 4u;
@@ -200,8 +253,8 @@ void lketkf_tile_kernel(LkTileParams P) {
     const unsigned ospec_step = qp >= 2 ? 0u : (unsigned)(2 * S) * 4u;
     constexpr int NBP = NP / 2, NB = (R / 2) * NBP;
     // software pipeline, one row block per stage (a scheduling barrier closes every stage): the operands of block b + 1 are
-    // read from LDS, block b's products are issued (a chain of NS dependent MFMAs: 32 cycles each, back to back), and block
-    // b - 1 -- its chain finished long ago -- goes through exp2, masking and into its home registers
+    // read from LDS, block b's differences are squared, split and multiplied, and block b - 1 goes through exp2, masking and
+    // into its home registers
     auto ld_block = [&](int bb, f4w (&ta)[UT], f4w (&tb)[UT]) {
       const int ip = bb / NBP, nn = bb % NBP;
       const unsigned oa = aoff + (unsigned)(2 * ip * S) * 4u;
@@ -217,7 +270,7 @@ void lketkf_tile_kernel(LkTileParams P) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = 2 * nn + (q >> 1), hf = q & 1;
-        float kv = __builtin_amdgcn_exp2f(acc[q] * P.ng2);
+        float kv = __builtin_amdgcn_exp2f(acc[q] * exparg);
         if (pad) {          // rows / columns beyond the ensemble (k < 4 R): zero
           const int dlt = n < H ? n + 1 - hf : (n == H ? (hf ? H : 0) : 0);
           const int a = R * h + 2 * ip + hf;
@@ -235,12 +288,18 @@ void lketkf_tile_kernel(LkTileParams P) {
       if (bb + 1 < NB) ld_block(bb + 1, ta[(bb + 1) & 1], tb[(bb + 1) & 1]);
       f4w ac = f4w{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < UT; ++t)
+      for (int g = 0; g < NT2; ++g) {
+        float l8[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float dl = ta[bb & 1][t][q] - tb[bb & 1][t][q];
-          ac = __builtin_amdgcn_mfma_f32_16x16x4f32(dl * dl, bsq[4 * t + q], ac, 0, 0, 0);
+        for (int i = 0; i < 8; ++i) {
+          const int t = 2 * g + (i >> 2);
+          const float dl = t < UT ? ta[bb & 1][t < UT ? t : 0][i & 3] - tb[bb & 1][t < UT ? t : 0][i & 3] : 0.0f;
+          l8[i] = dl * dl;
         }
+        h8v ah, al;
+        split8_tied(l8, ah, al);
+        ac = t2_mfma3(ac, ah, al, bh[g], bl[g]);
+      }
       acc[bb & 1] = ac;
       if (bb >= 1) fin_block(bb - 1, acc[(bb - 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
@@ -465,11 +524,7 @@ extern "C" int mia_debug_lk_stamps(long long* host, int n_tiles) {
 }
 #endif
 
-static size_t lk_lds_bytes(int r, int ut) {
-  const size_t img = ((size_t)(6 * r + 1) * (16 * ut + 4) * 4 + (size_t)16 * ut * 4 + 15) / 16 * 16;
-  const int h = 2 * r, nv = r >= 10 ? LK_NV : h + 1;
-  return img + (size_t)(r / 2) * (h + 1 - nv) * 64 * 8;
-}
+static size_t lk_lds_bytes(int r, int ut) { return (size_t)(6 * r + 1) * (16 * ut + 4) * 4 + (size_t)16 * ut * 12; }
 
 template <int R, int UT, bool PAD>
 static int lk_launch_p(const LkTileParams& tp, hipStream_t stream) {
