@@ -39,7 +39,10 @@
 #include "mia_tiles.h"
 
 #ifndef LK_NV
-#define LK_NV 18
+#define LK_NV 12
+#endif
+#ifndef LK_NV_PAD
+#define LK_NV_PAD 18
 #endif
 #ifndef LK_MVSB
 #define LK_MVSB
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(64, 1)
 void lketkf_tile_kernel(LkTileParams P) {
   constexpr int KP = 4 * R, H = 2 * R, NP = H + 2, NS = 4 * UT, NSLOT = 16 * UT, S = NSLOT + 4;
   constexpr int ROBS = KP + H, NROW = ROBS + 1;
-  constexpr int NV = R >= 10 ? LK_NV : H + 1;     // pairs n < NV of a row pair stay in architectural registers
+  constexpr int NV = R >= 10 ? (PAD ? LK_NV_PAD : LK_NV) : H + 1;     // pairs n < NV of a row pair stay in architectural registers
   static_assert(R % 2 == 0 && R >= 2 && R <= 10, "row pairs per lane");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* T = reinterpret_cast<float*>(smem);                    // [NROW][S]: member rows (wrapped copy of the first H), obs row
