@@ -299,6 +299,11 @@ int mia_letkf_weights_tiles_f32(const float* X, int64_t ldx, int m, int k, int64
  * csrc/lketkf_tile.hip).  2 <= k <= 40, a tile's union within 64 slots; MIA_ERR_UNSUPPORTED otherwise
  * (mia_letkf_analysis_matfun_f32 with gamma > 0 takes every shape).  flags / retry_count as mia_letkf_analysis_tiles_f32;
  * declined points are redone by mia_letkf_analysis_retry_f32 (gamma > 0) from per-point lists. */
+/* Whether the tile-route kernels take a shape (1) or not (0): the test mia_letkf_analysis_tiles_f32 (gamma <= 0) /
+ * mia_lketkf_rbf_analysis_tiles_f32 (gamma > 0) apply before launching -- ensemble size, slots of a tile's union, LDS, and
+ * every global access as base + 32-bit byte offset (k * ldx * 4, k * ldo * 4 [, k * P * 4] < 2^31). */
+int mia_letkf_tiles_cover(int m, int k, int p_max, int extra_blocks, int64_t ldx, int64_t ldo, int64_t n_points, int64_t P,
+                          float gamma);
 int mia_lketkf_rbf_analysis_tiles_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
                                       const float* Yb, const float* d, int64_t P, const void* tile_lists, int p_max,
                                       int extra_blocks, float inf_factor, float gamma, float* Xa, int64_t ldo, int64_t o0,

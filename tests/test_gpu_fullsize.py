@@ -69,17 +69,21 @@ def test_tile_route_at_full_size(eng, name, k, stride, c):
 
 
 def test_config5_at_full_size(eng):
-    """Config 5 (RBF-kernelised filter, gamma 0.5, k = 40) at 1e5 grid points: 64 oracle points, determinism, the eigensolver
-    route on a 2000-point shard agrees with the matrix-function route."""
+    """Config 5 (RBF-kernelised filter, gamma 0.5, k = 40) at 1e5 grid points on the tile route: 64 oracle points, determinism,
+    the one-point-per-wavefront kernel agrees, the eigensolver route on a 2000-point shard agrees."""
     import bench
     dev = torch.device("cuda:0")
     G = 100000
     X, gx, ox, Yb, d = bench.make_case(G, 40, 2, dev, seed=43)
     nb = eng.localize(gx, ox, [10.0])
     rec = eng.pack_obs(Yb, d, torch.float32)
-    xa, fl = eng.analysis(X, None, None, nb, 1.1, rec=rec, rbf_gamma=0.5, return_flags=True, method="matfun")
-    assert int((fl & 0xff).max().item()) == 0 and bool(torch.isfinite(xa).all())
-    assert torch.equal(xa, eng.analysis(X, None, None, nb, 1.1, rec=rec, rbf_gamma=0.5, method="matfun"))
+    tiles = eng.localize_tiles(gx, ox, [10.0], nb.p_max)
+    assert tiles.stats.tolist() == [nb.p_max, 0]
+    xa, fl, retry = eng.analysis_tiles_rbf(X, Yb, d, tiles, 1.1, 0.5)           # the tile route (csrc/lketkf_tile.hip)
+    assert int(retry.item()) == 0 and int((fl & 0xff).max().item()) == 0 and bool(torch.isfinite(xa).all())
+    assert torch.equal(xa, eng.analysis_tiles_rbf(X, Yb, d, tiles, 1.1, 0.5)[0])
+    xp = eng.analysis(X, None, None, nb, 1.1, rec=rec, rbf_gamma=0.5, method="matfun")      # one point per wavefront
+    assert float(torch.linalg.norm(xa - xp) / torch.linalg.norm(xp)) < 1e-6
     nb_s = eng.localize(gx, ox, [10.0], g0=50000, g1=52000)
     xe = eng.analysis(X, None, None, nb_s, 1.1, rec=rec, rbf_gamma=0.5, method="eig")
     part = xa[:, :, 50000:52000]

@@ -65,6 +65,7 @@ _PROTOS = {
     "mia_letkf_split_record_bytes": ([i32, C.POINTER(sz)], i32),
     "mia_letkf_pack_split_f32": ([vp, vp, i32, i64, vp, vp], i32),
     "mia_letkf_analysis_tiles_f32": ([vp, i64, i32, i32, i64, i64, vp, i64, vp, i32, i32, f32, vp, i64, i64, vp, vp, vp], i32),
+    "mia_letkf_tiles_cover": ([i32, i32, i32, i32, i64, i64, i64, i64, f32], i32),
     "mia_lketkf_rbf_analysis_tiles_f32": ([vp, i64, i32, i32, i64, i64, vp, vp, i64, vp, i32, i32, f32, f32, vp, i64, i64,
                                            vp, vp, vp], i32),
     "mia_letkf_weights_tiles_f32": ([vp, i64, i32, i32, i64, i64, vp, i64, vp, i32, i32, f32, vp, i64, i64, vp, vp, vp, vp], i32),

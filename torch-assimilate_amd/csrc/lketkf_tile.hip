@@ -561,7 +561,7 @@ bool lketkf_tile_covers(int m, int k, int p_max, int extra_blocks, int64_t ldx, 
   if ((int64_t)k * ldx * 4 >= ((int64_t)1 << 31) || (int64_t)k * ldo * 4 >= ((int64_t)1 << 31)) return false;
   if ((int64_t)k * (P > 0 ? P : 1) * 4 >= ((int64_t)1 << 31)) return false;
   const int ut = tile_ut_for(p_max) + extra_blocks;
-  if (ut > 4) return false;
+  if (ut > 4 || ut > ((k + 15) >> 4) + 1) return false;       // (the workspace of the step driver is sized by the same rule)
   return ((ng + 15) >> 4) <= (int64_t)65536 * 65535;
 }
 
@@ -624,4 +624,10 @@ extern "C" int mia_lketkf_rbf_analysis_tiles_f32(const float* X, int64_t ldx, in
   if (!cheb_primal_table(stream, &th, &tc)) return MIA_ERR_UNSUPPORTED;
   return lketkf_tile_launch(X, ldx, m, k, g0, g1 - g0, Yb, d, P, tile_lists, tile_ut_for(p_max) + extra_blocks, inf_factor, gamma,
                             Xa, ldo, o0, flags, retry_count, option(MIA_OPT_CHEB_DMAX), th, tc, stream, 0, 0, nullptr);
+}
+
+extern "C" int mia_letkf_tiles_cover(int m, int k, int p_max, int extra_blocks, int64_t ldx, int64_t ldo, int64_t n_points,
+                                     int64_t P, float gamma) {
+  if (gamma > 0.0f) return lketkf_tile_covers(m, k, p_max, extra_blocks, ldx, ldo, n_points, P) ? 1 : 0;
+  return tile2_covers(m, k, p_max, extra_blocks, ldx, ldo, n_points) ? 1 : 0;
 }

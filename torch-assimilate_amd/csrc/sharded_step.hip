@@ -708,10 +708,15 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
   const int pm_tl = p_max_assumed < L.cap ? p_max_assumed : L.cap;
   const int2* tl_th = nullptr;
   const float2* tl_tc = nullptr;
+  // (gamma > 0: the RBF-kernelised filter on the same tile lists -- lketkf_tile_kernel reads Yb and d themselves, no records)
+  const bool tl_rbf = gamma > 0.0f;
   const bool tl_route = mia::option(MIA_OPT_TILE_LISTS) != 0 && !(step_flags & MIA_STEP_NO_TILE_LISTS) && (n_chunks == 1 || exch) &&
-                        method != 1 && !(gamma > 0.0f) && blk > 0 && P > 0 && L.ut <= 6 && mia::option(MIA_OPT_TILE) != 0 &&
-                        mia::option(MIA_OPT_TILE_SPLIT) != 0 && mia::tile2_covers(m, k, pm_tl, (step_flags >> 4) & 7, G, exch ? L.nc : G, blk) &&
-                        mia::cheb_dual_table((hipStream_t)(prep_stream ? prep_stream : stream), &tl_th, &tl_tc);
+                        method != 1 && blk > 0 && P > 0 && L.ut <= 6 && mia::option(MIA_OPT_TILE) != 0 &&
+                        (tl_rbf ? mia::lketkf_tile_covers(m, k, pm_tl, (step_flags >> 4) & 7, G, exch ? L.nc : G, blk, P) &&
+                                      mia::cheb_primal_table((hipStream_t)(prep_stream ? prep_stream : stream), &tl_th, &tl_tc)
+                                : mia::option(MIA_OPT_TILE_SPLIT) != 0 &&
+                                      mia::tile2_covers(m, k, pm_tl, (step_flags >> 4) & 7, G, exch ? L.nc : G, blk) &&
+                                      mia::cheb_dual_table((hipStream_t)(prep_stream ? prep_stream : stream), &tl_th, &tl_tc));
   const bool tl_bucket = tl_route && mia::option(MIA_OPT_BUCKET_INDEX) != 0 && !(step_flags & MIA_STEP_SCAN_INDEX);
   // geometry epoch: the tile lists this workspace holds are used again (the caller vouches for unchanged coordinates, radii,
   // eps and block); only the split records are rebuilt.  Nothing to clear after the analysis: no index was built
@@ -769,8 +774,10 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
       }
     }
     if (b1 > b0 && tl_reuse) {
-      rc = mia::split_pack_launch(Yb, d, k, P, base + L.hrec, ps);
-      if (rc != MIA_OK) return rc;
+      if (!tl_rbf) {
+        rc = mia::split_pack_launch(Yb, d, k, P, base + L.hrec, ps);
+        if (rc != MIA_OK) return rc;
+      }
     } else if (b1 > b0 && tl_route) {
       const mia::ZeroJob zj{{counters, exch ? ctr : nullptr, exch ? done : nullptr},
                             {8, exch ? 4 : 0, exch ? (int64_t)done_ints : 0}};
@@ -782,13 +789,13 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
       if (tl_bucket)
         rc = mia::index_bucket_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, base + L.loc, L.loc_bytes, ps,
                                           zero_in_kernel ? &zj : nullptr,
-                                          !(step_flags & MIA_STEP_WS_CLEAN) || (step_flags & MIA_STEP_FRESH_BOX), &sj);
+                                          !(step_flags & MIA_STEP_WS_CLEAN) || (step_flags & MIA_STEP_FRESH_BOX), tl_rbf ? nullptr : &sj);
       else
         rc = mia::index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, base + L.loc, L.loc_bytes, ps, nullptr,
                                    zero_in_kernel ? &zj : nullptr, (step_flags & MIA_STEP_WS_CLEAN) != 0, false);
       if (rc != MIA_OK) return rc;
       rc = mia::tile_lists_launch(grid_xyz, b0, b1 - b0, P, n_coord, coord_group, gc_c, n_r, gc_eps, MIA_TAPER_GC, L.ut,
-                                  base + L.tl, ctr, base + L.loc, ps, tl_bucket ? nullptr : &sj, tl_bucket);
+                                  base + L.tl, ctr, base + L.loc, ps, (tl_bucket || tl_rbf) ? nullptr : &sj, tl_bucket);
       if (rc != MIA_OK) return rc;
     } else if (b1 > b0) {
       // the record packing rides inside the first index kernel too (independent work, no launch of its own)
@@ -815,7 +822,10 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
     // tile route with several pieces: ONE launch over the block, every tile writes into its piece's buffer; the pieces are
     // exchanged once it has finished (the kernel is a fraction of one piece's all-gather: nothing to overlap inside it)
     if (tl_route && n_chunks > 1 && b1 > b0) {
-      rc = mia::tile2_analysis_launch(X, G, m, k, b0, b1 - b0, base + L.hrec, P, base + L.tl, L.ut, inf_factor,
+      rc = tl_rbf ? mia::lketkf_tile_launch(X, G, m, k, b0, b1 - b0, Yb, d, P, base + L.tl, L.ut, inf_factor, gamma,
+                                            (float*)(base + L.bufs), L.nc, 0, flags, ctr + 2, mia::option(MIA_OPT_CHEB_DMAX), tl_th, tl_tc, s,
+                                            (int)L.nc, (int64_t)(L.chunk_bytes / sizeof(float)), (tl_bucket && !tl_reuse) ? &tl_hk : nullptr)
+                  : mia::tile2_analysis_launch(X, G, m, k, b0, b1 - b0, base + L.hrec, P, base + L.tl, L.ut, inf_factor,
                                       (float*)(base + L.bufs), L.nc, 0, flags, ctr + 2, mia::option(MIA_OPT_CHEB_DMAX), tl_th, tl_tc, s,
                                       (int)L.nc, (int64_t)(L.chunk_bytes / sizeof(float)), (tl_bucket && !tl_reuse) ? &tl_hk : nullptr);
       if (rc != MIA_OK) return rc;
@@ -890,7 +900,11 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
             mia::launch_start_event() = t_start;
           }
           const unsigned long long tiles_before = mia::tile_launch_count();
-          if (tl_route)
+          if (tl_route && tl_rbf)
+            rc = mia::lketkf_tile_launch(X, G, m, k, c0, c1 - c0, Yb, d, P, base + L.tl, L.ut, inf_factor, gamma, dst, ldo, o0,
+                                         cfl, ctr + 2, mia::option(MIA_OPT_CHEB_DMAX), tl_th, tl_tc, (hipStream_t)stream, 0, 0,
+                                         (tl_bucket && !tl_reuse) ? &tl_hk : nullptr);
+          else if (tl_route)
             rc = mia::tile2_analysis_launch(X, G, m, k, c0, c1 - c0, base + L.hrec, P, base + L.tl, L.ut, inf_factor, dst, ldo, o0,
                                             cfl, ctr + 2, mia::option(MIA_OPT_CHEB_DMAX), tl_th, tl_tc, (hipStream_t)stream, 0, 0,
                                             (tl_bucket && !tl_reuse) ? &tl_hk : nullptr);

@@ -287,7 +287,7 @@ class LetkfEngine:
     def weights_retry(self, X: torch.Tensor, Yb: torch.Tensor, d: torch.Tensor, nbrs: NeighbourLists, inf_factor: float,
                       out: torch.Tensor, W: torch.Tensor, flags: torch.Tensor):
         """Eigensolver redo (analysis + weights) of the points flagged MIA_FLAG_RETRY (mia_letkf_weights_retry_f32)."""
-        X = X.contiguous()
+        X = X.to(device=self.device, dtype=torch.float32).contiguous()
         m, k, G = X.shape
         rec = self.pack_obs(Yb, d, torch.float32)
         _cabi.check(self.lib.mia_letkf_weights_retry_f32(
@@ -295,32 +295,33 @@ class LetkfEngine:
             nbrs.p_cap, nbrs.p_max, float(inf_factor), 0.0, _ptr(out), out.shape[-1], 0, _ptr(W), _ptr(flags), self._stream()),
             "mia_letkf_weights_retry_f32")
 
-    def tile_route_applies(self, X: torch.Tensor, p_max: int, extra_blocks: int = 0, rbf_gamma=None, method: str = "auto") -> bool:
-        """Whether the tile route (tile lists + split records + csrc/letkf_tile2.hip) takes this analysis: float32, plain ETKF
-        core, dual route p_max <= k <= 96, the union's row blocks within what the ensemble size allows, route options on."""
-        if X.dtype != torch.float32 or rbf_gamma is not None or method == "eig" or X.dim() != 3:
-            return False
-        k = X.shape[1]
-        ut = max(1, (int(p_max) + 8 + 15) // 16) + int(extra_blocks)
-        if not (2 <= k <= 96 and p_max <= k and ut <= min(6, (k + 15) // 16 + 1)):
+    def tile_route_applies(self, X: torch.Tensor, p_max: int, extra_blocks: int = 0, rbf_gamma=None, method: str = "auto",
+                           P: int = 1, n_points: Optional[int] = None, ldo: Optional[int] = None) -> bool:
+        """Whether the tile route (tile lists + csrc/letkf_tile2.hip, or csrc/lketkf_tile.hip for the RBF-kernelised filter)
+        takes this analysis: float32, route options on, and the shape test the C side applies before launching
+        (mia_letkf_tiles_cover: ensemble size, slots of a tile's union, LDS, 32-bit byte offsets)."""
+        if X.dtype != torch.float32 or method == "eig" or X.dim() != 3:
             return False
         v = C.c_int(0)
-        for name in (b"tile", b"tile_split", b"tile_lists"):
+        for name in (b"tile", b"tile_lists") + (() if rbf_gamma is not None else (b"tile_split",)):
             self.lib.mia_get_option(name, C.byref(v))
             if not v.value:
                 return False
-        return True
+        m, k, G = X.shape
+        n = G if n_points is None else int(n_points)
+        return bool(self.lib.mia_letkf_tiles_cover(m, k, int(p_max), int(extra_blocks), G, n if ldo is None else int(ldo), n, int(P),
+                                                   float(rbf_gamma) if rbf_gamma is not None else 0.0))
 
     def retry_points(self, X: torch.Tensor, Yb: torch.Tensor, d: torch.Tensor, nbrs: NeighbourLists, inf_factor: float,
-                     out: torch.Tensor, flags: torch.Tensor, out_offset: int = 0):
+                     out: torch.Tensor, flags: torch.Tensor, out_offset: int = 0, rbf_gamma: Optional[float] = None):
         """Eigensolver redo of the grid points flagged MIA_FLAG_RETRY (mia_letkf_analysis_retry_f32) from per-point lists."""
-        X = X.contiguous()
+        X = X.to(device=self.device, dtype=torch.float32).contiguous()
         m, k, G = X.shape
         rec = self.pack_obs(Yb, d, torch.float32)
         _cabi.check(self.lib.mia_letkf_analysis_retry_f32(
             _ptr(X), G, m, k, nbrs.g0, nbrs.g1, _ptr(rec), rec.shape[0], _ptr(nbrs.cnt), _ptr(nbrs.idx), _ptr(nbrs.w),
-            nbrs.p_cap, nbrs.p_max, float(inf_factor), 0.0, _ptr(out), out.shape[-1], out_offset, _ptr(flags), self._stream()),
-            "mia_letkf_analysis_retry_f32")
+            nbrs.p_cap, nbrs.p_max, float(inf_factor), float(rbf_gamma) if rbf_gamma is not None else 0.0, _ptr(out), out.shape[-1],
+            out_offset, _ptr(flags), self._stream()), "mia_letkf_analysis_retry_f32")
 
     def build_index(self, obs_xyz, radii: Sequence[float], coord_group: Optional[Sequence[int]] = None) -> ObsIndex:
         """Bin the observations into the uniform cell grid used by the fused-localisation analysis."""

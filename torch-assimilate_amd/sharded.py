@@ -75,6 +75,8 @@ class ShardedLetkf:
         self.engine.lib.mia_get_option(b"tile_split", C.byref(sp))
         tl = C.c_int(1)
         self.engine.lib.mia_get_option(b"tile_lists", C.byref(tl))
+        if v.value and tl.value and not self._no_tile_lists and self.rbf_gamma is not None:
+            return "lketkf_tile_kernel<10, 2, false>"
         if v.value and sp.value and tl.value and not self._no_tile_lists and self.native_step:
             return "letkf_tile2_kernel<2, 3, false>"
         return ("letkf_tile_kernel<2, 3, false, %s>" % ("true" if sp.value else "false")) if v.value else "letkf_cheb_kernel<20, 1, false>"
@@ -266,7 +268,8 @@ class ShardedLetkf:
         more slots per tile until the format has no more (then None: per-point lists).  Declined points are redone by the
         eigensolver kernel from the per-point lists ``nb``."""
         eng = self.engine
-        while eng.tile_route_applies(X, nb.p_max, self._tile_extra, self.rbf_gamma, self.method):
+        P = int(Yb.shape[1])
+        while eng.tile_route_applies(X, nb.p_max, self._tile_extra, self.rbf_gamma, self.method, P=P, n_points=g1 - g0):
             tiles = eng.localize_tiles(grid_xyz, obs_xyz, self.radii, nb.p_max, self.coord_group, self.eps, g0, g1,
                                        extra_blocks=self._tile_extra)
             if int(tiles.stats[1].item()) == 0:                 # host sync (first call on a geometry only)
@@ -276,14 +279,19 @@ class ShardedLetkf:
             if self._tile_extra:
                 self._no_tile_lists, self._tile_extra = True, 0
             return None
-        Xc = X.contiguous()
-        rec = eng.pack_split(Yb, d)
-        xa, flags, retry = eng.analysis_tiles(Xc, rec, Yb.shape[1], tiles, self.inf_factor)
+        Xc = X.to(eng.device, torch.float32).contiguous()
+        if self.rbf_gamma is not None:      # RBF-kernelised filter: from the perturbations themselves (csrc/lketkf_tile.hip)
+            res = eng.analysis_tiles_rbf(Xc, Yb, d, tiles, self.inf_factor, self.rbf_gamma)
+        else:
+            res = eng.analysis_tiles(Xc, eng.pack_split(Yb, d), P, tiles, self.inf_factor)
+        if res is None:
+            return None
+        xa, flags, retry = res
         n_retry = int(retry.item())
         if n_retry:
             if not nb.confirm():                                # (lists built on an assumed bound that did not hold)
                 nb = eng.localize(grid_xyz, obs_xyz, self.radii, self.coord_group, self.eps, g0, g1)
-            eng.retry_points(Xc, Yb, d, nb, self.inf_factor, xa, flags)
+            eng.retry_points(Xc, Yb, d, nb, self.inf_factor, xa, flags, rbf_gamma=self.rbf_gamma)
         self.last_retries = n_retry
         self._p_max_hint = max(int(tiles.stats[0].item()), 0)
         self.last_p_max = nb.p_max
@@ -939,8 +947,10 @@ class ShardedLetkf:
         fused = (self.fused_localization and self.method != "eig" and self._p_max_hint is not None
                  and X.dtype == torch.float32)
         tiles_route = (not fused and not self._no_tile_lists and len(obs_xyz) > 0 and self._p_max_hint is not None
-                       and eng.tile_route_applies(X, self._p_max_hint, self._tile_extra, self.rbf_gamma, self.method))
-        names = ["pack_split" if tiles_route else "pack_obs",
+                       and eng.tile_route_applies(X, self._p_max_hint, self._tile_extra, self.rbf_gamma, self.method,
+                                                  P=int(Yb.shape[1]), n_points=g1 - g0))
+        rbf_tiles = tiles_route and self.rbf_gamma is not None
+        names = ["(no records: the kernel reads Yb, d)" if rbf_tiles else ("pack_split" if tiles_route else "pack_obs"),
                  "obs_index_build" if fused else ("localize_tiles entry (scan index: 5 kernels, + tile lists; the step driver bins with ONE bucket kernel instead)" if tiles_route
                                                   else "localize(index+lists, incl. host sync)"), "analysis_kernel"]
         acc = dict.fromkeys(names, 0.0)
@@ -949,7 +959,7 @@ class ShardedLetkf:
             nk = 1
             e = [ev() for _ in range(4)]
             e[0].record()
-            rec = eng.pack_split(Yb, d) if tiles_route else eng.pack_obs(Yb, d, X.dtype)
+            rec = None if rbf_tiles else (eng.pack_split(Yb, d) if tiles_route else eng.pack_obs(Yb, d, X.dtype))
             e[1].record()
             if fused:
                 index = eng.build_index(obs_xyz, self.radii, self.coord_group)
@@ -963,7 +973,10 @@ class ShardedLetkf:
                 out = torch.empty((X.shape[0], X.shape[1], g1 - g0), dtype=torch.float32, device=X.device)
                 e[2].record()
                 for _ in range(burst):
-                    eng.analysis_tiles(X, rec, Yb.shape[1], tiles, self.inf_factor, out=out)
+                    if rbf_tiles:
+                        eng.analysis_tiles_rbf(X, Yb, d, tiles, self.inf_factor, self.rbf_gamma, out=out)
+                    else:
+                        eng.analysis_tiles(X, rec, Yb.shape[1], tiles, self.inf_factor, out=out)
                 nk = burst
                 fin = lambda: 0
             else:
