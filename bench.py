@@ -390,7 +390,6 @@ def main():
                           max_in_flight=max(2, args.pipeline_depth),
                           prep_streams=int(os.environ.get("MIA_PREP_STREAMS", "5")),
                           analysis_streams=int(os.environ.get("MIA_ANALYSIS_STREAMS", "1")),
-                          prep_streams_shared=int(os.environ.get("MIA_PREP_SHARED", "2")),
                           # N > 1: direct peer writes into IPC-mapped result buffers when the node allows it (self-tested
                           # at set-up, RCCL all-gather otherwise); the result is consumed from the slot buffer, no copy
                           peer_exchange=os.environ.get("MIA_PEER_EXCHANGE", "auto"), copy_results=False)
@@ -727,11 +726,10 @@ def main():
                       "eigensolver_route_kernel_ms": eig_ms,
                       "eigensolver_route_kernel_analyses_per_s": (gpg / (eig_ms * 1e-3)) if eig_ms else None},
             "pipeline": {"depth": depth, "serial_ms_per_step": serial_ms,
-                         "preparation_streams": {"n": runner.prep_streams, "on_the_analysis_streams_hardware_queue": runner.prep_streams_shared,
-                                                 "free_and_shared_streams_seen_by_the_probe": runner.prep_stream_pick,
-                                                 "note": "ROCm multiplexes HIP streams over 4 hardware queues; the runner probes fresh "
-                                                         "streams and takes this mix (DESIGN.md 6): 5 / 2 keeps the analysis kernel at "
-                                                         "~36 us in the loop, 5 / 1 is the fastest loop (2.18e9/s) at ~44 us"},
+                         "preparation_streams": {"n": runner.prep_streams,
+                                                 "note": "plain HIP streams taken in turn by the steps in flight (the hardware-queue "
+                                                         "probing of round 3 measured no gain under these flags and is gone: "
+                                                         "profiles/r04_stream_ab.txt)"},
                          "fixed_geometry": fixed_geo,
                          "serial_analyses_per_s": (G / (serial_ms * 1e-3)) if serial_ms else None,
                          "note": "depth d > 1: consecutive (independent) steps are software-pipelined over d slots / HIP "

@@ -174,24 +174,19 @@ def test_geometry_epoch_reuses_the_tile_lists(mia):
     assert torch.equal(g2, r2) and torch.equal(g3, r2)
 
 
-def test_preparation_streams_are_picked_by_hardware_queue(mia):
-    """Steps in flight: the runner sorts freshly created streams into those that share the analysis stream's hardware queue and
-    those that do not (ShardedLetkf._shares_queue: a spin kernel on one stream, a tiny kernel on the other) and takes the
-    configured mix; results do not depend on the mix."""
+def test_results_do_not_depend_on_the_number_of_preparation_streams(mia):
+    """Steps in flight rotate through `prep_streams` preparation streams (plain streams: the hardware-queue probing of round 3
+    is gone): results do not depend on how many there are."""
     import bench
     dev_ = torch.device("cuda:0")
     X, gx, ox, Yb, d = bench.make_case(20000, 40, 2, dev_, seed=4)
     outs = []
-    for n, shared in ((5, 2), (3, 0), (4, 4)):
-        r = mia.ShardedLetkf(dev_, 0, 1, radii=[10.0], inf_factor=1.1, max_in_flight=4, prep_streams=n, prep_streams_shared=shared)
+    for n in (5, 2, 1):
+        r = mia.ShardedLetkf(dev_, 0, 1, radii=[10.0], inf_factor=1.1, max_in_flight=4, prep_streams=n)
         r.assimilate(X, gx, ox, Yb, d)
         pend = [r.submit(X, gx, ox, Yb, d) for _ in range(4)]
         res = [h.result() for h in pend]
         assert all(torch.equal(res[0], x) for x in res[1:])
         outs.append(res[0].clone())
-        free, sh = r.prep_stream_pick
-        assert free >= n - shared and sh >= shared            # both kinds exist among a few dozen streams (4 hardware queues)
+        r.close()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-    s1, s2 = torch.cuda.Stream(device=dev_), torch.cuda.Stream(device=dev_)
-    assert mia.ShardedLetkf._shares_queue(s1, s1)            # a stream shares its queue with itself
-    assert isinstance(mia.ShardedLetkf._shares_queue(s1, s2), bool)

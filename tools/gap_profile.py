@@ -56,4 +56,3 @@ for mod in (a.prep_streams, a.depth):
     print("mean gap by (step mod %d):" % mod, np.array2string(np.array([gap[idx % mod == r].mean() for r in range(mod)]), precision=1))
 print("first 48 gaps:", np.array2string(gap[:48], precision=0, max_line_width=220))
 print("first 48 durations:", np.array2string(dur[:48], precision=0, max_line_width=220))
-print("preparation streams picked / rejected (shared the analysis stream's hardware queue):", getattr(runner, "prep_stream_pick", None))

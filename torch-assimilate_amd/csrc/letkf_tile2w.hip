@@ -42,6 +42,9 @@ constexpr int kWPts = 4;        // points of a tile per wavefront
 // float64 eigensolver as well (MIA_FLAG_RETRY is added to the flag the analysis launch wrote, the point is counted): the random
 // sweep of tools/stress_tile.py peaked at 7.4e-6 for degrees in the fifties, 3e-6 below the cap
 constexpr int kWDegCap = 36;
+#ifndef MIA_W_TRIM
+#define MIA_W_TRIM 2
+#endif
 
 template <int UT, int KT>
 __global__ __launch_bounds__(64, KT <= 3 ? 3 : 2)
@@ -393,11 +396,14 @@ void letkf_tile2w_kernel(Tile2wParams P) {
     const int g = kWPts * sub + i;                 // (wave-uniform)
     if (g >= npts) break;
     if (__builtin_amdgcn_readlane((int)decl, g)) continue;
-    const int deg_g = __builtin_amdgcn_readlane(deg, g);
-    if (deg_g > kWDegCap) {
+    const int deg_t = __builtin_amdgcn_readlane(deg, g);
+    if (deg_t > kWDegCap) {
       if (lane == 0) { atomicOr(P.flags + p0 + g, MIA_FLAG_RETRY); atomicAdd(P.retry_count, 1); }
       continue;
     }
+    // the table's degree carries two steps of margin over the a-priori count (cheb_table_kernel): the MATRIX recurrence, a
+    // thirteenth of this kernel's instructions per step, runs without them (tools/stress_tile.py --weights: unchanged worst case)
+    const int deg_g = deg_t - MIA_W_TRIM > 3 ? deg_t - MIA_W_TRIM : (deg_t < 3 ? deg_t : 3);
     const float alpha_g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha), g));
     const unsigned cbase = (unsigned)__builtin_amdgcn_readlane(tab_idx, g) * (unsigned)(kTabDeg * 8);
     auto coef = [&](int j) -> float {      // (uniform address: scalar loads); 2^-10 keeps M inside the half range for P

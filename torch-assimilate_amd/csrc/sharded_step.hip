@@ -658,6 +658,34 @@ constexpr int kStepPrepDone = 0x100;      // internal step flag: the launch thre
 
 static inline char* base_of(void* ws) { return (char*)ws; }
 
+// what the tile lists held by a step workspace were built for (geometry epochs, MIA_STEP_REUSE_LISTS)
+struct GeomStamp {
+  int route, ut, bucket, n_coord, n_r, rank, world, k;
+  int64_t G, P;
+  double eps, rc[MIA_MAX_RADII];
+  int cg[MIA_MAX_COORD];
+};
+static std::mutex g_stamp_mu;
+struct GeomEntry { void* ws; GeomStamp st; bool valid, reuse; };
+static std::deque<GeomEntry> g_stamps;        // (a handful of pipeline slots per process)
+// decide = true (a step's preparation): reuse is granted when asked for AND the workspace's stamp equals `now`; otherwise the
+// stamp becomes `now` (lists are rebuilt; route 0 = no tile lists).  decide = false: the decision taken for this workspace.
+static bool geom_reuse_decision(void* ws, const GeomStamp& now, bool asked, bool decide) {
+  std::lock_guard<std::mutex> lock(g_stamp_mu);
+  GeomEntry* e = nullptr;
+  for (auto& x : g_stamps)
+    if (x.ws == ws) { e = &x; break; }
+  if (!decide) return e ? e->reuse : false;
+  if (!e) {
+    if (g_stamps.size() >= 64) g_stamps.pop_front();
+    g_stamps.push_back(GeomEntry{ws, now, false, false});
+    e = &g_stamps.back();
+  }
+  e->reuse = asked && e->valid && memcmp(&e->st, &now, sizeof now) == 0;
+  if (!e->reuse) { memcpy(&e->st, &now, sizeof now); e->valid = now.route != 0; }      // (bytes, padding included: compared as bytes)
+  return e->reuse;
+}
+
 static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, const float* d, int64_t P,
                      const double* grid_xyz, const double* obs_xyz, int n_coord, const int32_t* coord_group,
                      const double* gc_c, int n_r, double gc_eps, float inf_factor, float gamma, int method, int p_max_assumed,
@@ -720,7 +748,18 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
   const bool tl_bucket = tl_route && mia::option(MIA_OPT_BUCKET_INDEX) != 0 && !(step_flags & MIA_STEP_SCAN_INDEX);
   // geometry epoch: the tile lists this workspace holds are used again (the caller vouches for unchanged coordinates, radii,
   // eps and block); only the split records are rebuilt.  Nothing to clear after the analysis: no index was built
-  const bool tl_reuse = tl_route && (step_flags & MIA_STEP_REUSE_LISTS) != 0;
+  // ... and the library checks what it can: a stamp of what this workspace's lists were built for (route, format, block, radii,
+  // eps, coordinate groups, sizes), kept on the host per workspace.  A step that asks for reuse with anything else -- an option or
+  // attribute changed in between, another kernel family -- silently rebuilds instead of analysing from stale memory.
+  GeomStamp stamp_now;
+  memset(&stamp_now, 0, sizeof stamp_now);
+  stamp_now.route = tl_route ? (tl_rbf ? 2 : 1) : 0;
+  stamp_now.ut = L.ut; stamp_now.bucket = tl_bucket ? 1 : 0; stamp_now.n_coord = n_coord; stamp_now.n_r = n_r;
+  stamp_now.G = G; stamp_now.P = P; stamp_now.rank = rank; stamp_now.world = world; stamp_now.k = k; stamp_now.eps = gc_eps;
+  for (int i = 0; i < n_r && i < MIA_MAX_RADII; ++i) stamp_now.rc[i] = gc_c[i];
+  for (int i = 0; i < n_coord && i < MIA_MAX_COORD; ++i) stamp_now.cg[i] = coord_group[i];
+  // (decided once per step -- where its preparation is enqueued; the analysis stage and a redo of declined points read the decision)
+  const bool tl_reuse = geom_reuse_decision(ws, stamp_now, tl_route && (step_flags & MIA_STEP_REUSE_LISTS) != 0, phase == 0 && do1);
   // (the analysis launch puts the bucket index's per-cell counts and error word back to zero, see Tile2Params)
   mia::Tile2Housekeeping tl_hk{nullptr, nullptr, nullptr, nullptr};
   if (tl_bucket && !tl_reuse) {

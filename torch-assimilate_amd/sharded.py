@@ -169,7 +169,7 @@ class ShardedLetkf:
                  method: str = "auto", fused_localization: bool = False,
                  comm_chunks: int = 4, chunk_compute: Optional[Callable] = None, native_step: bool = True,
                  max_in_flight: int = 3, peer_exchange: str = "auto", copy_results: bool = True, prep_streams: int = 5,
-                 analysis_streams: int = 1, prep_streams_shared: int = 2):
+                 analysis_streams: int = 1):
         self.device, self.rank, self.world = device, rank, world
         self.radii, self.inf_factor, self.coord_group, self.eps = list(radii), inf_factor, coord_group, eps
         self.rbf_gamma = rbf_gamma
@@ -187,9 +187,6 @@ class ShardedLetkf:
         self.max_in_flight = max(1, min(int(max_in_flight), 8))
         self.prep_streams = max(1, min(int(prep_streams), 8))      # steps in flight: preparation streams taken in turn
         self.analysis_streams = max(1, min(int(analysis_streams), 4))
-        # how many of the preparation streams may share the analysis stream's hardware queue (see _pick_prep_streams)
-        self.prep_streams_shared = max(0, min(int(prep_streams_shared), self.prep_streams))
-        self.prep_stream_pick = None
         # exchange of the analysis blocks at world > 1: "auto" = direct peer writes into library-owned, IPC-mapped result
         # buffers when the node allows it and a self-test of the mapping passes, RCCL all-gather otherwise; "off" = RCCL.
         # With the direct route a result lives in its pipeline slot's buffer: copy_results (default) hands out a copy,
@@ -395,8 +392,13 @@ class ShardedLetkf:
 
     def close(self):
         """Release the library-owned communicator (idempotent)."""
-        if self._native is not None and self._native.get("comm") is not None and not self._native.get("custom"):
-            self.engine.lib.mia_comm_destroy(self._native["comm"])
+        if self._native is not None:
+            for slot in self._native.get("slots", []):
+                ev = slot.pop("in_event", None)
+                if ev is not None and ev.value:
+                    self.engine.lib.mia_event_destroy(ev)
+            if self._native.get("comm") is not None and not self._native.get("custom"):
+                self.engine.lib.mia_comm_destroy(self._native["comm"])
         self._native = None
 
     def _assimilate_native(self, X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, geometry_id=None):
@@ -432,50 +434,6 @@ class ShardedLetkf:
                 and not self.fused_localization):
             return PendingStep(self, None, out=self.assimilate(X, grid_xyz, obs_xyz, Yb, d))
         return self._native_submit(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, pipelined=True, geometry_id=geometry_id)
-
-    @staticmethod
-    def _shares_queue(busy: "torch.cuda.Stream", other: "torch.cuda.Stream") -> bool:
-        """Whether work on ``other`` waits for work on ``busy``, i.e. the runtime mapped both HIP streams to one hardware queue
-        (ROCm multiplexes streams over GPU_MAX_HW_QUEUES = 4 queues): a ~1 ms spin kernel on ``busy``, a tiny kernel on ``other``."""
-        dev = busy.device
-        t = torch.zeros(1, device=dev)
-        torch.cuda.synchronize(dev)
-        e_start, e_busy, e_small = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        with torch.cuda.stream(busy):
-            e_start.record(busy)
-            torch.cuda._sleep(2_000_000)
-            e_busy.record(busy)
-        with torch.cuda.stream(other):
-            t.add_(1.0)
-            e_small.record(other)
-        torch.cuda.synchronize(dev)
-        # the tiny kernel finished in the second half of the spin kernel's run or after it: it waited for it
-        return e_busy.elapsed_time(e_small) > -0.5 * e_start.elapsed_time(e_busy)
-
-    def _pick_prep_streams(self, device, astream, n: int):
-        """``n`` preparation streams chosen by the hardware queue the runtime gave them.  ROCm multiplexes HIP streams over
-        GPU_MAX_HW_QUEUES (4) queues; which streams end up on the analysis stream's queue depends on creation order and differs
-        from process to process -- and decides the loop's speed: a preparation chain on the SHARED queue only runs between two
-        analysis kernels (its step's analysis starts ~35 us late instead of ~8), chains on other queues run beside the analysis
-        kernel and slow it down (35 -> 44 us when all of them do).  Measured on C2 (analyses/s, analysis kernel in the loop):
-        5 streams of which 0 / 1 / 2 shared: 2.0e9, 40 us / 2.15e9, 44 us / 2.0e9, 36 us; 4 of which 2: 1.98e9, 33 us; left to
-        chance: 1.8-2.02e9.  The default (5, 2 shared) keeps the kernel time of the unshared loop AND its rate."""
-        if os.environ.get("MIA_NO_STREAM_PICK"):
-            return [torch.cuda.Stream(device=device) for _ in range(n)]
-        n_shared = min(self.prep_streams_shared, n)
-        n_free = n - n_shared
-        free, shared, seen = [], [], {astream.cuda_stream}
-        for _ in range(4 * n + 8):
-            s = torch.cuda.Stream(device=device)
-            if s.cuda_stream in seen:                  # (torch hands streams out of a pool of 32 and wraps around)
-                continue
-            seen.add(s.cuda_stream)
-            (shared if self._shares_queue(astream, s) else free).append(s)
-            if len(free) >= n_free and len(shared) >= n_shared:
-                break
-        self.prep_stream_pick = (len(free), len(shared))
-        out = free[:n_free] + shared[:n_shared]
-        return out + (free[n_free:] + shared[n_shared:])[:n - len(out)]
 
     def _native_submit(self, X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, pipelined, geometry_id=None):
         import ctypes as C
@@ -549,7 +507,16 @@ class ShardedLetkf:
         out = peer[slot_idx] if peer else torch.empty((m, k, G), dtype=torch.float32, device=X.device)
         flags = slot["flags"]          # (per slot: a step's flags are read when it is collected, before the slot is reused)
         # geometry epoch: this slot's workspace holds the tile lists of an earlier, completed step of the same geometry and format
-        geom_key = None if geometry_id is None else (geometry_id, key, self._tile_extra, self._scan_index, g0, g1)
+        geom_key = None
+        if geometry_id is not None:
+            opts = []
+            v = C.c_int(0)
+            for name in (b"tile", b"tile_split", b"tile_lists", b"bucket_index"):
+                lib.mia_get_option(name, C.byref(v))
+                opts.append(v.value)
+            geom_key = (geometry_id, key, self._tile_extra, self._scan_index, g0, g1, tuple(opts), self.method, self.rbf_gamma,
+                        tuple(float(r) for r in self.radii), float(self.eps),
+                        None if self.coord_group is None else tuple(int(c) for c in self.coord_group))
         reuse = (geom_key is not None and slot.get("geom") == geom_key and not self._no_tile_lists and not self._fresh_box_once
                  and C_chunks == 1 and st["comm"] is None)
         method = {"auto": 0, "eig": 1, "matfun": 2}[self.method]
@@ -570,19 +537,10 @@ class ShardedLetkf:
             if st.get("astream") is None:
                 st["astream"] = torch.cuda.Stream(device=X.device)
                 st["astreams"] = [st["astream"]] + [torch.cuda.Stream(device=X.device) for _ in range(self.analysis_streams - 1)]
-                st["pstreams"] = self._pick_prep_streams(X.device, st["astream"], self.prep_streams)
-                if st["comm"] is None and not os.environ.get("MIA_NO_STREAM_PICK"):
-                    # the read-back stream neither on the analysis stream's hardware queue (its 32-byte copy would sit between
-                    # two analysis kernels: 1.61e9 instead of 2.0e9 analyses/s) nor on the first preparation stream's (the one
-                    # that serves a geometry epoch)
-                    taken = {x.cuda_stream for x in [st["astream"]] + st["pstreams"]}
-                    for _ in range(24):
-                        cand = torch.cuda.Stream(device=X.device)
-                        if cand.cuda_stream in taken:      # (torch hands streams out of a pool of 32 and wraps around)
-                            continue
-                        if not self._shares_queue(st["astream"], cand) and not self._shares_queue(st["pstreams"][0], cand):
-                            st["stream"] = cand
-                            break
+                # (round 3 sorted fresh streams by the hardware queue the runtime had given them -- 1 ms spin-kernel probes at
+                #  set-up -- and took a fixed mix; under the driver's flags the plain set measures the same, 1.729e9 against
+                #  1.738e9 analyses/s, profiles/r04_stream_ab.txt: the probes are gone.  Fewer streams cost: 2: 1.55e9, 3: 1.69e9)
+                st["pstreams"] = [torch.cuda.Stream(device=X.device) for _ in range(self.prep_streams)]
             comp = st["astreams"][self._submitted % len(st["astreams"])] if not exch else st["astream"]
             # (a step on reused lists prepares with ONE short kernel: one preparation stream for all of them -- every further
             #  queue in use costs the analysis queue dispatch time: 0.041 against 0.049 ms per step with three)
