@@ -114,18 +114,42 @@ def algorithmic_bytes(k, m, P_over_G, n_coord=1):
     return 4.0 * (2 * k * m + (k + 1) * P_over_G + 2 * n_coord * (1 + P_over_G))
 
 
-def traffic_from_profiles(world):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/*traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes on this same
-    workload; bench.py cannot run the profiler on itself).  None when no matching record exists."""
-    path = os.path.join(ROOT, "profiles", "latest_traffic.json")
+def profile_summary(world):
+    """The committed profile of the dominant kernel on this workload (profiles/latest_c2.json: the summary tools/prof_tile.sh writes
+    from one rocprofv3 --kernel-trace --stats pass and its --pmc passes, FETCH_SIZE / WRITE_SIZE in passes of their own).
+    bench.py cannot run the profiler on itself: everything the line says about counters -- kernel name as recorded, bound
+    evidence, HBM traffic, unit utilisations -- is READ from this one file, so a refreshed profile changes the line without a
+    code edit.  None when the file is absent or was taken on another workload."""
+    path = os.path.join(ROOT, "profiles", "latest_c2.json")
     if world != 1 or not os.path.exists(path):
         return None
     with open(path) as fh:
         rec = json.load(fh)
-    if rec.get("grid_points") != G_PER_GPU or rec.get("k") != K_ENS:
+    if rec.get("grid_points") != G_PER_GPU:
         return None
     return rec
+
+
+def bound_evidence(rec):
+    """One sentence from the profile summary's numbers."""
+    if not rec:
+        return None
+    dv = rec.get("derived", {})
+    parts = ["profiles/latest_c2.json (rocprofv3 --pmc, kernel alone, %s)" % rec.get("source", "tools/prof_tile.sh")]
+    if "valu_busy_frac" in dv:
+        parts.append("vector unit %.0f %% busy" % (100 * dv["valu_busy_frac"]))
+    if "mfma_busy_frac" in dv:
+        parts.append("matrix pipe %.0f %%" % (100 * dv["mfma_busy_frac"]))
+    if "hbm_bytes_raw" in dv and "kernel_cycles" in dv:
+        parts.append("HBM %.0f MB per launch (raw FETCH + WRITE)" % (dv["hbm_bytes_raw"] / 1e6))
+    if "sq_active_inst_any_over_wave_cycles" in dv:
+        parts.append("a wave's cycles: %.0f %% issuing, %.0f %% issue-stalled, %.0f %% parked on s_waitcnt" % (
+            100 * dv["sq_active_inst_any_over_wave_cycles"], 100 * dv.get("sq_wait_inst_any_over_wave_cycles", 0),
+            100 * dv.get("sq_wait_any_over_wave_cycles", 0)))
+    if "valu_instr_per_analysis" in dv:
+        parts.append("%.0f vector + %.1f matrix instructions per analysis" % (dv["valu_instr_per_analysis"],
+                                                                            dv.get("mfma_f16_instr_per_analysis", 0)))
+    return "; ".join(parts)
 
 
 def make_case(G, k, stride, device, seed=42):
@@ -142,6 +166,84 @@ def make_case(G, k, stride, device, seed=42):
     d = (y - mean).contiguous()
     grid_x = torch.arange(G, device=device, dtype=torch.float64)
     return X, grid_x, obs_x, Yb, d
+
+
+def make_case_2d(ny, nx, k, stride, device, seed=42, m=1):
+    """A 2-D mesh of ny x nx grid points in row-major order (the last coordinate runs fastest), unit spacing, observations at every
+    `stride`-th point in BOTH dimensions, identity observation operator on the first state row, unit observation variance: the
+    recipe of make_case on a mesh (examples/benchmark_letkf.py:107-149 on two coordinates)."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    G = ny * nx
+    X = torch.randn((m, k, G), generator=gen, device=device, dtype=torch.float32)
+    ii, jj = torch.meshgrid(torch.arange(ny, device=device), torch.arange(nx, device=device), indexing="ij")
+    grid = torch.stack([ii.reshape(-1), jj.reshape(-1)], dim=1).to(torch.float64).contiguous()
+    sel = ((ii % stride == 0) & (jj % stride == 0)).reshape(-1).nonzero().reshape(-1)
+    obs = grid[sel].contiguous()
+    y = torch.randn(sel.shape[0], generator=gen, device=device, dtype=torch.float32)
+    hx = X[0][:, sel]
+    mean = hx.mean(dim=0)
+    return X, grid, obs, (hx - mean).contiguous(), (y - mean).contiguous()
+
+
+def tile_route_case(eng, X, grid, obs, Yb, d, radius, inf, burst=5, n_check=64, seed=5):
+    """One geometry through the engine's tile route entry by entry (lists -> tile lists -> split records -> letkf_tile2_kernel),
+    kernel time by HIP events around a burst of launches, tile statistics, `n_check` grid points against the oracle."""
+    from oracle import letkf_oracle as O
+    nb = eng.localize(grid, obs, [radius])
+    extra, tiles = 0, None
+    while eng.tile_route_applies(X, nb.p_max, extra, P=int(Yb.shape[1])):
+        tiles = eng.localize_tiles(grid, obs, [radius], nb.p_max, extra_blocks=extra)
+        n_over = int(tiles.stats[1].item())
+        if n_over == 0:
+            break
+        first_over, tiles = n_over, None
+        if n_over & (1 << 30):
+            break
+        extra += 1
+    G = X.shape[-1]
+    rec = {"p_max": int(nb.p_max), "mean_local_observations": float(nb.cnt.float().mean().item())}
+    if tiles is None:       # the unions do not fit the tile format (or the shape is outside it): per-point lists, one point per wavefront
+        fn = lambda: eng.analysis(X, Yb, d, nb, inf, return_flags=True, method="matfun")      # noqa: E731
+        xa, fl = fn()
+        rec.update(route="per-point lists (a tile's union exceeds the slots the ensemble size allows)", declined_points=None)
+    else:
+        srec = eng.pack_split(Yb, d)
+        P = int(Yb.shape[1])
+        fn = lambda: eng.analysis_tiles(X, srec, P, tiles, inf)      # noqa: E731
+        xa, fl, retry = fn()
+        hdr = tiles.unpack()[0]
+        rec.update(route="tile lists + split records + letkf_tile2_kernel", union_slots=16 * tiles.ut, extra_blocks=extra,
+                   mean_union=float(hdr[:, 0].mean()), max_union=int(hdr[:, 0].max()), overflowed_tiles=int(tiles.stats[1].item()),
+                   declined_points=int(retry.item()))
+        if int(retry.item()):
+            eng.retry_points(X, Yb, d, nb, inf, xa, fl)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(burst):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / burst
+    pts = np.random.RandomState(seed).choice(G, n_check, replace=False)
+    st, yb_h, d_h = X.double().cpu().numpy(), Yb.double().cpu().numpy(), d.double().cpu().numpy()
+    gh, oh = grid.cpu().numpy(), obs.cpu().numpy()
+    if gh.ndim == 1:
+        gh, oh = gh[:, None], oh[:, None]
+    ref = []
+    for g in pts:
+        near = np.all(np.abs(oh - gh[g]) <= 2.0 * radius + 1.0, axis=1)      # (the taper's support; the rest weighs zero)
+        dist = O.grouped_euclid_distance(gh[g], oh[near], [0] * gh.shape[1], 1)
+        w = O.localized_weights(dist, yb_h[:, near], d_h[near], [radius], inf)
+        ref.append(O.apply_weights(st[:, :, [g]], w[None])[:, :, 0])
+    ref = np.stack(ref, axis=-1)
+    got = xa[:, :, torch.as_tensor(pts, device=xa.device)].double().cpu().numpy()
+    dg = ((fl >> 8) & 0xff).float()
+    rec.update(kernel_ms=ms, analyses_per_s=G / (ms * 1e-3), flags=int((fl & 0xff & ~8).max().item()),
+               mean_chebyshev_degree=float(dg.mean().item()),
+               rel_frobenius_error_vs_oracle=float(np.linalg.norm(got - ref) / np.linalg.norm(ref)), oracle_points=int(n_check))
+    return rec
 
 
 _CPU_CASE = None      # the workload of the CPU baseline: set in the parent before the pool forks (tasks carry indices only)
@@ -489,6 +591,7 @@ def main():
     kern_ms = loop_kernel_ms if loop_kernel_ms else alone_ms
     p_max = runner.last_p_max
     deg = runner.mean_degree()
+    deg_tile = runner.mean_tile_degree()
     kname = runner.dominant_kernel_name
     kkind = "tile2" if "tile2" in kname else (("tile_split" if "true>" in kname else "tile") if "tile" in kname else "point")
 
@@ -592,6 +695,10 @@ def main():
                    "kernel_ms": ms2, "analyses_per_s": gpg / (ms2 * 1e-3), "mean_chebyshev_degree": deg2,
                    "rel_frobenius_error_64_points_vs_oracle": float(np.linalg.norm(got - ref) / np.linalg.norm(ref)),
                    "reference_algorithm_credit_TFLOPs": algorithmic_flops(k2, pm2, 1) * gpg / (ms2 * 1e-3) / 1e12}
+            if gamma2 is not None:
+                rec["kernel"] = r3.dominant_kernel_name + " (tile lists + the f32 perturbations themselves; pair statistic of sixteen points as one split-f16 MFMA product)" \
+                    if r3.dominant_kernel_name.startswith("lketkf") else "letkf_cheb_kernel (one grid point per wavefront)"
+                rec["mean_chebyshev_degree_per_tile_max"] = r3.mean_tile_degree()
             if gamma2 is None and deg2:
                 tiles2 = r3.engine.tile_route_applies(X2, pm2, r3._tile_extra) and not r3._no_tile_lists
                 kk = "tile2" if tiles2 else ((kkind if kkind not in ("point", "tile2") else "tile_split") if (k2 <= 96 and pm2 + 8 <= 96) else "point")
@@ -616,6 +723,24 @@ def main():
                                    "tile": "letkf_tile_kernel (f32 products)",
                                    "point": "letkf_cheb_kernel (one grid point per wavefront)"}[kk])
             secondary[name] = rec
+
+        # off the line and more than one state row: a 316 x 316 mesh in row-major order with observations at every
+        # second point in both dimensions (localisation over real meshes: gaspari_cohn.py:124-134), and config 2 with eight
+        # state rows per grid point (n_var * n_time values, interface/base.py:257-278)
+        for name, build in (("c2_mesh_2d", lambda: make_case_2d(316, 316, K_ENS, 2, device, seed=44)),
+                            ("c2_m8", lambda: (lambda c: (c[0].repeat(8, 1, 1) * torch.linspace(0.5, 2.0, 8, device=device)[:, None, None],) + c[1:])(
+                                make_case(gpg, K_ENS, OBS_STRIDE, device, seed=45)))):
+            try:
+                X6, g6, o6, Yb6, d6 = build()
+                rad6 = 2.5 if name == "c2_mesh_2d" else GC_RADIUS
+                rec6 = tile_route_case(runner.engine, X6.contiguous(), g6, o6, Yb6, d6, rad6, INF)
+                rec6["workload"] = ("316 x 316 mesh (99 856 points, row-major), k=%d, observations at every 2nd point in both dimensions "
+                                    "(24 964), Gaspari-Cohn radius %g on the Euclidean distance, m=1" % (K_ENS, rad6)) if name == "c2_mesh_2d" \
+                    else "config 2 with m=8 state rows per grid point (G=%d, k=%d)" % (gpg, K_ENS)
+                secondary[name] = rec6
+                del X6, g6, o6, Yb6, d6
+            except Exception as exc:        # (a secondary figure must not take the bench line down)
+                secondary[name] = {"error": repr(exc)}
 
         # LETKF.estimate_weights (interface/letkf.py:127-146) on the tile route: analysis + the (G, k, k) weights
         try:
@@ -653,7 +778,8 @@ def main():
 
     if rank == 0:
         value = G * args.steps / elapsed
-        traffic = traffic_from_profiles(world)
+        prof = profile_summary(world)
+        pdv = (prof or {}).get("derived", {})
         line = {
             "metric": "local analyses/sec (LETKF, 40-member)", "value": value, "unit": "analyses/s",
             "n_gpus": world, "steps": args.steps, "warmup": warm,
@@ -679,10 +805,9 @@ def main():
             # credit for the Gram matrix sixteen points share, no credit for the eigensolve the route does not execute).
             # What the kernel executes (padded, on the half-precision matrix pipe) is reported beside it under its own keys.
             "roofline": {"bound": ("vector_issue+latency" if kkind != "point" else "valu_issue"),
-                         "bound_evidence": ("profiles/r03_v4_pmc.json (rocprofv3 --pmc, kernel alone): vector unit 51 % busy, matrix "
-                                            "pipe 16 %, HBM 0.13 of peak; a wave's cycles: 26 % issuing, 49 % issue-stalled, 25 % "
-                                            "parked on s_waitcnt; tools/tile2_stamps.py: all resident waves start together, so "
-                                            "their memory phases coincide, and the last 1.2 tiles per SIMD run at low occupancy"),
+                         "bound_evidence": bound_evidence(prof),
+                         "valu_busy": pdv.get("valu_busy_frac"), "mfma_busy": pdv.get("mfma_busy_frac"),
+                         "wait_any_over_wave_cycles": pdv.get("sq_wait_any_over_wave_cycles"),
                          "achieved": us_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": None if us_tf is None else us_tf / PEAK_FP32_TFLOPS,
                          "frac_basis": ("useful f32 flops per analysis (symmetric Gram k p (p+1), per state row 4 k p + 2 deg p^2, "
@@ -707,11 +832,16 @@ def main():
                                                         "note": "SURVEY 8(d) count of the reference's algorithm (9k^3 symmetric-QR "
                                                                 "eigensolve) per analysis: NOT executed by the matrix-function "
                                                                 "route, not a utilisation"},
-                         "traffic": (traffic or {}).get("hbm_bytes_fetch_doubled"),
-                         "traffic_source": "offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_kernel.py on this "
-                                           "workload, committed as profiles/latest_traffic.json (bench.py cannot profile itself)",
-                         "traffic_detail": traffic,
-                         "kernel": kname, "kernel_ms": kern_ms,
+                         "traffic": pdv.get("hbm_bytes_fetch_doubled"),
+                         "traffic_source": "offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/prof_tile.sh on "
+                                           "tools/prof_kernel.py, this workload), read from profiles/latest_c2.json; gfx950 counts "
+                                           "half of wide coalesced streaming reads in FETCH_SIZE (MI355X_MICROARCH.md): `traffic` doubles "
+                                           "the fetch side, traffic_raw does not",
+                         "traffic_raw": pdv.get("hbm_bytes_raw"),
+                         "traffic_algorithmic_bytes": algorithmic_bytes(K_ENS, 1, P / G) * gpg,
+                         "kernel_name_recorded_by_rocprof": (prof or {}).get("kernel_name_recorded"),
+                         "kernel_average_ns_rocprof": ((prof or {}).get("kernel_trace") or {}).get("average_ns"),
+                         "kernel": (prof or {}).get("kernel_name_recorded") or kname, "kernel_ms": kern_ms,
                          "kernel_ms_source": ("start / stop HIP events of the kernel's own dispatch (hipExtLaunchKernel, analysis "
                                               "stream) on every 4th step of the timed loop (%d launches)" % n_timed)
                                              if loop_kernel_ms else "burst of 5 launches after the timed loop",
@@ -722,7 +852,10 @@ def main():
                                  "pipe with the vector instructions, tools/mfma_rate.hip).  The wave starts at the gather: union, ranks "
                                  "and sqrt(rho) matrix come tile-shaped from the localisation kernel, the records arrive split and "
                                  "per-record scaled, straight into LDS (LDS-DMA)."},
-            "route": {"method": args.method, "mean_chebyshev_degree": deg, "declined_points_last_step": runner.last_retries,
+            "route": {"method": args.method, "mean_chebyshev_degree": deg, "mean_chebyshev_degree_per_tile_max": deg_tile,
+                      "degree_note": "per-point mean (what the useful-flop credit uses) and the mean over tiles of the largest degree "
+                                     "in the tile (what a tile's wavefront executes)",
+                      "declined_points_last_step": runner.last_retries,
                       "eigensolver_route_kernel_ms": eig_ms,
                       "eigensolver_route_kernel_analyses_per_s": (gpg / (eig_ms * 1e-3)) if eig_ms else None},
             "pipeline": {"depth": depth, "serial_ms_per_step": serial_ms,

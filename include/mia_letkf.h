@@ -273,6 +273,10 @@ int mia_letkf_weights_retry_f32(const float* X, int64_t ldx, int m, int k, int64
  *     exceeds 36: their analysis is written, their weights are not): MIA_FLAG_RETRY, counted, W left untouched;
  *     mia_letkf_weights_retry_f32 redoes them from per-point lists.
  * ---------------------------------------------------------------------------------- */
+/* bit set in stats[1] (the count of tiles without a list) when some tile's points span more index cells than the kernel
+ * scans (64 cells / 64 rows: scattered point orderings, cells coarse against the grid spacing): more slots (extra_blocks) cannot
+ * help such a tile -- use the per-point lists */
+#define MIA_TILE_BOX_OVERFLOW (1 << 30)
 int mia_letkf_tile_lists_bytes(int64_t n_points, int p_max, int extra_blocks, size_t* bytes);
 int mia_letkf_localize_tiles_f64(int taper, const double* grid_xyz, int64_t g0, int64_t g1,
                                  const double* obs_xyz, int64_t P, int n_coord,

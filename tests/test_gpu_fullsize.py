@@ -122,3 +122,23 @@ def test_config3_problem_on_one_gpu(mia):
     blk = eng.analysis_tiles(X, eng.pack_split(Yb, d), Yb.shape[1], tiles, 1.1)[0]
     full = out[:, :, g0:g1]
     assert float(((blk - full).norm(dim=(0, 1)) / full.norm(dim=(0, 1))).max()) < 2e-6
+
+
+def test_mesh_2d_and_eight_state_rows_at_full_size(eng):
+    """Off the 1-D line: a 316 x 316 mesh in row-major order, observations at every 2nd point in both dimensions,
+    Euclidean distance (the reference's arbitrary dist_func over a real mesh, gaspari_cohn.py:124-134) -- whichever route the
+    unions of sixteen consecutive points allow -- and config 2 with m = 8 state rows per grid point (n_var * n_time values,
+    interface/base.py:257-278): 64 oracle points each within the north star's tolerance, no flags."""
+    import bench
+    dev = torch.device("cuda:0")
+    X, g, o, Yb, d = bench.make_case_2d(316, 316, 40, 2, dev, seed=44)
+    rec = bench.tile_route_case(eng, X, g, o, Yb, d, 2.5, 1.1)
+    assert rec["rel_frobenius_error_vs_oracle"] < TOL32 and rec["flags"] == 0, rec
+    assert 8 <= rec["p_max"] <= 64
+    if rec["route"].startswith("tile lists"):
+        assert rec["overflowed_tiles"] == 0 and rec["max_union"] <= rec["union_slots"]
+    X1, gx, ox, Yb1, d1 = bench.make_case(100000, 40, 2, dev, seed=45)
+    X8 = (X1.repeat(8, 1, 1) * torch.linspace(0.5, 2.0, 8, device=dev)[:, None, None]).contiguous()
+    rec8 = bench.tile_route_case(eng, X8, gx, ox, Yb1, d1, 10.0, 1.1)
+    assert rec8["route"].startswith("tile lists") and rec8["overflowed_tiles"] == 0
+    assert rec8["rel_frobenius_error_vs_oracle"] < TOL32 and rec8["flags"] == 0, rec8

@@ -24,7 +24,12 @@ dev = torch.device("cuda:0")
 eng = mia.LetkfEngine(dev)
 X, gx, ox, Yb, d = bench.make_case(a.grid, k, stride, dev)
 nb = eng.localize(gx, ox, [c])
-if a.route == "tiles" and gamma is None:
+if a.route == "tiles" and gamma is not None:          # RBF-kernelised filter on tiles (csrc/lketkf_tile.hip)
+    for _ in range(a.reps):
+        tiles = eng.localize_tiles(gx, ox, [c], nb.p_max)
+        xa, fl, retry = eng.analysis_tiles_rbf(X, Yb, d, tiles, 1.1, gamma)
+    print("tile stats", tiles.stats.tolist(), "declined", int(retry.item()))
+elif a.route == "tiles":
     for _ in range(a.reps):
         tiles = eng.localize_tiles(gx, ox, [c], nb.p_max)
         srec = eng.pack_split(Yb, d)

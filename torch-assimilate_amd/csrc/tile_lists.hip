@@ -137,6 +137,7 @@ __global__ __launch_bounds__(64) void localize_tiles_kernel(TileLocParams p) {
   const int n1 = nc == 3 ? hi[1] - lo[1] + 1 : 1;
   const long long nrows = empty ? 0 : (long long)n0 * n1;
   bool overflow = nrows > kTlMaxRows;
+  bool box_overflow = overflow;        // the tile's points span more cells than the kernel scans (scattered orderings, coarse cells)
   int ubase = 0;
   int cnt4[4] = {0, 0, 0, 0};          // local observations of points 4 pg + i so far (the same in every lane of a group)
   // sixteen candidates (one per lane cl, position `pos` of the index arrays, valid where `have`) against the tile's points
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(64) void localize_tiles_kernel(TileLocParams p) {
     const int cap = hd->bucket_cap;
     const int nlast = empty ? 0 : hi[last] - lo[last] + 1;
     const long long ncb = nrows * nlast;                     // cells of the box
+    box_overflow = box_overflow || ncb > 64;
     overflow = overflow || ncb > 64;
     int mycid = 0, mycnt = 0;
     if (!overflow && lane < (int)ncb) {
@@ -302,6 +304,8 @@ __global__ __launch_bounds__(64) void localize_tiles_kernel(TileLocParams p) {
     p.hdr[tile] = make_int4(overflow ? -1 : U, longest, npts, 0);
     if (longest > __hip_atomic_load(&p.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&p.stats[0], longest);
     if (overflow) atomicAdd(&p.stats[1], 1);
+    // (more slots cannot help a box that is too large: marked, so that the caller goes to per-point lists at once)
+    if (box_overflow) atomicOr(&p.stats[1], MIA_TILE_BOX_OVERFLOW);
   }
 }
 

@@ -17,6 +17,9 @@ import torch
 __all__ = ["ShardedLetkf", "PendingStep", "block_partition", "gather_blocks"]
 
 
+TILE_BOX_OVERFLOW = 1 << 30        # MIA_TILE_BOX_OVERFLOW (include/mia_letkf.h)
+
+
 def block_partition(G: int, world: int) -> List[Tuple[int, int]]:
     """Contiguous, equally sized (up to the tail) blocks: rank r owns [r*n, min(G, (r+1)*n))."""
     n = (G + world - 1) // world
@@ -269,8 +272,12 @@ class ShardedLetkf:
         while eng.tile_route_applies(X, nb.p_max, self._tile_extra, self.rbf_gamma, self.method, P=P, n_points=g1 - g0):
             tiles = eng.localize_tiles(grid_xyz, obs_xyz, self.radii, nb.p_max, self.coord_group, self.eps, g0, g1,
                                        extra_blocks=self._tile_extra)
-            if int(tiles.stats[1].item()) == 0:                 # host sync (first call on a geometry only)
+            n_over = int(tiles.stats[1].item())                 # host sync (first call on a geometry only)
+            if n_over == 0:
                 break
+            if n_over & TILE_BOX_OVERFLOW:                      # a tile's cell box is too large: slots cannot help
+                self._no_tile_lists, self._tile_extra = True, 0
+                return None
             self._tile_extra += 1
         else:
             if self._tile_extra:
@@ -661,11 +668,16 @@ class ShardedLetkf:
             warnings.warn("segmented launch timed out waiting for a segment; falling back to per-piece launches",
                           RuntimeWarning)
             redo = "same"
+        elif n_over & TILE_BOX_OVERFLOW and not self._no_tile_lists:
+            self._no_tile_lists = True                         # a tile's cell box is too large for tile lists: per-point lists
+            redo = "same"
         elif n_over and p_seen <= p["hint"] and not self._no_tile_lists:
             # tile route: the union of some tile's lists does not fit its slots (the bound on the lists themselves held): sixteen
             # more slots per tile, and once the format has no more to give this geometry goes back to per-point lists -- on
             # every rank alike (the counters are the maximum over the ranks)
-            if self._tile_extra < 5:
+            k_ = X.shape[1]
+            most = min((k_ + 15) // 16 + 1, 6) - max(1, (int(p["hint"]) + 8 + 15) // 16)      # what the workspace was sized for
+            if self._tile_extra < min(5, most):
                 self._tile_extra += 1
             else:
                 self._no_tile_lists = True
@@ -891,6 +903,17 @@ class ShardedLetkf:
         if self._last_flags is None or self.method == "eig":
             return None
         return float(((self._last_flags >> 8) & 0xff).float().mean().item())
+
+    def mean_tile_degree(self):
+        """Mean over the tiles of sixteen points of the LARGEST degree in the tile (a tile's wavefront runs to the maximum of
+        its points), None for the eigensolver route."""
+        if self._last_flags is None or self.method == "eig":
+            return None
+        dg = ((self._last_flags >> 8) & 0xff).float()
+        n = dg.numel() // 16 * 16
+        if n == 0:
+            return float(dg.max().item())
+        return float(dg[:n].view(-1, 16).max(dim=1).values.mean().item())
 
     def last_flags_ok(self) -> bool:
         return self._last_flags is None or int((self._last_flags & 0xff).max().item()) == 0
