@@ -635,12 +635,44 @@ def main():
                 solo.assimilate(Xb, gb, obs_x, Yb, d)
             torch.cuda.synchronize()
             comp_ms = 1e3 * (time.perf_counter() - t0) / 50
+            # the analysis kept block-sharded (ShardedLetkf(gather=False): what the reference's dask chunks along `grid` do,
+            # interface/letkf.py:118-131): the same pipelined loop without the all-gather -- compute scaling by itself
+            keep = ShardedLetkf(device, rank, world, radii=[GC_RADIUS], inf_factor=INF, method=args.method, gather=False,
+                                max_in_flight=max(2, args.pipeline_depth))
+            keep._engine = runner.engine
+            for _ in range(3):
+                keep.assimilate(X, grid_x, obs_x, Yb, d)
+            n_keep = max(args.steps, 200)
+
+            def keep_loop(n):
+                pend = []
+                for _ in range(n):
+                    pend.append(keep.submit(X, grid_x, obs_x, Yb, d))
+                    if len(pend) == max(2, args.pipeline_depth):
+                        pend.pop(0).result()
+                for h in pend:
+                    h.result()
+            keep_loop(50)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            keep_loop(n_keep)
+            torch.cuda.synchronize()
+            dist.barrier()
+            keep_t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+            dist.all_reduce(keep_t, op=dist.ReduceOp.MAX)
+            keep_ms = 1e3 * float(keep_t.item()) / n_keep
+            keep.close()
             vals = torch.tensor([ex_ms, comp_ms], device=device, dtype=torch.float64)
             allv = [torch.zeros_like(vals) for _ in range(world)]
             dist.all_gather(allv, vals)
             per_link = ex_bytes / max(world - 1, 1)
             multi = {"exchange_route": runner.exchange_route, "exchange_ms_per_rank": [float(v[0]) for v in allv],
                      "compute_ms_per_rank_serial_block": [float(v[1]) for v in allv],
+                     "sharded_output": {"ms_per_step": keep_ms, "analyses_per_s": G / (keep_ms * 1e-3), "steps": n_keep,
+                                        "note": "ShardedLetkf(gather=False): every rank keeps its block of the analysis (the reference's "
+                                                "dask chunks along `grid`); max over ranks, barrier + synchronize on both sides: the "
+                                                "compute scaling without the all-gather -- `value` is the gathered metric"},
                      "bytes_sent_per_rank_per_step": ex_bytes, "bytes_per_link_per_step": per_link,
                      "xgmi_budget_ms": {"at_77_GBs_per_direction": 1e3 * per_link / 77e9, "at_153_GBs_per_direction": 1e3 * per_link / 153e9,
                                         "note": "direct route: every rank writes its block to each of its world - 1 peers over its own link "

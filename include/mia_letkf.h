@@ -521,6 +521,8 @@ typedef int (*mia_allreduce_max_i32_fn)(void* ctx, int32_t* buf, int n, void* st
 int mia_comm_load(const char* rccl_library_path /* NULL: "librccl.so" */);
 int mia_comm_unique_id(void* id128);
 int mia_comm_create(const void* id128, int rank, int world, mia_comm_t** comm);
+/* a communicator that only carries the partition (rank, world): for MIA_STEP_NO_GATHER steps; needs no RCCL */
+int mia_comm_create_partition(int rank, int world, mia_comm_t** out);
 int mia_comm_create_custom(int rank, int world, mia_allgather_fn allgather, mia_allreduce_max_i32_fn allreduce_max,
                            void* ctx, mia_comm_t** comm);
 /* Optional stream for the placement of gathered pieces (NULL: the exchange stream).  Used only by steps enqueued with
@@ -617,6 +619,11 @@ int mia_letkf_sharded_step_f32(const float* X /* [m][k][G] */, int64_t G, int m,
                                     * block and tile format -- and rebuild only the split records.  The reference recomputes the
                                     * localisation on every call (gaspari_cohn.py:97-136); results are identical when the
                                     * geometry is.  counters[0], [1] stay 0 */
+#define MIA_STEP_NO_GATHER 0x2000 /* world > 1: the analysis STAYS block-sharded (the reference's dask chunks along `grid`,
+                                   * interface/letkf.py:118-131): Xa is this rank's block, (m k, block length), block = grid
+                                   * points [rank n, min(G, (rank + 1) n)) with n = ceil(G / world); nothing is exchanged,
+                                   * counters[4..7] stay zero.  `comm` may be a partition-only communicator
+                                   * (mia_comm_create_partition) */
 #define MIA_STEP_NO_TILE_LISTS 8 /* per-point lists even where the tile route would apply (after a step reported tiles whose
                                    union did not fit: counters[1] != 0 with counters[0] <= p_max_assumed) */
 int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int m, int k,

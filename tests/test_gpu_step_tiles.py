@@ -190,3 +190,31 @@ def test_results_do_not_depend_on_the_number_of_preparation_streams(mia):
         outs.append(res[0].clone())
         r.close()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_sharded_output_keeps_the_block(mia):
+    """gather=False: rank r of a world of 4 (one process, one GPU: no communicator is needed) returns ITS BLOCK of the analysis
+    from the exact-list call, the one-call native step (MIA_STEP_NO_GATHER on a partition-only communicator) and steps in
+    flight -- equal to the same columns of the single-rank run per point to rounding (the tiles are cut elsewhere)."""
+    import bench
+    from torch_assimilate_amd.sharded import block_partition
+    dev_ = torch.device("cuda:0")
+    G = 30011
+    X, gx, ox, Yb, d = bench.make_case(G, 40, 2, dev_, seed=9)
+    full = mia.ShardedLetkf(dev_, 0, 1, radii=[10.0], inf_factor=1.1)
+    full.assimilate(X, gx, ox, Yb, d)
+    ref = full.assimilate(X, gx, ox, Yb, d)
+    for rank in (0, 2, 3):
+        g0, g1 = block_partition(G, 4)[rank]
+        r = mia.ShardedLetkf(dev_, rank, 4, radii=[10.0], inf_factor=1.1, gather=False, max_in_flight=3)
+        first = r.assimilate(X, gx, ox, Yb, d)
+        second = r.assimilate(X, gx, ox, Yb, d)
+        assert first.shape == (1, 40, g1 - g0) and second.shape == first.shape
+        assert r.native_steps == 1 and r.last_flags_ok()
+        pend = [r.submit(X, gx, ox, Yb, d) for _ in range(4)]
+        for h in pend:
+            assert torch.equal(h.result(), second)
+        part = ref[:, :, g0:g1]
+        for got in (first, second):
+            assert float(((got - part).norm(dim=(0, 1)) / part.norm(dim=(0, 1))).max()) < 2e-6
+        r.close()

@@ -95,3 +95,34 @@ def test_two_rank_shard_and_allgather(tmp_path, G, chunks, declining):
     case = O.synthetic_case(G, 12, 2)
     ref, _ = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], case["yb"], case["d"], 10.0, 1.1)
     np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)
+
+
+def _worker_sharded_output(rank, world, port, G, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import torch_assimilate_amd as mia
+    from torch_assimilate_amd.sharded import block_partition
+    case = O.synthetic_case(G, 12, 2)
+    X = torch.from_numpy(case["state"])
+    runner = mia.ShardedLetkf("cpu", rank, world, radii=[10.0], inf_factor=1.1, compute_shard=_oracle_shard, gather=False,
+                              comm_chunks=4)
+    blk = runner.assimilate(X, torch.from_numpy(case["grid_x"]), torch.from_numpy(case["obs_x"]),
+                            torch.from_numpy(case["yb"]), torch.from_numpy(case["d"]))
+    g0, g1 = block_partition(G, world)[rank]
+    assert blk.shape == (X.shape[0], X.shape[1], g1 - g0)
+    np.save(os.path.join(out_dir, "blk%d.npy" % rank), blk.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("G", [64, 51])
+def test_two_rank_sharded_output(tmp_path, G):
+    """gather=False: every rank keeps its block of the analysis (what the reference's dask chunks along `grid` do,
+    interface/letkf.py:118-131) -- no collective is entered; the blocks side by side are the full analysis."""
+    mp.spawn(_worker_sharded_output, args=(2, _free_port(), G, str(tmp_path)), nprocs=2, join=True)
+    case = O.synthetic_case(G, 12, 2)
+    ref, _ = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], case["yb"], case["d"], 10.0, 1.1)
+    got = np.concatenate([np.load(str(tmp_path / ("blk%d.npy" % r))) for r in range(2)], axis=-1)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)

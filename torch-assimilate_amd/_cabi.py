@@ -97,6 +97,7 @@ _PROTOS = {
     "mia_comm_load": ([C.c_char_p], i32),
     "mia_comm_unique_id": ([vp], i32),
     "mia_comm_create": ([vp, i32, i32, C.POINTER(vp)], i32),
+    "mia_comm_create_partition": ([i32, i32, C.POINTER(vp)], i32),
     "mia_comm_create_custom": ([i32, i32, vp, vp, vp, C.POINTER(vp)], i32),
     "mia_comm_set_place_stream": ([vp, vp], i32),
     "mia_letkf_step_submit": ([vp, i64, i32, i32, vp, vp, i64, vp, vp, i32, C.POINTER(C.c_int32), C.POINTER(f64), i32, f64,

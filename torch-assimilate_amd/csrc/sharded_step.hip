@@ -399,6 +399,18 @@ extern "C" int mia_comm_create_custom(int rank, int world, mia_allgather_fn allg
   return MIA_OK;
 }
 
+// a communicator that only carries the block partition (rank, world): for steps whose analysis STAYS block-sharded
+// (MIA_STEP_NO_GATHER -- what the reference's dask chunks along `grid` do, interface/letkf.py:118-131); no exchange can run on it
+extern "C" int mia_comm_create_partition(int rank, int world, mia_comm_t** out) {
+  if (!out) return MIA_ERR_NULL;
+  if (world <= 0 || rank < 0 || rank >= world) return MIA_ERR_SIZE;
+  mia_comm* c = new mia_comm();
+  c->rank = rank;
+  c->world = world;
+  *out = c;
+  return MIA_OK;
+}
+
 extern "C" int mia_comm_set_place_stream(mia_comm_t* c, void* stream) {
   if (!c) return MIA_ERR_NULL;
   c->place_stream = (hipStream_t)stream;
@@ -703,10 +715,15 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
   // exchange route: any real multi-rank world; a one-rank communicator takes it only when chunking is asked
   // for (lets a single-GPU box drive the RCCL calls and the chunk pipeline)
   // direct exchange: Xa is one of the communicator's peer-mapped result buffers (every rank passes the same slot)
-  const int peer_slot = (comm && world > 1) ? peer_slot_of(comm, Xa) : -1;
+  // MIA_STEP_NO_GATHER: this rank analyses its block of the partition and keeps it -- Xa is the block, (m k, block length),
+  // nothing is exchanged and no counter is reduced over the ranks (every rank validates its own step)
+  const bool no_gather = comm && (step_flags & MIA_STEP_NO_GATHER) != 0;
+  if (no_gather) n_chunks = 1;
+  if (comm && !no_gather && world > 1 && !comm->nccl && !comm->ag) return MIA_ERR_COMM;      // (a partition-only communicator)
+  const int peer_slot = (comm && world > 1 && !no_gather) ? peer_slot_of(comm, Xa) : -1;
   const bool peer = peer_slot >= 0;
   if (peer) n_chunks = 1;
-  const bool exch = comm && !peer && (world > 1 || n_chunks > 1);
+  const bool exch = comm && !peer && !no_gather && (world > 1 || n_chunks > 1);
   StepLayout L;
   int rc = step_layout(G, m, k, P, n_coord, world, n_chunks, p_max_assumed, &L, (step_flags >> 4) & 7);
   if (rc != MIA_OK) return rc;
@@ -740,10 +757,10 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
   const bool tl_rbf = gamma > 0.0f;
   const bool tl_route = mia::option(MIA_OPT_TILE_LISTS) != 0 && !(step_flags & MIA_STEP_NO_TILE_LISTS) && (n_chunks == 1 || exch) &&
                         method != 1 && blk > 0 && P > 0 && L.ut <= 6 && mia::option(MIA_OPT_TILE) != 0 &&
-                        (tl_rbf ? mia::lketkf_tile_covers(m, k, pm_tl, (step_flags >> 4) & 7, G, exch ? L.nc : G, blk, P) &&
+                        (tl_rbf ? mia::lketkf_tile_covers(m, k, pm_tl, (step_flags >> 4) & 7, G, exch ? L.nc : (no_gather ? blk : G), blk, P) &&
                                       mia::cheb_primal_table((hipStream_t)(prep_stream ? prep_stream : stream), &tl_th, &tl_tc)
                                 : mia::option(MIA_OPT_TILE_SPLIT) != 0 &&
-                                      mia::tile2_covers(m, k, pm_tl, (step_flags >> 4) & 7, G, exch ? L.nc : G, blk) &&
+                                      mia::tile2_covers(m, k, pm_tl, (step_flags >> 4) & 7, G, exch ? L.nc : (no_gather ? blk : G), blk) &&
                                       mia::cheb_dual_table((hipStream_t)(prep_stream ? prep_stream : stream), &tl_th, &tl_tc));
   const bool tl_bucket = tl_route && mia::option(MIA_OPT_BUCKET_INDEX) != 0 && !(step_flags & MIA_STEP_SCAN_INDEX);
   // geometry epoch: the tile lists this workspace holds are used again (the caller vouches for unchanged coordinates, radii,
@@ -886,8 +903,8 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
     const int64_t c0 = b0 + c * L.nc < b1 ? b0 + c * L.nc : b1;
     const int64_t c1 = c0 + L.nc < b1 ? c0 + L.nc : b1;
     float* dst = exch ? (float*)(base + L.bufs + L.chunk_bytes * c) : Xa;
-    const int64_t ldo = exch ? L.nc : G;
-    const int64_t o0 = exch ? 0 : c0;
+    const int64_t ldo = exch ? L.nc : (no_gather ? b1 - b0 : G);
+    const int64_t o0 = exch ? 0 : (no_gather ? c0 - b0 : c0);
     if (c1 > c0 && !segmented && !tl_block) {
       const int32_t* ccnt = cnt + (c0 - b0);
       const int32_t* cidx = idx + (size_t)(c0 - b0) * L.cap;

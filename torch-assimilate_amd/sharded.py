@@ -172,10 +172,14 @@ class ShardedLetkf:
                  method: str = "auto", fused_localization: bool = False,
                  comm_chunks: int = 4, chunk_compute: Optional[Callable] = None, native_step: bool = True,
                  max_in_flight: int = 3, peer_exchange: str = "auto", copy_results: bool = True, prep_streams: int = 5,
-                 analysis_streams: int = 1):
+                 analysis_streams: int = 1, gather: bool = True):
         self.device, self.rank, self.world = device, rank, world
         self.radii, self.inf_factor, self.coord_group, self.eps = list(radii), inf_factor, coord_group, eps
         self.rbf_gamma = rbf_gamma
+        # gather=False (world > 1): assimilate() / submit() return THIS RANK'S BLOCK of the analysis, (m, k, g1 - g0) with
+        # (g0, g1) = block_partition(G, world)[rank]: the analysis stays chunked along `grid`, as the reference's dask arrays do
+        # (interface/letkf.py:118-131); nothing crosses a link and no communicator is created
+        self.gather = bool(gather)
         self.method = method
         self.fused_localization = fused_localization
         self.comm_chunks = int(comm_chunks)
@@ -309,10 +313,10 @@ class ShardedLetkf:
                 and torch.is_tensor(X) and X.is_cuda and X.dtype == torch.float32 and X.dim() == 3
                 and not self.fused_localization):
             return self._assimilate_native(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, geometry_id)
-        if self.world > 1 and self.comm_chunks > 1:
+        if self.world > 1 and self.comm_chunks > 1 and self.gather:
             return self._assimilate_overlapped(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1)
         shard = self._compute(X, grid_xyz, obs_xyz, Yb, d, g0, g1)
-        return gather_blocks(shard, G, self.world, self.group)
+        return gather_blocks(shard, G, self.world, self.group) if self.gather else shard
 
     # ------------------------------------------------------------------ native step driver
     def _native_comm(self):
@@ -353,13 +357,19 @@ class ShardedLetkf:
     def _native_state(self):
         if self._native is None:
             st = dict(comm=None, stream=None, slots=[{} for _ in range(self.max_in_flight)])
-            if self.world > 1 or self._force_comm:
+            if (self.world > 1 and self.gather) or self._force_comm:
                 st["comm"] = self._native_comm()
+            elif self.world > 1:                       # the block partition only (no RCCL, no exchange)
+                import ctypes as C
+                from . import _cabi
+                st["part"] = C.c_void_p()
+                _cabi.check(self.engine.lib.mia_comm_create_partition(self.rank, self.world, C.byref(st["part"])),
+                            "mia_comm_create_partition")
             # exchange stream at high priority: its (few, multi-wave) RCCL workgroups should be placed ahead of the
             # bulk analysis kernel's next workgroups when wave slots fall free, not queue behind 1e5 of them
             # (single GPU: this stream only carries the 32-byte counter read-back -- normal priority like every other stream of the
             #  step: with high-priority preparation / read-back streams the loop ran 10 % slower, tools/ab_prio_streams.sh)
-            st["stream"] = torch.cuda.Stream(device=self.device, priority=-1 if (self.world > 1 or self._force_comm) else 0)
+            st["stream"] = torch.cuda.Stream(device=self.device, priority=-1 if st["comm"] is not None else 0)
             if st["comm"] is not None:
                 # gathered pieces are copied into the result on a stream of their own, so that with steps in flight the
                 # next all-gather starts as soon as the previous one has landed
@@ -375,7 +385,7 @@ class ShardedLetkf:
         """Create the library-owned communicator if needed.  Should that fail on ANY rank (RCCL library not found,
         ncclCommInitRank error), every rank falls back to the torch.distributed exchange route -- the decision is
         all-reduced so that no rank waits in a collective the others never enter."""
-        if self._native is not None or self.world == 1:
+        if self._native is not None or self.world == 1 or not self.gather:
             return True
         import warnings
         import torch.distributed as dist
@@ -406,6 +416,8 @@ class ShardedLetkf:
                     self.engine.lib.mia_event_destroy(ev)
             if self._native.get("comm") is not None and not self._native.get("custom"):
                 self.engine.lib.mia_comm_destroy(self._native["comm"])
+            if self._native.get("part") is not None:
+                self.engine.lib.mia_comm_destroy(self._native["part"])
         self._native = None
 
     def _assimilate_native(self, X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, geometry_id=None):
@@ -452,6 +464,8 @@ class ShardedLetkf:
             for h in list(self._in_flight):                       # drain: the exact-list route is synchronous
                 h.result()
             shard = self._engine_shard(X, grid_xyz, obs_xyz, Yb, d, g0, g1)
+            if not self.gather:
+                return PendingStep(self, None, out=shard)
             if self.world > 1:
                 t = torch.tensor([self._p_max_hint, self._tile_extra, int(self._no_tile_lists)], dtype=torch.int32, device=X.device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
@@ -511,7 +525,8 @@ class ShardedLetkf:
             slot["key"] = key
             slot["ws_clean"] = False                                   # fresh workspace: the first step clears the index header
         # direct exchange: the result IS the slot's peer-mapped buffer (every rank uses the same slot for the same step)
-        out = peer[slot_idx] if peer else torch.empty((m, k, G), dtype=torch.float32, device=X.device)
+        part = st.get("part")                       # gather=False: partition-only communicator, the result is this rank's block
+        out = peer[slot_idx] if peer else torch.empty((m, k, (g1 - g0) if part is not None else G), dtype=torch.float32, device=X.device)
         flags = slot["flags"]          # (per slot: a step's flags are read when it is collected, before the slot is reused)
         # geometry epoch: this slot's workspace holds the tile lists of an earlier, completed step of the same geometry and format
         geom_key = None
@@ -564,13 +579,15 @@ class ShardedLetkf:
         # (plain integers for the pointer arguments: ctypes converts them itself, a C.c_void_p object per argument was a
         #  third of this function's host time)
         cargs = [X.data_ptr(), G, m, k, Yb.data_ptr(), d.data_ptr(), P, grid.data_ptr(), obs.data_ptr(), nc, slot["cg"],
-                 slot["rc"], len(self.radii), float(self.eps), float(self.inf_factor), gamma, method, hint, st["comm"],
+                 slot["rc"], len(self.radii), float(self.eps), float(self.inf_factor), gamma, method, hint,
+                 st["comm"] if part is None else part,
                  C_chunks, 0, out.data_ptr(), flags.data_ptr(), slot["counters"].data_ptr(), slot["ws"].data_ptr(),
                  slot["ws"].numel(), comp.cuda_stream, side, prep.cuda_stream if prep is not None else None,
                  # MIA_STEP_NO_JOIN for steps in flight; MIA_STEP_WS_CLEAN: this slot's workspace was last used by a step that
                  # ran to completion (its index kernels leave the header zeroed)
                  (1 if pipelined else 0) | (4 if slot.get("ws_clean") else 0) | (8 if self._no_tile_lists else 0) | (self._tile_extra << 4) |
-                 (0x400 if self._fresh_box_once else 0) | (0x800 if self._scan_index else 0) | (0x1000 if reuse else 0)]
+                 (0x400 if self._fresh_box_once else 0) | (0x800 if self._scan_index else 0) | (0x1000 if reuse else 0) |
+                 (0x2000 if part is not None else 0)]
         self._fresh_box_once = False
         slot["ws_clean"] = False            # (until this step has been collected without an error)
         step_fn = lib.mia_letkf_sharded_step_streams_f32
