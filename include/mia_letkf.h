@@ -86,6 +86,9 @@ const char* mia_status_string(int status);
  *   "bucket_index"     1  step driver, tile route: the observations are binned by ONE kernel into fixed-capacity buckets of the cell
  *                         grid the step's workspace already holds (bounding box validated per observation, rebuilt when it no
  *                         longer holds) / 0: bounding box + count + scan + scatter kernels every step
+ *   "tile_pair"        1  tile route, unions of more than 32 slots and one state row per grid point: two wavefronts per tile,
+ *                         each with the Gram fragments and recurrence vectors of its own row blocks (csrc/letkf_tile2p.hip; config 4:
+ *                         0.186 -> 0.172 ms per 1e5 points, a 2-D mesh with 64-slot unions 0.092 -> 0.073) (1) or one (0)
  * Scope: process-wide defaults, read when a call ENQUEUES its work -- for steps handed to the launch threads
  * (mia_letkf_step_submit) at submission: a step runs with the routes that were in force when it was submitted, whatever is
  * set afterwards.  What differs per runner of one process travels in the call's own arguments (method, step_flags:

@@ -441,3 +441,31 @@ def test_weights_on_tiles_declined_points_and_mixed_magnitudes(eng):
     assert int(retry.item()) == 0
     ref_xa, ref_w = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], yb, d, c, 1.1)
     assert rel_fro(W.cpu().numpy(), ref_w) < TOL32 and rel_fro(W.cpu().numpy() - np.eye(40), ref_w - np.eye(40)) < 5e-5
+
+
+@pytest.mark.parametrize("k,stride,c", [(80, 1, 16.5), (40, 1, 9.0), (64, 1, 14.0), (96, 2, 30.0), (33, 1, 7.5)])
+def test_two_waves_per_tile_equal_one(eng, k, stride, c):
+    """Unions of more than 32 slots, one state row: the two-waves-per-tile kernel (csrc/letkf_tile2p.hip, option tile_pair) against
+    letkf_tile2_kernel on the same lists and records -- equal to rounding (x' w_mean is summed in two parts), same flags and
+    degrees -- and against the oracle; ragged last tile, three to six row blocks."""
+    case = O.synthetic_case(203, k, stride, seed=5 * k)
+    nb = eng.localize(case["grid_x"], case["obs_x"], [c])
+    tiles = eng.localize_tiles(case["grid_x"], case["obs_x"], [c], nb.p_max)
+    if tiles.stats.tolist()[1]:
+        tiles = eng.localize_tiles(case["grid_x"], case["obs_x"], [c], nb.p_max, extra_blocks=1)
+    assert tiles.stats.tolist()[1] == 0 and tiles.ut >= 3
+    rec = eng.pack_split(dev(case["yb"]), dev(case["d"]))
+    P = case["yb"].shape[1]
+    X = dev(case["state"])
+    set_option("tile_pair", 0)
+    xa1, fl1, r1 = eng.analysis_tiles(X, rec, P, tiles, 1.1)
+    set_option("tile_pair", 1)
+    xa2, fl2, r2 = eng.analysis_tiles(X, rec, P, tiles, 1.1)
+    assert torch.equal(fl1, fl2) and int(r1.item()) == int(r2.item())
+    ok = ((fl1 & 0xff) == 0)
+    assert float(torch.linalg.norm(xa1[:, :, ok] - xa2[:, :, ok]) / torch.linalg.norm(xa1[:, :, ok])) < 1e-6
+    assert torch.equal(xa2, eng.analysis_tiles(X, rec, P, tiles, 1.1)[0])
+    if int(r2.item()):
+        eng.retry_points(X, dev(case["yb"]), dev(case["d"]), nb, 1.1, xa2, fl2)
+    ref, _ = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], case["yb"], case["d"], c, 1.1)
+    assert rel_fro(xa2.cpu().numpy(), ref) < TOL32

@@ -684,6 +684,11 @@ int tile2_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0,
   tp.err_out = hk ? hk->err_out : nullptr;
   tp.stagger = 0;
   MIA_EXP_SET(tp.stagger, "MIA_TILE2_STAGGER", atoi);
+  // unions of more than 32 slots: two wavefronts per tile (letkf_tile2p.hip) where it has the shape
+  if (ut >= 3 && option(MIA_OPT_TILE_PAIR) != 0) {
+    const int prc = tile2p_launch_any(tp, ut, kt, stream);
+    if (prc != MIA_ERR_UNSUPPORTED) return prc;
+  }
 #ifdef MIA_TILE2_SINGLE        // (development builds: one instantiation, for register / ISA inspection)
   if (ut == 2 && kt == 3) return tile2_launch_s<2, 3>(tp, stream);
   return MIA_ERR_UNSUPPORTED;

@@ -15,6 +15,7 @@ enum {
   MIA_OPT_TILE_LISTS,        // step driver: tile-shaped lists + split records + letkf_tile2_kernel where the shape allows (1) or the per-point lists (0)
   MIA_OPT_BUCKET_INDEX,      // step driver, tile route: observations binned into fixed-capacity cell buckets by ONE kernel over the cell grid the
                              // workspace holds (1) or bounding box + count + scan + scatter every step (0)
+  MIA_OPT_TILE_PAIR,         // tile route, unions of more than 32 slots: two wavefronts per tile (letkf_tile2p.hip) (1) or one (0)
   MIA_OPT_COUNT_
 };
 

@@ -282,6 +282,9 @@ int tile2_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0,
                           int32_t* flags, int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c,
                           hipStream_t stream, int seg_len = 0, int64_t seg_stride = 0, const Tile2Housekeeping* hk = nullptr);
 
+// letkf_tile2p.hip: the same analysis with two wavefronts per tile (unions of more than 32 slots); MIA_ERR_UNSUPPORTED for
+// shapes it has no instantiation for
+int tile2p_launch_any(const Tile2Params& tp, int ut, int kt, hipStream_t stream);
 // lketkf_tile.hip: RBF-kernelised analysis from tile lists and the f32 perturbations themselves (no split records)
 bool lketkf_tile_covers(int m, int k, int p_max, int extra_blocks, int64_t ldx, int64_t ldo, int64_t ng, int64_t P);
 int lketkf_tile_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* Yb, const float* d,
