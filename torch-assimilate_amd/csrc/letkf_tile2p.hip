@@ -23,6 +23,7 @@
 #include "mia_options.h"
 #include "mia_tiles.h"
 #include <cstdio>
+#include <cstdlib>
 
 #ifdef MIA_T2P_STAMPS
 namespace mia {
@@ -65,12 +66,14 @@ __device__ __forceinline__ void split4_tied(const float (&x)[4], f2w& hi, f2w& l
 
 // MROWS = false (the only instantiation launched): one state row per grid point, straight-line code -- 212 registers at UT = 5,
 // KT = 5, two workgroups' waves per SIMD; the row loop of MROWS = true carries 382
-template <int UT, int KT, bool MROWS>
-__global__ __launch_bounds__(128, MROWS ? 1 : T2P_WAVES)
+// NW = wavefronts per tile (2 or 3): wave w owns row blocks [w OWN, (w + 1) OWN) and output member blocks [w J0, (w + 1) J0)
+template <int UT, int KT, bool MROWS, int NW>
+__global__ __launch_bounds__(64 * NW, MROWS ? 1 : (NW == 2 ? T2P_WAVES : NW))
 void letkf_tile2p_kernel(Tile2Params P) {
   constexpr int UMAX = 16 * UT, NB = (KT + 1) / 2, NKB = (UT + 1) / 2;
-  constexpr int T0 = (UT + 1) / 2, OWN = T0;        // wave 0: row blocks [0, T0), wave 1: [T0, UT); arrays sized for the larger
-  constexpr int J0 = (KT + 1) / 2;                  // member blocks of the output: wave 0 [0, J0), wave 1 [J0, KT)
+  constexpr int OWN = (UT + NW - 1) / NW;           // row blocks of the union per wave (the last wave may hold fewer)
+  constexpr int J0 = (KT + NW - 1) / NW;            // member blocks of the output per wave
+  constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lr = lane & 15, h = lane >> 4;
   const int k = P.k, nc8 = P.nc8;
@@ -79,17 +82,17 @@ void letkf_tile2p_kernel(Tile2Params P) {
   int* ukey = reinterpret_cast<int*>(smem + IMG + 512);      // [UMAX]
   float* wdl = reinterpret_cast<float*>(ukey + UMAX);        // [UMAX]
   float* El = wdl + UMAX;                                    // [UMAX]
-  float* xch = El + UMAX;                                    // [2 waves][3][16]: per-column scalars that cross between the waves
-  unsigned char* frag = reinterpret_cast<unsigned char*>(xch + 2 * 3 * 16);      // [2 buffers][NKB][hi / lo][64 lanes] 16 bytes
-  const int t_lo = wv == 0 ? 0 : T0, n_own = wv == 0 ? T0 : UT - T0;
-  const int j_lo = wv == 0 ? 0 : J0, n_out = wv == 0 ? J0 : KT - J0;
+  float* xch = El + UMAX;                                    // [NW waves][3][16]: per-column scalars that cross between the waves
+  unsigned char* frag = reinterpret_cast<unsigned char*>(xch + NW * 3 * 16);      // [buffers][NKB][hi / lo][64 lanes] 16 bytes
+  const int t_lo = wv * OWN, n_own = UT - t_lo < 0 ? 0 : (UT - t_lo < OWN ? UT - t_lo : OWN);
+  const int j_lo = wv * J0, n_out = KT - j_lo < 0 ? 0 : (KT - j_lo < J0 ? KT - j_lo : J0);
 
   const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
   const int64_t ntile = (P.ng + 15) >> 4;
   if (bid >= ntile) return;
   if (P.clr_counts) {
     const int ncl = *P.clr_n;
-    for (int64_t i = bid * 128 + tid; i < ncl; i += ntile * 128) P.clr_counts[i] = 0;
+    for (int64_t i = bid * NT + tid; i < ncl; i += ntile * NT) P.clr_counts[i] = 0;
     if (bid == 0 && tid == 0) {
       const unsigned e = *P.clr_err;
       if (e) { atomicOr(P.err_out, (int)(e << 3)); *P.clr_err = 0u; }
@@ -118,7 +121,7 @@ void letkf_tile2p_kernel(Tile2Params P) {
   }
   // ---- first round trip: header, slot table, sqrt(rho) matrix (every wave all of it), the first state row
   const int4 hd = P.thdr[tile];
-  for (int s = tid; s < UMAX; s += 128) ukey[s] = t2_ld<int32_t>(P.tidx + tile * UMAX, (unsigned)s * 4u);
+  for (int s = tid; s < UMAX; s += NT) ukey[s] = t2_ld<int32_t>(P.tidx + tile * UMAX, (unsigned)s * 4u);
   f4w dreg[UT];
 #pragma unroll
   for (int t = 0; t < UT; ++t) dreg[t] = t2_ld<f4w>(P.tD + (tile * UT + t) * 64, (unsigned)lane * 16u);
@@ -137,9 +140,9 @@ void letkf_tile2p_kernel(Tile2Params P) {
   };
   float xsb[NB][8];
   load_xs(0, xsb);
-  for (int i = tid; i < 32; i += 128) reinterpret_cast<f4w*>(zline)[i] = f4w{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < 32; i += NT) reinterpret_cast<f4w*>(zline)[i] = f4w{0.f, 0.f, 0.f, 0.f};
   // (the half fragments a missing row block would have written -- UT odd -- stay zero for the whole launch)
-  for (int i = tid; i < T2P_FRAG_BUFS * NKB * 2 * 64; i += 128) reinterpret_cast<f4w*>(frag)[i] = f4w{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < T2P_FRAG_BUFS * NKB * 2 * 64; i += NT) reinterpret_cast<f4w*>(frag)[i] = f4w{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   const int U = __builtin_amdgcn_readfirstlane(hd.x);
   if (U < 0) {                     // the union of this tile did not fit its slots: loud failure, never a truncated analysis
@@ -158,7 +161,7 @@ void letkf_tile2p_kernel(Tile2Params P) {
     int tc = (g >> 1) + 2 * wv;
     constexpr int NLmax = (UT * 2 * KT + 1) / 2;
 #pragma unroll
-    for (int u0 = 0; u0 < NLmax; u0 += 2) {
+    for (int u0 = 0; u0 < NLmax; u0 += NW) {
       const int u = u0 + wv;                             // (wave-uniform)
       if (2 * u < UT * nc8) {
         int t = 0, c = tc;
@@ -174,11 +177,11 @@ void letkf_tile2p_kernel(Tile2Params P) {
           __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>(src),
                                            (__attribute__((address_space(3))) void*)(smem + u * 1024), 16, 0, 0);
       }
-      tc += 4;
+      tc += 2 * NW;
     }
   }
   bool badrec = false;
-  for (int s = tid; s < UMAX; s += 128) {
+  for (int s = tid; s < UMAX; s += NT) {
     const int idx = ukey[s];
     const int64_t j = idx < 0 ? P.zero_rec : (int64_t)idx;
     const f2w tl = *reinterpret_cast<const f2w*>(P.rec + j * P.rb + 32 * nc8);
@@ -402,9 +405,15 @@ void letkf_tile2p_kernel(Tile2Params P) {
     float inv_s2;
     {
       if (mi == 0) {          // interval and degree of every point: shared by all rows
-        float L = fmaxf(xch[(0 * 3 + 0) * 16 + lr], xch[(1 * 3 + 0) * 16 + lr]);
-        const float l0 = xch[(0 * 3 + 0) * 16 + lr], l1 = xch[(1 * 3 + 0) * 16 + lr];
-        if (l0 != l0 || l1 != l1) L = __builtin_nanf("");
+        float L = 0.0f;
+        bool lnan = false;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          const float lw = xch[(w * 3 + 0) * 16 + lr];
+          lnan = lnan || lw != lw;
+          L = fmaxf(L, lw);
+        }
+        if (lnan) L = __builtin_nanf("");
         L = fmaxf(L, 1e-37f) * 1.002f;
         if (!(L == L) || !(fabsf(L) < 1e30f)) { pflag |= MIA_FLAG_NONFINITE; L = 1.0f; }
         tab_idx = (int)ceilf(float(kTabPerOctave) * (__builtin_amdgcn_logf(L * P.inv_reg) + 16.0f)) + kTabIdx0;
@@ -419,9 +428,14 @@ void letkf_tile2p_kernel(Tile2Params P) {
         }
         degmax = (int)wave_max_nonneg_dpp((colok && !decl) ? float(deg) : 0.0f);
       }
-      const unsigned z0 = __float_as_uint(xch[(0 * 3 + 1) * 16 + lr]), z1 = __float_as_uint(xch[(1 * 3 + 1) * 16 + lr]);
+      unsigned zall = 0u;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const unsigned zw = __float_as_uint(xch[(w * 3 + 1) * 16 + lr]);
+        zall = zw > zall ? zw : zall;
+      }
       int es2;
-      const float s2 = pow2_scale(z0 > z1 ? z0 : z1, 8, &es2);
+      const float s2 = pow2_scale(zall, 8, &es2);
       inv_s2 = __uint_as_float((unsigned)(127 - es2) << 23);
 #pragma unroll
       for (int o = 0; o < OWN; ++o) {
@@ -491,7 +505,10 @@ void letkf_tile2p_kernel(Tile2Params P) {
     if (h == 0) xch[(wv * 3 + 2) * 16 + lr] = zu;
     h8v ph_[NKB], pl_[NKB];
     exchange(aphi, ph_, pl_);          // (its barrier also publishes the partial sums)
-    zu = (xch[(0 * 3 + 2) * 16 + lr] + xch[(1 * 3 + 2) * 16 + lr]) * (P.cs_psi * funs);
+    zu = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) zu += xch[(w * 3 + 2) * 16 + lr];
+    zu *= P.cs_psi * funs;
     const float mterm = xm + zu;
     const float fo = P.cs_phi * funs;
     const float* xbase = P.X + (int64_t)mi * k * P.ldx + P.g0 + p0;
@@ -557,7 +574,9 @@ void letkf_tile2p_kernel(Tile2Params P) {
     if (h == 0) xch[(wv * 3 + 0) * 16 + lr] = (float)anyf;
     __syncthreads();
     if (wv == 0 && h == 0 && colok && !decl) {
-      const bool bad = xch[(0 * 3 + 0) * 16 + lr] != 0.0f || xch[(1 * 3 + 0) * 16 + lr] != 0.0f;
+      bool bad = false;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) bad = bad || xch[(w * 3 + 0) * 16 + lr] != 0.0f;
       P.flags[p0 + lr] = (bad ? MIA_FLAG_NONFINITE : 0) | (deg << 8);
     }
   }
@@ -570,16 +589,16 @@ extern "C" int mia_debug_t2p_stamps(long long* host, int n_tiles) {
 }
 #endif
 
-static size_t tile2p_lds_bytes(int ut, int k) {
+static size_t tile2p_lds_bytes(int ut, int k, int nw) {
   const int nkb = (ut + 1) / 2;
-  return (size_t)ut * split_nc8(k) * 512 + 512 + (size_t)16 * ut * 12 + 2 * 3 * 16 * 4 + (size_t)T2P_FRAG_BUFS * nkb * 2 * 64 * 16;
+  return (size_t)ut * split_nc8(k) * 512 + 512 + (size_t)16 * ut * 12 + (size_t)nw * 3 * 16 * 4 + (size_t)T2P_FRAG_BUFS * nkb * 2 * 64 * 16;
 }
 
-template <int UT, int KT, bool MROWS>
+template <int UT, int KT, bool MROWS, int NW>
 static int tile2p_launch_m(const Tile2Params& tp, hipStream_t stream) {
-  const size_t lds = tile2p_lds_bytes(UT, tp.k);
+  const size_t lds = tile2p_lds_bytes(UT, tp.k, NW);
   if (lds > kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
-  auto kern = letkf_tile2p_kernel<UT, KT, MROWS>;
+  auto kern = letkf_tile2p_kernel<UT, KT, MROWS, NW>;
   if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t ntile = (tp.ng + 15) >> 4;
   const int64_t gx = ntile < 65536 ? ntile : 65536;
@@ -588,17 +607,17 @@ static int tile2p_launch_m(const Tile2Params& tp, hipStream_t stream) {
 #ifdef MIA_EXPERIMENTS
   if (MIA_EXP_FLAG("MIA_T2P_OCC")) {
     int nb = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 128, lds);
-    fprintf(stderr, "letkf_tile2p_kernel<%d,%d,%d>: %d workgroups per CU at %zu bytes of LDS\n", UT, KT, (int)MROWS, nb, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 64 * NW, lds);
+    fprintf(stderr, "letkf_tile2p_kernel<%d,%d,%d,%d>: %d workgroups per CU at %zu bytes of LDS\n", UT, KT, (int)MROWS, NW, nb, lds);
   }
 #endif
   hipEvent_t& stop = launch_stop_event();
   if (stop) {
-    hipExtLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(128), (unsigned)lds, stream, launch_start_event(), stop, 0, tp);
+    hipExtLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(64 * NW), (unsigned)lds, stream, launch_start_event(), stop, 0, tp);
     stop = nullptr;
     launch_start_event() = nullptr;
   } else {
-    kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(128), lds, stream>>>(tp);
+    kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64 * NW), lds, stream>>>(tp);
   }
   ++tile_launch_count();
   MIA_LAUNCH_CHECK();
@@ -609,7 +628,15 @@ static int tile2p_launch_m(const Tile2Params& tp, hipStream_t stream) {
 // to one wave per tile (k = 80, m = 4: 0.75 against 0.51 ms per 1e5 points, tools/pair_ab.py)
 template <int UT, int KT>
 static int tile2p_launch(const Tile2Params& tp, hipStream_t stream) {
-  return tp.m == 1 ? tile2p_launch_m<UT, KT, false>(tp, stream) : MIA_ERR_UNSUPPORTED;
+  if (tp.m != 1) return MIA_ERR_UNSUPPORTED;
+#ifdef MIA_EXPERIMENTS        // (three waves per tile: 168 registers, three per SIMD -- config 4 0.175 against 0.177 ms with two, the mesh's four row
+  {                           //  blocks leave the third wave idle: 0.099 against 0.074; not instantiated in the shipped library)
+    int nw = 2;
+    MIA_EXP_SET(nw, "MIA_T2P_NW", atoi);
+    if (nw == 3) return tile2p_launch_m<UT, KT, false, 3>(tp, stream);
+  }
+#endif
+  return tile2p_launch_m<UT, KT, false, 2>(tp, stream);
 }
 
 // unions of 33 .. 96 slots (UT = 3 .. 6): MIA_ERR_UNSUPPORTED for every other shape (the caller launches letkf_tile2_kernel)
