@@ -335,9 +335,11 @@ def cpu_baseline(n_points_total=12000):
                       "(localize over all P obs -> mask/scale -> torch fp64 eigh weights -> transform), "
                       "1 thread/process, tasks of 10 grid points (the reference's default chunksize)" % n_points_total,
             "variants": {"chunksize_10": rates[10], "chunksize_1000": rates[1000],
-                         "batched_eigh_best_effort": batched,
+                         "batched_torch_eigh_float64": batched,
                          "batched_note": "%d analyses as batched torch float64 (window gather, Gram, linalg.eigh on (n, 40, 40), "
-                                         "weights, transform), %d threads; max |diff| to the per-point port on 64 points %.1e"
+                                         "weights, transform), %d threads -- SLOWER than the per-point loop on this host (torch's batched "
+                                         "eigh of small float64 matrices does not use the threads): reported, not a better baseline; max "
+                                         "|diff| to the per-point port on 64 points %.1e"
                                          % (nb, cores, float(np.abs(chk - ref).max()))}}
 
 
