@@ -185,3 +185,25 @@ def test_step_driver_takes_the_tile_route(mia):
     nb = eng.localize(gx, ox, [10.0])
     xo = eng.analysis(X, yb, d, nb, 1.1, rbf_gamma=0.5, method="matfun")
     assert float(torch.linalg.norm(second - xo) / torch.linalg.norm(xo)) < 1e-6
+
+
+def test_points_without_local_observations(eng):
+    """Observations on one third of the domain only: points that see none get the prior branch of ETKFModule.forward
+    (core/etkf.py:91-95: weights sqrt(inf) I, i.e. mean + sqrt(inf) x') from the same kernel, tiles that mix both kinds included."""
+    G, k = 400, 40
+    case = O.synthetic_case(G, k, 2, seed=17)
+    gx, ox = case["grid_x"], case["obs_x"]
+    keep = ox < 130.0
+    ox, yb, d = ox[keep], case["yb"][:, keep], case["d"][keep]
+    X = case["state"]
+    nb = eng.localize(gx, ox, [10.0])
+    tiles = eng.localize_tiles(gx, ox, [10.0], nb.p_max)
+    for inf in (1.0, 1.3):
+        xa, fl, retry = eng.analysis_tiles_rbf(dev(X), dev(yb), dev(d), tiles, inf, 0.5)
+        assert int(retry.item()) == 0 and int((fl & 0xff).max().item()) == 0
+        ref = oracle_analysis(X, gx, ox, yb, d, 10.0, inf, 0.5, range(G))
+        got = xa.cpu().numpy()
+        assert rel_fro(got, ref) < TOL32
+        far = gx > 160.0
+        mean = X.mean(axis=1, keepdims=True)
+        assert rel_fro(got[:, :, far], (mean + np.sqrt(inf) * (X - mean))[:, :, far]) < TOL32
