@@ -210,7 +210,8 @@ def tile_route_case(eng, X, grid, obs, Yb, d, radius, inf, burst=5, n_check=64, 
     else:
         srec = eng.pack_split(Yb, d)
         P = int(Yb.shape[1])
-        fn = lambda: eng.analysis_tiles(X, srec, P, tiles, inf)      # noqa: E731
+        out_buf = torch.empty((X.shape[0], X.shape[1], X.shape[2]), dtype=torch.float32, device=X.device)
+        fn = lambda: eng.analysis_tiles(X, srec, P, tiles, inf, out=out_buf)      # noqa: E731
         xa, fl, retry = fn()
         hdr = tiles.unpack()[0]
         rec.update(route="tile lists + split records + letkf_tile2_kernel", union_slots=16 * tiles.ut, extra_blocks=extra,
