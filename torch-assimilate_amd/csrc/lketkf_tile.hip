@@ -38,8 +38,11 @@
 #include "mia_options.h"
 #include "mia_tiles.h"
 
+#ifndef LK_SPLIT8
+#define LK_SPLIT8 split8
+#endif
 #ifndef LK_NV
-#define LK_NV 12
+#define LK_NV 14
 #endif
 #ifndef LK_NV_PAD
 #define LK_NV_PAD 18
@@ -139,7 +142,11 @@ void lketkf_tile_kernel(LkTileParams P) {
   LK_STAMP_REAL(10);
   // ---- first round trip: header, slot table, sqrt(rho) matrix
   const int4 hd = P.thdr[tile];
-  for (int s = lane; s < NSLOT; s += 64) ukey[s] = t2_ld<int32_t>(P.tidx + tile * NSLOT, (unsigned)s * 4u);
+  constexpr bool FIXSLOT = (64 % NSLOT) == 0;      // a lane's elements lane + 64 it all belong to slot lane % NSLOT
+  int myj = -1;
+  if constexpr (FIXSLOT) myj = t2_ld<int32_t>(P.tidx + tile * NSLOT, (unsigned)(lane & (NSLOT - 1)) * 4u);
+  else
+    for (int s = lane; s < NSLOT; s += 64) ukey[s] = t2_ld<int32_t>(P.tidx + tile * NSLOT, (unsigned)s * 4u);
   f4w dreg[UT];
 #pragma unroll
   for (int t = 0; t < UT; ++t) dreg[t] = t2_ld<f4w>(P.tD + (tile * UT + t) * 64, (unsigned)lane * 16u);
@@ -159,27 +166,47 @@ void lketkf_tile_kernel(LkTileParams P) {
   //      below 2^14, inside half precision); the scale returns through the weights, rho_hat = rho 2^-2e.
   {
     constexpr int NE = (KP + 1) * NSLOT, NLD = (NE + 63) / 64;
-    for (int s_ = lane; s_ < NSLOT; s_ += 64) smax[s_] = 0u;
+    if constexpr (!FIXSLOT)
+      for (int s_ = lane; s_ < NSLOT; s_ += 64) smax[s_] = 0u;
     float v[NLD];
 #pragma unroll
     for (int it = 0; it < NLD; ++it) {
       const int e = lane + 64 * it;
       const int a = e / NSLOT, sl = e - a * NSLOT;
-      const int j = e < NE ? ukey[sl] : -1;
+      int j;
+      if constexpr (FIXSLOT) j = e < NE ? myj : -1; else j = e < NE ? ukey[sl] : -1;
       const bool isobs = a == KP;
       const bool ld = j >= 0 && (a < k || isobs);
       const unsigned off = ((unsigned)(isobs ? 0 : a) * (unsigned)P.P + (unsigned)(j < 0 ? 0 : j)) * 4u;
       const float* src = isobs ? P.d : P.Yb;
       v[it] = ld ? t2_ld<float>(src, off) : 0.0f;
     }
-    MIA_T2_SYNC();
+    unsigned mymx = 0u;
+    if constexpr (FIXSLOT) {       // the column's largest magnitude: in registers, over the 64 / NSLOT lanes that share the slot
 #pragma unroll
-    for (int it = 0; it < NLD; ++it) {
-      const int e = lane + 64 * it;
-      const int a = e / NSLOT, sl = e - a * NSLOT;
-      if (e < NE) atomicMax(&smax[sl], __float_as_uint(v[it]) & 0x7fffffffu);
+      for (int it = 0; it < NLD; ++it) {
+        const unsigned a_ = __float_as_uint(v[it]) & 0x7fffffffu;
+        mymx = (lane + 64 * it < NE && a_ > mymx) ? a_ : mymx;
+      }
+      typedef unsigned u2v __attribute__((ext_vector_type(2)));
+      if constexpr (NSLOT <= 32) {
+        const u2v r_ = __builtin_amdgcn_permlane32_swap(mymx, mymx, false, false);
+        mymx = r_.x > r_.y ? r_.x : r_.y;
+      }
+      if constexpr (NSLOT <= 16) {
+        const u2v r_ = __builtin_amdgcn_permlane16_swap(mymx, mymx, false, false);
+        mymx = r_.x > r_.y ? r_.x : r_.y;
+      }
+    } else {
+      MIA_T2_SYNC();
+#pragma unroll
+      for (int it = 0; it < NLD; ++it) {
+        const int e = lane + 64 * it;
+        const int a = e / NSLOT, sl = e - a * NSLOT;
+        if (e < NE) atomicMax(&smax[sl], __float_as_uint(v[it]) & 0x7fffffffu);
+      }
+      MIA_T2_SYNC();
     }
-    MIA_T2_SYNC();
     bool badrec = false;
 #pragma unroll
     for (int it = 0; it < NLD; ++it) {
@@ -187,7 +214,7 @@ void lketkf_tile_kernel(LkTileParams P) {
       const int a = e / NSLOT, sl = e - a * NSLOT;
       const int pos = ((sl >> 2) & 3) * NS + 4 * (sl >> 4) + (sl & 3);
       if (e < NE) {
-        const unsigned mx = smax[sl];
+        const unsigned mx = FIXSLOT ? mymx : smax[sl];
         badrec = badrec || mx >= 0x7f800000u;
         int es;
         const float sc = pow2_scale(mx, 5, &es);
@@ -294,13 +321,16 @@ void lketkf_tile_kernel(LkTileParams P) {
       for (int g = 0; g < NT2; ++g) {
         float l8[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int t = 2 * g + (i >> 2);
-          const float dl = t < UT ? ta[bb & 1][t < UT ? t : 0][i & 3] - tb[bb & 1][t < UT ? t : 0][i & 3] : 0.0f;
-          l8[i] = dl * dl;
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * g + tt;
+          // (vector form: the compiler packs the four differences and squares of a 16-byte piece in pairs)
+          const f4w dl = t < UT ? ta[bb & 1][t < UT ? t : 0] - tb[bb & 1][t < UT ? t : 0] : f4w{0.f, 0.f, 0.f, 0.f};
+          const f4w sq = dl * dl;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) l8[4 * tt + q] = sq[q];
         }
         h8v ah, al;
-        split8_tied(l8, ah, al);
+        LK_SPLIT8(l8, ah, al);
         ac = t2_mfma3(ac, ah, al, bh[g], bl[g]);
       }
       acc[bb & 1] = ac;
@@ -319,21 +349,22 @@ void lketkf_tile_kernel(LkTileParams P) {
   // the forward products of all row pairs with w[j], the transposed products into the partial sum of target row j, which
   // leaves for its owner (this lane: j < R; the next lane: j < 2 R; the one after) as soon as it is complete and is added
   // two anti-diagonals later -- the live set is the matrix, the window (2 R), R accumulators and a few values in flight
-  auto matvec = [&](const float (&u)[R], float (&yo)[R]) {
-    float n1[R], n2[R];
+  // (vectors are carried as PAIRS of rows, (u[2 ip], u[2 ip + 1]): the multiplier of the transposed products and the
+  //  accumulators of the forward ones are such pairs as they stand -- no register moves to build operands)
+  auto matvec = [&](const f2w (&u)[R / 2], f2w (&yo)[R / 2]) {
+    f2w n1[R / 2], n2[R / 2];
 #pragma unroll
-    for (int i = 0; i < R; ++i) n1[i] = lk_bperm(adr_p1, u[i]);
-    auto wv = [&](int j) -> float { return j < R ? u[j] : (j < 2 * R ? n1[j - R] : n2[j - 2 * R]); };
-    f2w yo2[R / 2];
+    for (int ip = 0; ip < R / 2; ++ip) n1[ip] = f2w{lk_bperm(adr_p1, u[ip][0]), lk_bperm(adr_p1, u[ip][1])};
+    auto wv = [&](int j) -> float { return j < R ? u[j >> 1][j & 1] : (j < 2 * R ? n1[(j - R) >> 1][(j - R) & 1] : n2[(j - 2 * R) >> 1][(j - 2 * R) & 1]); };
 #pragma unroll
-    for (int ip = 0; ip < R / 2; ++ip) yo2[ip] = f2w{0.f, 0.f};
+    for (int ip = 0; ip < R / 2; ++ip) yo[ip] = f2w{0.f, 0.f};
     float pend[3 * R];
     LK_MVSB;
 #pragma unroll
     for (int j = 1; j <= 3 * R - 2; ++j) {
       if (j == R) {
 #pragma unroll
-        for (int i = 0; i < R; ++i) n2[i] = lk_bperm(adr_p2, u[i]);
+        for (int ip = 0; ip < R / 2; ++ip) n2[ip] = f2w{lk_bperm(adr_p2, u[ip][0]), lk_bperm(adr_p2, u[ip][1])};
       }
       f2w a2 = f2w{0.f, 0.f}, b2 = f2w{0.f, 0.f};
       const float wj = wv(j);
@@ -342,18 +373,19 @@ void lketkf_tile_kernel(LkTileParams P) {
         const int n = j - 1 - 2 * ip;
         if (n >= 0 && n < H) {
           const f2w kp = getK(ip, n);
-          yo2[ip] = lk_fma2(kp, f2w{wj, wj}, yo2[ip]);
-          const f2w mp = f2w{n <= H - 2 ? u[2 * ip] : 0.0f, n >= 1 ? u[2 * ip + 1] : 0.0f};
+          yo[ip] = lk_fma2(kp, f2w{wj, wj}, yo[ip]);
+          const f2w mp = (n >= 1 && n <= H - 2) ? u[ip] : f2w{n <= H - 2 ? u[ip][0] : 0.0f, n >= 1 ? u[ip][1] : 0.0f};
           if (ip & 1) b2 = lk_fma2(kp, mp, b2); else a2 = lk_fma2(kp, mp, a2);
         }
       }
-      const float ywj = (a2[0] + b2[0]) + (a2[1] + b2[1]);
+      const f2w ab = a2 + b2;
+      const float ywj = ab[0] + ab[1];
       if (j < R) pend[j] = ywj;
       else if (j < 2 * R) pend[j] = lk_bperm(adr_m1, ywj);
       else pend[j] = lk_bperm(adr_p2, ywj);
       if (j >= 3) {          // the partial sum of two anti-diagonals ago has arrived: into its row's accumulator
         const int jj = j - 2, i = jj < R ? jj : (jj < 2 * R ? jj - R : jj - 2 * R);
-        yo2[i >> 1][i & 1] += pend[jj];
+        yo[i >> 1][i & 1] += pend[jj];
       }
       LK_MVSB;
     }
@@ -361,44 +393,43 @@ void lketkf_tile_kernel(LkTileParams P) {
     for (int jj = 3 * R - 3; jj <= 3 * R - 2; ++jj) {
       if (jj >= 1) {
         const int i = jj < R ? jj : (jj < 2 * R ? jj - R : jj - 2 * R);
-        yo2[i >> 1][i & 1] += pend[jj];
+        yo[i >> 1][i & 1] += pend[jj];
       }
     }
 #pragma unroll
-    for (int ip = 0; ip < R / 2; ++ip) {       // the pairs that have no partner: (K[2ip][0], K[2ip+1][H])
-      yo2[ip] = lk_fma2(getK(ip, H), f2w{u[2 * ip], wv(2 * ip + 1 + H)}, yo2[ip]);
-      yo[2 * ip] = yo2[ip][0];
-      yo[2 * ip + 1] = yo2[ip][1];
-    }
+    for (int ip = 0; ip < R / 2; ++ip)         // the pairs that have no partner: (K[2ip][0], K[2ip+1][H])
+      yo[ip] = lk_fma2(getK(ip, H), f2w{u[ip][0], wv(2 * ip + 1 + H)}, yo[ip]);
     LK_MVSB;
   };
+  auto rowok = [&](int i) -> bool { return !pad || R * h + i < k; };
 
   // ---- row sums r = K 1: spectral bound (largest row sum), the centring terms of the kernel vector
   float alpha = 0.0f;
   int deg = 0, tab_idx = 0, degmax = 0, pflag = 0;
   bool decl = false;
   {
-    float ones[R], r[R];
+    f2w ones[R / 2], r[R / 2];
 #pragma unroll
-    for (int i = 0; i < R; ++i) ones[i] = (!pad || R * h + i < k) ? 1.0f : 0.0f;
+    for (int ip = 0; ip < R / 2; ++ip) ones[ip] = f2w{rowok(2 * ip) ? 1.0f : 0.0f, rowok(2 * ip + 1) ? 1.0f : 0.0f};
     matvec(ones, r);
-    float L = 0.0f, rs = 0.0f, kos = 0.0f;
+    float L = 0.0f;
+    f2w rs2 = f2w{0.f, 0.f}, ko2 = f2w{0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-      L = (r[i] > L || r[i] != r[i]) ? r[i] : L;
-      rs += r[i];
-      kos += (i & 1) ? KPr[i >> 1][H + 1][1] : KPr[i >> 1][H + 1][0];
+    for (int ip = 0; ip < R / 2; ++ip) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) L = (r[ip][c] > L || r[ip][c] != r[ip][c]) ? r[ip][c] : L;
+      rs2 += r[ip];
+      ko2 += KPr[ip][H + 1];
     }
     L = __uint_as_float(t2_max_h(__float_as_uint(L)));          // (non-negative or NaN: bit patterns order like the values)
-    rs = t2_add_h(rs) * P.inv_k * P.inv_k;                      // grand mean of K
-    kos = t2_add_h(kos) * P.inv_k;                              // mean of ko
+    const float rs = t2_add_h(rs2[0] + rs2[1]) * P.inv_k * P.inv_k;      // grand mean of K
+    const float kos = t2_add_h(ko2[0] + ko2[1]) * P.inv_k;               // mean of ko
     // koc = ko - mean(ko) - (rowmean - grand mean), ketkf.py:77-88
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-      const float ko = (i & 1) ? KPr[i >> 1][H + 1][1] : KPr[i >> 1][H + 1][0];
-      float kc = ko - kos - (r[i] * P.inv_k - rs);
-      if (pad && R * h + i >= k) kc = 0.0f;
-      if (i & 1) KPr[i >> 1][H + 1][1] = kc; else KPr[i >> 1][H + 1][0] = kc;
+    for (int ip = 0; ip < R / 2; ++ip) {
+      f2w kc = KPr[ip][H + 1] - f2w{kos, kos} - (r[ip] * f2w{P.inv_k, P.inv_k} - f2w{rs, rs});
+      if (pad) kc = f2w{rowok(2 * ip) ? kc[0] : 0.0f, rowok(2 * ip + 1) ? kc[1] : 0.0f};
+      KPr[ip][H + 1] = kc;
     }
     L = fmaxf(L, 1e-30f) * 1.00001f;
     if (!(L == L) || !(fabsf(L) < 1e30f)) { pflag |= MIA_FLAG_NONFINITE; L = 1.0f; }
@@ -421,57 +452,64 @@ void lketkf_tile_kernel(LkTileParams P) {
   auto coef = [&](int j) -> float2 { return t2_ld<float2>(P.tab_c, cbase + (unsigned)(j < kTabDeg ? j : kTabDeg - 1) * 8u); };
   for (int mi = 0; mi < P.m; ++mi) {
     const float* xbase = P.X + (int64_t)mi * k * P.ldx + P.g0 + p0;
-    float va[R], vb[R];
-    float xs = 0.0f;
+    f2w va[R / 2], vb[R / 2];
+    f2w xs2 = f2w{0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-      const int a = R * h + i;
-      const bool live = !pad || a < k;
-      va[i] = t2_ld<float>(xbase, (unsigned)(live ? a : 0) * ldxb + (unsigned)lrc * 4u);
-      va[i] = live ? va[i] : 0.0f;
-      xs += va[i];
+    for (int ip = 0; ip < R / 2; ++ip) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int a = R * h + 2 * ip + c;
+        const bool live = !pad || a < k;
+        const float x = t2_ld<float>(xbase, (unsigned)(live ? a : 0) * ldxb + (unsigned)lrc * 4u);
+        va[ip][c] = live ? x : 0.0f;
+      }
+      xs2 += va[ip];
     }
     const float2 c0 = coef(0), c1 = coef(1);
     float2 cn0 = coef(2), cn1 = coef(3);
-    const float xm = t2_add_h(xs) * P.inv_k;
+    const float xm = t2_add_h(xs2[0] + xs2[1]) * P.inv_k;
 #pragma unroll
-    for (int i = 0; i < R; ++i) va[i] = (!pad || R * h + i < k) ? va[i] - xm : 0.0f;
-    float aphi[R], zacc = 0.0f;
-    float y[R];
-    auto centre = [&](float (&yy)[R]) -> float {       // alpha * mean of K u over the members
-      float s = 0.0f;
+    for (int ip = 0; ip < R / 2; ++ip) {
+      va[ip] -= f2w{xm, xm};
+      if (pad) va[ip] = f2w{rowok(2 * ip) ? va[ip][0] : 0.0f, rowok(2 * ip + 1) ? va[ip][1] : 0.0f};
+    }
+    f2w aphi[R / 2], y[R / 2];
+    float zacc = 0.0f;
+    auto centre = [&](const f2w (&yy)[R / 2]) -> float {       // alpha * mean of K u over the members
+      f2w s2 = f2w{0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < R; ++i) s += yy[i];
-      return t2_add_h(s) * P.inv_k * alpha;
+      for (int ip = 0; ip < R / 2; ++ip) s2 += yy[ip];
+      return t2_add_h(s2[0] + s2[1]) * P.inv_k * alpha;
     };
-    auto kocdot = [&](const float (&vv)[R]) -> float {
-      float s = 0.0f;
+    auto kocdot = [&](const f2w (&vv)[R / 2]) -> float {
+      f2w s2 = f2w{0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < R; ++i) s = fmaf((i & 1) ? KPr[i >> 1][H + 1][1] : KPr[i >> 1][H + 1][0], vv[i], s);
-      return s;
+      for (int ip = 0; ip < R / 2; ++ip) s2 = lk_fma2(KPr[ip][H + 1], vv[ip], s2);
+      return s2[0] + s2[1];
     };
+    const f2w al2 = f2w{alpha, alpha};
     matvec(va, y);
     {
       const float am = centre(y);
 #pragma unroll
-      for (int i = 0; i < R; ++i) {
-        float vq = fmaf(alpha, y[i], -(va[i] + am));
-        if (pad && R * h + i >= k) vq = 0.0f;
-        vb[i] = vq;
-        aphi[i] = fmaf(c1.x, vq, c0.x * va[i]);
+      for (int ip = 0; ip < R / 2; ++ip) {
+        f2w vq = lk_fma2(al2, y[ip], -(va[ip] + f2w{am, am}));
+        if (pad) vq = f2w{rowok(2 * ip) ? vq[0] : 0.0f, rowok(2 * ip + 1) ? vq[1] : 0.0f};
+        vb[ip] = vq;
+        aphi[ip] = lk_fma2(f2w{c1.x, c1.x}, vq, f2w{c0.x, c0.x} * va[ip]);
       }
       zacc = fmaf(c1.y, kocdot(vb), c0.y * kocdot(va));
     }
-    auto advance = [&](float (&vold)[R], const float (&vcur)[R], const float2 cj) {
+    auto advance = [&](f2w (&vold)[R / 2], const f2w (&vcur)[R / 2], const float2 cj) {
       matvec(vcur, y);
       const float am = centre(y);
 #pragma unroll
-      for (int i = 0; i < R; ++i) {
-        const float tq = fmaf(alpha, y[i], -(vcur[i] + am));
-        float vn = fmaf(2.0f, tq, -vold[i]);
-        if (pad && R * h + i >= k) vn = 0.0f;
-        vold[i] = vn;
-        aphi[i] = fmaf(cj.x, vn, aphi[i]);
+      for (int ip = 0; ip < R / 2; ++ip) {
+        const f2w tq = lk_fma2(al2, y[ip], -(vcur[ip] + f2w{am, am}));
+        f2w vn = lk_fma2(f2w{2.0f, 2.0f}, tq, -vold[ip]);
+        if (pad) vn = f2w{rowok(2 * ip) ? vn[0] : 0.0f, rowok(2 * ip + 1) ? vn[1] : 0.0f};
+        vold[ip] = vn;
+        aphi[ip] = lk_fma2(f2w{cj.x, cj.x}, vn, aphi[ip]);
       }
       zacc = fmaf(cj.y, kocdot(vold), zacc);
     };
@@ -481,7 +519,7 @@ void lketkf_tile_kernel(LkTileParams P) {
       cn0 = cn1; cn1 = coef(j + 2);
       advance(va, vb, cj);
 #pragma unroll
-      for (int i = 0; i < R; ++i) { const float t = va[i]; va[i] = vb[i]; vb[i] = t; }
+      for (int ip = 0; ip < R / 2; ++ip) { const f2w t = va[ip]; va[ip] = vb[ip]; vb[ip] = t; }
     }
 #else
     int j = 2;
@@ -502,7 +540,7 @@ void lketkf_tile_kernel(LkTileParams P) {
 #pragma unroll
       for (int i = 0; i < R; ++i) {
         const int a = R * h + i;
-        const float o = fmaf(P.cs_phi, aphi[i], mterm);
+        const float o = fmaf(P.cs_phi, aphi[i >> 1][i & 1], mterm);
         if (!pad || a < k) {
           if (!(fabsf(o) <= 1e30f)) pf = MIA_FLAG_NONFINITE;
           *reinterpret_cast<float*>(reinterpret_cast<char*>(obase) + ((unsigned)a * ldob + (unsigned)lr * 4u)) = o;
