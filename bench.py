@@ -639,40 +639,45 @@ def main():
             torch.cuda.synchronize()
             comp_ms = 1e3 * (time.perf_counter() - t0) / 50
             # the analysis kept block-sharded (ShardedLetkf(gather=False): what the reference's dask chunks along `grid` do,
-            # interface/letkf.py:118-131): the same pipelined loop without the all-gather -- compute scaling by itself
-            keep = ShardedLetkf(device, rank, world, radii=[GC_RADIUS], inf_factor=INF, method=args.method, gather=False,
-                                max_in_flight=max(2, args.pipeline_depth))
-            keep._engine = runner.engine
-            for _ in range(3):
-                keep.assimilate(X, grid_x, obs_x, Yb, d)
+            # interface/letkf.py:118-131): the same pipelined loop without the all-gather -- compute scaling by itself.  The loop
+            # itself enters no collective (nothing is exchanged): a rank that fails here reports -1 and the maximum over the ranks,
+            # which every rank reaches, says so
             n_keep = max(args.steps, 200)
+            keep_local = -1.0
+            try:
+                keep = ShardedLetkf(device, rank, world, radii=[GC_RADIUS], inf_factor=INF, method=args.method, gather=False,
+                                    max_in_flight=max(2, args.pipeline_depth))
+                keep._engine = runner.engine
+                for _ in range(3):
+                    keep.assimilate(X, grid_x, obs_x, Yb, d)
 
-            def keep_loop(n):
-                pend = []
-                for _ in range(n):
-                    pend.append(keep.submit(X, grid_x, obs_x, Yb, d))
-                    if len(pend) == max(2, args.pipeline_depth):
-                        pend.pop(0).result()
-                for h in pend:
-                    h.result()
-            keep_loop(50)
-            dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            keep_loop(n_keep)
-            torch.cuda.synchronize()
-            dist.barrier()
-            keep_t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+                def keep_loop(n):
+                    pend = []
+                    for _ in range(n):
+                        pend.append(keep.submit(X, grid_x, obs_x, Yb, d))
+                        if len(pend) == max(2, args.pipeline_depth):
+                            pend.pop(0).result()
+                    for h in pend:
+                        h.result()
+                keep_loop(50)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                keep_loop(n_keep)
+                torch.cuda.synchronize()
+                keep_local = time.perf_counter() - t0
+                keep.close()
+            except Exception as exc:      # noqa: BLE001
+                sys.stderr.write("sharded-output loop failed on rank %d: %r\n" % (rank, exc))
+            keep_t = torch.tensor([keep_local, -keep_local], device=device, dtype=torch.float64)
             dist.all_reduce(keep_t, op=dist.ReduceOp.MAX)
-            keep_ms = 1e3 * float(keep_t.item()) / n_keep
-            keep.close()
+            keep_ms = None if float(keep_t[1].item()) > 0 else 1e3 * float(keep_t[0].item()) / n_keep      # (any rank at -1: no figure)
             vals = torch.tensor([ex_ms, comp_ms], device=device, dtype=torch.float64)
             allv = [torch.zeros_like(vals) for _ in range(world)]
             dist.all_gather(allv, vals)
             per_link = ex_bytes / max(world - 1, 1)
             multi = {"exchange_route": runner.exchange_route, "exchange_ms_per_rank": [float(v[0]) for v in allv],
                      "compute_ms_per_rank_serial_block": [float(v[1]) for v in allv],
-                     "sharded_output": {"ms_per_step": keep_ms, "analyses_per_s": G / (keep_ms * 1e-3), "steps": n_keep,
+                     "sharded_output": {"ms_per_step": keep_ms, "analyses_per_s": (G / (keep_ms * 1e-3)) if keep_ms else None, "steps": n_keep,
                                         "note": "ShardedLetkf(gather=False): every rank keeps its block of the analysis (the reference's "
                                                 "dask chunks along `grid`); max over ranks, barrier + synchronize on both sides: the "
                                                 "compute scaling without the all-gather -- `value` is the gathered metric"},
