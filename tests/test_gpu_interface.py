@@ -670,3 +670,38 @@ def test_direct_peer_exchange_between_two_processes_on_one_gpu(tmp_path):
     if not all(r["ipc"] for r in res):
         pytest.skip("device-memory IPC between processes is not available on this box: %s" % (res[0]["why"] or res[1]["why"]))
     assert all(r["ok"] for r in res), res
+
+
+def test_interface_classes_reach_the_tile_kernels(mia, golden, monkeypatch):
+    """LETKF / LKETKF.analyse_arrays (what assimilate() ends in) with a built-in distance take the tile route -- tile lists, then
+    letkf_tile2_kernel (plain) or lketkf_tile_kernel (RBF kernel) -- and a user-defined distance callable does not; both agree
+    with the reference's analysis (golden g7)."""
+    g = golden("g7_synthetic_configs.npz")
+    calls = {"plain": 0, "rbf": 0}
+    from torch_assimilate_amd.engine import LetkfEngine
+    orig_plain, orig_rbf = LetkfEngine.analysis_tiles, LetkfEngine.analysis_tiles_rbf
+
+    def spy_plain(self, *a, **k):
+        calls["plain"] += 1
+        return orig_plain(self, *a, **k)
+
+    def spy_rbf(self, *a, **k):
+        calls["rbf"] += 1
+        return orig_rbf(self, *a, **k)
+    monkeypatch.setattr(LetkfEngine, "analysis_tiles", spy_plain)
+    monkeypatch.setattr(LetkfEngine, "analysis_tiles_rbf", spy_rbf)
+    loc = mia.GaspariCohn(10.0, mia.AbsoluteDistance())
+    kw2 = dict(grid_coords=g["c2_grid_x"], obs_coords=g["c2_obs_x"])
+    xa = mia.LETKF(localization=loc, inf_factor=1.1).analyse_arrays(g["c2_state"], g["c2_yb"], g["c2_d"], **kw2)
+    assert calls == {"plain": 1, "rbf": 0} and rel_fro(xa.cpu().numpy(), g["c2_1p1_analysis"]) < 1e-5
+    xa3 = mia.LETKF(localization=loc, inf_factor=1.0).analyse_arrays(g["c2m3_state"], g["c2m3_yb"], g["c2m3_d"],
+                                                                      grid_coords=g["c2m3_grid_x"], obs_coords=g["c2m3_obs_x"])
+    assert calls["plain"] == 2 and rel_fro(xa3.cpu().numpy(), g["c2m3_1p0_analysis"]) < 1e-5
+    kw5 = dict(grid_coords=g["c5_grid_x"], obs_coords=g["c5_obs_x"])
+    xk = mia.LKETKF(mia.RBFKernel(0.5), localization=loc, inf_factor=1.1).analyse_arrays(g["c5_state"], g["c5_yb"], g["c5_d"], **kw5)
+    assert calls["rbf"] == 1 and rel_fro(xk.cpu().numpy(), g["c5_1p1_analysis"]) < 1e-5
+    # a user callable (the reference's arbitrary dist_func, gaspari_cohn.py:124-125): host-evaluated distances, per-point lists
+    user = mia.GaspariCohn(10.0, lambda grid, obs: np.abs(np.asarray(obs, dtype=np.float64).reshape(-1) - float(np.asarray(grid).reshape(-1)[0])))
+    before = dict(calls)
+    xu = mia.LETKF(localization=user, inf_factor=1.1).analyse_arrays(g["c2_state"], g["c2_yb"], g["c2_d"], **kw2)
+    assert calls == before and rel_fro(xu.cpu().numpy(), g["c2_1p1_analysis"]) < 1e-5

@@ -244,6 +244,43 @@ class LETKF(ETKF):
             eng.weights_retry(x, yb, d, nb, self.inf_factor, xa, W, flags)
         return W
 
+    def _analysis_on_tiles(self, x, yb, d, nb, grid_coords, obs_coords):
+        """The fused analysis on the TILE route -- tile lists from the built-in metric, then letkf_tile2_kernel / letkf_tile2p_kernel
+        (plain ETKF core: split records) or lketkf_tile_kernel (RBF / Gauss kernel: the perturbations themselves) -- where it
+        applies: float32, a built-in distance, a shape the kernels take (mia_letkf_tiles_cover).  Declined points are redone by
+        the eigensolver kernel from the per-point lists.  Returns (Xa, flags) or None: the caller takes the per-point route."""
+        eng = self.engine
+        ka = self._kernel_args()
+        gamma = ka.get("rbf_gamma")
+        if (ka.get("kernel_program") is not None or self.localization is None or not hasattr(self.localization, "tile_lists")
+                or nb.g1 - nb.g0 <= 0 or x.dtype != torch.float32 or yb.shape[1] == 0):
+            return None
+        P = int(yb.shape[1])
+        tiles = None
+        for extra in range(0, 6):
+            if not eng.tile_route_applies(x, nb.p_max, extra, rbf_gamma=gamma, P=P, n_points=nb.g1 - nb.g0):
+                return None
+            tiles = self.localization.tile_lists(eng, grid_coords, obs_coords, nb.p_max, nb.g0, nb.g1, extra_blocks=extra)
+            if tiles is None:
+                return None
+            n_over = int(tiles.stats[1].item())
+            if n_over == 0:
+                break
+            if n_over & (1 << 30):          # MIA_TILE_BOX_OVERFLOW: more slots cannot help
+                return None
+        else:
+            return None
+        if gamma is not None:
+            res = eng.analysis_tiles_rbf(x, yb, d, tiles, self.inf_factor, gamma)
+        else:
+            res = eng.analysis_tiles(x, eng.pack_split(yb, d), P, tiles, self.inf_factor)
+        if res is None:
+            return None
+        xa, flags, retry = res
+        if int(retry.item()):
+            eng.retry_points(x, yb, d, nb, self.inf_factor, xa, flags, rbf_gamma=gamma)
+        return xa, flags
+
     def analyse_arrays(self, state, yb, d, grid_coords=None, obs_coords=None, g0=0, g1=None,
                        grid_info=None, obs_info=None) -> torch.Tensor:
         """Fused path: the weights never leave the GPU's LDS -- unless a ``weight_save_path`` asks for them: then
@@ -262,8 +299,12 @@ class LETKF(ETKF):
             xa = self.engine.apply_local_weights(st.reshape(-1, shp[-2], shp[-1]), W, g0, g0 + W.shape[0])
             return xa.reshape(shp[:-1] + (W.shape[0],))
         nb = self._lists(grid_coords, obs_coords, g0, g1, grid_info, obs_info)
-        xa, flags = self.engine.analysis(st.reshape(-1, shp[-2], shp[-1]), self._dev(yb), self._dev(d), nb,
-                                         self.inf_factor, return_flags=True, **self._kernel_args())
+        st3, ybd, dd = st.reshape(-1, shp[-2], shp[-1]), self._dev(yb), self._dev(d)
+        res = self._analysis_on_tiles(st3, ybd, dd, nb, grid_coords, obs_coords)
+        if res is not None:
+            xa, flags = res
+        else:
+            xa, flags = self.engine.analysis(st3, ybd, dd, nb, self.inf_factor, return_flags=True, **self._kernel_args())
         bad = int((flags & 0xff).max().item()) if flags.numel() else 0
         if bad & 1:
             raise RuntimeError("LETKF kernel: local observation list overflow (engine bug: lists are sized from counts)")
