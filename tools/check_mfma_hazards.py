@@ -5,7 +5,7 @@ included (the compiler had padded only the fall-through side).  Usage: python to
 (compiles to assembly with hipcc -S --cuda-device-only and walks every kernel)."""
 import re, subprocess, sys, os, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NEED = 8
+NEED = 8          # what the compiler itself pads v_mfma_f32_16x16x32_f16 (4 passes) -> vector reader to on straight-line code
 
 
 def regs(tok):
@@ -73,12 +73,19 @@ def check(asm):
 
 if __name__ == "__main__":
     src = sys.argv[1]
-    flags = sys.argv[2:]
+    # the flags the shipped object of this source is built with (torch-assimilate_amd/_build.py: SOURCE_FLAGS), then the caller's
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_mia_build", os.path.join(ROOT, "torch-assimilate_amd", "_build.py"))
+    bld = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bld)
+    flags = list(bld.SOURCE_FLAGS.get(os.path.basename(src), [])) + sys.argv[2:]
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
                "-I" + os.path.join(ROOT, "torch-assimilate_amd", "csrc"), "--cuda-device-only", "-S", src, "-o", out] + flags
-        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            sys.exit("hipcc failed:\n" + res.stderr)
         bad = check(open(out).read())
     for b in bad[:40]:
         print("HAZARD kernel %s: mfma at line %d read at line %d after %d wait states\n   %s\n   %s" % b)

@@ -67,6 +67,19 @@ __device__ __forceinline__ void split4_tied(const float (&x)[4], f2w& hi, f2w& l
 // MROWS = false (the only instantiation launched): one state row per grid point, straight-line code -- 212 registers at UT = 5,
 // KT = 5, two workgroups' waves per SIMD; the row loop of MROWS = true carries 382
 // NW = wavefronts per tile (2 or 3): wave w owns row blocks [w OWN, (w + 1) OWN) and output member blocks [w J0, (w + 1) J0)
+// Products behind wave-uniform branches (`o < n_own`): the compiler pads the wait states between a matrix instruction and the first
+// vector read of its result on the fall-through side of a branch only (tools/check_mfma_hazards.py found reads six
+// and seven states behind a skipped block).  Sixteen explicit wait states, tied to the accumulators on both sides so that neither
+// the products nor the reads move across them.
+template <int N>
+__device__ __forceinline__ void mfma_settle(f4w* z) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(z[i]));
+  asm volatile("s_nop 7\n\ts_nop 7");
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(z[i]));
+}
+
 template <int UT, int KT, bool MROWS, int NW>
 __global__ __launch_bounds__(64 * NW, MROWS ? 1 : (NW == 2 ? T2P_WAVES : NW))
 void letkf_tile2p_kernel(Tile2Params P) {
@@ -263,6 +276,7 @@ void letkf_tile2p_kernel(Tile2Params P) {
         }
       }
     }
+    mfma_settle<UT * OWN>(&G[0][0]);
     // D_hat = D E for every row block (the Gershgorin products and the right-hand sides need all of them)
 #pragma unroll
     for (int t = 0; t < UT; ++t) {
@@ -383,6 +397,7 @@ void letkf_tile2p_kernel(Tile2Params P) {
             const h8v ah = *reinterpret_cast<const h8v*>(smem + off), al = *reinterpret_cast<const h8v*>(smem + off + 256);
             Z[o] = t2_mfma3(Z[o], ah, al, xh[b], xl[b]);
           }
+      mfma_settle<OWN>(Z);
     }
     // u_0 = D^2 o Z of this wave's rows; its largest magnitude per column joins the spectral bound in the exchange
     f4w va[OWN], vb[OWN], aphi[OWN], apsi[OWN], ad2[OWN];
