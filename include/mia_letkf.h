@@ -89,6 +89,9 @@ const char* mia_status_string(int status);
  *   "tile_pair"        1  tile route, unions of more than 32 slots and one state row per grid point: two wavefronts per tile,
  *                         each with the Gram fragments and recurrence vectors of its own row blocks (csrc/letkf_tile2p.hip; config 4:
  *                         0.186 -> 0.172 ms per 1e5 points, a 2-D mesh with 64-slot unions 0.092 -> 0.073) (1) or one (0)
+ *   "tile_fused"       1  step driver, tile route over the bucket index, one state row per grid point, unions of at most 32 slots, no
+ *                         geometry epoch declared: every analysis wavefront localises its own tile first (csrc/letkf_tile2f.hip -- the
+ *                         list kernel's code, bit-identical results; no list kernel, no tile lists in memory) / 0: lists first
  * Scope: process-wide defaults, read when a call ENQUEUES its work -- for steps handed to the launch threads
  * (mia_letkf_step_submit) at submission: a step runs with the routes that were in force when it was submitted, whatever is
  * set afterwards.  What differs per runner of one process travels in the call's own arguments (method, step_flags:
@@ -622,6 +625,9 @@ int mia_letkf_sharded_step_f32(const float* X /* [m][k][G] */, int64_t G, int m,
                                     * block and tile format -- and rebuild only the split records.  The reference recomputes the
                                     * localisation on every call (gaspari_cohn.py:97-136); results are identical when the
                                     * geometry is.  counters[0], [1] stay 0 */
+#define MIA_STEP_KEEP_LISTS 0x4000 /* tile route: build this step's tile lists IN MEMORY (a later step of the same geometry epoch will
+                                    * ask for them with MIA_STEP_REUSE_LISTS) rather than inside the analysis wavefronts (option
+                                    * "tile_fused"); the results are the same bit for bit */
 #define MIA_STEP_NO_GATHER 0x2000 /* world > 1: the analysis STAYS block-sharded (the reference's dask chunks along `grid`,
                                    * interface/letkf.py:118-131): Xa is this rank's block, (m k, block length), block = grid
                                    * points [rank n, min(G, (rank + 1) n)) with n = ceil(G / world); nothing is exchanged,

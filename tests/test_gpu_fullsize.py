@@ -107,7 +107,7 @@ def test_config3_problem_on_one_gpu(mia):
     for _ in range(3):
         out = r.assimilate(X, gx, ox, Yb, d)
     assert r.native_steps == 2 and r.last_flags_ok() and bool(torch.isfinite(out).all())
-    assert r.dominant_kernel_name.startswith("letkf_tile2_kernel")
+    assert r.dominant_kernel_name.startswith("letkf_tile2")
     pend = [r.submit(X, gx, ox, Yb, d) for _ in range(3)]
     for h in pend:
         assert torch.equal(h.result(), out)

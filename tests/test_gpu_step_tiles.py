@@ -41,7 +41,7 @@ def test_bucket_index_equals_scan_index_and_engine_calls(mia):
         for _ in range(4):
             out = r.assimilate(*a)
         assert r.native_steps == 3 and torch.equal(out, ref) and r.last_flags_ok()
-        assert r.dominant_kernel_name.startswith("letkf_tile2_kernel")
+        assert r.dominant_kernel_name.startswith("letkf_tile2")
         pend = []
         for _ in range(7):
             pend.append(r.submit(*a))
@@ -113,7 +113,7 @@ def test_dense_network_gets_more_slots(mia):
     for _ in range(4):
         out = r.assimilate(*a)
     assert torch.equal(out, ref) and r._tile_extra == 1 and not r._no_tile_lists
-    assert r.dominant_kernel_name.startswith("letkf_tile2_kernel")
+    assert r.dominant_kernel_name.startswith("letkf_tile2")
 
 
 def test_declined_points_are_redone_from_lists_built_then(mia):
@@ -218,3 +218,64 @@ def test_sharded_output_keeps_the_block(mia):
         for got in (first, second):
             assert float(((got - part).norm(dim=(0, 1)) / part.norm(dim=(0, 1))).max()) < 2e-6
         r.close()
+
+
+def test_wavefronts_localising_their_own_tiles_equal_lists_in_memory(mia):
+    """``fuse_tile_lists`` (option tile_fused, csrc/letkf_tile2f.hip): the analysis wavefronts run the list kernel's code on their own
+    tile -- bit for bit the analysis from lists in memory, one step at a time, with steps in flight (the two per-cell count arrays
+    of a workspace alternate: the launch that reads one clears the other), when the two kinds of step follow each other on
+    the same workspaces, with new observation positions every step, and for 2-D / 3-D coordinates with two radii."""
+    import bench
+    dev_ = torch.device("cuda:0")
+    X, gx, ox, Yb, d = bench.make_case(30000, 40, 2, dev_, seed=12)
+    lists = mia.ShardedLetkf(dev_, 0, 1, radii=[10.0], inf_factor=1.1, max_in_flight=3, fuse_tile_lists=False)
+    fused = mia.ShardedLetkf(dev_, 0, 1, radii=[10.0], inf_factor=1.1, max_in_flight=3, fuse_tile_lists=True)
+    mixed = mia.ShardedLetkf(dev_, 0, 1, radii=[10.0], inf_factor=1.1, max_in_flight=3)
+    assert fused.dominant_kernel_name.startswith("letkf_tile2f_kernel")
+    gen = torch.Generator(device=dev_)
+    gen.manual_seed(5)
+    geoms = [(ox + 0.3 * torch.rand(ox.shape, generator=gen, device=dev_, dtype=ox.dtype)).contiguous() for _ in range(9)]
+    ref = [lists.assimilate(X, gx, o, Yb, d).clone() for o in geoms]
+    assert lists.last_flags_ok()
+    got = [fused.assimilate(X, gx, o, Yb, d).clone() for o in geoms]
+    assert fused.last_flags_ok() and fused.native_steps >= 8
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    for runner in (fused, mixed):
+        pend, out = [], []
+        for o in geoms:
+            pend.append(runner.submit(X, gx, o, Yb, d))
+            if len(pend) == 3:
+                out.append(pend.pop(0).result().clone())
+        out += [h.result().clone() for h in pend]
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b)
+        # ... and one at a time again on the workspaces the steps in flight used
+        assert torch.equal(runner.assimilate(X, gx, geoms[4], Yb, d), ref[4])
+        assert torch.equal(runner.assimilate(X, gx, geoms[5], Yb, d), ref[5])
+    # counters: the longest list comes from the analysis launch now
+    assert fused._p_max_hint == lists._p_max_hint
+    for r in (lists, fused, mixed):
+        r.close()
+    # 2-D and 3-D networks with short lists (unions of at most 32 slots), two radii
+    rng = np.random.default_rng(8)
+    for nc, shape, radii, groups in ((2, (60, 50), [1.3, 1.1], [0, 1]), (3, (14, 15, 16), [1.2, 1.05], [0, 0, 1])):
+        axes = np.meshgrid(*[np.arange(n, dtype=np.float64) for n in shape], indexing="ij")
+        grid = np.stack([a.ravel() for a in axes], axis=1)
+        Gn, k = grid.shape[0], 24
+        pick = rng.permutation(Gn)[: Gn // 3]
+        obs = grid[np.sort(pick)] + rng.uniform(-0.2, 0.2, (pick.size, nc))
+        Xn = torch.as_tensor(rng.standard_normal((1, k, Gn)), dtype=torch.float32, device=dev_)
+        Yn = torch.as_tensor(rng.standard_normal((k, pick.size)), dtype=torch.float32, device=dev_)
+        Yn = Yn - Yn.mean(dim=0, keepdim=True)
+        dn = torch.as_tensor(rng.standard_normal(pick.size), dtype=torch.float32, device=dev_)
+        gt, ot = torch.as_tensor(grid, device=dev_), torch.as_tensor(obs, device=dev_)
+        outs = {}
+        for fz in (False, True):
+            r = mia.ShardedLetkf(dev_, 0, 1, radii=radii, coord_group=groups, inf_factor=1.05, fuse_tile_lists=fz)
+            for _ in range(3):
+                o = r.assimilate(Xn, gt, ot, Yn, dn)
+            outs[fz] = (o.clone(), r._no_tile_lists, r._tile_extra, r.last_flags_ok())
+            r.close()
+        assert outs[True][1:] == outs[False][1:], (nc, outs[True][1:], outs[False][1:])
+        assert torch.equal(outs[True][0], outs[False][0]), nc

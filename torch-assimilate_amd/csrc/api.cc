@@ -24,7 +24,7 @@ extern "C" const char* mia_status_string(int status) {
 #include "mia_options.h"
 
 namespace mia {
-static std::atomic<int> g_opt[MIA_OPT_COUNT_] = {62, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+static std::atomic<int> g_opt[MIA_OPT_COUNT_] = {62, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
 // A thread may run under a SNAPSHOT of the options (the step driver's launch threads: a job is enqueued with the routes that
 // were in force when the caller submitted it, whatever mia_set_option does in the meantime)
 static thread_local const int* t_override = nullptr;
@@ -38,8 +38,8 @@ void option_override(const int* snapshot) { t_override = snapshot; }
 
 static const char* const kOptNames[MIA_OPT_COUNT_] = {"cheb_dmax", "cheb_table", "cheb_rowbatch", "cheb_big", "tile",
                                                       "tile_split", "localize_quad", "step_hostwait", "step_lazy_sort",
-                                                      "segment_signal", "tile_lists", "bucket_index", "tile_pair"};
-static const int kOptDefault[MIA_OPT_COUNT_] = {62, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+                                                      "segment_signal", "tile_lists", "bucket_index", "tile_pair", "tile_fused"};
+static const int kOptDefault[MIA_OPT_COUNT_] = {62, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
 
 extern "C" int mia_set_option(const char* name, int value) {
   if (!name) return MIA_ERR_NULL;

@@ -700,7 +700,7 @@ __global__ __launch_bounds__(64) void index_bucket_kernel(IndexParams p) {
 
 int index_bucket_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_t* coord_group, const double* gc_c, int n_r,
                             void* ws, size_t ws_bytes, hipStream_t stream, const ZeroJob* zero, bool fresh_box,
-                            const SplitPackJob* spack) {
+                            const SplitPackJob* spack, int* counts) {
   if (P <= 0 || n_coord < 1 || n_coord > MIA_MAX_COORD || n_r < 1 || n_r > MIA_MAX_RADII) return MIA_ERR_SIZE;
   if (P > 500000000LL) return MIA_ERR_UNSUPPORTED;
   if (!coord_group || !gc_c || !obs_xyz || !ws) return MIA_ERR_NULL;
@@ -712,6 +712,7 @@ int index_bucket_build_impl(const double* obs_xyz, int64_t P, int n_coord, const
   ip.hdr = L.hdr; ip.start = L.start; ip.cursor = L.cursor; ip.sorted = L.sorted; ip.cell_of = L.cell_of; ip.rank_of = L.rank_of;
   ip.sxyz = L.sxyz;
   ip.bucket_total = (long long)L.bucket_total; ip.bidx = L.bidx; ip.bxyz = L.bxyz;
+  if (counts) ip.cursor = counts;        // (the per-cell counts of this build: one of the layout's two arrays, the caller alternates)
   ip.pack = PackJob{nullptr, nullptr, nullptr, 0, 0};
   ip.zero = ZeroJob{{nullptr, nullptr, nullptr}, {0, 0, 0}};
   ip.scatter_xyz = 0;

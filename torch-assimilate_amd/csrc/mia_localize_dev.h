@@ -78,6 +78,12 @@ struct ScanParams {
   double eps;
   int taper;            // MIA_TAPER_*
 };
+// what the analysis kernel's fused variant (letkf_tile2f.hip) needs to localise its tiles itself: the scan over the step's bucket
+// index and the step's counters
+struct Tile2Loc {
+  ScanParams scan;
+  int32_t* stats;        // [0] longest list (running maximum), [1] tiles whose union did not fit (+ MIA_TILE_BOX_OVERFLOW)
+};
 
 // One wavefront scans the 3^d cells around grid point g (the innermost coordinate's three cells are one
 // contiguous range), evaluates distance and taper in float64 and compacts the observations whose weight
@@ -202,6 +208,6 @@ int make_scan_params(ScanParams* sp, const double* grid_xyz, int64_t P, int n_co
 struct SplitPackJob;
 int index_bucket_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_t* coord_group, const double* gc_c, int n_r,
                             void* ws, size_t ws_bytes, hipStream_t stream, const ZeroJob* zero, bool fresh_box,
-                            const SplitPackJob* spack = nullptr);
+                            const SplitPackJob* spack = nullptr, int* counts = nullptr);
 
 }  // namespace mia

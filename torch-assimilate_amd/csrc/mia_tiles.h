@@ -254,7 +254,7 @@ int split_pack_launch(const float* Yb, const float* d, int k, int64_t P, void* r
 // stats: [0] longest list (running maximum), [1] tiles whose union did not fit (added)
 int tile_lists_launch(const double* grid_xyz, int64_t g0, int64_t ng, int64_t P, int n_coord, const int32_t* coord_group,
                       const double* gc_c, int n_r, double gc_eps, int taper, int ut, void* tile_lists, int32_t* stats,
-                      void* index_ws, hipStream_t stream, const SplitPackJob* pack, bool bucket = false);
+                      void* index_ws, hipStream_t stream, const SplitPackJob* pack, bool bucket = false, const int* counts = nullptr);
 // letkf_tile2.hip
 // housekeeping the analysis launch does for the bucket index (see Tile2Params)
 struct Tile2Params {
@@ -280,7 +280,13 @@ bool tile2_covers(int m, int k, int p_max, int extra_blocks, int64_t ldx, int64_
 int tile2_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const void* rec, int64_t P,
                           const void* tile_lists, int ut, float inf_factor, float* Xa, int64_t ldo, int64_t o0,
                           int32_t* flags, int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c,
-                          hipStream_t stream, int seg_len = 0, int64_t seg_stride = 0, const Tile2Housekeeping* hk = nullptr);
+                          hipStream_t stream, int seg_len = 0, int64_t seg_stride = 0, const Tile2Housekeeping* hk = nullptr,
+                          const struct Tile2Loc* loc = nullptr);
+// letkf_tile2f.hip: the same analysis with the localisation of each tile done by its own wavefront (loc: mia_localize_dev.h) --
+// shapes: one state row, unions of at most 32 slots
+bool tile2f_covers(int m, int k, int ut, int n_coord);
+int tile2f_launch(const Tile2Params& tp, const struct Tile2Loc& loc, int ut, int kt, hipStream_t stream);
+size_t tile2_lds_bytes(int ut, int k);
 
 // letkf_tile2p.hip: the same analysis with two wavefronts per tile (unions of more than 32 slots); MIA_ERR_UNSUPPORTED for
 // shapes it has no instantiation for

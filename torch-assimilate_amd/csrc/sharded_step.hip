@@ -678,7 +678,11 @@ struct GeomStamp {
   int cg[MIA_MAX_COORD];
 };
 static std::mutex g_stamp_mu;
-struct GeomEntry { void* ws; GeomStamp st; bool valid, reuse; };
+// ... and which of the index layout's two per-cell count arrays (cursor / start: the bucket index needs no starts) the workspace's
+// NEXT bucket build bins into.  Every bucket step uses one and has its analysis launch put the OTHER back to zero -- the one the
+// previous bucket step on this workspace left dirty -- because with the fused kernel (letkf_tile2f.hip) the wavefronts that read
+// the counts and the ones that would clear them are the same launch.  cnt_use / fused: the decision taken for the step in flight.
+struct GeomEntry { void* ws; GeomStamp st; bool valid, reuse; int cnt_cur, cnt_use; bool fused; };
 static std::deque<GeomEntry> g_stamps;        // (a handful of pipeline slots per process)
 // decide = true (a step's preparation): reuse is granted when asked for AND the workspace's stamp equals `now`; otherwise the
 // stamp becomes `now` (lists are rebuilt; route 0 = no tile lists).  decide = false: the decision taken for this workspace.
@@ -690,12 +694,41 @@ static bool geom_reuse_decision(void* ws, const GeomStamp& now, bool asked, bool
   if (!decide) return e ? e->reuse : false;
   if (!e) {
     if (g_stamps.size() >= 64) g_stamps.pop_front();
-    g_stamps.push_back(GeomEntry{ws, now, false, false});
+    g_stamps.push_back(GeomEntry{ws, now, false, false, 0, 0, false});
     e = &g_stamps.back();
   }
   e->reuse = asked && e->valid && memcmp(&e->st, &now, sizeof now) == 0;
   if (!e->reuse) { memcpy(&e->st, &now, sizeof now); e->valid = now.route != 0; }      // (bytes, padding included: compared as bytes)
   return e->reuse;
+}
+
+// The count array of a step's bucket build and whether its analysis localises in the kernel.  decide = true (the step's
+// preparation; after geom_reuse_decision, which creates the entry): `bucket_step` takes the workspace's current array and flips it
+// for the next one; decide = false: what was decided.  scan_build: a scan-based index is about to be built on the workspace -- it
+// needs array 0 (cursor) clean, returns false when a full clear must come first, and leaves array 0 the current one.
+static void count_array_decision(void* ws, bool decide, bool bucket_step, bool fused, int* use, bool* fused_out) {
+  std::lock_guard<std::mutex> lock(g_stamp_mu);
+  GeomEntry* e = nullptr;
+  for (auto& x : g_stamps)
+    if (x.ws == ws) { e = &x; break; }
+  if (!e) { *use = 0; *fused_out = false; return; }
+  if (decide) {
+    e->fused = bucket_step && fused;
+    e->cnt_use = e->cnt_cur;
+    if (bucket_step) e->cnt_cur ^= 1;
+  }
+  *use = e->cnt_use;
+  *fused_out = e->fused;
+}
+static bool count_arrays_clean_for_scan(void* ws) {
+  std::lock_guard<std::mutex> lock(g_stamp_mu);
+  for (auto& x : g_stamps)
+    if (x.ws == ws) {
+      const bool clean = x.cnt_cur == 0;
+      x.cnt_cur = 0;
+      return clean;
+    }
+  return true;
 }
 
 static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, const float* d, int64_t P,
@@ -768,20 +801,30 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
   // ... and the library checks what it can: a stamp of what this workspace's lists were built for (route, format, block, radii,
   // eps, coordinate groups, sizes), kept on the host per workspace.  A step that asks for reuse with anything else -- an option or
   // attribute changed in between, another kernel family -- silently rebuilds instead of analysing from stale memory.
+  // Fused localisation (letkf_tile2f.hip): the analysis wavefronts build their tiles' lists themselves over the bucket index -- no
+  // list kernel, no lists in memory (the workspace's stamp says so: route 0).  Not when the caller declares a geometry epoch: the
+  // lists are what an epoch keeps.
+  const bool want_fused = tl_route && tl_bucket && !tl_rbf && !(step_flags & (MIA_STEP_REUSE_LISTS | MIA_STEP_KEEP_LISTS)) &&
+                          mia::option(MIA_OPT_TILE_FUSED) != 0 && mia::tile2f_covers(m, k, L.ut, n_coord);
   GeomStamp stamp_now;
   memset(&stamp_now, 0, sizeof stamp_now);
-  stamp_now.route = tl_route ? (tl_rbf ? 2 : 1) : 0;
+  stamp_now.route = (tl_route && !want_fused) ? (tl_rbf ? 2 : 1) : 0;
   stamp_now.ut = L.ut; stamp_now.bucket = tl_bucket ? 1 : 0; stamp_now.n_coord = n_coord; stamp_now.n_r = n_r;
   stamp_now.G = G; stamp_now.P = P; stamp_now.rank = rank; stamp_now.world = world; stamp_now.k = k; stamp_now.eps = gc_eps;
   for (int i = 0; i < n_r && i < MIA_MAX_RADII; ++i) stamp_now.rc[i] = gc_c[i];
   for (int i = 0; i < n_coord && i < MIA_MAX_COORD; ++i) stamp_now.cg[i] = coord_group[i];
   // (decided once per step -- where its preparation is enqueued; the analysis stage and a redo of declined points read the decision)
   const bool tl_reuse = geom_reuse_decision(ws, stamp_now, tl_route && (step_flags & MIA_STEP_REUSE_LISTS) != 0, phase == 0 && do1);
-  // (the analysis launch puts the bucket index's per-cell counts and error word back to zero, see Tile2Params)
+  int cnt_use = 0;
+  bool tl_fused = false;
+  count_array_decision(ws, phase == 0 && do1, tl_bucket && !tl_reuse, want_fused && !tl_reuse, &cnt_use, &tl_fused);
+  // (the analysis launch puts the OTHER per-cell count array and the build's error word back to zero, see Tile2Params / GeomEntry)
   mia::Tile2Housekeeping tl_hk{nullptr, nullptr, nullptr, nullptr};
+  int* tl_counts = nullptr;
   if (tl_bucket && !tl_reuse) {
     const mia::IndexLayout IL = mia::index_layout(base_of(ws) + L.loc, P, n_coord);
-    tl_hk = mia::Tile2Housekeeping{IL.cursor, &IL.hdr->ncell, &IL.hdr->err, nullptr};      // (err_out: below, once ctr is known)
+    tl_counts = cnt_use ? IL.start : IL.cursor;
+    tl_hk = mia::Tile2Housekeeping{cnt_use ? IL.cursor : IL.start, &IL.hdr->ncell, &IL.hdr->err, nullptr};      // (err_out: below, once ctr is known)
   }
   // a step in flight whose analysis is ONE plain launch (stage 2 after the host-side wait): the launch carries its completion
   // (and timing) events in its own dispatch packet
@@ -802,6 +845,13 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
   int32_t* ctr = exch ? (int32_t*)(base + L.bufs + L.chunk_bytes * (n_chunks - 1) + (size_t)rows * L.nc * sizeof(float))
                       : counters;
   tl_hk.err_out = ctr + 3;
+  mia::Tile2Loc tl_loc;
+  if (tl_fused) {
+    rc = mia::make_scan_params(&tl_loc.scan, grid_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, base + L.loc, MIA_TAPER_GC, true);
+    if (rc != MIA_OK) return rc;
+    tl_loc.scan.start = tl_counts;
+    tl_loc.stats = ctr;
+  }
   (void)hipGetLastError();
   if (exch || peer) {
     rc = comm_events(comm);
@@ -845,14 +895,19 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
       if (tl_bucket)
         rc = mia::index_bucket_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, base + L.loc, L.loc_bytes, ps,
                                           zero_in_kernel ? &zj : nullptr,
-                                          !(step_flags & MIA_STEP_WS_CLEAN) || (step_flags & MIA_STEP_FRESH_BOX), tl_rbf ? nullptr : &sj);
-      else
+                                          !(step_flags & MIA_STEP_WS_CLEAN) || (step_flags & MIA_STEP_FRESH_BOX), tl_rbf ? nullptr : &sj,
+                                          tl_counts);
+      else {
+        const bool arrays_clean = count_arrays_clean_for_scan(ws);      // (a scan-based build counts in array 0)
         rc = mia::index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, base + L.loc, L.loc_bytes, ps, nullptr,
-                                   zero_in_kernel ? &zj : nullptr, (step_flags & MIA_STEP_WS_CLEAN) != 0, false);
+                                   zero_in_kernel ? &zj : nullptr, (step_flags & MIA_STEP_WS_CLEAN) != 0 && arrays_clean, false);
+      }
       if (rc != MIA_OK) return rc;
-      rc = mia::tile_lists_launch(grid_xyz, b0, b1 - b0, P, n_coord, coord_group, gc_c, n_r, gc_eps, MIA_TAPER_GC, L.ut,
-                                  base + L.tl, ctr, base + L.loc, ps, (tl_bucket || tl_rbf) ? nullptr : &sj, tl_bucket);
-      if (rc != MIA_OK) return rc;
+      if (!tl_fused) {
+        rc = mia::tile_lists_launch(grid_xyz, b0, b1 - b0, P, n_coord, coord_group, gc_c, n_r, gc_eps, MIA_TAPER_GC, L.ut,
+                                    base + L.tl, ctr, base + L.loc, ps, (tl_bucket || tl_rbf) ? nullptr : &sj, tl_bucket, tl_counts);
+        if (rc != MIA_OK) return rc;
+      }
     } else if (b1 > b0) {
       // the record packing rides inside the first index kernel too (independent work, no launch of its own)
       const mia::PackJob job{Yb, d, rec, k, (k + 1 + 3) / 4 * 4};
@@ -860,7 +915,8 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
                             {8, exch ? 4 : 0, exch ? (int64_t)done_ints : 0}};
       rc = mia::localize_impl(grid_xyz, b0, b1, obs_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, L.cap,
                               cnt, idx, w, ctr, base + L.loc, L.loc_bytes, ps, P > 0 ? &job : nullptr, true,
-                              zero_in_kernel ? &zj : nullptr, MIA_TAPER_GC, (step_flags & MIA_STEP_WS_CLEAN) != 0, !lazy);
+                              zero_in_kernel ? &zj : nullptr, MIA_TAPER_GC,
+                              (step_flags & MIA_STEP_WS_CLEAN) != 0 && count_arrays_clean_for_scan(ws), !lazy);
       if (rc != MIA_OK) return rc;
     }
     if (ps != s) {   // the analysis stream starts once the preparation stream has produced records and lists
@@ -883,7 +939,8 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
                                             (int)L.nc, (int64_t)(L.chunk_bytes / sizeof(float)), (tl_bucket && !tl_reuse) ? &tl_hk : nullptr)
                   : mia::tile2_analysis_launch(X, G, m, k, b0, b1 - b0, base + L.hrec, P, base + L.tl, L.ut, inf_factor,
                                       (float*)(base + L.bufs), L.nc, 0, flags, ctr + 2, mia::option(MIA_OPT_CHEB_DMAX), tl_th, tl_tc, s,
-                                      (int)L.nc, (int64_t)(L.chunk_bytes / sizeof(float)), (tl_bucket && !tl_reuse) ? &tl_hk : nullptr);
+                                      (int)L.nc, (int64_t)(L.chunk_bytes / sizeof(float)), (tl_bucket && !tl_reuse) ? &tl_hk : nullptr,
+                                      tl_fused ? &tl_loc : nullptr);
       if (rc != MIA_OK) return rc;
       tl_block = true;
     }
@@ -917,6 +974,7 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
           rc = mia_letkf_pack_obs_f32(Yb, d, k, P, rec, stream);
           if (rc != MIA_OK) return rc;
           if (tl_bucket) {      // (the buckets are no scan-based index: build one, unsorted like the lazy route's)
+            (void)count_arrays_clean_for_scan(ws);      // (cleared whole below; the scan counts in array 0)
             rc = mia::index_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, base + L.loc, L.loc_bytes, (hipStream_t)stream,
                                        nullptr, nullptr, false, false);
             if (rc != MIA_OK) return rc;
@@ -963,7 +1021,7 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
           else if (tl_route)
             rc = mia::tile2_analysis_launch(X, G, m, k, c0, c1 - c0, base + L.hrec, P, base + L.tl, L.ut, inf_factor, dst, ldo, o0,
                                             cfl, ctr + 2, mia::option(MIA_OPT_CHEB_DMAX), tl_th, tl_tc, (hipStream_t)stream, 0, 0,
-                                            (tl_bucket && !tl_reuse) ? &tl_hk : nullptr);
+                                            (tl_bucket && !tl_reuse) ? &tl_hk : nullptr, tl_fused ? &tl_loc : nullptr);
           else
             rc = mia_letkf_analysis_matfun_f32(X, G, m, k, c0, c1, rec, P, ccnt, cidx, cw, L.cap, p_max_assumed,
                                                inf_factor, gamma, dst, ldo, o0, cfl, ctr + 2, stream);

@@ -14,10 +14,9 @@
 #include "mia_options.h"
 #include "mia_localize_dev.h"
 #include "mia_tiles.h"
+#include "mia_tile_localize.h"
 
 namespace mia {
-
-#define MIA_TL_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 struct SplitPackParams { SplitPackJob job; int64_t P; };
 __global__ __launch_bounds__(64) void pack_split_kernel(SplitPackParams p) {
@@ -41,28 +40,6 @@ int split_pack_launch(const float* Yb, const float* d, int k, int64_t P, void* r
 }
 
 // ---- tile lists ------------------------------------------------------------------------------------------------------
-// Gaspari-Cohn taper in float32 from the float64 squared distance -- the weights enter a float32 analysis, so float32
-// accuracy is what they need; what must stay the reference's is the DECISION `w > eps`, and that is re-taken in float64 for the
-// (rare) pairs whose float32 weight lies within 1e-4 of eps (localize_tiles_kernel).  Written so that nothing cancels:
-//   outer branch  f2(r) = (2 - r)^4 (r^2 / 12 + r / 6 - 1 / 24) / r      (the polynomial of gaspari_cohn.py:87-95 has a fourth-
-//   order zero at r = 2; its Horner form loses all digits there in float32), and 2 - r = (4 c^2 - d^2) / (c^2 (2 + r)) with the
-//   numerator formed in float64 -- relative error of the weight ~6e-7 up to the edge of the support.
-__device__ __forceinline__ float gc_taper_fast(double d2, double four_c2, float inv_c, float c, float inv_c2) {
-  const float d2f = (float)d2;
-  if (!(d2f > 0.0f)) return d2 == 0.0 ? 1.0f : 0.0f;             // r = 0 -> 1; NaN -> 0
-  const float y = __builtin_amdgcn_rsqf(d2f);
-  const float r = d2f * y * inv_c, rinv = c * y;
-  const float f1 = (((-0.25f * r + 0.5f) * r + 0.625f) * r - 5.0f / 3.0f) * r * r + 1.0f;
-  const float t = (float)(four_c2 - d2) * inv_c2 * __builtin_amdgcn_rcpf(2.0f + r);      // 2 - r
-  const float t2 = t * t;
-  const float f2 = t2 * t2 * ((r * (1.0f / 12.0f) + 1.0f / 6.0f) * r - 1.0f / 24.0f) * rinv;
-  return r < 1.0f ? f1 : (r < 2.0f ? f2 : 0.0f);
-}
-
-
-constexpr int kTlUmax = 96;           // largest union (UT = 6)
-constexpr int kTlMaxRows = 64;        // cell rows of a tile's box (outer coordinates); more = scattered points: no tile list
-
 struct TileLocParams {
   ScanParams scan;
   int64_t g0, ng;
@@ -74,14 +51,7 @@ struct TileLocParams {
   int64_t P;
 };
 
-// BUCKET: the observations sit in fixed-capacity buckets per cell (index_bucket_kernel, localize.hip) instead of the scan-based
-// layout: scan.start = per-cell counts, scan.sorted / scan.sxyz = bucket entries, cell c at c * bucket_cap.  The candidates of a
-// tile are then the entries of the cells of its box taken as ONE flat sequence (a prefix sum over the box's <= 64 cells).  (The
-// per-cell counts and the build's error word are put back to zero by the analysis kernel that follows -- letkf_tile2_kernel's
-// first workgroups -- so the workspace is left as the next build needs to find it, without a clearing launch and without a
-// completion counter: 6250 atomics on one address cost 75 us.)
-// NC = number of coordinates, TAPER = MIA_TAPER_*: compile-time, so that the distance loops unroll and the taper is one
-// straight-line polynomial (the generic form spent more scalar instructions on its loops than vector ones on the weights).
+// The localisation itself: tile_localize<BUCKET, NC, TAPER> (mia_tile_localize.h), shared with the analysis kernel's fused variant.
 template <bool BUCKET, int NC, int TAPER>
 __global__ __launch_bounds__(64) void localize_tiles_kernel(TileLocParams p) {
   MIA_PREP_PRIORITY();
@@ -92,230 +62,35 @@ __global__ __launch_bounds__(64) void localize_tiles_kernel(TileLocParams p) {
   }
   const int lane = threadIdx.x, cl = lane & 15, pg = lane >> 4;
   const int UMAX = 16 * p.ut;
-  double* gxs = reinterpret_cast<double*>(tl_lds);                    // [16][3] grid coordinates of the tile's points
-  int* cgs = reinterpret_cast<int*>(gxs + 16 * MIA_MAX_COORD);        // [16][3] their cells
-  int* ukey = cgs + 16 * MIA_MAX_COORD;                               // [kTlUmax] observation index of union member u
-  int* uinv = ukey + kTlUmax;                                         // [kTlUmax] member of slot s, -1 = unused
-  float* Wt = reinterpret_cast<float*>(uinv + kTlUmax);               // [16 ut][16] sqrt(rho) of (member, point), 0 = not local
-  const ScanParams& q = p.scan;
-  const IndexHeader* hd = q.hdr;
-  constexpr int nc = NC;
   const int64_t tile = blockIdx.x;
-  const int64_t p0 = tile << 4;
-  const int npts = p.ng - p0 < 16 ? (int)(p.ng - p0) : 16;
-  if (lane < 16) {
-    const int64_t pt = p.g0 + p0 + (lane < npts ? lane : npts - 1);
-    for (int c = 0; c < MIA_MAX_COORD; ++c) {
-      double gx = 0.0;
-      int cg = 0;
-      if (c < nc) {
-        gx = q.grid[pt * nc + c];
-        cg = cell_coord(gx, hd->mn[c], hd->invh[c], hd->n[c]);
-      }
-      gxs[lane * MIA_MAX_COORD + c] = gx;
-      cgs[lane * MIA_MAX_COORD + c] = cg;
-    }
-  }
-  for (int s = lane; s < kTlUmax; s += 64) uinv[s] = -1;
-  MIA_TL_SYNC();
-  // the tile's cell box: [min cell - 1, max cell + 1] per coordinate, clipped to the cell grid
-  int lo[MIA_MAX_COORD], hi[MIA_MAX_COORD];
-  for (int c = 0; c < MIA_MAX_COORD; ++c) {
-    int mn = 0x7fffffff, mx = -0x7fffffff;
-    for (int i = 0; i < npts; ++i) { const int v = cgs[i * MIA_MAX_COORD + c]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
-    lo[c] = mn - 1 < 0 ? 0 : mn - 1;
-    hi[c] = mx + 1 > hd->n[c] - 1 ? hd->n[c] - 1 : mx + 1;
-    if (c >= nc) { lo[c] = 0; hi[c] = 0; }
-    lo[c] = __builtin_amdgcn_readfirstlane(lo[c]);       // (the same in every lane: scalar loop bounds below)
-    hi[c] = __builtin_amdgcn_readfirstlane(hi[c]);
-  }
-  const int last = nc - 1;
-  bool empty = false;
-  for (int c = 0; c < nc; ++c) empty = empty || lo[c] > hi[c];
-  // outer coordinates (all but the last, whose cells are contiguous in the index): rows of the box
-  const int n0 = nc >= 2 ? hi[0] - lo[0] + 1 : 1;
-  const int n1 = nc == 3 ? hi[1] - lo[1] + 1 : 1;
-  const long long nrows = empty ? 0 : (long long)n0 * n1;
-  bool overflow = nrows > kTlMaxRows;
-  bool box_overflow = overflow;        // the tile's points span more cells than the kernel scans (scattered orderings, coarse cells)
-  int ubase = 0;
-  int cnt4[4] = {0, 0, 0, 0};          // local observations of points 4 pg + i so far (the same in every lane of a group)
-  // sixteen candidates (one per lane cl, position `pos` of the index arrays, valid where `have`) against the tile's points
-  // (the coordinates of this lane's four points -- point group pg -- and the radius groups, in registers)
-  double gxr[4][NC];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) gxr[i][c] = gxs[(4 * pg + i) * MIA_MAX_COORD + c];
-  int grp[NC];
-#pragma unroll
-  for (int c = 0; c < NC; ++c) grp[c] = NC == 1 ? 0 : q.group[c];
-  const int n_r = NC == 1 ? 1 : q.n_r;
-  // (float32 copies of the taper's constants, float64 4 c^2)
-  const float epsf = (float)q.eps;
-  double fc2[MIA_MAX_RADII];
-  float icf[MIA_MAX_RADII], ccf[MIA_MAX_RADII], ic2f[MIA_MAX_RADII];
-#pragma unroll
-  for (int r = 0; r < MIA_MAX_RADII; ++r) {
-    fc2[r] = 4.0 * q.cc[r] * q.cc[r];
-    icf[r] = (float)q.inv_c[r]; ccf[r] = (float)q.cc[r]; ic2f[r] = (float)(q.inv_c[r] * q.inv_c[r]);
-  }
-  auto weigh = [&](bool have, int64_t pos) {
-    const int oj = q.sorted[pos];
-    double ox[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) ox[c] = q.sxyz[pos * NC + c];
-    f4w wq = {0.f, 0.f, 0.f, 0.f};
-    bool anyu = false;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int pt = 4 * pg + i;
-      double d2[MIA_MAX_RADII] = {0.0, 0.0, 0.0};
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const double dx = ox[c] - gxr[i][c];
-#pragma unroll
-        for (int r = 0; r < (NC == 1 ? 1 : MIA_MAX_RADII); ++r)
-          if (grp[c] == r) d2[r] += dx * dx;
-      }
-      bool use;
-      if constexpr (TAPER == MIA_TAPER_GC) {
-        float wf = 1.0f;
-#pragma unroll
-        for (int r = 0; r < (NC == 1 ? 1 : MIA_MAX_RADII); ++r)
-          if (r < n_r) wf *= gc_taper_fast(d2[r], fc2[r], icf[r], ccf[r], ic2f[r]);
-        use = wf > epsf;
-        // the decision is the float64 one: pairs whose float32 weight is within 1e-4 of eps are weighed again in float64
-        const bool amb = have && pt < npts && fabsf(wf - epsf) < 1e-4f * epsf;
-        if (__any(amb)) {
-          if (amb) {
-            double wgt = 1.0;
-            for (int r = 0; r < n_r; ++r) wgt *= gc_taper_d2(d2[r], q.inv_c[r], q.cc[r]);
-            use = wgt > q.eps;
-          }
-        }
-        use = use && have && pt < npts;
-        wq[i] = use ? wf * __builtin_amdgcn_rsqf(wf) : 0.0f;
-      } else {
-        double wgt = 1.0;
-#pragma unroll
-        for (int r = 0; r < (NC == 1 ? 1 : MIA_MAX_RADII); ++r)
-          if (r < n_r) wgt *= gc_inf_taper_d2(d2[r], q.inv_c[r], q.cc[r]);
-        use = have && pt < npts && wgt > q.eps;
-        wq[i] = use ? (float)(wgt * rsqrt_f64(wgt)) : 0.0f;
-      }
-      anyu = anyu || use;
-      const unsigned long long bal = __ballot(use);
-      cnt4[i] += __popc((unsigned)(bal >> (16 * pg)) & 0xffffu);
-    }
-    // a candidate is a member of the union when any of its four lanes (one per point group) uses it
-    const unsigned long long anyb = __ballot(anyu);
-    const unsigned memb = (unsigned)((anyb | (anyb >> 16) | (anyb >> 32) | (anyb >> 48)) & 0xffffull);
-    const bool member = (memb >> cl) & 1u;
-    const int u = ubase + __popc(memb & ((1u << cl) - 1u));
-    if (member && u < UMAX) {
-      if (pg == 0) ukey[u] = oj;
-      *reinterpret_cast<f4w*>(Wt + u * 16 + 4 * pg) = wq;
-    }
-    ubase += __popc(memb);
-  };
-  if constexpr (BUCKET) {
-    const int cap = hd->bucket_cap;
-    const int nlast = empty ? 0 : hi[last] - lo[last] + 1;
-    const long long ncb = nrows * nlast;                     // cells of the box
-    box_overflow = box_overflow || ncb > 64;
-    overflow = overflow || ncb > 64;
-    int mycid = 0, mycnt = 0;
-    if (!overflow && lane < (int)ncb) {
-      const int row = lane / nlast, cc = lane - row * nlast;
-      int base_cell = 0;
-      if (nc == 2) base_cell = (lo[0] + row) * hd->n[1];
-      else if (nc == 3) base_cell = ((lo[0] + row / n1) * hd->n[1] + (lo[1] + row % n1)) * hd->n[2];
-      mycid = base_cell + lo[last] + cc;
-      mycnt = q.start[mycid];
-      mycnt = mycnt > cap ? cap : mycnt;
-    }
-    int incl = mycnt;                                        // inclusive prefix over the box's cells (lane = cell)
-    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
-    const int total = overflow ? 0 : __builtin_amdgcn_readfirstlane(__shfl(incl, 63, 64));
-    int* pref = uinv;                                        // (scratch until the ranks are formed: [<= 64] exclusive prefix | cell id)
-    pref[lane] = incl - mycnt;
-    MIA_TL_SYNC();
-    const int ncbi = (int)(ncb > 64 ? 64 : ncb);
-    for (int q0 = 0; q0 < total; q0 += 16) {
-      const int qi = q0 + cl;
-      const bool have = qi < total;
-      const int qc = have ? qi : total - 1;
-      int sel = 0;                                           // the cell of candidate qc: last cell whose prefix is <= qc
-      for (int i = 1; i < ncbi; ++i) sel += pref[i] <= qc ? 1 : 0;
-      const int cid = __shfl(mycid, sel, 64), pf = pref[sel];
-      weigh(have, (int64_t)cid * cap + (qc - pf));
-    }
-    MIA_TL_SYNC();
-    for (int s_ = lane; s_ < kTlUmax; s_ += 64) uinv[s_] = -1;
-  } else {
-    for (int row = 0; row < (overflow ? 0 : (int)nrows); ++row) {
-      int base_cell = 0;
-      if (nc == 2) base_cell = (lo[0] + row) * hd->n[1];
-      else if (nc == 3) base_cell = ((lo[0] + row / n1) * hd->n[1] + (lo[1] + row % n1)) * hd->n[2];
-      const int beg = __builtin_amdgcn_readfirstlane(q.start[base_cell + lo[last]]);
-      const int end = __builtin_amdgcn_readfirstlane(q.start[base_cell + hi[last] + 1]);
-      for (int pos0 = beg; pos0 < end; pos0 += 16) {
-        const bool have = pos0 + cl < end;
-        weigh(have, have ? pos0 + cl : end - 1);
-      }
-    }
-  }
-  const int U = ubase;
-  overflow = overflow || U > UMAX;
-  MIA_TL_SYNC();
-  // rank of every member by observation index -> slot
-  if (!overflow) {
-    for (int u = lane; u < U; u += 64) {
-      const int key = ukey[u];
-      int rk = 0;
-      for (int v = 0; v < U; ++v) rk += ukey[v] < key ? 1 : 0;
-      uinv[16 * (rk >> 4) + 4 * (rk & 3) + ((rk >> 2) & 3)] = u;
-    }
-  }
-  MIA_TL_SYNC();
+  const TileLocOut r = tile_localize<BUCKET, NC, TAPER>(p.scan, p.g0, p.ng, p.ut, tile, tl_lds, lane);
+  const TileLocLds L(tl_lds);
+  const bool overflow = r.overflow;
   for (int s = lane; s < UMAX; s += 64) {
-    const int u = overflow ? -1 : uinv[s];
-    p.uidx[tile * UMAX + s] = u < 0 ? -1 : ukey[u];
+    const int u = overflow ? -1 : L.uinv[s];
+    p.uidx[tile * UMAX + s] = u < 0 ? -1 : L.ukey[u];
   }
   for (int t = 0; t < p.ut; ++t) {
     f4w v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
-      const int u = overflow ? -1 : uinv[16 * t + 4 * pg + qq];
-      v[qq] = u < 0 ? 0.0f : Wt[u * 16 + cl];
+      const int u = overflow ? -1 : L.uinv[16 * t + 4 * pg + qq];
+      v[qq] = u < 0 ? 0.0f : L.Wt[u * 16 + cl];
     }
     p.D[(tile * p.ut + t) * 64 + lane] = v;
   }
-  // longest list of the tile (every lane of a point group holds the counts of its four points)
-  int mx = cnt4[0] > cnt4[1] ? cnt4[0] : cnt4[1];
-  mx = cnt4[2] > mx ? cnt4[2] : mx;
-  mx = cnt4[3] > mx ? cnt4[3] : mx;
-  const int m0 = __builtin_amdgcn_readlane(mx, 0), m1 = __builtin_amdgcn_readlane(mx, 16);
-  const int m2 = __builtin_amdgcn_readlane(mx, 32), m3 = __builtin_amdgcn_readlane(mx, 48);
-  const int m01 = m0 > m1 ? m0 : m1, m23 = m2 > m3 ? m2 : m3;
-  const int longest = m01 > m23 ? m01 : m23;
   if (lane == 0) {
-    p.hdr[tile] = make_int4(overflow ? -1 : U, longest, npts, 0);
-    if (longest > __hip_atomic_load(&p.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&p.stats[0], longest);
+    p.hdr[tile] = make_int4(overflow ? -1 : r.U, r.longest, r.npts, 0);
+    if (r.longest > __hip_atomic_load(&p.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&p.stats[0], r.longest);
     if (overflow) atomicAdd(&p.stats[1], 1);
     // (more slots cannot help a box that is too large: marked, so that the caller goes to per-point lists at once)
-    if (box_overflow) atomicOr(&p.stats[1], MIA_TILE_BOX_OVERFLOW);
+    if (r.box_overflow) atomicOr(&p.stats[1], MIA_TILE_BOX_OVERFLOW);
   }
-}
-
-static size_t tile_loc_lds(int ut) {
-  return 16 * MIA_MAX_COORD * (sizeof(double) + sizeof(int)) + 2 * kTlUmax * sizeof(int) + (size_t)16 * ut * 16 * sizeof(float);
 }
 
 int tile_lists_launch(const double* grid_xyz, int64_t g0, int64_t ng, int64_t P, int n_coord, const int32_t* coord_group,
                       const double* gc_c, int n_r, double gc_eps, int taper, int ut, void* tile_lists, int32_t* stats,
-                      void* index_ws, hipStream_t stream, const SplitPackJob* pack, bool bucket) {
+                      void* index_ws, hipStream_t stream, const SplitPackJob* pack, bool bucket, const int* counts) {
   if (ng < 0 || P < 0 || ut < 1 || ut > 6) return MIA_ERR_SIZE;
   if (!tile_lists || !stats) return MIA_ERR_NULL;
   const TileListLayout L = tile_list_layout(ng, ut);
@@ -346,6 +121,7 @@ int tile_lists_launch(const double* grid_xyz, int64_t g0, int64_t ng, int64_t P,
   if (!grid_xyz || !index_ws) return MIA_ERR_NULL;
   int rc = make_scan_params(&tp.scan, grid_xyz, P, n_coord, coord_group, gc_c, n_r, gc_eps, index_ws, taper, bucket);
   if (rc != MIA_OK) return rc;
+  if (bucket && counts) tp.scan.start = counts;      // (which of the layout's two per-cell count arrays this step's build filled)
   tp.nb_main = (unsigned)L.ntile;
   void (*kern)(TileLocParams) = nullptr;
 #define MIA_TL_PICK(B, T)                                                                                                  \

@@ -81,8 +81,18 @@ class ShardedLetkf:
         if v.value and tl.value and not self._no_tile_lists and self.rbf_gamma is not None:
             return "lketkf_tile_kernel<10, 2, false>"
         if v.value and sp.value and tl.value and not self._no_tile_lists and self.native_step:
+            fu, bk = C.c_int(1), C.c_int(1)
+            self.engine.lib.mia_get_option(b"tile_fused", C.byref(fu))
+            self.engine.lib.mia_get_option(b"bucket_index", C.byref(bk))
+            if fu.value and bk.value and not self._scan_index and self.fuse_tile_lists is True:
+                return "letkf_tile2f_kernel<2, 3, 1>"      # (every step outside a geometry epoch: the wavefronts localise themselves)
             return "letkf_tile2_kernel<2, 3, false>"
         return ("letkf_tile_kernel<2, 3, false, %s>" % ("true" if sp.value else "false")) if v.value else "letkf_cheb_kernel<20, 1, false>"
+
+    def _fuse_now(self, pipelined: bool) -> bool:
+        if self.fuse_tile_lists == "auto":
+            return not pipelined
+        return bool(self.fuse_tile_lists)
 
     @property
     def exchange_route(self):
@@ -172,7 +182,7 @@ class ShardedLetkf:
                  method: str = "auto", fused_localization: bool = False,
                  comm_chunks: int = 4, chunk_compute: Optional[Callable] = None, native_step: bool = True,
                  max_in_flight: int = 3, peer_exchange: str = "auto", copy_results: bool = True, prep_streams: int = 5,
-                 analysis_streams: int = 1, gather: bool = True):
+                 analysis_streams: int = 1, gather: bool = True, fuse_tile_lists="auto"):
         self.device, self.rank, self.world = device, rank, world
         self.radii, self.inf_factor, self.coord_group, self.eps = list(radii), inf_factor, coord_group, eps
         self.rbf_gamma = rbf_gamma
@@ -182,6 +192,12 @@ class ShardedLetkf:
         self.gather = bool(gather)
         self.method = method
         self.fused_localization = fused_localization
+        # native step driver, tile route: True = the analysis wavefronts localise their tiles themselves (csrc/letkf_tile2f.hip, option
+        # "tile_fused": no list kernel, no lists in memory; same bits), False = tile lists in memory first, "auto" = fused for
+        # steps taken one at a time (assimilate(): one launch and ~10 us less per step) and lists first for steps in flight
+        # (submit(): the list kernel of the next step runs beside the analysis kernel of the previous one, which the fused kernel
+        # cannot -- measured 1.75e9 against 1.68e9 analyses/s at config 2)
+        self.fuse_tile_lists = fuse_tile_lists
         self.comm_chunks = int(comm_chunks)
         self._chunk_compute = chunk_compute
         self._comm_stream = None
@@ -586,7 +602,7 @@ class ShardedLetkf:
                  # MIA_STEP_NO_JOIN for steps in flight; MIA_STEP_WS_CLEAN: this slot's workspace was last used by a step that
                  # ran to completion (its index kernels leave the header zeroed)
                  (1 if pipelined else 0) | (4 if slot.get("ws_clean") else 0) | (8 if self._no_tile_lists else 0) | (self._tile_extra << 4) |
-                 (0x400 if self._fresh_box_once else 0) | (0x800 if self._scan_index else 0) | (0x1000 if reuse else 0) |
+                 (0x400 if self._fresh_box_once else 0) | (0x800 if self._scan_index else 0) | (0x1000 if reuse else 0) | (0x4000 if (geom_key is not None or not self._fuse_now(pipelined)) else 0) |
                  (0x2000 if part is not None else 0)]
         self._fresh_box_once = False
         slot["ws_clean"] = False            # (until this step has been collected without an error)
