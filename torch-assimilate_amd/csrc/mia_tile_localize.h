@@ -102,8 +102,13 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
   // the tile's cell box: [min cell - 1, max cell + 1] per coordinate, clipped to the cell grid
   int lo[MIA_MAX_COORD], hi[MIA_MAX_COORD];
   for (int c = 0; c < MIA_MAX_COORD; ++c) {
-    int mn = 0x7fffffff, mx = -0x7fffffff;
-    for (int i = 0; i < npts; ++i) { const int v = cgs[i * MIA_MAX_COORD + c]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+    // (lane cl holds point cl's cell -- points past the tile's end repeat its last one, see above -- and the sixteen lanes of a row
+    //  reduce with four DPP steps each way; the loop over the points in LDS this replaces was a sixth of the kernel's instructions)
+    int mn = cgs[cl * MIA_MAX_COORD + c], mx = mn;
+#define MIA_TL_ROW_STEP(ctrl) do { const int a_ = __builtin_amdgcn_update_dpp(0, mn, ctrl, 0xf, 0xf, false), b_ = __builtin_amdgcn_update_dpp(0, mx, ctrl, 0xf, 0xf, false); \
+                                   mn = a_ < mn ? a_ : mn; mx = b_ > mx ? b_ : mx; } while (0)
+    MIA_TL_ROW_STEP(0xB1); MIA_TL_ROW_STEP(0x4E); MIA_TL_ROW_STEP(0x124); MIA_TL_ROW_STEP(0x128);      // quad_perm x 2, row_ror:4, row_ror:8
+#undef MIA_TL_ROW_STEP
     lo[c] = mn - 1 < 0 ? 0 : mn - 1;
     hi[c] = mx + 1 > hd->n[c] - 1 ? hd->n[c] - 1 : mx + 1;
     if (c >= nc) { lo[c] = 0; hi[c] = 0; }
@@ -141,12 +146,21 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
     fc2[r] = 4.0 * q.cc[r] * q.cc[r];
     icf[r] = (float)q.inv_c[r]; ccf[r] = (float)q.cc[r]; ic2f[r] = (float)(q.inv_c[r] * q.inv_c[r]);
   }
-  auto weigh = [&](bool have, int64_t pos) {
+  // a candidate: its observation index and coordinates (requested one trip ahead of their use by the bucket loop below)
+  struct Cand { int oj; double ox[NC]; };
+  auto fetch = [&](int64_t pos) {
+    Cand cd;
+    cd.oj = q.sorted[pos];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) cd.ox[c] = q.sxyz[pos * NC + c];
+    return cd;
+  };
+  auto weigh = [&](bool have, const Cand& cd) {
 #pragma clang fp contract(off)      // (the same bits in every kernel this is inlined into, see gc_taper_fast)
-    const int oj = q.sorted[pos];
+    const int oj = cd.oj;
     double ox[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) ox[c] = q.sxyz[pos * NC + c];
+    for (int c = 0; c < NC; ++c) ox[c] = cd.ox[c];
     f4w wq = {0.f, 0.f, 0.f, 0.f};
     bool anyu = false;
 #pragma unroll
@@ -224,14 +238,22 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
     pref[lane] = incl - mycnt;
     MIA_TL_SYNC();
     const int ncbi = (int)(ncb > 64 ? 64 : ncb);
-    for (int q0 = 0; q0 < total; q0 += 16) {
+    // position of candidate q0 + cl in the bucket arrays (the last candidate again where there is none)
+    auto locate = [&](int q0) -> int64_t {
       const int qi = q0 + cl;
-      const bool have = qi < total;
-      const int qc = have ? qi : total - 1;
+      const int qc = qi < total ? qi : total - 1;
       int sel = 0;                                           // the cell of candidate qc: last cell whose prefix is <= qc
       for (int i = 1; i < ncbi; ++i) sel += pref[i] <= qc ? 1 : 0;
       const int cid = __shfl(mycid, sel, 64), pf = pref[sel];
-      weigh(have, (int64_t)cid * cap + (qc - pf));
+      return (int64_t)cid * cap + (qc - pf);
+    };
+    // (the candidates of trip t + 1 are requested before trip t is weighed: one memory round trip per tile instead of one per trip)
+    Cand nxt;
+    if (total > 0) nxt = fetch(locate(0));
+    for (int q0 = 0; q0 < total; q0 += 16) {
+      const Cand cur = nxt;
+      if (q0 + 16 < total) nxt = fetch(locate(q0 + 16));
+      weigh(q0 + cl < total, cur);
     }
     MIA_TL_SYNC();
     for (int s_ = lane; s_ < kTlUmax; s_ += 64) uinv[s_] = -1;
@@ -244,7 +266,7 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
       const int end = __builtin_amdgcn_readfirstlane(q.start[base_cell + hi[last] + 1]);
       for (int pos0 = beg; pos0 < end; pos0 += 16) {
         const bool have = pos0 + cl < end;
-        weigh(have, have ? pos0 + cl : end - 1);
+        weigh(have, fetch(have ? pos0 + cl : end - 1));
       }
     }
   }
