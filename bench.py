@@ -587,6 +587,46 @@ def main():
                      "bitwise_equal_to_full_rebuild": bool(torch.equal(outg, out)),
                      "note": "submit(..., geometry_id=): tile lists reused while grid / observation coordinates stay the same "
                              "(MIA_STEP_REUSE_LISTS); records, analysis, read-back every step"}
+    # separate keys, NOT `value`: the steps in flight on the fused kernel (letkf_tile2f.hip: every analysis wavefront localises its
+    # own tile, two launches per step, no lists in memory) -- with one analysis stream as the headline has it, and with three
+    # analysis / three preparation streams (two or three fused kernels share the chip: more steps per second, each launch slower)
+    fused_flight = None
+    if world == 1 and depth != 1 and args.method != "eig":
+        fused_flight = {}
+        for label, n_an, n_pr in (("one_analysis_stream", 1, 5), ("three_analysis_streams", 3, 3)):
+            r2 = ShardedLetkf(device, rank, world, radii=[GC_RADIUS], inf_factor=INF, method=args.method, comm_chunks=1,
+                              max_in_flight=max(2, depth), prep_streams=n_pr, analysis_streams=n_an, copy_results=False,
+                              fuse_tile_lists=True)
+
+            def run2(n):
+                pend, o = collections.deque(), None
+                for it in range(n):
+                    if it % 4 == 0:
+                        r2.time_next_step()
+                    pend.append(r2.submit(X, grid_x, obs_x, Yb, d))
+                    if len(pend) == depth:
+                        o = pend.popleft().result()
+                while pend:
+                    o = pend.popleft().result()
+                return o
+            run2(2 * depth + 2)
+            run2(max(50, args.warmup))
+            r2.kernel_timings.clear()
+            reg = []
+            for _ in range(max(5, repeats // 4)):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                o2 = run2(args.steps)
+                torch.cuda.synchronize()
+                reg.append(time.perf_counter() - t0)
+            el2 = float(np.median(reg))
+            fused_flight[label] = {"ms_per_step": 1e3 * el2 / args.steps, "analyses_per_s": G * args.steps / el2,
+                                   "kernel_ms_in_loop": r2.kernel_ms(), "kernel": r2.dominant_kernel_name,
+                                   "preparation_streams": n_pr, "bitwise_equal_to_lists_in_memory": bool(torch.equal(o2, out))}
+            r2.close()
+        fused_flight["note"] = ("ShardedLetkf(fuse_tile_lists=True): index_bucket (+ record packing) -> letkf_tile2f_kernel, nothing "
+                                "else; the default ('auto') takes this route for steps one at a time (serial_ms_per_step) and "
+                                "lists in memory for steps in flight (`value`: same rate, the analysis launch alone is shorter)")
     assert out.shape == (1, K_ENS, G) and bool(torch.isfinite(out).all())
     assert runner.last_flags_ok(), "kernel flagged grid points"
 
@@ -900,11 +940,15 @@ def main():
                       "eigensolver_route_kernel_ms": eig_ms,
                       "eigensolver_route_kernel_analyses_per_s": (gpg / (eig_ms * 1e-3)) if eig_ms else None},
             "pipeline": {"depth": depth, "serial_ms_per_step": serial_ms,
+                         "serial_route": ("index_bucket (+ record packing) -> letkf_tile2f_kernel (the wavefronts localise their own "
+                                          "tiles: two launches per step)") if getattr(runner, "fuse_tile_lists", None) in ("auto", True)
+                                         else "index_bucket (+ record packing) -> localize_tiles -> letkf_tile2_kernel",
                          "preparation_streams": {"n": runner.prep_streams,
                                                  "note": "plain HIP streams taken in turn by the steps in flight (the hardware-queue "
                                                          "probing of round 3 measured no gain under these flags and is gone: "
                                                          "profiles/r04_stream_ab.txt)"},
                          "fixed_geometry": fixed_geo,
+                         "fused_in_flight": fused_flight,
                          "serial_analyses_per_s": (G / (serial_ms * 1e-3)) if serial_ms else None,
                          "note": "depth d > 1: consecutive (independent) steps are software-pipelined over d slots / HIP "
                                  "streams; every step is fully computed, exchanged and validated inside the timed "
