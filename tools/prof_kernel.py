@@ -15,14 +15,23 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="c2")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--grid", type=int, default=100000)
-ap.add_argument("--route", default="tiles", choices=["tiles", "lists"],
-                help="tiles: tile lists + split records + letkf_tile2_kernel (configs 2, 4); lists: per-point lists + round-2 kernels")
+ap.add_argument("--route", default="tiles", choices=["tiles", "lists", "step"],
+                help="tiles: tile lists + split records + letkf_tile2_kernel (configs 2, 4); lists: per-point lists + round-2 kernels; "
+                     "step: whole steps of the native driver, one at a time, the wavefronts localising their own tiles (letkf_tile2f_kernel)")
 ap.add_argument("--weights", action="store_true", help="tiles route: also the (G, k, k) weights (letkf_tile2w_kernel)")
 a = ap.parse_args()
 k, stride, c, gamma = {"c2": (40, 2, 10.0, None), "c4": (80, 1, 16.5, None), "c5": (40, 2, 10.0, 0.5)}[a.config]
 dev = torch.device("cuda:0")
 eng = mia.LetkfEngine(dev)
 X, gx, ox, Yb, d = bench.make_case(a.grid, k, stride, dev)
+if a.route == "step":
+    r = mia.ShardedLetkf(dev, 0, 1, radii=[c], inf_factor=1.1, rbf_gamma=gamma, fuse_tile_lists=True)
+    for _ in range(a.reps + 2):
+        out = r.assimilate(X, gx, ox, Yb, d)
+    torch.cuda.synchronize()
+    print("kernel", r.dominant_kernel_name, "flags ok", r.last_flags_ok(), "p_max", r.last_p_max, "mean degree", r.mean_degree())
+    r.close()
+    sys.exit(0)
 nb = eng.localize(gx, ox, [c])
 if a.route == "tiles" and gamma is not None:          # RBF-kernelised filter on tiles (csrc/lketkf_tile.hip)
     for _ in range(a.reps):
