@@ -38,7 +38,7 @@ namespace mia {
 
 template <int UT, int KT, bool MROWS, int WAVES>
 __global__ __launch_bounds__(64, WAVES)
-void letkf_tile2_kernel(Tile2Params P) { tile2_body<UT, KT, MROWS, 0>(P, nullptr); }
+void letkf_tile2_kernel(Tile2Params P) { tile2_body<UT, KT, MROWS, 0>(P, nullptr, (int64_t)blockIdx.y * gridDim.x + blockIdx.x); }
 
 #ifdef MIA_TILE_STAMPS
 extern "C" int mia_debug_tile2_stamps(long long* host, int n_tiles) {
@@ -150,6 +150,7 @@ int tile2_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0,
   tp.err_out = hk ? hk->err_out : nullptr;
   tp.stagger = 0;
   MIA_EXP_SET(tp.stagger, "MIA_TILE2_STAGGER", atoi);
+  { int pm = 0, tr = 0; MIA_EXP_SET(pm, "MIA_TILE2_PRIO", atoi); MIA_EXP_SET(tr, "MIA_TILE2_TRIM", atoi); tp.stagger |= (pm & 0xff) << 8 | tr << 16; }
   // the wavefronts localise their tiles themselves (the caller built no lists: it asked tile2f_covers first)
   if (loc) return tile2f_launch(tp, *loc, ut, kt, stream);
   // unions of more than 32 slots: two wavefronts per tile (letkf_tile2p.hip) where it has the shape

@@ -41,7 +41,7 @@ static __device__ long long g_tile2_stamps[kT2StampTiles * kT2StampN];      // (
 // union, ranks and sqrt(rho) as the list kernel's) before anything else; its scratch shares the LDS of the record image, which is
 // filled afterwards.  No tile list is written or read, one launch and one memory round trip less per step.
 template <int UT, int KT, bool MROWS, int LOC>
-__device__ __forceinline__ void tile2_body(Tile2Params P, const Tile2Loc* loc) {
+__device__ __forceinline__ void tile2_body(Tile2Params P, const Tile2Loc* loc, const int64_t bid) {
   constexpr int UMAX = 16 * UT, NB = (KT + 1) / 2, NKB = (UT + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x, lr = lane & 15, h = lane >> 4;
@@ -54,7 +54,6 @@ __device__ __forceinline__ void tile2_body(Tile2Params P, const Tile2Loc* loc) {
 
   // XCD-aware block -> tile map: blocks b, b + 8, ... share an XCD (and its L2) and take consecutive tiles, whose
   // records overlap
-  const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
   const int64_t ntile = (P.ng + 15) >> 4;
   if (bid >= ntile) return;
   if (P.clr_counts) {
@@ -80,6 +79,16 @@ __device__ __forceinline__ void tile2_body(Tile2Params P, const Tile2Loc* loc) {
   const bool colok = lr < npts;
 
 #ifdef MIA_EXPERIMENTS
+  // (bits 8..: wave priority by phase -- 1: prologue high, compute normal; 2: prologue normal, compute high)
+  const int prio_mode = (P.stagger >> 8) & 0xff, exp_trim = P.stagger >> 16;      // (bits 16..: steps taken off the table's degree)
+  P.stagger &= 0xff;
+  if (prio_mode == 1) __builtin_amdgcn_s_setprio(3);
+  if (prio_mode >= 3) {     // fast lanes: the waves of some slots of a SIMD run at high priority, retire early and hand their slot (and
+                            // its priority) to a tile of the second round while the other slots' waves are still at work
+    const int wid = (int)(__builtin_amdgcn_s_getreg((4 << 11) | 4) & 0xf);      // HW_ID wave id
+    const bool fast = prio_mode == 3 ? (wid & 1) : (prio_mode == 4 ? wid < 2 : (prio_mode == 5 ? wid == 0 : (wid % 3) == 0));
+    if (fast) __builtin_amdgcn_s_setprio(3);
+  }
   if (P.stagger > 0) {      // waves of one SIMD start their memory phases apart
     const int slot = (int)(__builtin_amdgcn_s_getreg((4 << 11) | 4) & 0xf);      // HW_ID wave id
     for (int i = 0; i < slot * P.stagger; ++i) __builtin_amdgcn_s_sleep(1);
@@ -259,6 +268,10 @@ __device__ __forceinline__ void tile2_body(Tile2Params P, const Tile2Loc* loc) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // records in LDS (x, D, tails in registers)
     __builtin_amdgcn_wave_barrier();
     T2_STAMP(3);        // ... and landed
+#ifdef MIA_EXPERIMENTS
+    if (prio_mode == 1) __builtin_amdgcn_s_setprio(0);
+    if (prio_mode == 2) __builtin_amdgcn_s_setprio(3);
+#endif
     f4w G[UT][UT];          // G[t1][t2][q] = Gram[16 t1 + 4 h + q][16 t2 + lr]
 #pragma unroll
     for (int t1 = 0; t1 < UT; ++t1)
@@ -366,6 +379,9 @@ __device__ __forceinline__ void tile2_body(Tile2Params P, const Tile2Loc* loc) {
     tab_idx = tab_idx < 0 ? 0 : (tab_idx > kTabN - 1 ? kTabN - 1 : tab_idx);
     const int2 th = t2_ld<int2>(P.tab_hdr, (unsigned)tab_idx * 8u);
     deg = th.x;
+#ifdef MIA_EXPERIMENTS
+    deg = deg - exp_trim > 3 ? deg - exp_trim : (deg < 3 ? deg : 3);
+#endif
     alpha = __builtin_ldexpf(__int_as_float(th.y) * P.inv_reg, 16);
     decl = colok && (deg > P.dmax || deg > kTabDeg - 1);
     if (decl && h == 0) {

@@ -19,7 +19,7 @@ struct Tile2FParams { Tile2Params t; Tile2Loc loc; };
 
 template <int UT, int KT, int NC, int WAVES>
 __global__ __launch_bounds__(64, WAVES)
-void letkf_tile2f_kernel(Tile2FParams PF) { tile2_body<UT, KT, false, NC>(PF.t, &PF.loc); }
+void letkf_tile2f_kernel(Tile2FParams PF) { tile2_body<UT, KT, false, NC>(PF.t, &PF.loc, (int64_t)blockIdx.y * gridDim.x + blockIdx.x); }
 
 #ifdef MIA_TILE_STAMPS
 extern "C" int mia_debug_tile2f_stamps(long long* host, int n_tiles) {
