@@ -279,3 +279,25 @@ def test_wavefronts_localising_their_own_tiles_equal_lists_in_memory(mia):
             r.close()
         assert outs[True][1:] == outs[False][1:], (nc, outs[True][1:], outs[False][1:])
         assert torch.equal(outs[True][0], outs[False][0]), nc
+
+
+@pytest.mark.parametrize("k,stride,radius", [(8, 4, 6.0), (16, 2, 4.0), (24, 2, 10.0), (50, 2, 10.0), (70, 2, 10.0), (96, 2, 10.0),
+                                             (40, 7, 10.0), (33, 40, 10.0)])
+def test_fused_localisation_over_ensemble_sizes(mia, k, stride, radius):
+    """Every member-block count (k = 8 .. 96) and both union sizes (one or two row blocks of slots; hardly any observation at all
+    with a stride of 40) of letkf_tile2f_kernel against the oracle and, bit for bit, against lists in memory."""
+    dev = torch.device("cuda:0")
+    case = O.synthetic_case(1500, k, stride, seed=20 + k)
+    a = args_of(case, dev)
+    oracle = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], case["yb"], case["d"], radius, 1.1)[0]
+    outs = {}
+    for fz in (False, True):
+        r = mia.ShardedLetkf(dev, 0, 1, radii=[radius], inf_factor=1.1, fuse_tile_lists=fz)
+        for _ in range(3):
+            out = r.assimilate(*a)
+        assert r.last_flags_ok() and r.native_steps == 2
+        outs[fz] = (out.clone(), r._no_tile_lists, r._tile_extra, r.last_p_max)
+        r.close()
+    assert outs[True][1:] == outs[False][1:]
+    assert torch.equal(outs[True][0], outs[False][0])
+    assert rel_fro(outs[True][0].cpu().numpy(), oracle) < 1e-5

@@ -6,7 +6,7 @@ from concurrent.futures import ThreadPoolExecutor
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SOURCES = ["letkf_tile2.hip", "letkf_tile2p.hip", "letkf_tile2w.hip", "lketkf_tile.hip"]
+SOURCES = ["letkf_tile2.hip", "letkf_tile2f.hip", "letkf_tile2p.hip", "letkf_tile2w.hip", "lketkf_tile.hip", "letkf_tile_split.hip"]
 
 
 def _check(name):
@@ -17,7 +17,7 @@ def _check(name):
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
 def test_tile_kernels_have_no_unpadded_mfma_reads():
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         results = list(ex.map(_check, SOURCES))
     bad = [(n, out) for n, rc, out in results if rc != 0]
     assert not bad, "\n".join("%s:\n%s" % b for b in bad)

@@ -71,6 +71,51 @@ def check(asm):
     return bad
 
 
+NEED_WAR = 3       # the compiler's own table (and what it pads its own code to): SrcC read of a 4-pass matrix instruction -> vector write over it
+
+
+def check_war(asm):
+    """A vector instruction (in practice: one inside an inline-asm statement, which the compiler's hazard recognizer does not look
+    into) overwriting the accumulator INPUT of a matrix instruction fewer than NEED_WAR wait states after it."""
+    lines = asm.splitlines()
+    labels = {l.split(":")[0]: i for i, l in enumerate(lines) if re.match(r"^[.\w$]+:", l)}
+    bad = []
+    kernel = None
+    for i, l in enumerate(lines):
+        if re.match(r"^_Z\w+:", l):
+            kernel = l.split(":")[0]
+        op, ops = operands(l)
+        if not op.startswith("v_mfma") or len(ops) < 4:
+            continue
+        src_c = regs(ops[3]) - regs(ops[0])          # (in-place accumulation: the instruction's own write is ordered)
+        if not src_c:
+            continue
+        stack, seen = [(i + 1, 0)], set()
+        while stack:
+            j, ws = stack.pop()
+            while j < len(lines) and ws < NEED_WAR:
+                if (j, ws) in seen:
+                    break
+                seen.add((j, ws))
+                o, a = operands(lines[j])
+                if not o or o.endswith(":") or o.startswith(".") or o.startswith(";"):
+                    j += 1
+                    continue
+                if o == "s_endpgm":
+                    break
+                if o.startswith("v_") and not o.startswith(("v_mfma", "v_cmp", "v_readlane", "v_readfirstlane")) and a and regs(a[0]) & src_c:
+                    bad.append((kernel, i + 1, j + 1, ws, lines[i].strip(), lines[j].strip()))
+                    break
+                ws += int(a[0]) + 1 if o == "s_nop" else 1
+                if o == "s_branch":
+                    j = labels.get(a[0], len(lines))
+                    continue
+                if o.startswith("s_cbranch"):
+                    stack.append((labels.get(a[0], len(lines)), ws))
+                j += 1
+    return bad
+
+
 if __name__ == "__main__":
     src = sys.argv[1]
     # the flags the shipped object of this source is built with (torch-assimilate_amd/_build.py: SOURCE_FLAGS), then the caller's
@@ -86,8 +131,12 @@ if __name__ == "__main__":
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             sys.exit("hipcc failed:\n" + res.stderr)
-        bad = check(open(out).read())
+        text = open(out).read()
+        bad = check(text)
+        war = check_war(text)
     for b in bad[:40]:
         print("HAZARD kernel %s: mfma at line %d read at line %d after %d wait states\n   %s\n   %s" % b)
-    print("%s: %d hazard(s)" % (os.path.basename(src), len(bad)))
-    sys.exit(1 if bad else 0)
+    for b in war[:40]:
+        print("WAR HAZARD kernel %s: mfma at line %d, its SrcC overwritten at line %d after %d wait states\n   %s\n   %s" % b)
+    print("%s: %d hazard(s), %d write-after-read hazard(s) on SrcC" % (os.path.basename(src), len(bad), len(war)))
+    sys.exit(1 if bad or war else 0)

@@ -116,9 +116,12 @@ __device__ __forceinline__ void tile_split8(const float (&x)[8], h8t& hi, h8t& l
     const unsigned au = __builtin_bit_cast(unsigned, a);
     // the remainders x - hi straight from the packed halves (v_fma_mix_f32 reads an f16 operand in place; the compiler's
     // own form is two conversions + a packed subtraction, and packed f32 instructions are slow beside MFMAs)
-    f2v r;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(au), "v"(v[0]));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(au), "v"(v[1]));
+    // (written over a COPY of x: the copy is the compiler's instruction, so the wait states behind a matrix instruction that
+    //  wrote or read the register it picks are the compiler's to pad; a fresh output of the assembly itself was found 5-6
+    //  states behind such a write by tools/check_mfma_hazards.py)
+    f2v r = v;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(r[0]) : "v"(au));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r[1]) : "v"(au));
     const h2t b = __builtin_convertvector(r, h2t);
     hi[2 * i] = a[0]; hi[2 * i + 1] = a[1];
     lo[2 * i] = b[0]; lo[2 * i + 1] = b[1];

@@ -84,7 +84,11 @@ __device__ __forceinline__ void split8(const float (&x)[8], h8v& hi, h8v& lo) {
   // the (exact) f32 difference once.  ONE statement for the eight values, closed by the two wait states a matrix instruction
   // needs after a vector instruction wrote one of its operands: the compiler pads nothing around inline assembly (without
   // them an MFMA scheduled right behind read a stale operand -- found on the UT = 1 many-rows instantiation).
-  asm("v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+  // ... and OPENED by three: the outputs are fresh registers of the allocator's choice, and it likes the accumulator input (SrcC) of the
+  // matrix instruction issued just before -- the compiler keeps three wait states between such a read and a vector write over it
+  // in its own code (write-after-read), and pads nothing in front of inline assembly (tools/check_mfma_hazards.py: WAR rule).
+  asm("s_nop 2\n\t"
+      "v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
       "v_fma_mixhi_f16 %0, %4, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
       "v_fma_mixlo_f16 %1, %5, -1.0, %10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
       "v_fma_mixhi_f16 %1, %5, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
