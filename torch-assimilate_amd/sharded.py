@@ -647,6 +647,11 @@ class ShardedLetkf:
                 _cabi.check(lib.mia_letkf_step_timing_events(timing[0].cuda_event, timing[1].cuda_event),
                             "mia_letkf_step_timing_events")
             call(0)
+            # read-back as the steps in flight do it: 32 bytes into pinned memory behind the analysis, one event to wait for
+            # (a synchronous Tensor.tolist() of the device counters was ~10 us of this path's host time per step)
+            raw = comp.cuda_stream if comp is not None else cur_raw
+            if lib.mia_letkf_step_readback(slot["counters"].data_ptr(), slot["host"].data_ptr(), raw, raw, C.byref(slot["event"])) == 0:
+                ev = slot["event"]
         h = PendingStep(self, dict(slot=slot, call=call, comp=comp, cur=cur, cur_raw=cur_raw, dev_index=dev_index, ev=ev, job=job, out=out, flags=flags, hint=hint,
                                    last=last, peer=bool(peer),
                                    C_chunks=C_chunks, args=(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1),
@@ -663,9 +668,10 @@ class ShardedLetkf:
         p = h._st
         slot, st = p["slot"], self._native_state()
         if p["ev"] is not None:
-            rc = self.engine.lib.mia_letkf_step_join(p["job"])  # the launch thread has enqueued this step ...
-            if rc != 0:
-                _cabi.check(rc, "mia_letkf_sharded_step_streams_f32 (launch thread)")
+            if p["job"] is not None:
+                rc = self.engine.lib.mia_letkf_step_join(p["job"])  # the launch thread has enqueued this step ...
+                if rc != 0:
+                    _cabi.check(rc, "mia_letkf_sharded_step_streams_f32 (launch thread)")
             self.engine.lib.mia_event_synchronize(p["ev"])     # ... and this is the one host wait for the GPU
             cnt = slot["host"].tolist()
         else:
