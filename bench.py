@@ -853,6 +853,35 @@ def main():
                     "ms": wms, "analyses_per_s": G / (wms * 1e-3), "weights_bytes": int(Wd.numel() * 4),
                     "hbm_floor_ms": Wd.numel() * 4 / 8e12 * 1e3, "declined_points": int(res[3].item()),
                     "rel_frobenius_error_64_points_vs_oracle": float(np.linalg.norm(gotw - refw) / np.linalg.norm(refw))}
+                # _apply_weights with those per-point weights (interface/base.py:257-278) on 16 state rows: csrc/apply_local.hip
+                try:
+                    gen = torch.Generator(device=device)
+                    gen.manual_seed(7)
+                    m_rows = 16
+                    Xr = torch.randn((m_rows, K_ENS, G), generator=gen, device=device)
+                    Xr[0] = X[0]
+                    xa_r = eng.apply_local_weights(Xr, Wd)
+                    torch.cuda.synchronize()
+                    ts = []
+                    for _ in range(7):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        xa_r = eng.apply_local_weights(Xr, Wd)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        ts.append(e0.elapsed_time(e1))
+                    ams = float(np.median(ts[1:]))
+                    nbytes = 4.0 * (Wd.numel() + 2.0 * Xr.numel())
+                    refx = O.apply_weights(Xr[:, :, torch.as_tensor(pts, device=device)].double().cpu().numpy(), gotw)
+                    gotx = xa_r[:, :, torch.as_tensor(pts, device=device)].double().cpu().numpy()
+                    secondary["c2_apply_weights"] = {
+                        "workload": "G=%d, k=%d: xa = mean + (x - mean) W_g for %d state rows per grid point, W from c2_weights "
+                                    "(mia_apply_local_weights_f32: apply_local_tile_kernel<3>)" % (G, K_ENS, m_rows),
+                        "ms": ams, "compulsory_bytes": nbytes, "GBs": nbytes / ams / 1e6, "hbm_frac": nbytes / ams / 1e6 / PEAK_HBM_GBS,
+                        "rel_frobenius_error_64_points_vs_oracle": float(np.linalg.norm(gotx - refx) / np.linalg.norm(refx))}
+                    del Xr, xa_r
+                except Exception as exc:
+                    secondary["c2_apply_weights"] = {"error": repr(exc)}
                 del Wd, res
         except Exception as exc:        # (a secondary figure must not take the bench line down)
             secondary["c2_weights"] = {"error": repr(exc)}

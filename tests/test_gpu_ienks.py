@@ -80,12 +80,20 @@ def test_localised_ienks_vs_reference(mia, golden, dtype, tol):
 
 
 @pytest.mark.parametrize("m,k,G,dtype,tol", [(3, 40, 1000, torch.float64, 1e-14), (1, 7, 333, torch.float32, 1e-6),
-                                             (2, 80, 257, torch.float32, 1e-6)])
+                                             (2, 80, 257, torch.float32, 1e-6),
+                                             # the tile kernel of csrc/apply_local.hip: every member-block count, ragged tiles, row
+                                             # chunks of sixteen with a remainder, k not a multiple of four
+                                             (16, 40, 1000, torch.float32, 1e-6), (33, 40, 999, torch.float32, 1e-6),
+                                             (5, 96, 300, torch.float32, 1e-6), (20, 48, 517, torch.float32, 1e-6),
+                                             (2, 3, 211, torch.float32, 1e-6), (70, 17, 403, torch.float32, 1e-6),
+                                             (9, 64, 256, torch.float32, 1e-6), (4, 100, 250, torch.float32, 1e-6)])
 def test_apply_local_weights_vs_oracle(eng, m, k, G, dtype, tol):
     rs = np.random.RandomState(k)
     X, W = rs.normal(size=(m, k, G)), rs.normal(size=(G, k, k)) / np.sqrt(k)
+    X[0] += 300.0                                # (a variable with a large mean: the transform works on perturbations)
     got = eng.apply_local_weights(torch.tensor(X, dtype=dtype), torch.tensor(W, dtype=dtype))
     assert rel_fro(got.cpu().numpy(), O.apply_weights(X, W)) < tol
+    assert rel_fro(got.cpu().numpy()[0] - 300.0, O.apply_weights(X, W)[0] - 300.0) < 100 * tol
     sub = eng.apply_local_weights(torch.tensor(X, dtype=dtype), torch.tensor(W[100:200], dtype=dtype), 100, 200)
     np.testing.assert_array_equal(sub.cpu().numpy(), got.cpu().numpy()[:, :, 100:200])
     with pytest.raises(ValueError):

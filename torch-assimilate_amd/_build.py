@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmia_letkf.so")
 STAMP = os.path.join(LIB_DIR, "libmia_letkf.stamp")
-SOURCES = ["localize.hip", "letkf_entry.hip", "etkf_global.hip", "letkf_wave.hip", "letkf_sys.hip", "letkf_cheb.hip", "letkf_tile.hip", "letkf_tile_split.hip", "letkf_tile2.hip", "letkf_tile2w.hip", "letkf_tile2p.hip", "letkf_tile2f.hip", "lketkf_tile.hip", "tile_lists.hip", "sharded_step.hip", "obs_space.hip", "ienks.hip", "api.cc"]
+SOURCES = ["localize.hip", "letkf_entry.hip", "etkf_global.hip", "letkf_wave.hip", "letkf_sys.hip", "letkf_cheb.hip", "letkf_tile.hip", "letkf_tile_split.hip", "letkf_tile2.hip", "letkf_tile2w.hip", "letkf_tile2p.hip", "letkf_tile2f.hip", "lketkf_tile.hip", "tile_lists.hip", "sharded_step.hip", "obs_space.hip", "ienks.hip", "apply_local.hip", "api.cc"]
 HEADERS = ["mia_common.h", "mia_options.h", "mia_jacobi.h", "mia_jacobi_sym.h", "mia_kernel_prog.h", "mia_localize_dev.h", "mia_kernels.h", "mia_pack_dev.h", "mia_tiles.h", os.path.join(ROOT, "include", "mia_letkf.h")]
 INCLUDES = {"letkf_tile_split.hip": ["letkf_tile.hip"]}     # sources that include another source
 # per-source flags.  letkf_tile2.hip: no SLP vectoriser -- it packs the recurrence's scalar f32 multiply-adds into v_pk_fma_f32,

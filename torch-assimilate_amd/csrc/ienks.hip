@@ -447,6 +447,11 @@ extern "C" int mia_lienks_update_f64(const double* W_in, int64_t w_stride, int k
 extern "C" int mia_apply_local_weights_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
                                            const float* W, float* Xa, int64_t ldo, int64_t o0, void* stream) {
   (void)hipGetLastError();
+  // tiles of sixteen points (apply_local.hip) where the shape allows: the same argument checks first
+  if (g1 > g0 && g0 >= 0 && m >= 1 && k >= 2 && X && W && Xa && ldx >= g1 && ldo >= o0 + (g1 - g0)) {
+    const int rc = apply_local_tile_launch(X, ldx, m, k, g0, g1 - g0, W, Xa, ldo, o0, (hipStream_t)stream);
+    if (rc != MIA_ERR_UNSUPPORTED) return rc;
+  }
   return apply_local_weights_impl<float>(X, ldx, m, k, g0, g1, W, Xa, ldo, o0, (hipStream_t)stream);
 }
 extern "C" int mia_apply_local_weights_f64(const double* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
