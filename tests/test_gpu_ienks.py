@@ -186,3 +186,22 @@ def test_weight_save_path_streams_weights_through_disk(mia, golden, tmp_path):
     e = mia.ETKF(inf_factor=1.1, dtype=torch.float64, weight_save_path=path)
     xg = e.analyse_arrays(g["c1_state"], g["c1_yb"], g["c1_d"])
     assert rel_fro(xg.cpu().numpy(), g["c1_1p1_analysis"]) < 1e-10
+
+
+@pytest.mark.parametrize("m,k,G,dtype,tol", [(3, 40, 1000, torch.float64, 1e-14), (1, 20, 40, torch.float32, 1e-6),
+                                             (16, 40, 1003, torch.float32, 1e-6), (5, 96, 300, torch.float32, 1e-6),
+                                             (2, 3, 211, torch.float32, 1e-6), (7, 17, 403, torch.float32, 1e-6),
+                                             (4, 64, 256, torch.float32, 1e-6), (3, 100, 250, torch.float32, 1e-6)])
+def test_apply_global_weights_vs_oracle(eng, m, k, G, dtype, tol):
+    """_apply_weights with ONE weight matrix (the global ETKF's transform, base.py:257-278): the grid-points-as-columns kernel of
+    csrc/apply_local.hip for float32 and k <= 96, the round-1 kernel otherwise; sub-ranges of the grid, a variable with a large mean."""
+    rs = np.random.RandomState(100 + k)
+    X, W = rs.normal(size=(m, k, G)), rs.normal(size=(k, k)) / np.sqrt(k)
+    X[0] += 300.0
+    got = eng.apply_weights(torch.tensor(X, dtype=dtype), torch.tensor(W, dtype=dtype))
+    ref = O.apply_weights(X, W)
+    assert rel_fro(got.cpu().numpy(), ref) < tol
+    assert rel_fro(got.cpu().numpy()[0] - 300.0, ref[0] - 300.0) < 100 * tol
+    if G > 200:
+        sub = eng.apply_weights(torch.tensor(X, dtype=dtype), torch.tensor(W, dtype=dtype), 100, 200)
+        np.testing.assert_array_equal(sub.cpu().numpy(), got.cpu().numpy()[:, :, 100:200])

@@ -22,4 +22,15 @@ for m in [int(a) for a in sys.argv[3:]] or [1, 4, 16, 32, 64, 96, 112, 128, 160,
     err = float(torch.linalg.norm(out[:2, :, :2000] - ref) / torch.linalg.norm(ref))
     bytes_ = 4.0 * (G * k * k + 2.0 * m * k * G)
     print("m = %3d: %.3f ms, %.0f GB/s of compulsory traffic (W once + x in + xa out), error %.1e" % (m, ms, bytes_ / ms / 1e6, err), flush=True)
+    # ... and with ONE weight matrix for all points (the global ETKF's transform)
+    eng.apply_weights(X, W[0]); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        outg = eng.apply_weights(X, W[0])
+    e1.record(); torch.cuda.synchronize()
+    msg = e0.elapsed_time(e1) / 5
+    refg = torch.einsum("mig,ij->mjg", X[:2, :, :2000] - X[:2, :, :2000].mean(dim=1, keepdim=True), W[0]) + X[:2, :, :2000].mean(dim=1, keepdim=True)
+    errg = float(torch.linalg.norm(outg[:2, :, :2000] - refg) / torch.linalg.norm(refg))
+    print("         one W for all points: %.3f ms, %.0f GB/s (x in + xa out), error %.1e" % (msg, 8.0 * m * k * G / msg / 1e6, errg), flush=True)
+    del outg
     del X, out

@@ -139,6 +139,102 @@ __global__ __launch_bounds__(256, KT <= 4 ? 3 : 1) void apply_local_tile_kernel(
   }
 }
 
+// ONE weight matrix for all grid points (the global ETKF: _apply_weights with weights of dims (ensemble, ensemble_new),
+// interface/etkf.py:99-120 + base.py:257-278): xa_v (k x G) = W^T x_v' + mean is a plain product with the GRID POINTS as the
+// columns -- sixteen consecutive points are the N dimension of the matrix instruction, so the B operand (64-byte runs of a
+// member's row) and the result (64-byte runs of a new member's row) go straight between memory and registers: no LDS, no
+// transposition.  One wavefront per tile of sixteen points, all state rows; W^T stays in registers.
+template <int KT>
+__global__ __launch_bounds__(256) void apply_global_tile_kernel(ApplyTileParams P) {
+  constexpr int KS = 4 * KT;
+  constexpr bool kWholeW = KT <= 3;
+  const int lane = threadIdx.x & 63, lr = lane & 15, h = lane >> 4;
+  const int k = P.k;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t p0 = tile << 4;
+  if (p0 >= P.ng) return;
+  const int npts = P.ng - p0 < 16 ? (int)(P.ng - p0) : 16;
+  const float inv_k = 1.0f / (float)k;
+  auto load_w = [&](int jb, float (&a)[KS]) {                          // a[ks] = W[4 ks + h][16 jb + lr]
+    const int j = 16 * jb + lr;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int i = 4 * ks + h;
+      a[ks] = (i < k && j < k) ? P.W[i * k + j] : 0.0f;
+    }
+  };
+  float aw[kWholeW ? KT : 1][KS];
+  if constexpr (kWholeW) {
+#pragma unroll
+    for (int jb = 0; jb < KT; ++jb) load_w(jb, aw[jb]);
+  }
+  const bool col = lr < npts;
+  const unsigned xoff = (unsigned)lr * 4u, xstep = (unsigned)P.ldx * 4u, ostep = (unsigned)P.ldo * 4u;
+  for (int v = 0; v < P.m; ++v) {
+    const char* xb = reinterpret_cast<const char*>(P.X + (int64_t)v * k * P.ldx + P.g0 + p0);
+    char* ob = reinterpret_cast<char*>(P.Xa + (int64_t)v * k * P.ldo + P.o0 + p0);
+    float b[KS];
+    float part = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int i = 4 * ks + h;
+      b[ks] = (col && i < k) ? *reinterpret_cast<const float*>(xb + (xoff + (unsigned)i * xstep)) : 0.0f;
+      part += b[ks];
+    }
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    const float mean = part * inv_k;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) b[ks] -= mean;                     // (members past k meet zero rows of W)
+#pragma unroll
+    for (int jb = 0; jb < KT; ++jb) {
+      if (16 * jb < k) {                                               // (uniform)
+        f4a acc = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (kWholeW) {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[jb][ks], b[ks], acc, 0, 0, 0);
+        } else {
+          float one[KS];
+          load_w(jb, one);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(one[ks], b[ks], acc, 0, 0, 0);
+        }
+        float out[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[q] = acc[q] + mean;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = 16 * jb + 4 * h + q;
+          if (col && j < k) *reinterpret_cast<float*>(ob + (xoff + (unsigned)j * ostep)) = out[q];
+        }
+      }
+    }
+  }
+}
+
+int apply_global_tile_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* W, float* Xa,
+                             int64_t ldo, int64_t o0, hipStream_t stream) {
+  if (k < 2 || k > 96 || m < 1 || ng < 1) return MIA_ERR_UNSUPPORTED;
+  if ((int64_t)(k + 1) * ldx * 4 >= ((int64_t)1 << 32) || (int64_t)(k + 1) * ldo * 4 >= ((int64_t)1 << 32)) return MIA_ERR_UNSUPPORTED;
+  const int64_t nb = (((ng + 15) >> 4) + 3) >> 2;
+  if (nb > 2147483647LL) return MIA_ERR_UNSUPPORTED;
+  ApplyTileParams p{X, ldx, m, k, g0, ng, W, Xa, ldo, o0, (k + 3) & ~3, 0, 0};
+  const int kt = (k + 15) >> 4;
+  void (*kern)(ApplyTileParams) = nullptr;
+  switch (kt) {
+    case 1: kern = apply_global_tile_kernel<1>; break;
+    case 2: kern = apply_global_tile_kernel<2>; break;
+    case 3: kern = apply_global_tile_kernel<3>; break;
+    case 4: kern = apply_global_tile_kernel<4>; break;
+    case 5: kern = apply_global_tile_kernel<5>; break;
+    case 6: kern = apply_global_tile_kernel<6>; break;
+    default: return MIA_ERR_UNSUPPORTED;
+  }
+  kern<<<dim3((unsigned)nb), dim3(256), 0, stream>>>(p);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
 // float32, 2 <= k <= 96; MIA_ERR_UNSUPPORTED otherwise (the caller keeps the one-point-per-wavefront kernel of ienks.hip)
 int apply_local_tile_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* W, float* Xa,
                             int64_t ldo, int64_t o0, hipStream_t stream) {

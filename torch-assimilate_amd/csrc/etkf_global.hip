@@ -12,6 +12,7 @@
 #include "mia_common.h"
 #include "mia_jacobi.h"
 #include "mia_kernel_prog.h"
+#include "mia_kernels.h"
 
 namespace mia {
 
@@ -366,6 +367,11 @@ extern "C" int mia_etkf_weights_f64(const double* Yb, const double* d, int k, in
 extern "C" int mia_apply_weights_f32(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,
                                      const float* W, float* Xa, int64_t ldo, int64_t o0, void* stream) {
   (void)hipGetLastError();  // drop stale per-thread error state left by other users of the runtime
+  // grid points as the columns of a matrix-instruction product (apply_local.hip) where the shape allows: the same checks first
+  if (g1 > g0 && g0 >= 0 && m >= 1 && k >= 2 && X && W && Xa && ldx >= g1 && ldo >= o0 + (g1 - g0) && m <= 65535) {
+    const int rc = apply_global_tile_launch(X, ldx, m, k, g0, g1 - g0, W, Xa, ldo, o0, (hipStream_t)stream);
+    if (rc != MIA_ERR_UNSUPPORTED) return rc;
+  }
   return apply_weights_impl<float>(X, ldx, m, k, g0, g1, W, Xa, ldo, o0, (hipStream_t)stream);
 }
 extern "C" int mia_apply_weights_f64(const double* X, int64_t ldx, int m, int k, int64_t g0, int64_t g1,

@@ -28,6 +28,10 @@ int cheb_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
 int apply_local_tile_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* W, float* Xa,
                             int64_t ldo, int64_t o0, hipStream_t stream);
 
+// ... and with ONE weight matrix for all points (the global ETKF's transform): grid points as the columns of a plain product
+int apply_global_tile_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* W, float* Xa,
+                             int64_t ldo, int64_t o0, hipStream_t stream);
+
 // Chebyshev coefficient tables of the matfun kernels (letkf_cheb.hip, cheb_coef_table): geometric grid of scaled
 // spectral bounds T = L / reg, 32 per octave over 2^-24 .. 2^8; entry i holds {degree, bits of 2 / T} and 64 (phi, psi)
 // coefficient pairs, zero beyond the degree.
