@@ -1,5 +1,5 @@
-"""Where a serial step's wall time goes: the caller's time in submit (argument set-up + the C call that enqueues the step's
-launches) and in finish (the wait for the GPU + validation), beside the step's kernels (rocprofv3 gives those)."""
+"""Where a serial step's wall time goes on the host: the caller's time in submit (argument set-up, the C call that enqueues the
+step's launches, the read-back call) and in finish (the wait for the GPU + validation).  The kernels themselves: rocprofv3."""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,11 +13,26 @@ for _ in range(20):
     r.assimilate(*case)
 X, gx, ox, Yb, d = case
 G = X.shape[2]
-ts, tf, tc = 0.0, 0.0, 0.0
-import ctypes as C
 lib = r.engine.lib
-orig = lib.mia_letkf_sharded_step_streams_f32
-N = 300
+acc = {"step": 0.0, "rb": 0.0, "sync": 0.0}
+
+
+def wrap(name, key):
+    fn = getattr(lib, name)
+
+    def w(*a):
+        t = time.perf_counter()
+        rc = fn(*a)
+        acc[key] += time.perf_counter() - t
+        return rc
+    setattr(lib, name, w)
+
+
+wrap("mia_letkf_sharded_step_streams_f32", "step")
+wrap("mia_letkf_step_readback", "rb")
+wrap("mia_event_synchronize", "sync")
+N = 500
+ts = tf = 0.0
 torch.cuda.synchronize()
 t_all = time.perf_counter()
 for _ in range(N):
@@ -30,13 +45,7 @@ for _ in range(N):
     tf += t2 - t1
 torch.cuda.synchronize()
 t_all = time.perf_counter() - t_all
-print("serial step %.1f us: submit %.1f us (set-up + enqueue), finish %.1f us (wait + validation)" % (1e6 * t_all / N, 1e6 * ts / N, 1e6 * tf / N))
-# the C call alone, same arguments, nothing waited for in between (queue fills: launch cost only)
-import cProfile, pstats
-pr = cProfile.Profile()
-pr.enable()
-for _ in range(200):
-    r.assimilate(*case)
-pr.disable()
-st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(12)
+u = 1e6 / N
+print("serial step %.1f us = submit %.1f (of which the step's C call %.1f, the read-back call %.1f, Python %.1f) + finish %.1f "
+      "(of which the wait for the event %.1f, Python %.1f)" % (t_all * u, ts * u, acc["step"] * u, acc["rb"] * u,
+                                                            (ts - acc["step"] - acc["rb"]) * u, tf * u, acc["sync"] * u, (tf - acc["sync"]) * u))

@@ -738,7 +738,7 @@ class ShardedLetkf:
         if n_retry:
             self.engine.lib.mia_letkf_step_drain()             # (after the steps already handed to the launch thread)
             p["call"](1)                                       # eigensolver redoes declined points; re-exchange
-        if p["ev"] is not None or p["comp"] is not p["cur"]:
+        if p["job"] is not None or p["comp"] is not p["cur"]:     # (a step taken one at a time ran on torch's stream itself)
             # consumers on torch's stream see the result.  Wait for THIS step's completion event only: waiting for
             # the analysis stream as a whole would also wait for the later steps already enqueued on it, and the
             # next submit's preparation (which waits for torch's stream) would serialise behind them
