@@ -301,3 +301,21 @@ def test_fused_localisation_over_ensemble_sizes(mia, k, stride, radius):
     assert outs[True][1:] == outs[False][1:]
     assert torch.equal(outs[True][0], outs[False][0])
     assert rel_fro(outs[True][0].cpu().numpy(), oracle) < 1e-5
+
+
+def test_more_workspaces_than_the_library_keeps_state_for(mia):
+    """The library keeps per-workspace state (which of the two per-cell count arrays is current, what the tile lists were built
+    for) for a bounded number of workspaces; one that fell out of the table is treated as unknown -- its next step clears the
+    index tables whatever the caller says about it -- instead of binning into an array the table no longer knows to be dirty."""
+    dev = torch.device("cuda:0")
+    case = O.synthetic_case(700, 24, 2, seed=31)
+    a = args_of(case, dev)
+    ref = mia.ShardedLetkf(dev, 0, 1, radii=[8.0], inf_factor=1.1, native_step=False).assimilate(*a)
+    runners = [mia.ShardedLetkf(dev, 0, 1, radii=[8.0], inf_factor=1.1, max_in_flight=2) for _ in range(72)]
+    for sweep in range(4):
+        for r in runners:
+            out = r.assimilate(*a)
+            assert torch.equal(out, ref), sweep
+    assert all(r.last_flags_ok() for r in runners) and runners[0].native_steps >= 3
+    for r in runners:
+        r.close()

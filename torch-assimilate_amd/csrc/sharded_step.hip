@@ -682,7 +682,10 @@ static std::mutex g_stamp_mu;
 // NEXT bucket build bins into.  Every bucket step uses one and has its analysis launch put the OTHER back to zero -- the one the
 // previous bucket step on this workspace left dirty -- because with the fused kernel (letkf_tile2f.hip) the wavefronts that read
 // the counts and the ones that would clear them are the same launch.  cnt_use / fused: the decision taken for the step in flight.
-struct GeomEntry { void* ws; GeomStamp st; bool valid, reuse; int cnt_cur, cnt_use; bool fused; };
+// unknown: the entry was made for a workspace this table knows nothing about (its first step -- or one whose entry was pushed out of
+// the table since): the state of its count arrays is not known either, so its next index build clears them whatever the caller
+// says about the workspace (MIA_STEP_WS_CLEAN).
+struct GeomEntry { void* ws; GeomStamp st; bool valid, reuse; int cnt_cur, cnt_use; bool fused; bool unknown; };
 static std::deque<GeomEntry> g_stamps;        // (a handful of pipeline slots per process)
 // decide = true (a step's preparation): reuse is granted when asked for AND the workspace's stamp equals `now`; otherwise the
 // stamp becomes `now` (lists are rebuilt; route 0 = no tile lists).  decide = false: the decision taken for this workspace.
@@ -694,7 +697,7 @@ static bool geom_reuse_decision(void* ws, const GeomStamp& now, bool asked, bool
   if (!decide) return e ? e->reuse : false;
   if (!e) {
     if (g_stamps.size() >= 64) g_stamps.pop_front();
-    g_stamps.push_back(GeomEntry{ws, now, false, false, 0, 0, false});
+    g_stamps.push_back(GeomEntry{ws, now, false, false, 0, 0, false, true});
     e = &g_stamps.back();
   }
   e->reuse = asked && e->valid && memcmp(&e->st, &now, sizeof now) == 0;
@@ -706,13 +709,16 @@ static bool geom_reuse_decision(void* ws, const GeomStamp& now, bool asked, bool
 // preparation; after geom_reuse_decision, which creates the entry): `bucket_step` takes the workspace's current array and flips it
 // for the next one; decide = false: what was decided.  scan_build: a scan-based index is about to be built on the workspace -- it
 // needs array 0 (cursor) clean, returns false when a full clear must come first, and leaves array 0 the current one.
-static void count_array_decision(void* ws, bool decide, bool bucket_step, bool fused, int* use, bool* fused_out) {
+// *must_clear: the workspace's count arrays are in an unknown state (see GeomEntry): the build about to run clears them first.
+static void count_array_decision(void* ws, bool decide, bool bucket_step, bool fused, int* use, bool* fused_out, bool* must_clear) {
   std::lock_guard<std::mutex> lock(g_stamp_mu);
   GeomEntry* e = nullptr;
   for (auto& x : g_stamps)
     if (x.ws == ws) { e = &x; break; }
-  if (!e) { *use = 0; *fused_out = false; return; }
+  *must_clear = false;
+  if (!e) { *use = 0; *fused_out = false; *must_clear = true; return; }
   if (decide) {
+    if (bucket_step && e->unknown) { *must_clear = true; e->unknown = false; e->cnt_cur = 0; }
     e->fused = bucket_step && fused;
     e->cnt_use = e->cnt_cur;
     if (bucket_step) e->cnt_cur ^= 1;
@@ -724,11 +730,12 @@ static bool count_arrays_clean_for_scan(void* ws) {
   std::lock_guard<std::mutex> lock(g_stamp_mu);
   for (auto& x : g_stamps)
     if (x.ws == ws) {
-      const bool clean = x.cnt_cur == 0;
+      const bool clean = x.cnt_cur == 0 && !x.unknown;
       x.cnt_cur = 0;
+      x.unknown = false;      // (the caller clears everything when told "not clean")
       return clean;
     }
-  return true;
+  return false;
 }
 
 static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, const float* d, int64_t P,
@@ -817,7 +824,8 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
   const bool tl_reuse = geom_reuse_decision(ws, stamp_now, tl_route && (step_flags & MIA_STEP_REUSE_LISTS) != 0, phase == 0 && do1);
   int cnt_use = 0;
   bool tl_fused = false;
-  count_array_decision(ws, phase == 0 && do1, tl_bucket && !tl_reuse, want_fused && !tl_reuse, &cnt_use, &tl_fused);
+  bool cnt_must_clear = false;
+  count_array_decision(ws, phase == 0 && do1, tl_bucket && !tl_reuse, want_fused && !tl_reuse, &cnt_use, &tl_fused, &cnt_must_clear);
   // (the analysis launch puts the OTHER per-cell count array and the build's error word back to zero, see Tile2Params / GeomEntry)
   mia::Tile2Housekeeping tl_hk{nullptr, nullptr, nullptr, nullptr};
   int* tl_counts = nullptr;
@@ -895,7 +903,8 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
       if (tl_bucket)
         rc = mia::index_bucket_build_impl(obs_xyz, P, n_coord, coord_group, gc_c, n_r, base + L.loc, L.loc_bytes, ps,
                                           zero_in_kernel ? &zj : nullptr,
-                                          !(step_flags & MIA_STEP_WS_CLEAN) || (step_flags & MIA_STEP_FRESH_BOX), tl_rbf ? nullptr : &sj,
+                                          !(step_flags & MIA_STEP_WS_CLEAN) || (step_flags & MIA_STEP_FRESH_BOX) || cnt_must_clear,
+                                          tl_rbf ? nullptr : &sj,
                                           tl_counts);
       else {
         const bool arrays_clean = count_arrays_clean_for_scan(ws);      // (a scan-based build counts in array 0)
