@@ -142,3 +142,31 @@ def test_mesh_2d_and_eight_state_rows_at_full_size(eng):
     rec8 = bench.tile_route_case(eng, X8, gx, ox, Yb1, d1, 10.0, 1.1)
     assert rec8["route"].startswith("tile lists") and rec8["overflowed_tiles"] == 0
     assert rec8["rel_frobenius_error_vs_oracle"] < TOL32 and rec8["flags"] == 0, rec8
+
+
+def test_weight_transforms_at_config3_size(mia):
+    """_apply_weights at config 3's grid (1e6 points, k = 40): per-point weights on a block of 2e5 points of it, and one weight
+    matrix for all points -- the tile kernels of csrc/apply_local.hip with their 32-bit lane offsets at that leading dimension;
+    against torch on slices."""
+    dev = torch.device("cuda:0")
+    eng = mia.LetkfEngine(dev)
+    G, k, m = 1000000, 40, 3
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(11)
+    X = torch.randn((m, k, G), generator=gen, device=dev)
+    X[1] += 250.0
+    g0, g1 = 700000, 900000
+    W = torch.randn((g1 - g0, k, k), generator=gen, device=dev) / k ** 0.5
+    out = eng.apply_local_weights(X, W, g0, g1)
+    assert out.shape == (m, k, g1 - g0)
+    for a, b in ((0, 3000), (g1 - g0 - 3001, g1 - g0)):
+        xs = X[:, :, g0 + a:g0 + b].double()
+        mean = xs.mean(dim=1, keepdim=True)
+        ref = torch.einsum("mig,gij->mjg", xs - mean, W[a:b].double()) + mean
+        assert float(torch.linalg.norm(out[:, :, a:b].double() - ref) / torch.linalg.norm(ref)) < 1e-6
+    outg = eng.apply_weights(X, W[0])
+    for a, b in ((0, 2000), (G - 2001, G)):
+        xs = X[:, :, a:b].double()
+        mean = xs.mean(dim=1, keepdim=True)
+        ref = torch.einsum("mig,ij->mjg", xs - mean, W[0].double()) + mean
+        assert float(torch.linalg.norm(outg[:, :, a:b].double() - ref) / torch.linalg.norm(ref)) < 1e-6

@@ -60,9 +60,10 @@ __global__ __launch_bounds__(256, KT <= 4 ? 3 : 1) void apply_local_tile_kernel(
 #pragma unroll
         for (int vb = 0; vb < 16; vb += 8) {
           float val[8];
+          const char* xv = xb + (int64_t)vb * xrow32;                  // (uniform; the 32-bit lane offsets span eight rows)
 #pragma unroll
           for (int u = 0; u < 8; ++u)
-            val[u] = (keep && vb + u < nrows) ? *reinterpret_cast<const float*>(xb + (off + (unsigned)(vb + u) * xrow32)) : 0.0f;
+            val[u] = (keep && vb + u < nrows) ? *reinterpret_cast<const float*>(xv + (off + (unsigned)u * xrow32)) : 0.0f;
 #pragma unroll
           for (int u = 0; u < 8; ++u) img[(vb + u) * pitch + i * 16 + sg] = val[u];
         }
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256, KT <= 4 ? 3 : 1) void apply_local_tile_kernel(
         const unsigned off = ((unsigned)i * (unsigned)P.ldo + (unsigned)sg) * 4u;
         if (sg < npts && !(P.exp_skip & 4)) {
 #pragma unroll 4
-          for (int v = 0; v < nrows; ++v) *reinterpret_cast<float*>(ob + (off + (unsigned)v * orow32)) = img[v * pitch + i * 16 + sg];
+          for (int v = 0; v < nrows; ++v) *reinterpret_cast<float*>(ob + (int64_t)v * orow32 + off) = img[v * pitch + i * 16 + sg];
         }
       }
     }
@@ -239,8 +240,8 @@ int apply_global_tile_launch(const float* X, int64_t ldx, int m, int k, int64_t 
 int apply_local_tile_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* W, float* Xa,
                             int64_t ldo, int64_t o0, hipStream_t stream) {
   if (k < 2 || k > 96 || m < 1 || ng < 1) return MIA_ERR_UNSUPPORTED;
-  // (32-bit lane offsets inside a chunk of sixteen state rows)
-  if ((int64_t)17 * k * ldx * 4 >= ((int64_t)1 << 32) || (int64_t)17 * k * ldo * 4 >= ((int64_t)1 << 32)) return MIA_ERR_UNSUPPORTED;
+  // (32-bit lane offsets: eight state rows of x, one member row of xa)
+  if ((int64_t)9 * k * ldx * 4 >= ((int64_t)1 << 32) || (int64_t)(k + 1) * ldo * 4 >= ((int64_t)1 << 32)) return MIA_ERR_UNSUPPORTED;
   const int64_t ntile = (ng + 15) >> 4;
   if (ntile > 2147483647LL) return MIA_ERR_UNSUPPORTED;
   ApplyTileParams p{X, ldx, m, k, g0, ng, W, Xa, ldo, o0, (k + 3) & ~3, 0, 0};
