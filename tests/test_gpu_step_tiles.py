@@ -319,3 +319,38 @@ def test_more_workspaces_than_the_library_keeps_state_for(mia):
     assert all(r.last_flags_ok() for r in runners) and runners[0].native_steps >= 3
     for r in runners:
         r.close()
+
+
+def test_random_geometries_against_the_oracle(mia):
+    """Twenty seeded random 1-D problems -- ensemble size, network density, radius, inflation, state rows, magnitudes of state and
+    observations, ragged grid lengths -- through the step driver (one step at a time: the fused kernel where it has the shape,
+    every other route where it does not) against the ORACLE (not against another route of this library), north-star bound 1e-5."""
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(2024)
+    worst = 0.0
+    for case_no in range(20):
+        k = int(rs.choice([5, 8, 13, 24, 40, 57]))
+        stride = int(rs.choice([1, 2, 3, 7]))
+        radius = float(rs.choice([2.5, 6.0, 10.0]))
+        inf = float(rs.choice([1.0, 1.1, 1.5]))
+        m = int(rs.choice([1, 1, 3]))
+        G = int(rs.choice([97, 256, 401]))
+        sx, sy = float(10.0 ** rs.uniform(-2, 2)), float(10.0 ** rs.uniform(-1, 1))
+        case = O.synthetic_case(G, k, stride, seed=1000 + case_no, m=m)
+        state = case["state"] * sx + rs.normal(size=(m, 1, 1)) * 50.0 * sx
+        yb, d = case["yb"] * sy, case["d"] * sy
+        a = (torch.as_tensor(state, dtype=torch.float32, device=dev), torch.as_tensor(case["grid_x"], device=dev),
+             torch.as_tensor(case["obs_x"], device=dev), torch.as_tensor(yb, dtype=torch.float32, device=dev),
+             torch.as_tensor(d, dtype=torch.float32, device=dev))
+        r = mia.ShardedLetkf(dev, 0, 1, radii=[radius], inf_factor=inf)
+        for _ in range(3):
+            out = r.assimilate(*a)
+        oracle = O.letkf_analysis(state, case["grid_x"], case["obs_x"], yb, d, radius, inf)[0]
+        err = rel_fro(out.cpu().numpy(), oracle)
+        # the stricter figure: the increments (analysis minus the prior mean), relative to their own size
+        prior_mean = state.mean(axis=1, keepdims=True)
+        err_inc = rel_fro(out.cpu().numpy() - prior_mean, oracle - prior_mean)
+        worst = max(worst, err)
+        assert err < 1e-5 and err_inc < 1e-4, (case_no, k, stride, radius, inf, m, G, sx, sy, err, err_inc)
+        r.close()
+    assert worst < 1e-5
