@@ -589,7 +589,10 @@ def main():
                              "(MIA_STEP_REUSE_LISTS); records, analysis, read-back every step"}
     # separate keys, NOT `value`: the steps in flight on the fused kernel (letkf_tile2f.hip: every analysis wavefront localises its
     # own tile, two launches per step, no lists in memory) -- with one analysis stream as the headline has it, and with three
-    # analysis / three preparation streams (two or three fused kernels share the chip: more steps per second, each launch slower)
+    # analysis / three preparation streams (two or three fused kernels share the chip: more steps per second, each launch slower).
+    # (Two "step streams" -- prep_streams=0, analysis_streams=2: a step's two launches back to back on one of two streams --
+    #  measured 2.11e9 in a process of its own and 1.24e9 as the third runner of this one: whether two streams run beside each
+    #  other depends on the hardware queues the runtime hands out, HISTORY.md; not reported here.)
     fused_flight = None
     if world == 1 and depth != 1 and args.method != "eig":
         fused_flight = {}

@@ -181,15 +181,17 @@ def test_results_do_not_depend_on_the_number_of_preparation_streams(mia):
     dev_ = torch.device("cuda:0")
     X, gx, ox, Yb, d = bench.make_case(20000, 40, 2, dev_, seed=4)
     outs = []
-    for n in (5, 2, 1):
-        r = mia.ShardedLetkf(dev_, 0, 1, radii=[10.0], inf_factor=1.1, max_in_flight=4, prep_streams=n)
+    for n, extra in ((5, {}), (2, {}), (1, {}), (0, dict(analysis_streams=2, fuse_tile_lists=True)), (0, {})):
+        # (0: no preparation stream at all -- a step's launches back to back on its analysis stream; with the fused kernel and two
+        #  analysis streams: "two step streams")
+        r = mia.ShardedLetkf(dev_, 0, 1, radii=[10.0], inf_factor=1.1, max_in_flight=4, prep_streams=n, **extra)
         r.assimilate(X, gx, ox, Yb, d)
         pend = [r.submit(X, gx, ox, Yb, d) for _ in range(4)]
         res = [h.result() for h in pend]
         assert all(torch.equal(res[0], x) for x in res[1:])
         outs.append(res[0].clone())
         r.close()
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
 def test_sharded_output_keeps_the_block(mia):

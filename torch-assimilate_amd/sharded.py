@@ -208,7 +208,7 @@ class ShardedLetkf:
         self._time_next = False        # time_next_step(): the next native step brackets its analysis kernel with events
         self.kernel_timings = []       # [(start, stop)] torch events recorded on the analysis stream by the library
         self.max_in_flight = max(1, min(int(max_in_flight), 8))
-        self.prep_streams = max(1, min(int(prep_streams), 8))      # steps in flight: preparation streams taken in turn
+        self.prep_streams = max(0, min(int(prep_streams), 8))      # steps in flight: preparation streams taken in turn (0: none, tools)
         self.analysis_streams = max(1, min(int(analysis_streams), 4))
         # exchange of the analysis blocks at world > 1: "auto" = direct peer writes into library-owned, IPC-mapped result
         # buffers when the node allows it and a self-test of the mapping passes, RCCL all-gather otherwise; "off" = RCCL.
@@ -578,11 +578,17 @@ class ShardedLetkf:
                 # (round 3 sorted fresh streams by the hardware queue the runtime had given them -- 1 ms spin-kernel probes at
                 #  set-up -- and took a fixed mix; under the driver's flags the plain set measures the same, 1.729e9 against
                 #  1.738e9 analyses/s, profiles/r04_stream_ab.txt: the probes are gone.  Fewer streams cost: 2: 1.55e9, 3: 1.69e9)
-                st["pstreams"] = [torch.cuda.Stream(device=X.device) for _ in range(self.prep_streams)]
+                st["pstreams"] = [torch.cuda.Stream(device=X.device) for _ in range(max(1, self.prep_streams))]
             comp = st["astreams"][self._submitted % len(st["astreams"])] if not exch else st["astream"]
             # (a step on reused lists prepares with ONE short kernel: one preparation stream for all of them -- every further
             #  queue in use costs the analysis queue dispatch time: 0.041 against 0.049 ms per step with three)
             prep = st["pstreams"][0 if reuse else self._submitted % len(st["pstreams"])]
+            if self.prep_streams == 0 and not exch:
+                # the whole step on its analysis stream: no preparation stream, no event between streams.  With the fused kernel
+                # (two launches per step) and analysis_streams=2 the simplest pipeline and the highest rate measured -- 2.11e9
+                # analyses/s at config 2 against 1.73e9, at 51 us per analysis launch instead of 35 -- WHEN the two streams get
+                # hardware queues of their own: as the third runner of a process the same set-up ran at 1.24e9 (HISTORY.md)
+                prep = comp
             if "in_event" not in slot:
                 slot["in_event"] = C.c_void_p()
             _cabi.check(lib.mia_stream_wait_stream(prep.cuda_stream, cur_raw, C.byref(slot["in_event"])),
