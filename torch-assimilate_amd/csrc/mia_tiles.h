@@ -188,7 +188,7 @@ struct SplitPackJob { const float* Yb; const float* d; unsigned char* rec; int k
 
 // ---- split records ---------------------------------------------------------------------------------------------------
 // One wavefront packs records j0 .. j0 + 63 (indices up to P: record P is the all-zero record).  Lane j reads entry j of
-// every row of Yb (256-byte row segments, sixteen rows requested before any is consumed) into an LDS image [64][ls], ls odd;
+// every row of Yb (256-byte row segments, twenty-four rows requested before any is consumed) into an LDS image [64][ls], ls odd;
 // every lane then finds its record's largest member magnitude (-> power of two), writes the tail, and the chunks of the
 // 64 records are converted by all lanes, one chunk of eight members (32 bytes out) per lane and trip.
 // lds: 64 * ls floats + 64 floats, ls = (k + 1) | 1.
@@ -201,18 +201,19 @@ __device__ inline void pack_split_wave(const SplitPackJob& J, int64_t P, int64_t
   const int64_t j = j0 + lane;
   const bool real = j < P;                    // (j == P: the zero record; j > P: nothing)
   const int64_t jc = real ? j : (P > 0 ? P - 1 : 0);
-  for (int i0 = 0; i0 < k; i0 += 16) {
-    float v[16];
+  const float dj = (real && P > 0) ? J.d[jc] : 0.0f;                   // (requested with the first rows)
+  constexpr int kRowsInFlight = 24;                                    // (k = 40: two round trips instead of three)
+  for (int i0 = 0; i0 < k; i0 += kRowsInFlight) {
+    float v[kRowsInFlight];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < kRowsInFlight; ++u) {
       const int i = i0 + u < k ? i0 + u : k - 1;
       v[u] = (P > 0) ? J.Yb[(int64_t)i * P + jc] : 0.0f;
     }
 #pragma unroll
-    for (int u = 0; u < 16; ++u)
+    for (int u = 0; u < kRowsInFlight; ++u)
       if (i0 + u < k) lds[lane * ls + i0 + u] = real ? v[u] : 0.0f;
   }
-  const float dj = (real && P > 0) ? J.d[jc] : 0.0f;
   do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0);
   unsigned mx = 0u;
   for (int i = 0; i < k; ++i) {
