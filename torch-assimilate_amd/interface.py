@@ -244,6 +244,49 @@ class LETKF(ETKF):
             eng.weights_retry(x, yb, d, nb, self.inf_factor, xa, W, flags)
         return W
 
+    def _analysis_by_step_driver(self, x, yb, d, grid_coords, obs_coords, g0, g1):
+        """The whole analysis as ONE call of the native step driver (sharded.ShardedLetkf on one rank: observation index, the
+        tiles' localisation inside the analysis wavefronts, float64 redo of declined points, the list bound carried from call
+        to call) where it applies: float32, Gaspari-Cohn on a built-in distance, the plain ETKF core or the RBF / Gauss kernel,
+        the whole grid.  The class route below (per-point lists -> tile lists -> records -> analysis, each an engine call with
+        its own host round trips) takes 0.32 ms per call at config 2 where this takes 0.09, with the same bits.  None: not this
+        shape -- the caller goes on."""
+        ka = self._kernel_args()
+        loc = self.localization
+        G = x.shape[-1]
+        if (ka.get("kernel_program") is not None or loc is None or getattr(loc, "_taper", 1) != 0
+                or getattr(loc, "builtin_metric", None) is None or x.dtype != torch.float32 or yb.shape[1] == 0
+                or g0 != 0 or (g1 is not None and g1 != G) or G == 0):
+            return None
+        from .sharded import ShardedLetkf
+        grid = torch.as_tensor(np.asarray(grid_coords) if not torch.is_tensor(grid_coords) else grid_coords)
+        obs = torch.as_tensor(np.asarray(obs_coords) if not torch.is_tensor(obs_coords) else obs_coords)
+        nc = 1 if grid.dim() == 1 else int(grid.shape[1])
+        if grid.shape[0] != G or obs.shape[0] != yb.shape[1]:
+            return None
+        key = (tuple(float(r) for r in loc.radius), tuple(loc.builtin_metric.groups(nc, len(loc.radius))), float(loc.epsilon),
+               float(self.inf_factor), ka.get("rbf_gamma"), nc)
+        runner = getattr(self, "_step_runner", None)
+        if runner is None or getattr(self, "_step_runner_key", None) != key:
+            if runner is not None:
+                runner.close()
+            runner = ShardedLetkf(self.engine.device, 0, 1, radii=list(key[0]), coord_group=list(key[1]), eps=key[2],
+                                  inf_factor=key[3], rbf_gamma=key[4])
+            runner._engine = self.engine
+            self._step_runner, self._step_runner_key = runner, key
+        dev = self.engine.device
+        xa = runner.assimilate(x, grid.to(device=dev, dtype=torch.float64), obs.to(device=dev, dtype=torch.float64), yb, d)
+        fl = runner._last_flags
+        bad = int((fl & 0xff).max().item()) if fl is not None and fl.numel() else 0
+        if bad & 1:
+            raise RuntimeError("LETKF kernel: local observation list overflow (engine bug: lists are sized from counts)")
+        if bad & 4:
+            warnings.warn("LETKF kernel met non-finite values in at least one local block", RuntimeWarning)
+        if bad & 2:
+            warnings.warn("LETKF eigensolver reached its sweep cap for at least one grid point (result returned)",
+                          RuntimeWarning)
+        return xa
+
     def _analysis_on_tiles(self, x, yb, d, nb, grid_coords, obs_coords):
         """The fused analysis on the TILE route -- tile lists from the built-in metric, then letkf_tile2_kernel / letkf_tile2p_kernel
         (plain ETKF core: split records) or lketkf_tile_kernel (RBF / Gauss kernel: the perturbations themselves) -- where it
@@ -298,8 +341,11 @@ class LETKF(ETKF):
             W = self._through_disk(W, grid_index=gidx)
             xa = self.engine.apply_local_weights(st.reshape(-1, shp[-2], shp[-1]), W, g0, g0 + W.shape[0])
             return xa.reshape(shp[:-1] + (W.shape[0],))
-        nb = self._lists(grid_coords, obs_coords, g0, g1, grid_info, obs_info)
         st3, ybd, dd = st.reshape(-1, shp[-2], shp[-1]), self._dev(yb), self._dev(d)
+        xa = self._analysis_by_step_driver(st3, ybd, dd, grid_coords, obs_coords, g0, g1)
+        if xa is not None:
+            return xa.reshape(shp[:-1] + (xa.shape[-1],))
+        nb = self._lists(grid_coords, obs_coords, g0, g1, grid_info, obs_info)
         res = self._analysis_on_tiles(st3, ybd, dd, nb, grid_coords, obs_coords)
         if res is not None:
             xa, flags = res
