@@ -705,3 +705,23 @@ def test_interface_classes_reach_the_tile_kernels(mia, golden, monkeypatch):
     before = dict(calls)
     xu = mia.LETKF(localization=user, inf_factor=1.1).analyse_arrays(g["c2_state"], g["c2_yb"], g["c2_d"], **kw2)
     assert calls == before and rel_fro(xu.cpu().numpy(), g["c2_1p1_analysis"]) < 1e-5
+
+
+def test_weights_with_a_carried_list_bound_follow_a_changing_network(mia):
+    """estimate_weights_arrays carries the list bound of its last call and builds the per-point lists only when needed: the
+    same weights as a fresh object -- for the same network, for a denser one (the bound breaks: exact lists first) and back."""
+    import bench
+    dev = torch.device("cuda:0")
+    X, gx, ox, Yb, d = bench.make_case(6000, 40, 2, dev, seed=21)
+    loc = lambda: mia.GaspariCohn(6.0, mia.AbsoluteDistance())
+    a = mia.LETKF(loc(), inf_factor=1.1)
+    w1 = a.estimate_weights_arrays(Yb, d, grid_coords=gx[:, None], obs_coords=ox[:, None]).clone()
+    w1b = a.estimate_weights_arrays(Yb, d, grid_coords=gx[:, None], obs_coords=ox[:, None]).clone()       # carried bound
+    assert torch.equal(w1, w1b) and a._w_hint is not None
+    # the same number of observations, packed into half the domain: lists twice as long -- the carried bound does not hold
+    ox_dense = (ox * 0.5).contiguous()
+    fresh = mia.LETKF(loc(), inf_factor=1.1).estimate_weights_arrays(Yb, d, grid_coords=gx[:, None], obs_coords=ox_dense[:, None])
+    w2 = a.estimate_weights_arrays(Yb, d, grid_coords=gx[:, None], obs_coords=ox_dense[:, None])
+    assert torch.equal(w2, fresh)
+    w3 = a.estimate_weights_arrays(Yb, d, grid_coords=gx[:, None], obs_coords=ox[:, None])
+    assert torch.equal(w3, w1)

@@ -206,8 +206,21 @@ class LETKF(ETKF):
             W = ETKF.estimate_weights_arrays(self, yb, d)
             return W[None].expand(G - g0, -1, -1).contiguous()
         yb, d = self._dev(yb), self._dev(d)
-        nb = self._lists(grid_coords, obs_coords, g0, g1, grid_info, obs_info)
         k = yb.shape[0]
+        # the list bound of the last call on this object, when the problem has the same sizes: tile lists are built for it at once
+        # and checked afterwards (longest list, unions that fit); the per-point lists -- a third of this call's time at config 2
+        # -- are only built when that fails or a declined point needs them
+        G = len(grid_coords)
+        hint_key = (G, int(yb.shape[1]), g0, G if g1 is None else g1)
+        hint = getattr(self, "_w_hint", None)
+        if hint is not None and hint[0] == hint_key and self.localization is not None:
+            x = torch.zeros((1, k, hint_key[3]), dtype=self.dtype, device=self.engine.device)
+            W = self._weights_on_tiles(x, yb, d, None, grid_coords, obs_coords, p_max=hint[1], g0=g0, g1=hint_key[3],
+                                       lists=lambda: self._lists(grid_coords, obs_coords, g0, g1, grid_info, obs_info))
+            if W is not None:
+                return W
+        nb = self._lists(grid_coords, obs_coords, g0, g1, grid_info, obs_info)
+        self._w_hint = (hint_key, int(nb.p_max))
         x = torch.zeros((1, k, nb.g1), dtype=self.dtype, device=self.engine.device)
         W = self._weights_on_tiles(x, yb, d, nb, grid_coords, obs_coords)
         if W is not None:
@@ -215,23 +228,30 @@ class LETKF(ETKF):
         _, W = self.engine.analysis(x, yb, d, nb, self.inf_factor, return_weights=True, **self._kernel_args())
         return W
 
-    def _weights_on_tiles(self, x, yb, d, nb, grid_coords, obs_coords):
+    def _weights_on_tiles(self, x, yb, d, nb, grid_coords, obs_coords, p_max=None, g0=None, g1=None, lists=None):
         """The tile route of the weights (engine.weights_tiles: tile lists + split records, csrc/letkf_tile2w.hip) where it
         applies -- float32, plain ETKF core, a built-in distance, unions of at most 32 observations per tile; declined points are
-        redone with weights by the eigensolver kernel from the per-point lists.  None: the caller takes the per-point route."""
+        redone with weights by the eigensolver kernel from the per-point lists.  None: the caller takes the per-point route.
+        ``nb`` None: the lists are not built yet -- ``p_max`` is a bound carried over from an earlier call (checked against the
+        longest list the tile kernel met: None when it does not hold), ``lists()`` builds them if a declined point needs them."""
         eng = self.engine
         ka = self._kernel_args()
+        if nb is not None:
+            p_max, g0, g1 = nb.p_max, nb.g0, nb.g1
         if (ka.get("rbf_gamma") is not None or ka.get("kernel_program") is not None
-                or not hasattr(self.localization, "tile_lists") or nb.g1 - nb.g0 <= 0):
+                or not hasattr(self.localization, "tile_lists") or g1 - g0 <= 0):
             return None
         tiles = None
         for extra in (0, 1):
-            if not eng.tile_route_applies(x, nb.p_max, extra) or max(1, (nb.p_max + 8 + 15) // 16) + extra > 2:
+            if not eng.tile_route_applies(x, p_max, extra) or max(1, (p_max + 8 + 15) // 16) + extra > 2:
                 return None
-            tiles = self.localization.tile_lists(eng, grid_coords, obs_coords, nb.p_max, nb.g0, nb.g1, extra_blocks=extra)
+            tiles = self.localization.tile_lists(eng, grid_coords, obs_coords, p_max, g0, g1, extra_blocks=extra)
             if tiles is None:
                 return None
-            if int(tiles.stats[1].item()) == 0:
+            st_ = tiles.stats.tolist()
+            if nb is None and st_[0] > p_max:
+                return None                      # (the carried bound does not hold for this network: exact lists first)
+            if st_[1] == 0:
                 break
         else:
             return None
@@ -241,6 +261,8 @@ class LETKF(ETKF):
             return None
         xa, W, flags, retry = res
         if int(retry.item()):
+            if nb is None:
+                nb = lists()
             eng.weights_retry(x, yb, d, nb, self.inf_factor, xa, W, flags)
         return W
 
