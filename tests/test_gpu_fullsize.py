@@ -170,3 +170,46 @@ def test_weight_transforms_at_config3_size(mia):
         mean = xs.mean(dim=1, keepdim=True)
         ref = torch.einsum("mig,ij->mjg", xs - mean, W[0].double()) + mean
         assert float(torch.linalg.norm(outg[:, :, a:b].double() - ref) / torch.linalg.norm(ref)) < 1e-6
+
+
+def test_size_independent_properties_at_config2(mia):
+    """Config 2 at full size through the step driver, checked by properties that need no oracle: (1) scaling the state by a power
+    of two scales the analysis by it EXACTLY (every scale factor inside the kernels is a power of two); (2) the order of the
+    observations does not matter beyond rounding (tiles rank their unions by observation index: a permutation changes the
+    summation order only); (3) grid points out of every observation's reach get the prior ensemble with inflated perturbations,
+    mean + sqrt(inf) (x - mean) (core/etkf.py:57-66 with no observation); (4) the analysis is linear in the state rows:
+    analysing two variables at once equals analysing each alone."""
+    import bench
+    dev = torch.device("cuda:0")
+    G, k = 100000, 40
+    X, gx, ox, Yb, d = bench.make_case(G, k, 2, dev, seed=5)
+    r = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1)
+    for _ in range(3):
+        base = r.assimilate(X, gx, ox, Yb, d).clone()
+    assert r.last_flags_ok() and r.native_steps >= 2
+    # (1)
+    scaled = r.assimilate(X * 8.0, gx, ox, Yb, d)
+    assert torch.equal(scaled, base * 8.0)
+    # (2)
+    perm = torch.randperm(ox.shape[0], generator=torch.Generator().manual_seed(1)).to(dev)
+    shuffled = r.assimilate(X, gx, ox[perm].contiguous(), Yb[:, perm].contiguous(), d[perm].contiguous())
+    assert float(torch.linalg.norm(shuffled - base) / torch.linalg.norm(base)) < 2e-6
+    # (3) observations only in the first half of the domain: points beyond their reach keep the inflated prior
+    half = ox < 0.5 * G
+    out_h = r.assimilate(X, gx, ox[half].contiguous(), Yb[:, half].contiguous(), d[half].contiguous())
+    far = slice(int(0.5 * G) + 50, G)
+    mean = X[:, :, far].mean(dim=1, keepdim=True)
+    prior = mean + (1.1 ** 0.5) * (X[:, :, far] - mean)
+    assert float(torch.linalg.norm(out_h[:, :, far] - prior) / torch.linalg.norm(prior)) < 1e-6
+    r.close()
+    # (4)
+    X2 = torch.cat([X, torch.flip(X, dims=[2]) * 3.0 + 1.0], dim=0).contiguous()
+    r2 = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1)
+    for _ in range(3):
+        both = r2.assimilate(X2, gx, ox, Yb, d)
+    assert float(torch.linalg.norm(both[0] - base[0]) / torch.linalg.norm(base[0])) < 2e-6
+    r3 = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1)
+    for _ in range(3):
+        second = r3.assimilate(X2[1:].contiguous(), gx, ox, Yb, d)
+    assert float(torch.linalg.norm(both[1] - second[0]) / torch.linalg.norm(second[0])) < 2e-6
+    r2.close(); r3.close()
