@@ -31,10 +31,11 @@ static __device__ long long g_tile2_stamps[kT2StampTiles * kT2StampN];      // (
 #define MIA_TILE2_WAVES_UT2 4
 #endif
 
-// MROWS = false: one state row per grid point (the benchmark configurations), straight-line code -- 102 registers at UT = 2,
-// KT = 3, four wavefronts per SIMD.  MROWS = true: any number of rows in a loop that shares the union, the Gram matrix and the
-// coefficients; the compiler hoists the loop's invariant addresses and predicates in front of it (227 registers at the same
-// shape), so these instantiations run at two wavefronts per SIMD.
+// MROWS = false: one state row per grid point (the benchmark configurations), straight-line code -- 86 registers at UT = 2,
+// KT = 3, five wavefronts per SIMD.  MROWS = true: any number of rows in a loop that shares the union, the Gram matrix and the
+// coefficients.  Left alone the compiler hoists the loop's invariant addresses and predicates in front of it (199-227 registers at
+// the same shape, two wavefronts per SIMD); the loop launders the lane-derived indices at its top, so that work stays inside
+// the row: 100 registers, four wavefronts per SIMD, 0.0196 instead of 0.0211 ms per row and 1e5 points.
 //
 // LOC = 0: lists from memory (localize_tiles_kernel ran before).  LOC = 1, 2, 3 (the number of coordinates): the wavefront
 // LOCALISES ITS TILE ITSELF over the step's bucket index (tile_localize, mia_tile_localize.h -- the same code and therefore the same
@@ -44,7 +45,7 @@ template <int UT, int KT, bool MROWS, int LOC>
 __device__ __forceinline__ void tile2_body(Tile2Params P, const Tile2Loc* loc, const int64_t bid) {
   constexpr int UMAX = 16 * UT, NB = (KT + 1) / 2, NKB = (UT + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x, lr = lane & 15, h = lane >> 4;
+  int lane = threadIdx.x, lr = lane & 15, h = lane >> 4;      // (not const: the row loop launders them, see there)
   const int k = P.k, nc8 = P.nc8;
   const unsigned IMG = (unsigned)(UT * nc8) * 512u;
   unsigned char* zline = smem + IMG;                         // 512 zero bytes: the chunks a record does not have
@@ -75,8 +76,8 @@ __device__ __forceinline__ void tile2_body(Tile2Params P, const Tile2Loc* loc, c
     P.Xa += (int64_t)sgi * P.seg_stride;
   }
   const unsigned ldxb = (unsigned)P.ldx * 4u, ldob = (unsigned)P.ldo * 4u;       // (k ld 4 < 2^31: checked on the host)
-  const int lrc = lr < npts ? lr : npts - 1;
-  const bool colok = lr < npts;
+  int lrc = lr < npts ? lr : npts - 1;
+  bool colok = lr < npts;
 
 #ifdef MIA_EXPERIMENTS
   // (bits 8..: wave priority by phase -- 1: prologue high, compute normal; 2: prologue normal, compute high)
@@ -141,7 +142,7 @@ __device__ __forceinline__ void tile2_body(Tile2Params P, const Tile2Loc* loc, c
     MIA_T2_SYNC();      // (every lane has read the scratch: the slot table and the record image may take its place)
   }
   // member (b, i) of lane group h = 8 sigma(b, h) + i, sigma = 4 b + 2 (h & 1) + (h >> 1): column lr of the state row
-  const int sg = 2 * (h & 1) + (h >> 1);
+  int sg = 2 * (h & 1) + (h >> 1);
   auto load_xs = [&](int mi, float (&xr)[NB][8]) {
     const float* xbase = P.X + (int64_t)mi * k * P.ldx + P.g0 + p0;
 #pragma unroll
@@ -572,6 +573,14 @@ __device__ __forceinline__ void tile2_body(Tile2Params P, const Tile2Loc* loc, c
   row_tail(0, Z0, xm0, inv_sx0);
   if constexpr (MROWS) {
     for (int mi = 1; mi < P.m; ++mi) {
+      // Everything a row needs beyond its own values -- fragment offsets, output addresses, predicates -- derives from the lane
+      // number; left alone the compiler computes all of it once in front of the loop and carries it through (227 registers,
+      // two wavefronts per SIMD).  Laundering the lane-derived indices here makes that work part of each row: a few dozen
+      // integer instructions per row against half the registers.
+      asm volatile("" : "+v"(lane), "+v"(lr), "+v"(h));
+      lrc = lr < npts ? lr : npts - 1;
+      colok = lr < npts;
+      sg = 2 * (h & 1) + (h >> 1);
       load_xs(mi, xsb);
       float xm, inv_sx;
       h8v xh[NB], xl[NB];
