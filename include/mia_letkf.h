@@ -89,7 +89,7 @@ const char* mia_status_string(int status);
  *   "tile_pair"        1  tile route, unions of more than 32 slots and one state row per grid point: two wavefronts per tile,
  *                         each with the Gram fragments and recurrence vectors of its own row blocks (csrc/letkf_tile2p.hip; config 4:
  *                         0.186 -> 0.172 ms per 1e5 points, a 2-D mesh with 64-slot unions 0.092 -> 0.073) (1) or one (0)
- *   "tile_fused"       1  step driver, tile route over the bucket index, one state row per grid point, unions of at most 32 slots, no
+ *   "tile_fused"       1  step driver, tile route over the bucket index, unions of at most 32 slots, no
  *                         geometry epoch declared: every analysis wavefront localises its own tile first (csrc/letkf_tile2f.hip -- the
  *                         list kernel's code, bit-identical results; no list kernel, no tile lists in memory) / 0: lists first
  * Scope: process-wide defaults, read when a call ENQUEUES its work -- for steps handed to the launch threads

@@ -356,3 +356,23 @@ def test_random_geometries_against_the_oracle(mia):
         assert err < 1e-5 and err_inc < 1e-4, (case_no, k, stride, radius, inf, m, G, sx, sy, err, err_inc)
         r.close()
     assert worst < 1e-5
+
+
+def test_fused_localisation_with_several_state_rows(mia):
+    """Several state rows per grid point through the fused kernel's row loop: bit for bit the analysis from lists in memory, and
+    against the oracle."""
+    dev = torch.device("cuda:0")
+    for k, m in ((40, 5), (24, 2), (70, 3)):
+        case = O.synthetic_case(1300, k, 2, seed=40 + k, m=m)
+        a = args_of(case, dev)
+        oracle = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], case["yb"], case["d"], 10.0, 1.1)[0]
+        outs = {}
+        for fz in (False, True):
+            r = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1, fuse_tile_lists=fz)
+            for _ in range(3):
+                out = r.assimilate(*a)
+            assert r.last_flags_ok() and r.native_steps == 2
+            outs[fz] = out.clone()
+            r.close()
+        assert torch.equal(outs[True], outs[False]), (k, m)
+        assert rel_fro(outs[True].cpu().numpy(), oracle) < 1e-5

@@ -254,7 +254,10 @@ __device__ __forceinline__ void tile2_body(Tile2Params P, const Tile2Loc* loc, c
         float t8[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) t8[i] = xsb[b][i] * sx;
-        split8(t8, xh[b], xl[b]);
+        // (tied in the row loop: there this follows the previous row's output products closely and the fresh outputs of the untied
+        //  form landed on an accumulator still in flight -- tools/check_mfma_hazards.py on the fused many-rows instantiations)
+        if constexpr (MROWS) split8_tied(t8, xh[b], xl[b]);
+        else split8(t8, xh[b], xl[b]);
       }
     };
   // ---- first state row: Gram matrix, interval and degree of every point (shared by all rows), its own Z

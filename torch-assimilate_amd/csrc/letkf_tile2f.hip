@@ -4,8 +4,8 @@
 // Reference: GaspariCohn.localize_obs (pytassim/localization/gaspari_cohn.py:97-136) + wrapper_localization
 // (pytassim/interface/wrapper.py:86-98) + the ETKF weights and transform (pytassim/core/etkf.py:57-103), per grid point.
 // What it removes from a step: the list kernel's launch, 2.5 KB of lists per tile written and read back, and one dependent
-// memory round trip of the analysis prologue (header -> slot table).  Shapes: one state row, unions of at most 32 slots (larger
-// unions go through lists to the two-wavefronts-per-tile kernel).
+// memory round trip of the analysis prologue (header -> slot table).  Shapes: unions of at most 32 slots (larger
+// unions go through lists to the two-wavefronts-per-tile kernel); any number of state rows.
 #include "mia_common.h"
 #include <hip/hip_ext.h>
 #include "mia_kernels.h"
@@ -17,9 +17,9 @@ namespace mia {
 
 struct Tile2FParams { Tile2Params t; Tile2Loc loc; };
 
-template <int UT, int KT, int NC, int WAVES>
+template <int UT, int KT, int NC, bool MROWS, int WAVES>
 __global__ __launch_bounds__(64, WAVES)
-void letkf_tile2f_kernel(Tile2FParams PF) { tile2_body<UT, KT, false, NC>(PF.t, &PF.loc, (int64_t)blockIdx.y * gridDim.x + blockIdx.x); }
+void letkf_tile2f_kernel(Tile2FParams PF) { tile2_body<UT, KT, MROWS, NC>(PF.t, &PF.loc, (int64_t)blockIdx.y * gridDim.x + blockIdx.x); }
 
 #ifdef MIA_TILE_STAMPS
 extern "C" int mia_debug_tile2f_stamps(long long* host, int n_tiles) {
@@ -30,15 +30,15 @@ extern "C" int mia_debug_tile2f_stamps(long long* host, int n_tiles) {
 
 bool tile2f_covers(int m, int k, int ut, int n_coord) {
   const int kt = (k + 15) >> 4;
-  return m == 1 && ut >= 1 && ut <= 2 && kt >= 1 && kt <= 6 && n_coord >= 1 && n_coord <= MIA_MAX_COORD;
+  return m >= 1 && ut >= 1 && ut <= 2 && kt >= 1 && kt <= 6 && n_coord >= 1 && n_coord <= MIA_MAX_COORD;
 }
 
-template <int UT, int KT, int NC>
-static int tile2f_launch_n(const Tile2FParams& pf, hipStream_t stream) {
+template <int UT, int KT, int NC, bool MROWS>
+static int tile2f_launch_m(const Tile2FParams& pf, hipStream_t stream) {
   const size_t a = tile2_lds_bytes(UT, pf.t.k), b = tile_loc_lds(UT);
   const size_t lds = a > b ? a : b;
   if (lds > kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
-  auto kern = letkf_tile2f_kernel<UT, KT, NC, MIA_TILE2_WAVES_UT2>;
+  auto kern = letkf_tile2f_kernel<UT, KT, NC, MROWS, MROWS ? 2 : MIA_TILE2_WAVES_UT2>;
   if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t ntile = (pf.t.ng + 15) >> 4;
   const int64_t gx = ntile < 65536 ? ntile : 65536;
@@ -55,6 +55,11 @@ static int tile2f_launch_n(const Tile2FParams& pf, hipStream_t stream) {
   ++tile_launch_count();
   MIA_LAUNCH_CHECK();
   return MIA_OK;
+}
+
+template <int UT, int KT, int NC>
+static int tile2f_launch_n(const Tile2FParams& pf, hipStream_t stream) {        // one state row: straight-line code; more: the row loop
+  return pf.t.m == 1 ? tile2f_launch_m<UT, KT, NC, false>(pf, stream) : tile2f_launch_m<UT, KT, NC, true>(pf, stream);
 }
 
 template <int UT, int KT>

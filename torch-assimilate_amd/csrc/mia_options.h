@@ -16,7 +16,7 @@ enum {
   MIA_OPT_BUCKET_INDEX,      // step driver, tile route: observations binned into fixed-capacity cell buckets by ONE kernel over the cell grid the
                              // workspace holds (1) or bounding box + count + scan + scatter every step (0)
   MIA_OPT_TILE_PAIR,         // tile route, unions of more than 32 slots: two wavefronts per tile (letkf_tile2p.hip) (1) or one (0)
-  MIA_OPT_TILE_FUSED,        // step driver, tile route, one state row, unions of at most 32 slots: the analysis wavefronts localise their
+  MIA_OPT_TILE_FUSED,        // step driver, tile route, unions of at most 32 slots: the analysis wavefronts localise their
                              // tiles themselves (letkf_tile2f.hip: no list kernel, no lists in memory) (1) or lists first (0)
   MIA_OPT_COUNT_
 };

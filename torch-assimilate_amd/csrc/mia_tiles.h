@@ -288,7 +288,7 @@ int tile2_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0,
                           hipStream_t stream, int seg_len = 0, int64_t seg_stride = 0, const Tile2Housekeeping* hk = nullptr,
                           const struct Tile2Loc* loc = nullptr);
 // letkf_tile2f.hip: the same analysis with the localisation of each tile done by its own wavefront (loc: mia_localize_dev.h) --
-// shapes: one state row, unions of at most 32 slots
+// shapes: unions of at most 32 slots, any number of state rows
 bool tile2f_covers(int m, int k, int ut, int n_coord);
 int tile2f_launch(const Tile2Params& tp, const struct Tile2Loc& loc, int ut, int kt, hipStream_t stream);
 size_t tile2_lds_bytes(int ut, int k);
