@@ -9,12 +9,17 @@ NEED = 8          # what the compiler itself pads v_mfma_f32_16x16x32_f16 (4 pas
 
 
 def regs(tok):
+    """Registers an operand token names, as (file, index) pairs: 'v' = vector registers, 'a' = accumulation registers (gfx90a+
+    keeps both in one physical file, but the assembler's names -- and the hazards -- are per name space)."""
     tok = tok.strip().rstrip(",")
-    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    m = re.fullmatch(r"([va])\[(\d+):(\d+)\]", tok)
     if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
-    m = re.fullmatch(r"v(\d+)", tok)
-    return {int(m.group(1))} if m else set()
+        return {(m.group(1), r) for r in range(int(m.group(2)), int(m.group(3)) + 1)}
+    m = re.fullmatch(r"([va])(\d+)", tok)
+    return {(m.group(1), int(m.group(2)))} if m else set()
+
+
+MATCHED = {"mfma": 0, "dst_regs": 0}       # (the test fails when a source holds matrix instructions whose operands were not parsed)
 
 
 def operands(line):
@@ -37,6 +42,8 @@ def check(asm):
         if not op.startswith("v_mfma"):
             continue
         dst = regs(ops[0])
+        MATCHED["mfma"] += 1
+        MATCHED["dst_regs"] += len(dst)
         stack, seen = [(i + 1, 0)], set()
         while stack:
             j, ws = stack.pop()
@@ -138,5 +145,9 @@ if __name__ == "__main__":
         print("HAZARD kernel %s: mfma at line %d read at line %d after %d wait states\n   %s\n   %s" % b)
     for b in war[:40]:
         print("WAR HAZARD kernel %s: mfma at line %d, its SrcC overwritten at line %d after %d wait states\n   %s\n   %s" % b)
-    print("%s: %d hazard(s), %d write-after-read hazard(s) on SrcC" % (os.path.basename(src), len(bad), len(war)))
-    sys.exit(1 if bad or war else 0)
+    print("%s: %d hazard(s), %d write-after-read hazard(s) on SrcC; %d matrix instructions, %d result registers parsed"
+          % (os.path.basename(src), len(bad), len(war), MATCHED["mfma"], MATCHED["dst_regs"]))
+    unparsed = "v_mfma" in text and (MATCHED["mfma"] == 0 or MATCHED["dst_regs"] < 4 * MATCHED["mfma"])
+    if unparsed:
+        print("CHECKER ERROR: the assembly holds matrix instructions whose result registers were not parsed")
+    sys.exit(1 if bad or war or unparsed else 0)

@@ -93,7 +93,11 @@ __device__ __forceinline__ f2w lk_fma2(f2w a, f2w b, f2w c) { return __builtin_e
 // of a lane: the tail of every row's band lives in AGPRs and is read into a temporary where it is used)
 // (the compiler pads nothing around inline assembly: the value parked is the result of a transcendental instruction, whose
 //  consumer needs a wait state -- without the s_nop the write picked up the register's previous content)
-__device__ __forceinline__ float lk_park(float v) { float a; asm("s_nop 1\n\tv_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v)); return a; }
+// (round 5: the write into the accumulation register is the COMPILER's -- the empty statement only pins the value's register
+//  class -- so its hazard recognizer pads it where an in-flight matrix instruction still reads or writes that register: the
+//  hand-written v_accvgpr_write of round 4 sat 2 wait states behind a matrix instruction's SrcC read and 7 behind a result
+//  write in one instantiation, tools/check_mfma_hazards.py)
+__device__ __forceinline__ float lk_park(float v) { float a = v; asm("" : "+a"(a)); return a; }
 __device__ __forceinline__ float lk_fetch(float a) { float v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; }
 
 // PAD: the ensemble is smaller than the 4 R rows the lanes of a point hold (k < 4 R): rows / columns beyond it are zeroed
