@@ -318,3 +318,177 @@ def test_xarray_shim_on_a_stand_in(golden, monkeypatch):
         xr_adapter.assimilate(algo, state.transpose("time", "var_name", "ensemble", "grid"), ds)
     with pytest.warns(UserWarning, match="No observation is given"):
         assert xr_adapter.assimilate(algo, state, ()) is state
+
+
+# ---- the shim against objects that carry REAL pandas indexes (what xarray's ``.indexes`` hands out: DatetimeIndex for
+#      ``time``, MultiIndex for a stacked ``grid`` / ``obs_grid_1``, state.py:164-222, base.py:223-241) -------------------
+pd = pytest.importorskip("pandas")
+
+
+class PdDataArray(FakeDataArray):
+    """FakeDataArray whose ``indexes`` are pandas objects built the way xarray builds them from coordinates."""
+
+    @staticmethod
+    def _index(name, values):
+        if isinstance(values, pd.Index):
+            return values
+        v = np.asarray(values)
+        if np.issubdtype(v.dtype, np.datetime64):
+            return pd.DatetimeIndex(v, name=name)
+        return pd.Index(v, name=name)
+
+    @property
+    def indexes(self):
+        return {d: self._index(d, self.coords[d]) for d in self.dims if d in self.coords}
+
+    def isel(self, time):
+        ax = self.dims.index("time")
+        c = dict(self.coords)
+        c["time"] = self._index("time", self.coords["time"])[list(time)]
+        return PdDataArray(np.take(self.values, list(time), axis=ax), self.dims, c)
+
+    def transpose(self, *dims):
+        return PdDataArray(self.values.transpose([self.dims.index(d) for d in dims]), dims, self.coords)
+
+    def copy(self, data):
+        return PdDataArray(data, self.dims, self.coords)
+
+
+class PdDataset(FakeDataset):
+    @property
+    def indexes(self):
+        return {d: PdDataArray._index(d, v) for d, v in self.coords.items()}
+
+    def isel(self, time):
+        v = {n: (a.isel(time) if "time" in a.dims else a) for n, a in self.vars.items()}
+        c = dict(self.coords)
+        c["time"] = PdDataArray._index("time", self.coords["time"])[list(time)]
+        out = PdDataset(v, c)
+        return out
+
+
+class OracleAlgoND(OracleAlgo):
+    """As OracleAlgo on any number of coordinates: Euclidean distance over all grid levels (one radius)."""
+
+    def analyse_arrays(self, state, yb, d, grid_coords=None, obs_coords=None, grid_info=None, obs_info=None):
+        self.seen = dict(yb=yb, d=d, grid_info=grid_info, obs_info=obs_info, state_shape=state.shape,
+                         grid_coords=grid_coords, obs_coords=obs_coords)
+        nc = grid_coords.shape[1]
+        xa, _ = O.letkf_analysis(np.asarray(state), grid_coords, obs_coords, yb, d, self.radius, self.inf_factor,
+                                 coord_group=[0] * nc)
+        return xa
+
+
+def _mesh_case(golden):
+    """The reference fixture's 40 grid points laid out as an 8 x 5 (lat, lon) mesh with a MultiIndex ``grid``; subset A observes
+    every point at all three times (correlated R), subset B fifteen points at two of them (variances)."""
+    g = golden("g6_reference_fixture_letkf.npz")
+    t_idx = pd.DatetimeIndex((g["state_time"] * 1e9).astype("int64").astype("datetime64[ns]"), name="time")
+    lat, lon = np.divmod(np.arange(40), 5)
+    grid = pd.MultiIndex.from_arrays([lat.astype(float), lon.astype(float) * 2.0], names=("lat", "lon"))
+    state = PdDataArray(g["state"], F.STATE_DIMS, dict(time=t_idx, grid=grid, ensemble=pd.RangeIndex(10, name="ensemble"),
+                                                       var_name=pd.Index(["x", "y"], name="var_name")))
+    obs_a_grid = pd.MultiIndex.from_arrays([lat.astype(float), lon.astype(float) * 2.0], names=("obs_lat", "obs_lon"))
+    pts_b = np.arange(2, 40, 38 // 14)[:15]
+    obs_b_grid = pd.MultiIndex.from_arrays([lat[pts_b] + 0.25, lon[pts_b] * 2.0 - 0.5], names=("obs_lat", "obs_lon"))
+    t_b = t_idx[[0, 2]]
+    rs = np.random.RandomState(11)
+    y_b = g["state"][1][[0, 2]].mean(axis=1)[:, pts_b] + rs.normal(0, 0.3, (2, 15))       # variable 'y', times 0 and 2
+    var_b = rs.uniform(0.2, 0.6, 15)
+
+    def op_a(obs_ds, pseudo):       # variable 'x' at every point, the subset's own times (testing/dummy.py:39-66)
+        return PdDataArray(pseudo.values[0], ("time", "ensemble", "obs_grid_1"),
+                           dict(time=obs_ds.coords["time"], obs_grid_1=obs_a_grid))
+
+    def op_b(obs_ds, pseudo):       # variable 'y' at fifteen points, at the SUBSET's times (a subset of the state's)
+        want = PdDataArray._index("time", obs_ds.coords["time"])
+        have = PdDataArray._index("time", pseudo.coords["time"])
+        pos = have.get_indexer(want)
+        assert (pos >= 0).all()
+        return PdDataArray(pseudo.values[1][pos][:, :, pts_b], ("time", "ensemble", "obs_grid_1"),
+                           dict(time=want, obs_grid_1=obs_b_grid))
+
+    ds_a = PdDataset(dict(observations=PdDataArray(g["obs"], ("time", "obs_grid_1"), dict(time=t_idx, obs_grid_1=obs_a_grid)),
+                          covariance=PdDataArray(g["cov"], ("obs_grid_1", "obs_grid_2"), {})),
+                     dict(time=t_idx, obs_grid_1=obs_a_grid), op_a)
+    ds_b = PdDataset(dict(observations=PdDataArray(y_b, ("time", "obs_grid_1"), dict(time=t_b, obs_grid_1=obs_b_grid)),
+                          covariance=PdDataArray(var_b, ("obs_grid_1",), {})),
+                     dict(time=t_b, obs_grid_1=obs_b_grid), op_b)
+    return g, state, ds_a, ds_b, dict(lat=lat, lon=lon, pts_b=pts_b, y_b=y_b, var_b=var_b, t_idx=t_idx)
+
+
+def _with_fake_xarray(monkeypatch):
+    fake = types.ModuleType("xarray")
+    fake.DataArray, fake.Dataset = FakeDataArray, FakeDataset       # (the Pd* classes derive from them)
+    monkeypatch.setitem(sys.modules, "xarray", fake)
+    from torch_assimilate_amd import xr_adapter
+    return xr_adapter
+
+
+def test_shim_with_multiindex_grid_and_datetime_index_filter_mode(golden, monkeypatch):
+    """MultiIndex ``grid`` / ``obs_grid_1`` become (n, levels) float tables (utilities/pandas.py:70-102), a DatetimeIndex becomes
+    unix seconds (utilities/pandas.py:28-45); filter mode cuts BOTH subsets to the analysis time (filter.py:39-55) and stacks
+    subset A's 40 observations before subset B's 15 (base.py:223-241)."""
+    xr_adapter = _with_fake_xarray(monkeypatch)
+    g, state, ds_a, ds_b, c = _mesh_case(golden)
+    algo = OracleAlgoND(radius=3.0)
+    ana = xr_adapter.assimilate(algo, state, (ds_a, ds_b), analysis_time=c["t_idx"][0])
+    s = algo.seen
+    assert s["yb"].shape == (10, 55) and s["state_shape"] == (2, 1, 10, 40)
+    # state table: [t0 in unix seconds, lat, lon] per grid point (mixin_local.py:50-69)
+    np.testing.assert_array_equal(s["grid_info"], np.column_stack([np.full(40, g["state_time"][0]), c["lat"], c["lon"] * 2.0]))
+    oi = s["obs_info"]
+    assert list(oi.columns) == ["time", "obs_lat", "obs_lon"] and len(oi) == 55
+    np.testing.assert_array_equal(oi["time"].values, np.full(55, g["state_time"][0]))
+    np.testing.assert_array_equal(oi["obs_lat"].values, np.concatenate([c["lat"], c["lat"][c["pts_b"]] + 0.25]))
+    np.testing.assert_array_equal(oi["obs_lon"].values, np.concatenate([c["lon"] * 2.0, c["lon"][c["pts_b"]] * 2.0 - 0.5]))
+    # the numbers, recomputed independently: subset A through the Cholesky factor of R, subset B through its variances
+    yb_a, d_a = O.obs_space_corr(g["state"][0, 0], g["obs"][0], g["cov"])
+    yb_b, d_b = O.obs_space_uncorr(g["state"][1, 0][:, c["pts_b"]], c["y_b"][0], c["var_b"])
+    np.testing.assert_allclose(s["yb"], np.concatenate([yb_a, yb_b], axis=1), atol=1e-12)
+    np.testing.assert_allclose(s["d"], np.concatenate([d_a, d_b]), atol=1e-12)
+    ref, _ = O.letkf_analysis(g["state"][:, :1], s["grid_coords"], s["obs_coords"], s["yb"], s["d"], 3.0, 1.1, coord_group=[0, 0])
+    assert isinstance(ana, PdDataArray) and ana.dims == F.STATE_DIMS
+    np.testing.assert_allclose(ana.values, ref, atol=1e-12)
+    assert isinstance(ana.indexes["grid"], pd.MultiIndex) and list(ana.indexes["grid"].names) == ["lat", "lon"]
+    assert ana.indexes["time"].equals(c["t_idx"][[0]])
+
+
+def test_shim_smoother_mode_two_subsets_with_different_times(golden, monkeypatch):
+    """Smoother mode keeps every time: subset A contributes 3 x 40 observations (time-major), subset B 2 x 15 at ITS times
+    (the first and the last state time); the observation table carries each row's own time."""
+    xr_adapter = _with_fake_xarray(monkeypatch)
+    g, state, ds_a, ds_b, c = _mesh_case(golden)
+    algo = OracleAlgoND(radius=3.0, smoother=True)
+    ana = xr_adapter.assimilate(algo, state, [ds_a, ds_b])
+    s = algo.seen
+    assert s["yb"].shape == (10, 150) and s["state_shape"] == (2, 3, 10, 40) and ana.values.shape == (2, 3, 10, 40)
+    oi = s["obs_info"]
+    t = g["state_time"]
+    np.testing.assert_array_equal(oi["time"].values, np.concatenate([np.repeat(t, 40), np.repeat(t[[0, 2]], 15)]))
+    np.testing.assert_array_equal(oi["obs_lat"].values[120:], np.tile(c["lat"][c["pts_b"]] + 0.25, 2))
+    blocks = [O.obs_space_corr(g["state"][0, i], g["obs"][i], g["cov"]) for i in range(3)]
+    yb_b, d_b = O.obs_space_uncorr(g["state"][1][[0, 2]].transpose(1, 0, 2)[:, :, c["pts_b"]].reshape(10, 30),
+                                   c["y_b"].reshape(30), np.tile(c["var_b"], 2))
+    np.testing.assert_allclose(s["yb"], np.concatenate([b[0] for b in blocks] + [yb_b], axis=1), atol=1e-12)
+    np.testing.assert_allclose(s["d"], np.concatenate([b[1] for b in blocks] + [d_b]), atol=1e-12)
+    # state table: the FIRST state time for every grid point (mixin_local.py:55-58), also in smoother mode
+    np.testing.assert_array_equal(s["grid_info"][:, 0], np.full(40, t[0]))
+
+
+def test_shim_dimension_order_and_missing_analysis_time(golden, monkeypatch):
+    """The reference accepts (var_name, time, ensemble, grid) in THAT order only (state.py:103-129): a permuted state is a
+    StateError, the same state transposed back passes; a subset without the analysis time is a KeyError in filter mode
+    (``obs.sel(time=[analysis_time])``, filter.py:50)."""
+    xr_adapter = _with_fake_xarray(monkeypatch)
+    g, state, ds_a, ds_b, c = _mesh_case(golden)
+    algo = OracleAlgoND(radius=3.0)
+    perm = state.transpose("ensemble", "var_name", "time", "grid")
+    with pytest.raises(F.StateError):
+        xr_adapter.assimilate(algo, perm, ds_a)
+    back = perm.transpose(*F.STATE_DIMS)
+    a1 = xr_adapter.assimilate(algo, back, ds_a, analysis_time=c["t_idx"][2])
+    a2 = xr_adapter.assimilate(algo, state, ds_a, analysis_time=c["t_idx"][2])
+    np.testing.assert_array_equal(a1.values, a2.values)
+    with pytest.raises(KeyError):
+        xr_adapter.assimilate(algo, state, (ds_a, ds_b), analysis_time=c["t_idx"][1])      # subset B has no such time

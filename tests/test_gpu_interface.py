@@ -112,7 +112,7 @@ def test_lketkf_linear_equals_letkf_and_rbf_vs_reference(mia, golden):
     a.kernel = mia.RBFKernel(0.5)
     xa_rbf = a.analyse_arrays(st, g["c5_yb"], g["c5_d"], **kw)
     assert rel_fro(xa_rbf.cpu().numpy(), g["c5_1p1_analysis"]) < 1e-9
-    a32 = mia.LKETKF(mia.RBFKernel(0.5), localization=loc, inf_factor=1.1)
+    a32 = mia.LKETKF(mia.RBFKernel(0.5), localization=loc, inf_factor=1.1, dtype=torch.float32)
     assert rel_fro(a32.analyse_arrays(st, g["c5_yb"], g["c5_d"], **kw).cpu().numpy(), g["c5_1p1_analysis"]) < 1e-5
     ke = mia.KETKF(mia.RBFKernel(0.5), inf_factor=1.1, dtype=torch.float64)
     gg = golden("g3_g4_core_blocks.npz")
@@ -692,18 +692,18 @@ def test_interface_classes_reach_the_tile_kernels(mia, golden, monkeypatch):
     monkeypatch.setattr(LetkfEngine, "analysis_tiles_rbf", spy_rbf)
     loc = mia.GaspariCohn(10.0, mia.AbsoluteDistance())
     kw2 = dict(grid_coords=g["c2_grid_x"], obs_coords=g["c2_obs_x"])
-    xa = mia.LETKF(localization=loc, inf_factor=1.1).analyse_arrays(g["c2_state"], g["c2_yb"], g["c2_d"], **kw2)
+    xa = mia.LETKF(localization=loc, inf_factor=1.1, dtype=torch.float32).analyse_arrays(g["c2_state"], g["c2_yb"], g["c2_d"], **kw2)
     assert calls == {"plain": 1, "rbf": 0} and rel_fro(xa.cpu().numpy(), g["c2_1p1_analysis"]) < 1e-5
-    xa3 = mia.LETKF(localization=loc, inf_factor=1.0).analyse_arrays(g["c2m3_state"], g["c2m3_yb"], g["c2m3_d"],
+    xa3 = mia.LETKF(localization=loc, inf_factor=1.0, dtype=torch.float32).analyse_arrays(g["c2m3_state"], g["c2m3_yb"], g["c2m3_d"],
                                                                       grid_coords=g["c2m3_grid_x"], obs_coords=g["c2m3_obs_x"])
     assert calls["plain"] == 2 and rel_fro(xa3.cpu().numpy(), g["c2m3_1p0_analysis"]) < 1e-5
     kw5 = dict(grid_coords=g["c5_grid_x"], obs_coords=g["c5_obs_x"])
-    xk = mia.LKETKF(mia.RBFKernel(0.5), localization=loc, inf_factor=1.1).analyse_arrays(g["c5_state"], g["c5_yb"], g["c5_d"], **kw5)
+    xk = mia.LKETKF(mia.RBFKernel(0.5), localization=loc, inf_factor=1.1, dtype=torch.float32).analyse_arrays(g["c5_state"], g["c5_yb"], g["c5_d"], **kw5)
     assert calls["rbf"] == 1 and rel_fro(xk.cpu().numpy(), g["c5_1p1_analysis"]) < 1e-5
     # a user callable (the reference's arbitrary dist_func, gaspari_cohn.py:124-125): host-evaluated distances, per-point lists
     user = mia.GaspariCohn(10.0, lambda grid, obs: np.abs(np.asarray(obs, dtype=np.float64).reshape(-1) - float(np.asarray(grid).reshape(-1)[0])))
     before = dict(calls)
-    xu = mia.LETKF(localization=user, inf_factor=1.1).analyse_arrays(g["c2_state"], g["c2_yb"], g["c2_d"], **kw2)
+    xu = mia.LETKF(localization=user, inf_factor=1.1, dtype=torch.float32).analyse_arrays(g["c2_state"], g["c2_yb"], g["c2_d"], **kw2)
     assert calls == before and rel_fro(xu.cpu().numpy(), g["c2_1p1_analysis"]) < 1e-5
 
 
@@ -714,13 +714,13 @@ def test_weights_with_a_carried_list_bound_follow_a_changing_network(mia):
     dev = torch.device("cuda:0")
     X, gx, ox, Yb, d = bench.make_case(6000, 40, 2, dev, seed=21)
     loc = lambda: mia.GaspariCohn(6.0, mia.AbsoluteDistance())
-    a = mia.LETKF(loc(), inf_factor=1.1)
+    a = mia.LETKF(loc(), inf_factor=1.1, dtype=torch.float32)
     w1 = a.estimate_weights_arrays(Yb, d, grid_coords=gx[:, None], obs_coords=ox[:, None]).clone()
     w1b = a.estimate_weights_arrays(Yb, d, grid_coords=gx[:, None], obs_coords=ox[:, None]).clone()       # carried bound
     assert torch.equal(w1, w1b) and a._w_hint is not None
     # the same number of observations, packed into half the domain: lists twice as long -- the carried bound does not hold
     ox_dense = (ox * 0.5).contiguous()
-    fresh = mia.LETKF(loc(), inf_factor=1.1).estimate_weights_arrays(Yb, d, grid_coords=gx[:, None], obs_coords=ox_dense[:, None])
+    fresh = mia.LETKF(loc(), inf_factor=1.1, dtype=torch.float32).estimate_weights_arrays(Yb, d, grid_coords=gx[:, None], obs_coords=ox_dense[:, None])
     w2 = a.estimate_weights_arrays(Yb, d, grid_coords=gx[:, None], obs_coords=ox_dense[:, None])
     assert torch.equal(w2, fresh)
     w3 = a.estimate_weights_arrays(Yb, d, grid_coords=gx[:, None], obs_coords=ox[:, None])

@@ -72,6 +72,15 @@ def test_interface_constructor_surface():
     a.inf_factor = 1.3
     assert a.inf_factor == 1.3
     assert repr(mia.ETKF(1.0)) == "ETKF(1.0)"
+    # working precision: the reference's default and its setter's error (interface/base.py:68,73,106-118)
+    import torch
+    assert a.dtype is torch.float64 and mia.ETKF().dtype is torch.float64 and mia.KETKF(mia.LinearKernel()).dtype is torch.float64
+    a.dtype = torch.float32
+    assert a.dtype is torch.float32
+    with pytest.raises(TypeError):
+        a.dtype = "float32"
+    with pytest.raises(TypeError):
+        mia.LETKF(dtype=np.float64)
     k = mia.LKETKF(mia.RBFKernel(0.5), localization=loc)
     assert k._kernel_args() == dict(rbf_gamma=0.5, kernel_program=None)
     k.kernel = mia.LinearKernel()

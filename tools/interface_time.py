@@ -21,7 +21,7 @@ def timed(fn, reps=10):
     return (time.perf_counter() - t0) / reps * 1e3, r
 
 
-a = mia.LETKF(mia.GaspariCohn(10.0, mia.AbsoluteDistance()), inf_factor=1.1)
+a = mia.LETKF(mia.GaspariCohn(10.0, mia.AbsoluteDistance()), inf_factor=1.1, dtype=torch.float32)
 ms, xa = timed(lambda: a.analyse_arrays(X, Yb, d, grid_coords=gxx, obs_coords=oxx))
 print("LETKF.analyse_arrays (fused path): %.3f ms per call (%d points)" % (ms, G), flush=True)
 ms2, W = timed(lambda: a.estimate_weights_arrays(Yb, d, grid_coords=gxx, obs_coords=oxx))

@@ -46,7 +46,7 @@ class ETKF:
     def __init__(self, inf_factor: float = 1.0, smoother: bool = False, gpu: bool = True,
                  pre_transform: Optional[Iterable] = None, post_transform: Optional[Iterable] = None,
                  weight_save_path: Optional[str] = None, forward_model: Optional[Callable] = None,
-                 dtype: torch.dtype = torch.float32, engine: Optional[LetkfEngine] = None):
+                 dtype: torch.dtype = torch.float64, engine: Optional[LetkfEngine] = None):
         self._inf_factor = float(inf_factor)
         self.smoother = smoother
         self.gpu = gpu
@@ -54,11 +54,27 @@ class ETKF:
         self.post_transform = post_transform
         self.weight_save_path = weight_save_path
         self.forward_model = forward_model
+        # the reference's working precision: float64 unless the caller says otherwise (interface/base.py:68,73).  The float32
+        # tile kernels -- the benchmarked hot path -- are chosen with an explicit dtype=torch.float32
+        self._dtype = torch.float64
         self.dtype = dtype
         self._engine = engine
         self._kernel = None
 
     # ---- properties mirroring the reference ------------------------------------------------
+    @property
+    def dtype(self) -> torch.dtype:
+        return self._dtype
+
+    @dtype.setter
+    def dtype(self, new_type):
+        """interface/base.py:106-118: anything but a torch.dtype is a TypeError."""
+        if not isinstance(new_type, torch.dtype):
+            raise TypeError("Given object is not a valid torch.dtype, instead it has as type: {0}".format(type(new_type)))
+        if new_type not in (torch.float32, torch.float64):
+            raise TypeError("the gfx950 engine computes in torch.float32 or torch.float64, not {0}".format(new_type))
+        self._dtype = new_type
+
     @property
     def inf_factor(self) -> float:
         return self._inf_factor
@@ -162,7 +178,7 @@ class LETKF(ETKF):
     def __init__(self, localization: Optional[GaspariCohn] = None, inf_factor: float = 1.0,
                  smoother: bool = False, gpu: bool = True, pre_transform=None, post_transform=None,
                  chunksize: int = 10, weight_save_path=None, forward_model=None,
-                 dtype: torch.dtype = torch.float32, engine: Optional[LetkfEngine] = None):
+                 dtype: torch.dtype = torch.float64, engine: Optional[LetkfEngine] = None):
         super().__init__(inf_factor=inf_factor, smoother=smoother, gpu=gpu, pre_transform=pre_transform,
                          post_transform=post_transform, weight_save_path=weight_save_path,
                          forward_model=forward_model, dtype=dtype, engine=engine)
@@ -389,7 +405,7 @@ class KETKF(ETKF):
 
     def __init__(self, kernel, inf_factor: float = 1.0, smoother: bool = False, gpu: bool = True,
                  pre_transform=None, post_transform=None, weight_save_path=None, forward_model=None,
-                 dtype: torch.dtype = torch.float32, engine: Optional[LetkfEngine] = None):
+                 dtype: torch.dtype = torch.float64, engine: Optional[LetkfEngine] = None):
         super().__init__(inf_factor=inf_factor, smoother=smoother, gpu=gpu, pre_transform=pre_transform,
                          post_transform=post_transform, weight_save_path=weight_save_path,
                          forward_model=forward_model, dtype=dtype, engine=engine)
@@ -416,7 +432,7 @@ class LKETKF(LETKF):
     def __init__(self, kernel, localization: Optional[GaspariCohn] = None, inf_factor: float = 1.0,
                  smoother: bool = False, gpu: bool = True, pre_transform=None, post_transform=None,
                  chunksize: int = 10, weight_save_path=None, forward_model=None,
-                 dtype: torch.dtype = torch.float32, engine: Optional[LetkfEngine] = None):
+                 dtype: torch.dtype = torch.float64, engine: Optional[LetkfEngine] = None):
         super().__init__(localization=localization, inf_factor=inf_factor, smoother=smoother, gpu=gpu,
                          pre_transform=pre_transform, post_transform=post_transform, chunksize=chunksize,
                          weight_save_path=weight_save_path, forward_model=forward_model, dtype=dtype, engine=engine)
