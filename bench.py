@@ -114,18 +114,39 @@ def algorithmic_bytes(k, m, P_over_G, n_coord=1):
     return 4.0 * (2 * k * m + (k + 1) * P_over_G + 2 * n_coord * (1 + P_over_G))
 
 
-def profile_summary(world):
+def kernel_base_name(name):
+    """'void mia::letkf_tile2f_kernel<2, 3, 1, false, 4>(mia::Tile2FParams)' -> 'letkf_tile2f_kernel<2, 3, 1, false, 4>'."""
+    if not name:
+        return ""
+    name = name.strip()
+    if name.startswith("void "):
+        name = name[5:]
+    if name.startswith("mia::"):
+        name = name[5:]
+    depth = 0
+    for i, ch in enumerate(name):
+        depth += ch == "<"
+        depth -= ch == ">"
+        if ch == "(" and depth == 0:
+            return name[:i]
+    return name
+
+
+def profile_summary(world, launched=None, k=K_ENS, grid=G_PER_GPU):
     """The committed profile of the dominant kernel on this workload (profiles/latest_c2.json: the summary tools/prof_tile.sh writes
-    from one rocprofv3 --kernel-trace --stats pass and its --pmc passes, FETCH_SIZE / WRITE_SIZE in passes of their own).
-    bench.py cannot run the profiler on itself: everything the line says about counters -- kernel name as recorded, bound
-    evidence, HBM traffic, unit utilisations -- is READ from this one file, so a refreshed profile changes the line without a
-    code edit.  None when the file is absent or was taken on another workload."""
+    from one rocprofv3 --kernel-trace --stats pass of bench.py and its --pmc passes, FETCH_SIZE / WRITE_SIZE in passes of their own).
+    bench.py cannot run the profiler on itself: what the line says about counters -- bound evidence, HBM traffic, unit
+    utilisations -- is READ from this one file, so a refreshed profile changes the line without a code edit.  None when the
+    file is absent, was taken on another workload, or is a profile of ANOTHER KERNEL than the one this run launched (`launched`:
+    mia_last_analysis_kernel, template arguments included): counter figures of one kernel never sit beside another's times."""
     path = os.path.join(ROOT, "profiles", "latest_c2.json")
     if world != 1 or not os.path.exists(path):
         return None
     with open(path) as fh:
         rec = json.load(fh)
-    if rec.get("grid_points") != G_PER_GPU:
+    if rec.get("grid_points") != grid or rec.get("k", K_ENS) != k:
+        return None
+    if launched is not None and kernel_base_name(rec.get("kernel_name_recorded")) != kernel_base_name(launched):
         return None
     return rec
 
@@ -493,8 +514,10 @@ def main():
                           comm_chunks=int(os.environ.get("MIA_COMM_CHUNKS", "4" if args.pipeline_depth == 1 else "1")),
                           native_step=os.environ.get("MIA_NATIVE_STEP", "1") != "0",
                           max_in_flight=max(2, args.pipeline_depth),
-                          prep_streams=int(os.environ.get("MIA_PREP_STREAMS", "5")),
-                          analysis_streams=int(os.environ.get("MIA_ANALYSIS_STREAMS", "1")),
+                          # the fastest route measured under `--steps 20` (profiles/r05_stream_ab.txt): the analysis wavefronts localise
+                          # their own tiles (letkf_tile2f_kernel: two launches per step), three analysis and three preparation streams
+                          prep_streams=int(os.environ.get("MIA_PREP_STREAMS", "3")),
+                          analysis_streams=int(os.environ.get("MIA_ANALYSIS_STREAMS", "3")),
                           fuse_tile_lists={"auto": "auto", "1": True, "0": False}[os.environ.get("MIA_FUSE_TILE_LISTS", "auto")],
                           # N > 1: direct peer writes into IPC-mapped result buffers when the node allows it (self-tested
                           # at set-up, RCCL all-gather otherwise); the result is consumed from the slot buffer, no copy
@@ -566,6 +589,8 @@ def main():
         regions.append(el_i)
     elapsed = float(np.median(regions))
     loop_kernel_ms = runner.kernel_ms()      # the dominant kernel inside the timed loop (every 4th step)
+    runner._note_kernel()                    # ... and its name as the library launched it (before the other routes below run)
+    kname = runner.dominant_kernel_name
     n_timed = len(runner.kernel_timings)
     serial_ms = None
     if depth != 1:           # secondary figure: the unpipelined step (latency of one step incl. its read-back)
@@ -587,49 +612,42 @@ def main():
                      "bitwise_equal_to_full_rebuild": bool(torch.equal(outg, out)),
                      "note": "submit(..., geometry_id=): tile lists reused while grid / observation coordinates stay the same "
                              "(MIA_STEP_REUSE_LISTS); records, analysis, read-back every step"}
-    # separate keys, NOT `value`: the steps in flight on the fused kernel (letkf_tile2f.hip: every analysis wavefront localises its
-    # own tile, two launches per step, no lists in memory) -- with one analysis stream as the headline has it, and with three
-    # analysis / three preparation streams (two or three fused kernels share the chip: more steps per second, each launch slower).
-    # (Two "step streams" -- prep_streams=0, analysis_streams=2: a step's two launches back to back on one of two streams --
-    #  measured 2.11e9 in a process of its own and 1.24e9 as the third runner of this one: whether two streams run beside each
-    #  other depends on the hardware queues the runtime hands out, HISTORY.md; not reported here.)
-    fused_flight = None
+    # separate key, NOT `value`: the same loop on round 4's default route -- tile lists in memory (index_bucket -> localize_tiles ->
+    # letkf_tile2_kernel), one analysis stream, five preparation streams -- so that the two routes are measured in one process, and
+    # their results compared bit for bit
+    lists_flight = None
     if world == 1 and depth != 1 and args.method != "eig":
-        fused_flight = {}
-        for label, n_an, n_pr in (("one_analysis_stream", 1, 5), ("three_analysis_streams", 3, 3)):
-            r2 = ShardedLetkf(device, rank, world, radii=[GC_RADIUS], inf_factor=INF, method=args.method, comm_chunks=1,
-                              max_in_flight=max(2, depth), prep_streams=n_pr, analysis_streams=n_an, copy_results=False,
-                              fuse_tile_lists=True)
+        r2 = ShardedLetkf(device, rank, world, radii=[GC_RADIUS], inf_factor=INF, method=args.method, comm_chunks=1,
+                          max_in_flight=max(2, depth), prep_streams=5, analysis_streams=1, copy_results=False, fuse_tile_lists=False)
 
-            def run2(n):
-                pend, o = collections.deque(), None
-                for it in range(n):
-                    if it % 4 == 0:
-                        r2.time_next_step()
-                    pend.append(r2.submit(X, grid_x, obs_x, Yb, d))
-                    if len(pend) == depth:
-                        o = pend.popleft().result()
-                while pend:
+        def run2(n):
+            pend, o = collections.deque(), None
+            for it in range(n):
+                if it % 4 == 0:
+                    r2.time_next_step()
+                pend.append(r2.submit(X, grid_x, obs_x, Yb, d))
+                if len(pend) == depth:
                     o = pend.popleft().result()
-                return o
-            run2(2 * depth + 2)
-            run2(max(50, args.warmup))
-            r2.kernel_timings.clear()
-            reg = []
-            for _ in range(max(5, repeats // 4)):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                o2 = run2(args.steps)
-                torch.cuda.synchronize()
-                reg.append(time.perf_counter() - t0)
-            el2 = float(np.median(reg))
-            fused_flight[label] = {"ms_per_step": 1e3 * el2 / args.steps, "analyses_per_s": G * args.steps / el2,
-                                   "kernel_ms_in_loop": r2.kernel_ms(), "kernel": r2.dominant_kernel_name,
-                                   "preparation_streams": n_pr, "bitwise_equal_to_lists_in_memory": bool(torch.equal(o2, out))}
-            r2.close()
-        fused_flight["note"] = ("ShardedLetkf(fuse_tile_lists=True): index_bucket (+ record packing) -> letkf_tile2f_kernel, nothing "
-                                "else; the default ('auto') takes this route for steps one at a time (serial_ms_per_step) and "
-                                "lists in memory for steps in flight (`value`: same rate, the analysis launch alone is shorter)")
+            while pend:
+                o = pend.popleft().result()
+            return o
+        run2(2 * depth + 2)
+        run2(max(50, args.warmup))
+        r2.kernel_timings.clear()
+        reg = []
+        for _ in range(max(5, repeats // 4)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            o2 = run2(args.steps)
+            torch.cuda.synchronize()
+            reg.append(time.perf_counter() - t0)
+        el2 = float(np.median(reg))
+        lists_flight = {"ms_per_step": 1e3 * el2 / args.steps, "analyses_per_s": G * args.steps / el2,
+                        "kernel_ms_in_loop": r2.kernel_ms(), "kernel": r2.dominant_kernel_name,
+                        "analysis_streams": 1, "preparation_streams": 5, "bitwise_equal_to_value_route": bool(torch.equal(o2, out)),
+                        "note": "ShardedLetkf(fuse_tile_lists=False, analysis_streams=1, prep_streams=5): round 4's default; the list "
+                                "kernel of step i + 1 runs beside the analysis kernel of step i, whose launch is the shorter one"}
+        r2.close()
     assert out.shape == (1, K_ENS, G) and bool(torch.isfinite(out).all())
     assert runner.last_flags_ok(), "kernel flagged grid points"
 
@@ -639,7 +657,6 @@ def main():
     p_max = runner.last_p_max
     deg = runner.mean_degree()
     deg_tile = runner.mean_tile_degree()
-    kname = runner.dominant_kernel_name
     kkind = "tile2" if "tile2" in kname else (("tile_split" if "true>" in kname else "tile") if "tile" in kname else "point")
 
     def rates(k, p, m, dg, n_pts, ms, kind):
@@ -891,7 +908,7 @@ def main():
 
     if rank == 0:
         value = G * args.steps / elapsed
-        prof = profile_summary(world)
+        prof = profile_summary(world, launched=kname)
         pdv = (prof or {}).get("derived", {})
         line = {
             "metric": "local analyses/sec (LETKF, 40-member)", "value": value, "unit": "analyses/s",
@@ -914,57 +931,72 @@ def main():
                        "parallelism": "grid-point block shard x%d%s" % (world, " + all-gather of the analysis ensemble over xGMI "
                                                                         "(%s)" % runner.exchange_route if world > 1 else ""),
                        "ranks": world},
-            # frac = USEFUL f32 flops of one launch / its measured duration / FP32 peak: <= 1 by construction (no padding, no
-            # credit for the Gram matrix sixteen points share, no credit for the eigensolve the route does not execute).
-            # What the kernel executes (padded, on the half-precision matrix pipe) is reported beside it under its own keys.
-            "roofline": {"bound": ("vector_issue+latency" if kkind != "point" else "valu_issue"),
-                         "bound_evidence": bound_evidence(prof),
-                         "valu_busy": pdv.get("valu_busy_frac"), "mfma_busy": pdv.get("mfma_busy_frac"),
-                         "wait_any_over_wave_cycles": pdv.get("sq_wait_any_over_wave_cycles"),
-                         "achieved": us_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": None if us_tf is None else us_tf / PEAK_FP32_TFLOPS,
-                         "frac_basis": ("useful f32 flops per analysis (symmetric Gram k p (p+1), per state row 4 k p + 2 deg p^2, "
-                                        "taper 25 p: no padding, nothing shared) x analyses per launch / launch duration inside the "
-                                        "timed loop / FP32 peak"),
-                         "useful_flops_per_analysis": us_f,
-                         "frac_shared_gram_basis": None if not deg else useful_flops_shared(K_ENS, 20, 1, deg) * gpg / (kern_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
-                         "frac_shared_gram_note": "the same with the Gram matrix counted once per tile of sixteen points (k U (U+1) / 16 "
-                                                  "per analysis, U = 28): what a tile-shaped algorithm needs at least",
-                         "frac_alone": None if (us_f is None or not alone_ms) else us_f * gpg / (alone_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
-                         "executed_f32_equivalent": None if ex_tf is None else {
-                             "flops_per_analysis": ex_f, "TFLOPs": ex_tf, "ratio_to_fp32_peak": ex_tf / PEAK_FP32_TFLOPS,
-                             "note": "the f32 products (padding to 16 x 16 x 32 blocks and the shared Gram matrix included) that the "
-                                     "kernel's half-precision MFMA triples implement + its vector-unit update; they run on the "
-                                     "half-precision matrix pipe, so this ratio is NOT bounded by 1 and is not a utilisation"},
-                         "matrix_core": None if f16_tf is None else {
-                             "executed_f16_mfma_flops_per_analysis": f16_f, "achieved": f16_tf, "peak": PEAK_F16_TFLOPS,
-                             "unit": "TFLOP/s", "frac": f16_tf / PEAK_F16_TFLOPS,
-                             "note": "v_mfma_f32_16x16x32_f16, three per f32 product"},
-                         "reference_algorithm_credit": {"flops_per_analysis": algorithmic_flops(K_ENS, 20, 1), "TFLOPs": credit_tf,
-                                                        "ratio_to_peak": credit_tf / PEAK_FP32_TFLOPS,
-                                                        "note": "SURVEY 8(d) count of the reference's algorithm (9k^3 symmetric-QR "
-                                                                "eigensolve) per analysis: NOT executed by the matrix-function "
-                                                                "route, not a utilisation"},
-                         "traffic": pdv.get("hbm_bytes_fetch_doubled"),
-                         "traffic_source": "offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/prof_tile.sh on "
-                                           "tools/prof_kernel.py, this workload), read from profiles/latest_c2.json; gfx950 counts "
-                                           "half of wide coalesced streaming reads in FETCH_SIZE (MI355X_MICROARCH.md): `traffic` doubles "
-                                           "the fetch side, traffic_raw does not",
-                         "traffic_raw": pdv.get("hbm_bytes_raw"),
-                         "traffic_algorithmic_bytes": algorithmic_bytes(K_ENS, 1, P / G) * gpg,
-                         "kernel_name_recorded_by_rocprof": (prof or {}).get("kernel_name_recorded"),
-                         "kernel_average_ns_rocprof": ((prof or {}).get("kernel_trace") or {}).get("average_ns"),
-                         "kernel": (prof or {}).get("kernel_name_recorded") or kname, "kernel_ms": kern_ms,
-                         "kernel_ms_source": ("start / stop HIP events of the kernel's own dispatch (hipExtLaunchKernel, analysis "
-                                              "stream) on every 4th step of the timed loop (%d launches)" % n_timed)
+            # SURVEY 8(d) / the round contract: achieved = ALGORITHMIC bytes per launch (414 B per analysis at config 2: state in,
+            # analysis out, each observation's record and coordinates once) / the dominant kernel's launch duration measured in the
+            # timed loop; peak = HBM.  With the eigensolve gone (matrix functions instead: no 9 k^3 term is executed) HBM is the
+            # governing algorithmic roof; the ceilings that bind in practice -- vector issue, the matrix pipe -- are listed beside it.
+            "roofline": {"bound": "hbm",
+                         "achieved": hbm_alg, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_alg / PEAK_HBM_GBS,
+                         "frac_basis": "%.0f algorithmic bytes per analysis (SURVEY 8(d): 4 (2 k m + (k + 1) P / G + 2 n_coord (1 + P / G))) x %d "
+                                       "analyses per launch / kernel_ms / 8 TB/s" % (algorithmic_bytes(K_ENS, 1, P / G), gpg),
+                         "algorithmic_bytes_per_launch": algorithmic_bytes(K_ENS, 1, P / G) * gpg,
+                         "step_frac": algorithmic_bytes(K_ENS, 1, P / G) * gpg / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBS,
+                         "step_frac_note": "the same bytes / ms_per_step / peak: the whole step (index + packing + fused analysis) "
+                                           "against the HBM roof",
+                         "frac_alone": algorithmic_bytes(K_ENS, 1, P / G) * gpg / (alone_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if alone_ms else None,
+                         "kernel": kernel_base_name(kname), "kernel_ms": kern_ms,
+                         "kernel_ms_source": ("start / stop HIP events of the kernel's own dispatch (hipExtLaunchKernel, on the analysis "
+                                              "stream it is launched on) on every 4th step of the timed loop (%d launches); with %d "
+                                              "analysis streams up to that many of these launches share the chip, so a launch lasts "
+                                              "longer than it does alone (kernel_ms_alone: letkf_tile2_kernel on lists in memory, burst "
+                                              "of launches on an idle GPU)" % (n_timed, runner.analysis_streams))
                                              if loop_kernel_ms else "burst of 5 launches after the timed loop",
                          "kernel_ms_alone": alone_ms,
-                         "hbm_algorithmic_GBs": hbm_alg, "hbm_frac": hbm_alg / PEAK_HBM_GBS,
+                         "traffic": pdv.get("hbm_bytes_fetch_doubled"),
+                         "traffic_raw": pdv.get("hbm_bytes_raw"),
+                         "traffic_source": ("offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel on this workload, "
+                                            "read from profiles/latest_c2.json (%s); gfx950 counts half of wide coalesced streaming "
+                                            "reads in FETCH_SIZE (MI355X_MICROARCH.md): `traffic` doubles the fetch side, traffic_raw "
+                                            "does not" % (prof or {}).get("source")) if prof else
+                                           "none: profiles/latest_c2.json is absent or is a profile of another kernel / workload",
+                         "kernel_name_recorded_by_rocprof": (prof or {}).get("kernel_name_recorded"),
+                         "kernel_average_ns_rocprof": ((prof or {}).get("kernel_trace") or {}).get("average_ns"),
+                         "bound_evidence": bound_evidence(prof),
+                         # the ceilings beside the algorithmic one: which unit is how busy (counters: kernel alone, profiles/)
+                         "ceilings": {"hbm_algorithmic": hbm_alg / PEAK_HBM_GBS,
+                                      "matrix_core_f16": None if f16_tf is None else f16_tf / PEAK_F16_TFLOPS,
+                                      "vector_issue_busy": pdv.get("valu_busy_frac"), "matrix_pipe_busy": pdv.get("mfma_busy_frac"),
+                                      "wait_any_over_wave_cycles": pdv.get("sq_wait_any_over_wave_cycles"),
+                                      "note": "the kernel is bound by instruction issue and latency (vector unit ~50 % busy, a wave "
+                                              "issues on a quarter of its cycles), not by bytes or matrix flops: every fraction "
+                                              "here is far from 1, the largest is the vector unit's"},
+                         "compute_view": {
+                             "frac_useful_shared": None if not deg else useful_flops_shared(K_ENS, 20, 1, deg) * gpg / (kern_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                             "frac_useful_shared_basis": "useful f32 flops with the Gram matrix counted ONCE per tile of sixteen points "
+                                                         "(k U (U+1) / 16 per analysis, U = 28) + per state row 4 k p + 2 deg p^2 + taper "
+                                                         "25 p, no padding / kernel_ms / FP32 peak 157.3 TFLOP/s",
+                             "frac_unshared_credit": None if us_tf is None else us_tf / PEAK_FP32_TFLOPS,
+                             "frac_unshared_credit_note": "rounds 2-4 quoted this as `frac`: it credits the shared Gram matrix sixteen "
+                                                          "times (a per-point algorithm's count) -- kept for continuity, not a roofline",
+                             "useful_flops_per_analysis_unshared": us_f,
+                             "executed_f32_equivalent": None if ex_tf is None else {
+                                 "flops_per_analysis": ex_f, "TFLOPs": ex_tf, "ratio_to_fp32_peak": ex_tf / PEAK_FP32_TFLOPS,
+                                 "note": "the f32 products (padding to 16 x 16 x 32 blocks and the shared Gram matrix included) that the "
+                                         "kernel's half-precision MFMA triples implement + its vector-unit update; they run on the "
+                                         "half-precision matrix pipe, so this ratio is NOT bounded by 1 and is not a utilisation"},
+                             "matrix_core": None if f16_tf is None else {
+                                 "executed_f16_mfma_flops_per_analysis": f16_f, "achieved": f16_tf, "peak": PEAK_F16_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": f16_tf / PEAK_F16_TFLOPS,
+                                 "note": "v_mfma_f32_16x16x32_f16, three per f32 product"},
+                             "reference_algorithm_credit": {"flops_per_analysis": algorithmic_flops(K_ENS, 20, 1), "TFLOPs": credit_tf,
+                                                            "ratio_to_fp32_peak": credit_tf / PEAK_FP32_TFLOPS,
+                                                            "note": "SURVEY 8(d) count of the reference's algorithm (9k^3 symmetric-QR "
+                                                                    "eigensolve) per analysis: NOT executed by the matrix-function "
+                                                                    "route (the ratio exceeds 1), not a utilisation"}},
                          "note": "sixteen grid points per wavefront share one Gram matrix; every contraction is a triple of "
-                                 "half-precision MFMAs on operands carried as pairs of halves (f32 accuracy; f32 MFMAs share the FP32 "
-                                 "pipe with the vector instructions, tools/mfma_rate.hip).  The wave starts at the gather: union, ranks "
-                                 "and sqrt(rho) matrix come tile-shaped from the localisation kernel, the records arrive split and "
-                                 "per-record scaled, straight into LDS (LDS-DMA)."},
+                                 "half-precision MFMAs on operands carried as pairs of halves (f32 accuracy).  The wavefront "
+                                 "localises its own tile over the step's bucket index (Gaspari-Cohn, union, ranks, sqrt(rho)), then "
+                                 "gathers the union's split records straight into LDS (LDS-DMA) and analyses the tile."},
             "route": {"method": args.method, "mean_chebyshev_degree": deg, "mean_chebyshev_degree_per_tile_max": deg_tile,
                       "degree_note": "per-point mean (what the useful-flop credit uses) and the mean over tiles of the largest degree "
                                      "in the tile (what a tile's wavefront executes)",
@@ -972,21 +1004,33 @@ def main():
                       "eigensolver_route_kernel_ms": eig_ms,
                       "eigensolver_route_kernel_analyses_per_s": (gpg / (eig_ms * 1e-3)) if eig_ms else None},
             "pipeline": {"depth": depth, "serial_ms_per_step": serial_ms,
-                         "serial_route": ("index_bucket (+ record packing) -> letkf_tile2f_kernel (the wavefronts localise their own "
-                                          "tiles: two launches per step)") if getattr(runner, "fuse_tile_lists", None) in ("auto", True)
-                                         else "index_bucket (+ record packing) -> localize_tiles -> letkf_tile2_kernel",
+                         "route": ("index_bucket (+ record packing) -> letkf_tile2f_kernel (the wavefronts localise their own "
+                                   "tiles: two launches per step)") if "tile2f" in kname
+                                  else "index_bucket (+ record packing) -> localize_tiles -> %s" % kernel_base_name(kname),
+                         "analysis_streams": runner.analysis_streams,
                          "preparation_streams": {"n": runner.prep_streams,
-                                                 "note": "plain HIP streams taken in turn by the steps in flight (the hardware-queue "
-                                                         "probing of round 3 measured no gain under these flags and is gone: "
-                                                         "profiles/r04_stream_ab.txt)"},
+                                                 "note": "plain HIP streams taken in turn by the steps in flight; stream counts "
+                                                         "A/B under --steps 20: profiles/r05_stream_ab.txt"},
                          "fixed_geometry": fixed_geo,
-                         "fused_in_flight": fused_flight,
+                         "lists_in_memory_in_flight": lists_flight,
                          "serial_analyses_per_s": (G / (serial_ms * 1e-3)) if serial_ms else None,
                          "note": "depth d > 1: consecutive (independent) steps are software-pipelined over d slots / HIP "
                                  "streams; every step is fully computed, exchanged and validated inside the timed "
                                  "region.  serial_*: the same step run one at a time (what a cycled filter, whose step i+1 "
                                  "depends on step i, gets)"},
             "multi_gpu": multi,
+            # stated BEFORE any 8-GPU run exists, from this run's own step time and the xGMI link rate: at N ranks
+            # every rank sends its (m k G/N... here gpg-point) block to N - 1 peers, one link each, all links at once
+            "multi_gpu_prediction": (lambda t1, blk: {
+                "step_ms_1gpu": t1, "block_bytes_per_rank": blk,
+                "exchange_ms_at_77_GBs_per_link_direction": 1e3 * blk / 77e9,
+                "predicted_speedup_gathered": {str(n): n * t1 / max(t1, 1e3 * blk / 77e9) for n in (2, 4, 8)},
+                "predicted_speedup_sharded_output": {str(n): float(n) for n in (2, 4, 8)},
+                "note": "weak scaling, %d points per rank: gathered = every rank ends with the whole analysis (the all-gather's %.0f MB "
+                        "per link and step bound the step once they take longer than the compute: >= 6x is out of reach of the gathered "
+                        "metric on xGMI); sharded output (ShardedLetkf(gather=False), what the reference's dask chunks do) has no "
+                        "exchange.  No N > 1 measurement exists yet (no 8-GPU node was available to any round)" % (gpg, blk / 1e6)})(
+                    1e3 * elapsed / args.steps if world == 1 else None, 4.0 * K_ENS * gpg) if world == 1 else None,
             "e2e_ms_incl_h2d_d2h": e2e_ms,
             "stages_ms": stage_ms,
             "secondary": secondary,

@@ -99,6 +99,10 @@ const char* mia_status_string(int status);
  * Returns MIA_ERR_UNSUPPORTED for an unknown name, MIA_ERR_SIZE for a value out of range. */
 int mia_set_option(const char* name, int value);
 int mia_get_option(const char* name, int* value);
+/* The analysis kernel launched last by any entry point of this process, under the name rocprofv3 records for it (template
+ * arguments included, e.g. "letkf_tile2f_kernel<2, 3, 1, false, 4>"), NUL-terminated into buf[n]; "" before the first launch.
+ * Diagnostics only (bench lines and tools label their figures with the kernel that ran): not a route switch. */
+int mia_last_analysis_kernel(char* buf, int n);
 
 /* ------------------------------------------------------------------------------------
  * Gaspari-Cohn taper of normalised distances r = dist / c (unit-testable stage).
@@ -590,6 +594,11 @@ int mia_comm_destroy(mia_comm_t* comm);
 const char* mia_comm_last_error(void);
 int mia_letkf_sharded_step_workspace_bytes(int64_t G, int m, int k, int64_t P, int n_coord, int world,
                                            int n_chunks, int p_max_assumed, size_t* bytes);
+/* The library remembers, per workspace ADDRESS, what the tile lists in it were built for (geometry epochs, MIA_STEP_REUSE_LISTS)
+ * and which of its two per-cell count arrays the next bucket build takes.  Call this before a step workspace is freed or handed to
+ * another geometry's steps: the next step on that address then starts from scratch (full clear, lists rebuilt), whatever its
+ * flags say.  A step in flight is not affected (its decisions travel with it).  Always MIA_OK. */
+int mia_letkf_step_workspace_release(void* ws);
 int mia_letkf_sharded_step_f32(const float* X /* [m][k][G] */, int64_t G, int m, int k,
                                const float* Yb /* [k][P] */, const float* d /* [P] */, int64_t P,
                                const double* grid_xyz /* [G][n_coord] */, const double* obs_xyz /* [P][n_coord] */,

@@ -22,6 +22,25 @@ def pytest_configure(config):
         torch.set_num_threads(4)
     except Exception:
         pass
+    # GPU sessions: fork the oracle's worker pool NOW, before any test initialises the GPU in this process (tests/oracle_pool.py:
+    # the all-points comparisons of tests/test_gpu_fullsize.py).  torch.cuda.device_count() does not create a HIP context.
+    expr = (config.getoption("-m", default="") or "").replace(" ", "")
+    if "gpu" in expr and "notgpu" not in expr:
+        try:
+            import torch
+            if torch.cuda.device_count() > 0:
+                import oracle_pool
+                oracle_pool.start()
+        except Exception:       # (the tests that need the pool say so)
+            pass
+
+
+def pytest_unconfigure(config):
+    try:
+        import oracle_pool
+        oracle_pool.stop()
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

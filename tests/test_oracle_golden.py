@@ -199,3 +199,27 @@ def test_g9_localised_ienks(golden):
             w = O.lienks_weights(w, gx, ox, yb * (1.0 if eps is None else eps), d, 10.0, tau, eps)
             assert rel_fro(w[::8], g[f"loc_{vname}_it{it}_weights"]) < 1e-10, (vname, it)
         assert rel_fro(O.apply_weights(st, w), g[f"loc_{vname}_analysis"]) < 1e-10
+
+
+def test_oracle_pool_equals_the_oracle_called_directly():
+    """tests/oracle_pool.py (the worker pool behind the all-points GPU comparisons): windowed per-point evaluation in forked workers
+    == letkf_oracle.letkf_analysis over all observations, ETKF and RBF-KETKF cores."""
+    import oracle_pool
+    from oracle import letkf_oracle as O
+    case = O.synthetic_case(600, 12, 2)
+    was = oracle_pool.started()
+    oracle_pool.start()
+    try:
+        pts = np.arange(0, 600, 3)
+        got = oracle_pool.oracle_analysis(case["state"], case["grid_x"], case["obs_x"], case["yb"], case["d"], 10.0, 1.1, pts, chunk=37)
+        ref, _ = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], case["yb"], case["d"], 10.0, 1.1)
+        np.testing.assert_allclose(got, ref[:, :, pts], rtol=0, atol=1e-12)
+        core = lambda a, b, i: O.ketkf_weights(a, b, lambda x, y: O.rbf_kernel(x, y, 0.5), i)      # noqa: E731
+        gk = oracle_pool.oracle_analysis(case["state"], case["grid_x"], case["obs_x"], case["yb"], case["d"], 10.0, 1.1, pts[:40], gamma=0.5)
+        rk, _ = O.letkf_analysis(case["state"][:, :, pts[:40]], case["grid_x"][pts[:40]], case["obs_x"], case["yb"], case["d"], 10.0, 1.1, core=core)
+        np.testing.assert_allclose(gk, rk, rtol=0, atol=1e-12)
+        per, fro = oracle_pool.per_point_errors(got, ref[:, :, pts])
+        assert per.shape == (len(pts),) and fro < 1e-12
+    finally:
+        if not was:
+            oracle_pool.stop()

@@ -6,6 +6,10 @@ included (the compiler had padded only the fall-through side).  Usage: python to
 import re, subprocess, sys, os, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NEED = 8          # what the compiler itself pads v_mfma_f32_16x16x32_f16 (4 passes) -> vector reader to on straight-line code
+# wait states an INTERVENING matrix instruction stands for: the matrix pipe of a SIMD takes its instructions in order and is busy 16
+# cycles (4 passes) with a 16x16x32 half-precision one (MI355X_MICROARCH.md: ~16 cycles per MFMA back to back on one SIMD), so the one
+# behind it cannot have started, let alone a vector instruction behind that, earlier than 4 issue slots after it
+MFMA_WS = 4
 
 
 def regs(tok):
@@ -67,6 +71,8 @@ def check(asm):
                         break
                 if o == "s_nop":
                     ws += int(a[0]) + 1
+                elif o.startswith("v_mfma"):
+                    ws += MFMA_WS        # the matrix pipe issues in order: a later matrix instruction starts >= 16 cycles after this one
                 else:
                     ws += 1
                 if o == "s_branch":

@@ -22,6 +22,7 @@ _PROTOS = {
     "mia_status_string": ([i32], C.c_char_p),
     "mia_set_option": ([C.c_char_p, i32], i32),
     "mia_get_option": ([C.c_char_p, C.POINTER(C.c_int)], i32),
+    "mia_last_analysis_kernel": ([C.c_char_p, i32], i32),
     "mia_gaspari_cohn_f64": ([vp, i64, vp, vp], i32),
     "mia_gaspari_cohn_f32": ([vp, i64, vp, vp], i32),
     "mia_gaspari_cohn_inf_f64": ([vp, i64, vp, vp], i32),
@@ -121,6 +122,7 @@ _PROTOS = {
     "mia_comm_destroy": ([vp], i32),
     "mia_comm_last_error": ([], C.c_char_p),
     "mia_letkf_sharded_step_workspace_bytes": ([i64, i32, i32, i64, i32, i32, i32, i32, C.POINTER(sz)], i32),
+    "mia_letkf_step_workspace_release": ([vp], i32),
     "mia_letkf_sharded_step_f32": ([vp, i64, i32, i32, vp, vp, i64, vp, vp, i32, C.POINTER(C.c_int32), C.POINTER(f64),
                                     i32, f64, f32, f32, i32, i32, vp, i32, i32, vp, vp, vp, vp, sz, vp, vp], i32),
     "mia_letkf_step_timing_events": ([vp, vp], i32),
@@ -164,6 +166,13 @@ def set_option(name: str, value: int) -> int:
     check(lib().mia_get_option(name.encode(), C.byref(old)), "mia_get_option(%s)" % name)
     check(lib().mia_set_option(name.encode(), int(value)), "mia_set_option(%s)" % name)
     return old.value
+
+
+def last_analysis_kernel() -> str:
+    """mia_last_analysis_kernel: the analysis kernel launched last, as rocprofv3 names it ('' before the first launch)."""
+    buf = C.create_string_buffer(160)
+    check(lib().mia_last_analysis_kernel(buf, 160), "mia_last_analysis_kernel")
+    return buf.value.decode()
 
 
 def check(status, what):

@@ -36,6 +36,31 @@ void option_snapshot(int* out) { for (int i = 0; i < MIA_OPT_COUNT_; ++i) out[i]
 void option_override(const int* snapshot) { t_override = snapshot; }
 }  // namespace mia
 
+// ---- the analysis kernel launched last (any thread), as rocprofv3 names it
+#include <cstdarg>
+#include <cstdio>
+#include <mutex>
+namespace mia {
+static std::mutex g_last_mu;
+static char g_last_kernel[160] = "";
+void note_analysis_kernel(const char* fmt, ...) {
+  char buf[sizeof(g_last_kernel)];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  std::lock_guard<std::mutex> lk(g_last_mu);
+  memcpy(g_last_kernel, buf, sizeof(buf));
+}
+}  // namespace mia
+
+extern "C" int mia_last_analysis_kernel(char* buf, int n) {
+  if (!buf || n < 1) return MIA_ERR_NULL;
+  std::lock_guard<std::mutex> lk(mia::g_last_mu);
+  snprintf(buf, (size_t)n, "%s", mia::g_last_kernel);
+  return MIA_OK;
+}
+
 static const char* const kOptNames[MIA_OPT_COUNT_] = {"cheb_dmax", "cheb_table", "cheb_rowbatch", "cheb_big", "tile",
                                                       "tile_split", "localize_quad", "step_hostwait", "step_lazy_sort",
                                                       "segment_signal", "tile_lists", "bucket_index", "tile_pair", "tile_fused"};

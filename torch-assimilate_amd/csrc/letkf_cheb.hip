@@ -1536,6 +1536,7 @@ static int cheb_launch_w(const ChebParams& ap, size_t lds, hipStream_t stream) {
   const int64_t gy = (nblk + gx - 1) / gx;
   if (gy > 65535) return MIA_ERR_UNSUPPORTED;
   kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64 * WPB), tot, stream>>>(ap);
+  note_analysis_kernel("letkf_cheb_kernel<%d, %d, %s, %d>", NMAX, KL, FUSED ? "true" : "false", WPB);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

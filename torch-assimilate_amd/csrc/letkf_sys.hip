@@ -19,6 +19,7 @@
 //    out in natural order at every sweep boundary (the only place the loop can stop).
 #include <cstdlib>
 #include "mia_common.h"
+#include "mia_kernels.h"
 #include "mia_options.h"
 
 namespace mia {
@@ -611,6 +612,7 @@ static int sys_launch(const SysParams& ap, size_t lds, dim3 grid, hipStream_t st
   auto kern = letkf_sys_kernel<NMAX, NT>;
   if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   kern<<<grid, dim3(NT), lds, stream>>>(ap);
+  if (!ap.only_flagged) note_analysis_kernel("letkf_sys_kernel<%d, %d>", NMAX, NT);      // (the redo of declined points is not a step's analysis kernel)
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

@@ -1078,6 +1078,7 @@ static int tile_launch_s(const TileParams& tp, hipStream_t stream) {
     kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64), lds, stream>>>(tpl);
   }
   ++tile_launch_count();
+  note_analysis_kernel("letkf_tile_kernel<%d, %d, %s, %s>", UT, KT, SEG ? "true" : "false", SPL ? "true" : "false");
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

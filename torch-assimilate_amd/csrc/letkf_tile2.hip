@@ -79,6 +79,7 @@ static int tile2_launch_m(const Tile2Params& tp, hipStream_t stream) {
     kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64), lds, stream>>>(tp);
   }
   ++tile_launch_count();
+  note_analysis_kernel("letkf_tile2_kernel<%d, %d, %s, %d>", UT, KT, MROWS ? "true" : "false", WAVES);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
@@ -123,6 +124,9 @@ bool tile2_covers(int m, int k, int p_max, int extra_blocks, int64_t ldx, int64_
   return ((ng + 15) >> 4) <= (int64_t)65536 * 65535;
 }
 
+// the kernels address a record as base + 32-bit byte offset: (P + 1) records must fit 4 GB (2.4e7 observations at k = 40)
+bool tile2_records_addressable(int k, int64_t P) { return (P + 1) * (int64_t)split_rec_bytes(k) < ((int64_t)1 << 32); }
+
 int tile2_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const void* rec, int64_t P,
                           const void* tile_lists, int ut, float inf_factor, float* Xa, int64_t ldo, int64_t o0,
                           int32_t* flags, int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c,
@@ -131,6 +135,7 @@ int tile2_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0,
   if (!flags || !retry_count || !tab_hdr || !tab_c || !tile_lists || !rec) return MIA_ERR_UNSUPPORTED;
   const int kt = (k + 15) >> 4;
   if (ut < 1 || ut > 6 || ut > kt + 1 || !tile2_covers(m, k, 0, ut - 1, ldx, ldo, ng)) return MIA_ERR_UNSUPPORTED;
+  if (!tile2_records_addressable(k, P)) return MIA_ERR_UNSUPPORTED;
   const TileListLayout L = tile_list_layout(ng, ut);
   const char* base = (const char*)tile_lists;
   Tile2Params tp;

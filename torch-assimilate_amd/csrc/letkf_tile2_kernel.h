@@ -182,33 +182,50 @@ __device__ __forceinline__ void tile2_body(Tile2Params P, const Tile2Loc* loc, c
   // ---- second round trip: the union's records, straight into the LDS image (load u, lane l = piece line 4 u + (l >> 4), column
   //      l & 15), and their tails (innovation, scale) -- consumed only after the Gram product
   {
-    const int g = lane >> 4, hl = g & 1;
-    int tc = g >> 1;                                     // (row block, chunk) index of this lane's piece line, load 0
+    // Every lane's pieces belong to at most 2 UT records: row 16 t + ((lr - 8 par) & 15) of row block t for the chunks of parity
+    // par.  Their byte offsets into the record array are formed ONCE (32-bit: (P + 1) rb < 2^32, checked on the host) -- round 4
+    // looked the slot up in LDS and multiplied in 64 bits for every one of the five or six loads (25 vector instructions each).
+    const int g = lane >> 4, hl = g & 1, gh = g >> 1;
+    unsigned roff[UT][2];
+#pragma unroll
+    for (int t = 0; t < UT; ++t)
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const int idx = ukey[16 * t + ((lr - 8 * par) & 15)];
+        roff[t][par] = (unsigned)(idx < 0 ? (int)P.zero_rec : idx) * (unsigned)P.rb + 16u * (unsigned)hl;
+      }
     constexpr int NLmax = (UT * 2 * KT + 1) / 2;
 #pragma unroll
     for (int u = 0; u < NLmax; ++u) {
       if (2 * u < UT * nc8) {                            // (wave-uniform)
-        int t = 0, c = tc;
+        // piece lines 2 u (lane groups 0, 1) and 2 u + 1 (groups 2, 3): (row block, chunk) of each -- scalar arithmetic
+        int tA = 0, cA = 2 * u, tB = 0, cB = 2 * u + 1;
 #pragma unroll
-        for (int i = 1; i < UT; ++i)
-          if (c >= nc8) { c -= nc8; ++t; }
-        const bool valid = tc < UT * nc8;
-        const int r = 16 * t + ((lr - 8 * (c & 1)) & 15);
-        const int idx = valid ? ukey[r] : -1;
-        const int64_t j = idx < 0 ? P.zero_rec : (int64_t)idx;
-        const unsigned char* src = P.rec + j * P.rb + (32 * c + 16 * hl);
+        for (int i = 1; i < UT; ++i) {
+          if (cA >= nc8) { cA -= nc8; ++tA; }
+          if (cB >= nc8) { cB -= nc8; ++tB; }
+        }
+        unsigned roA = roff[0][0], roB = roff[0][0];
+#pragma unroll
+        for (int t = 0; t < UT; ++t)
+#pragma unroll
+          for (int par = 0; par < 2; ++par) {
+            roA = (tA == t && (cA & 1) == par) ? roff[t][par] : roA;
+            roB = (tB == t && (cB & 1) == par) ? roff[t][par] : roB;
+          }
+        const unsigned off = gh ? roB + 32u * (unsigned)cB : roA + 32u * (unsigned)cA;
+        const bool valid = 2 * u + gh < UT * nc8;
         if (valid)
-          __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>(src),
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>(P.rec + off),
                                            (__attribute__((address_space(3))) void*)(smem + u * 1024), 16, 0, 0);
       }
-      tc += 2;
     }
   }
   f2w tails[(UMAX + 63) / 64];
 #pragma unroll
   for (int r = 0; r < (UMAX + 63) / 64; ++r) {
-    const int64_t j = myidx[r] < 0 ? P.zero_rec : (int64_t)myidx[r];
-    tails[r] = *reinterpret_cast<const f2w*>(P.rec + j * P.rb + 32 * nc8);
+    const unsigned j = (unsigned)(myidx[r] < 0 ? (int)P.zero_rec : myidx[r]);
+    tails[r] = *reinterpret_cast<const f2w*>(P.rec + (j * (unsigned)P.rb + 32u * (unsigned)nc8));
   }
   T2_STAMP(2);        // gather requested
 
@@ -225,40 +242,7 @@ __device__ __forceinline__ void tile2_body(Tile2Params P, const Tile2Loc* loc, c
   bool decl = false;
   // ---- x' = x - mean as scaled half pairs (one power of two per column)
   auto split_x = [&](float (&xsb)[NB][8], float& xm, float& inv_sx, h8v (&xh)[NB], h8v (&xl)[NB]) {
-      float xs = 0.0f;
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const bool live = colok && 8 * (4 * b + sg) + i < k;
-          xsb[b][i] = live ? xsb[b][i] : 0.0f;
-          xs += xsb[b][i];
-        }
-      xm = t2_add_h(xs) * P.inv_k;
-      unsigned xmax = 0u;
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const bool live = colok && 8 * (4 * b + sg) + i < k;
-          xsb[b][i] = live ? xsb[b][i] - xm : 0.0f;
-          const unsigned a = __float_as_uint(xsb[b][i]) & 0x7fffffffu;
-          xmax = a > xmax ? a : xmax;
-        }
-      xmax = t2_max_h(xmax);
-      int esx;
-      const float sx = pow2_scale(xmax, 9, &esx);
-      inv_sx = __uint_as_float((unsigned)(127 - esx) << 23);
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        float t8[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) t8[i] = xsb[b][i] * sx;
-        // (tied in the row loop: there this follows the previous row's output products closely and the fresh outputs of the untied
-        //  form landed on an accumulator still in flight -- tools/check_mfma_hazards.py on the fused many-rows instantiations)
-        if constexpr (MROWS) split8_tied(t8, xh[b], xl[b]);
-        else split8(t8, xh[b], xl[b]);
-      }
+      t2_split_x<NB, MROWS>(xsb, colok, sg, k, P.inv_k, xm, inv_sx, xh, xl);
     };
   // ---- first state row: Gram matrix, interval and degree of every point (shared by all rows), its own Z
   float xm0, inv_sx0;
@@ -368,14 +352,13 @@ __device__ __forceinline__ void tile2_body(Tile2Params P, const Tile2Loc* loc, c
           R[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, ag), dh, R[t], 0, 0, 0);
         }
       }
+    // (a plain maximum: a non-finite record was sent to the eigensolver kernel above, so nothing here is NaN; round 4's NaN-keeping
+    //  form was two comparisons and a select per value)
     float L = 0.0f;
 #pragma unroll
     for (int t = 0; t < UT; ++t)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float v = dreg[t][q] * R[t][q];
-        L = (v > L || v != v) ? v : L;
-      }
+      for (int q = 0; q < 4; ++q) L = __builtin_fmaxf(L, dreg[t][q] * R[t][q]);
     L = __uint_as_float(t2_max_h(__float_as_uint(L))) * inv_sd;
     L = fmaxf(L, 1e-37f) * 1.002f;       // (in units of 2^-16; half-precision operands: 2 x 2^-11)
     if (!(L == L) || !(fabsf(L) < 1e30f)) { pflag |= MIA_FLAG_NONFINITE; L = 1.0f; }
@@ -410,19 +393,16 @@ __device__ __forceinline__ void tile2_body(Tile2Params P, const Tile2Loc* loc, c
     f4w va[UT], vb[UT], aphi[UT], apsi[UT], ad2[UT];
     float inv_s2;
     {
-      unsigned zmax = 0u;
+      float zmaxf = 0.0f;
 #pragma unroll
       for (int t = 0; t < UT; ++t) {
         const f4w d2 = dreg[t] * dreg[t];
         ad2[t] = alpha * d2;
         va[t] = Z[t] * d2;                     // u_0
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const unsigned a = __float_as_uint(va[t][q]) & 0x7fffffffu;
-          zmax = a > zmax ? a : zmax;
-        }
+        for (int q = 0; q < 4; ++q) zmaxf = __builtin_fmaxf(zmaxf, __builtin_fabsf(va[t][q]));
       }
-      zmax = t2_max_h(zmax);
+      const unsigned zmax = t2_max_h(__float_as_uint(zmaxf));
       int es2;
       const float s2 = pow2_scale(zmax, 8, &es2);
       inv_s2 = __uint_as_float((unsigned)(127 - es2) << 23);

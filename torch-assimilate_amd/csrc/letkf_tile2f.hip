@@ -53,6 +53,7 @@ static int tile2f_launch_m(const Tile2FParams& pf, hipStream_t stream) {
     kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64), lds, stream>>>(pf);
   }
   ++tile_launch_count();
+  note_analysis_kernel("letkf_tile2f_kernel<%d, %d, %d, %s, %d>", UT, KT, NC, MROWS ? "true" : "false", MROWS ? 2 : MIA_TILE2_WAVES_UT2);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

@@ -208,37 +208,7 @@ void letkf_tile2p_kernel(Tile2Params P) {
     return c < nc8 ? (unsigned)(t * nc8 + c) * 512u + col : IMG + col;
   };
   auto split_x = [&](float (&xs_)[NB][8], float& xm, float& inv_sx, h8v (&xh)[NB], h8v (&xl)[NB]) {
-    float xs = 0.0f;
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const bool live = colok && 8 * (4 * b + sg) + i < k;
-        xs_[b][i] = live ? xs_[b][i] : 0.0f;
-        xs += xs_[b][i];
-      }
-    xm = t2_add_h(xs) * P.inv_k;
-    unsigned xmax = 0u;
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const bool live = colok && 8 * (4 * b + sg) + i < k;
-        xs_[b][i] = live ? xs_[b][i] - xm : 0.0f;
-        const unsigned a = __float_as_uint(xs_[b][i]) & 0x7fffffffu;
-        xmax = a > xmax ? a : xmax;
-      }
-    xmax = t2_max_h(xmax);
-    int esx;
-    const float sx = pow2_scale(xmax, 9, &esx);
-    inv_sx = __uint_as_float((unsigned)(127 - esx) << 23);
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      float t8[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) t8[i] = xs_[b][i] * sx;
-      split8_tied(t8, xh[b], xl[b]);
-    }
+    t2_split_x<NB, true>(xs_, colok, sg, k, P.inv_k, xm, inv_sx, xh, xl);      // (shared with letkf_tile2_kernel.h: the same bits)
   };
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // a tile with a non-finite record: every point goes to the eigensolver kernel (see letkf_tile2.hip)
@@ -635,6 +605,7 @@ static int tile2p_launch_m(const Tile2Params& tp, hipStream_t stream) {
     kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64 * NW), lds, stream>>>(tp);
   }
   ++tile_launch_count();
+  note_analysis_kernel("letkf_tile2p_kernel<%d, %d, %s, %d>", UT, KT, MROWS ? "true" : "false", NW);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

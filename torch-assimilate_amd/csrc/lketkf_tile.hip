@@ -588,6 +588,7 @@ static int lk_launch_p(const LkTileParams& tp, hipStream_t stream) {
     kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64), lds, stream>>>(tp);
   }
   ++tile_launch_count();
+  note_analysis_kernel("lketkf_tile_kernel<%d, %d, %s>", R, UT, PAD ? "true" : "false");
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
@@ -671,5 +672,5 @@ extern "C" int mia_lketkf_rbf_analysis_tiles_f32(const float* X, int64_t ldx, in
 extern "C" int mia_letkf_tiles_cover(int m, int k, int p_max, int extra_blocks, int64_t ldx, int64_t ldo, int64_t n_points,
                                      int64_t P, float gamma) {
   if (gamma > 0.0f) return lketkf_tile_covers(m, k, p_max, extra_blocks, ldx, ldo, n_points, P) ? 1 : 0;
-  return tile2_covers(m, k, p_max, extra_blocks, ldx, ldo, n_points) ? 1 : 0;
+  return (tile2_covers(m, k, p_max, extra_blocks, ldx, ldo, n_points) && tile2_records_addressable(k, P)) ? 1 : 0;
 }

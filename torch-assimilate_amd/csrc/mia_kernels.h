@@ -60,6 +60,10 @@ int tile_split_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_
 // that takes it.
 hipEvent_t& launch_stop_event();
 hipEvent_t& launch_start_event();     // optional timing partner of the above (the dispatch's own start time)
+// The analysis kernel a launch function has just put on a stream, under the name rocprofv3 records for it (template arguments
+// included): read back by mia_last_analysis_kernel, so that bench lines and tools label their figures with the kernel that
+// ran, not with a guess from the route options.  printf-style.
+void note_analysis_kernel(const char* fmt, ...);
 // launches of the tile kernel made by this thread so far; whether a launch with these sizes would be accepted by it
 unsigned long long& tile_launch_count();
 bool tile_launch_would_serve(int m, int k, int p_max, int p_cap, int64_t ldx, int64_t ldo, int64_t ng, int seg_len);

@@ -162,20 +162,27 @@ static inline size_t index_cell_cap(int64_t P) {
   return (size_t)cap;
 }
 static inline IndexLayout index_layout(void* ws, int64_t P, int nc) {
+  // (offsets first, pointers last: the size query passes a null base, and arithmetic on a null pointer is undefined behaviour --
+  //  found by the UBSan build of tests/test_host_sanitizers.py)
   IndexLayout L;
   L.cap = index_cell_cap(P);
-  char* base = (char*)ws;
-  L.hdr = (IndexHeader*)base; base += align_up(sizeof(IndexHeader), 256);
-  L.start = (int*)base; base += align_up((L.cap + 1) * sizeof(int), 256);
-  L.cursor = (int*)base; base += align_up(L.cap * sizeof(int), 256);
-  L.sorted = (int*)base; base += align_up((size_t)P * sizeof(int) + 4, 256);
-  L.cell_of = (int*)base; base += align_up((size_t)P * sizeof(int) + 4, 256);
-  L.rank_of = (int*)base; base += align_up((size_t)P * sizeof(int) + 4, 256);
-  L.sxyz = (double*)base; base += align_up((size_t)P * (size_t)nc * sizeof(double) + 8, 256);
   L.bucket_total = (size_t)(P > 0 ? 4 * P : 0) + 64;
-  L.bidx = (int*)base; base += align_up(L.bucket_total * sizeof(int), 256);
-  L.bxyz = (double*)base; base += align_up(L.bucket_total * (size_t)nc * sizeof(double), 256);
-  L.bytes = (size_t)(base - (char*)ws);
+  size_t o = 0;
+  const size_t o_hdr = o; o += align_up(sizeof(IndexHeader), 256);
+  const size_t o_start = o; o += align_up((L.cap + 1) * sizeof(int), 256);
+  const size_t o_cursor = o; o += align_up(L.cap * sizeof(int), 256);
+  const size_t o_sorted = o; o += align_up((size_t)P * sizeof(int) + 4, 256);
+  const size_t o_cell = o; o += align_up((size_t)P * sizeof(int) + 4, 256);
+  const size_t o_rank = o; o += align_up((size_t)P * sizeof(int) + 4, 256);
+  const size_t o_sxyz = o; o += align_up((size_t)P * (size_t)nc * sizeof(double) + 8, 256);
+  const size_t o_bidx = o; o += align_up(L.bucket_total * sizeof(int), 256);
+  const size_t o_bxyz = o; o += align_up(L.bucket_total * (size_t)nc * sizeof(double), 256);
+  L.bytes = o;
+  char* base = (char*)ws;
+  auto at = [&](size_t off) -> char* { return base ? base + off : nullptr; };
+  L.hdr = (IndexHeader*)at(o_hdr); L.start = (int*)at(o_start); L.cursor = (int*)at(o_cursor); L.sorted = (int*)at(o_sorted);
+  L.cell_of = (int*)at(o_cell); L.rank_of = (int*)at(o_rank); L.sxyz = (double*)at(o_sxyz);
+  L.bidx = (int*)at(o_bidx); L.bxyz = (double*)at(o_bxyz);
   return L;
 }
 

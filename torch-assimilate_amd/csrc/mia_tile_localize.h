@@ -21,18 +21,23 @@ namespace mia {
 // Floating-point contraction is OFF in here and in the distance loop of tile_localize, the fused multiply-adds are written out:
 // the function is inlined into two kernels (the list kernel and the analysis kernel's fused variant) and both must produce the
 // same bits -- left to the compiler, 2e3 of 4e6 analysis values differed in their last place (1e-9 relative) between the two.
+// Round 5: straight-line, ONE comparison.  Comparisons and selects are the expensive vector instructions here (tools/micro/valu_rates.hip:
+// a compare + select pair costs about six multiply-adds' issue time with several waves on the SIMD, a transcendental 3.5, a float64
+// operation 2): r comes from v_sqrt_f32 (sqrt(0) = 0: no special case for a zero distance; a NaN distance stays NaN and ends as
+// weight NaN, which the caller's `w > eps` rejects like the reference's comparisons do), the outer branch's zero beyond r = 2 from
+// clamping 2 - r at zero (v_max_f32) instead of a second comparison, and the compiler keeps no branch in it.
 __device__ __forceinline__ float gc_taper_fast(double d2, double four_c2, float inv_c, float c, float inv_c2) {
 #pragma clang fp contract(off)
   const float d2f = (float)d2;
-  if (!(d2f > 0.0f)) return d2 == 0.0 ? 1.0f : 0.0f;             // r = 0 -> 1; NaN -> 0
-  const float y = __builtin_amdgcn_rsqf(d2f);
-  const float r = d2f * y * inv_c, rinv = c * y;
+  const float r = __builtin_amdgcn_sqrtf(d2f) * inv_c;
+  const float rinv = c * __builtin_amdgcn_rsqf(d2f);             // (enters where r >= 1 only; inf at r = 0 is never selected)
   const float h1 = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-0.25f, r, 0.5f), r, 0.625f), r, -5.0f / 3.0f);
   const float f1 = __builtin_fmaf(h1 * r, r, 1.0f);
-  const float t = (float)(four_c2 - d2) * inv_c2 * __builtin_amdgcn_rcpf(2.0f + r);      // 2 - r
+  float t = (float)(four_c2 - d2) * inv_c2 * __builtin_amdgcn_rcpf(2.0f + r);      // 2 - r
+  t = __builtin_fmaxf(t, 0.0f);                                  // r >= 2: zero (strict `<` at 2, gaspari_cohn.py:127-133)
   const float t2 = t * t;
   const float f2 = t2 * t2 * __builtin_fmaf(__builtin_fmaf(r, 1.0f / 12.0f, 1.0f / 6.0f), r, -1.0f / 24.0f) * rinv;
-  return r < 1.0f ? f1 : (r < 2.0f ? f2 : 0.0f);
+  return r < 1.0f ? f1 : f2;
 }
 
 constexpr int kTlUmax = 96;           // largest union (UT = 6)
@@ -44,17 +49,22 @@ struct TileLocLds {
   int* cgs;         // [16][3] their cells
   int* ukey;        // [kTlUmax] observation index of union member u
   int* uinv;        // [kTlUmax] member of slot s, -1 = unused
+  double* cox;      // [64][3] coordinates of the candidates of one pass (bucket index: gathered once, lane = candidate)
+  int* coj;         // [64] their observation indices
   float* Wt;        // [16 ut][16] sqrt(rho) of (member, point), 0 = not local
   __device__ __forceinline__ explicit TileLocLds(unsigned char* base) {
     gxs = reinterpret_cast<double*>(base);
-    cgs = reinterpret_cast<int*>(gxs + 16 * MIA_MAX_COORD);
+    cox = gxs + 16 * MIA_MAX_COORD;
+    cgs = reinterpret_cast<int*>(cox + 64 * MIA_MAX_COORD);
     ukey = cgs + 16 * MIA_MAX_COORD;
     uinv = ukey + kTlUmax;
-    Wt = reinterpret_cast<float*>(uinv + kTlUmax);
+    coj = uinv + kTlUmax;
+    Wt = reinterpret_cast<float*>(coj + 64);
   }
 };
 static inline size_t tile_loc_lds(int ut) {
-  return 16 * MIA_MAX_COORD * (sizeof(double) + sizeof(int)) + 2 * kTlUmax * sizeof(int) + (size_t)16 * ut * 16 * sizeof(float);
+  return (16 + 64) * MIA_MAX_COORD * sizeof(double) + 16 * MIA_MAX_COORD * sizeof(int) + (2 * kTlUmax + 64) * sizeof(int) +
+         (size_t)16 * ut * 16 * sizeof(float);
 }
 
 struct TileLocOut {
@@ -78,6 +88,7 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
                                                     unsigned char* tl_lds, int lane) {
   const TileLocLds lds_(tl_lds);
   double* gxs = lds_.gxs; int* cgs = lds_.cgs; int* ukey = lds_.ukey; int* uinv = lds_.uinv; float* Wt = lds_.Wt;
+  double* cox = lds_.cox; int* coj = lds_.coj;
   const int cl = lane & 15, pg = lane >> 4;
   const int UMAX = 16 * ut;
   const IndexHeader* hd = q.hdr;
@@ -125,7 +136,6 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
   bool overflow = nrows > kTlMaxRows;
   bool box_overflow = overflow;        // the tile's points span more cells than the kernel scans (scattered orderings, coarse cells)
   int ubase = 0;
-  int cnt4[4] = {0, 0, 0, 0};          // local observations of points 4 pg + i so far (the same in every lane of a group)
   // sixteen candidates (one per lane cl, position `pos` of the index arrays, valid where `have`) against the tile's points
   // (the coordinates of this lane's four points -- point group pg -- and the radius groups, in registers)
   double gxr[4][NC];
@@ -155,6 +165,11 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
     for (int c = 0; c < NC; ++c) cd.ox[c] = q.sxyz[pos * NC + c];
     return cd;
   };
+  // points of this lane's group that exist (the last tile of a block may be ragged)
+  bool ptok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ptok[i] = 4 * pg + i < npts;
+  int cntl[4] = {0, 0, 0, 0};          // local observations of point 4 pg + i met by THIS lane (one candidate column); summed at the end
   auto weigh = [&](bool have, const Cand& cd) {
 #pragma clang fp contract(off)      // (the same bits in every kernel this is inlined into, see gc_taper_fast)
     const int oj = cd.oj;
@@ -162,47 +177,77 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
 #pragma unroll
     for (int c = 0; c < NC; ++c) ox[c] = cd.ox[c];
     f4w wq = {0.f, 0.f, 0.f, 0.f};
-    bool anyu = false;
+    bool use4[4];
+    if constexpr (TAPER == MIA_TAPER_GC) {
+      // float32 weights of the four pairs first; the (rare) pairs whose weight is within 1e-4 of eps are collected and weighed again
+      // in float64 behind ONE wave-level test per trip (round 4: one test and one branch per pair)
+      float wf4[4];
+      bool amb4[4], anyamb = false;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int pt = 4 * pg + i;
-      double d2[MIA_MAX_RADII] = {0.0, 0.0, 0.0};
+      for (int i = 0; i < 4; ++i) {
+        double d2[MIA_MAX_RADII] = {0.0, 0.0, 0.0};
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const double dx = ox[c] - gxr[i][c];
+        for (int c = 0; c < NC; ++c) {
+          const double dx = ox[c] - gxr[i][c];
 #pragma unroll
-        for (int r = 0; r < (NC == 1 ? 1 : MIA_MAX_RADII); ++r)
-          if (grp[c] == r) d2[r] = __builtin_fma(dx, dx, d2[r]);
-      }
-      bool use;
-      if constexpr (TAPER == MIA_TAPER_GC) {
+          for (int r = 0; r < (NC == 1 ? 1 : MIA_MAX_RADII); ++r)
+            if (grp[c] == r) d2[r] = __builtin_fma(dx, dx, d2[r]);
+        }
         float wf = 1.0f;
 #pragma unroll
         for (int r = 0; r < (NC == 1 ? 1 : MIA_MAX_RADII); ++r)
           if (r < n_r) wf *= gc_taper_fast(d2[r], fc2[r], icf[r], ccf[r], ic2f[r]);
-        use = wf > epsf;
-        // the decision is the float64 one: pairs whose float32 weight is within 1e-4 of eps are weighed again in float64
-        const bool amb = have && pt < npts && fabsf(wf - epsf) < 1e-4f * epsf;
-        if (__any(amb)) {
-          if (amb) {
+        wf4[i] = wf;
+        amb4[i] = have && ptok[i] && fabsf(wf - epsf) < 1e-4f * epsf;
+        anyamb = anyamb || amb4[i];
+      }
+      if (__any(anyamb)) {
+        // the decision is the float64 one: where float32 put an ambiguous weight on the wrong side of eps, the weight moves to the
+        // float value next to eps on the right side (a change of the order of its own rounding error, ~1e-6 relative, of a weight
+        // of 1e-5) -- so that every decision below is ONE comparison of the float32 weight
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (amb4[i]) {
             double wgt = 1.0;
-            for (int r = 0; r < n_r; ++r) wgt *= gc_taper_d2(d2[r], q.inv_c[r], q.cc[r]);
-            use = wgt > q.eps;
+            for (int r = 0; r < n_r; ++r) {
+              double d2r = 0.0;
+              for (int c = 0; c < NC; ++c)
+                if (grp[c] == r) { const double dx = ox[c] - gxr[i][c]; d2r = __builtin_fma(dx, dx, d2r); }
+              wgt *= gc_taper_d2(d2r, q.inv_c[r], q.cc[r]);
+            }
+            const bool u64 = wgt > q.eps;
+            if (u64 != (wf4[i] > epsf)) wf4[i] = u64 ? __uint_as_float(__float_as_uint(epsf) + 1u) : epsf;
           }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        use4[i] = wf4[i] > epsf && have && ptok[i];
+        wq[i] = use4[i] ? __builtin_amdgcn_sqrtf(wf4[i]) : 0.0f;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        double d2[MIA_MAX_RADII] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const double dx = ox[c] - gxr[i][c];
+#pragma unroll
+          for (int r = 0; r < (NC == 1 ? 1 : MIA_MAX_RADII); ++r)
+            if (grp[c] == r) d2[r] = __builtin_fma(dx, dx, d2[r]);
         }
-        use = use && have && pt < npts;
-        wq[i] = use ? wf * __builtin_amdgcn_rsqf(wf) : 0.0f;
-      } else {
         double wgt = 1.0;
 #pragma unroll
         for (int r = 0; r < (NC == 1 ? 1 : MIA_MAX_RADII); ++r)
           if (r < n_r) wgt *= gc_inf_taper_d2(d2[r], q.inv_c[r], q.cc[r]);
-        use = have && pt < npts && wgt > q.eps;
-        wq[i] = use ? (float)(wgt * rsqrt_f64(wgt)) : 0.0f;
+        use4[i] = have && ptok[i] && wgt > q.eps;
+        wq[i] = use4[i] ? (float)(wgt * rsqrt_f64(wgt)) : 0.0f;
       }
-      anyu = anyu || use;
-      const unsigned long long bal = __ballot(use);
-      cnt4[i] += __popc((unsigned)(bal >> (16 * pg)) & 0xffffu);
+    }
+    bool anyu = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      anyu = anyu || use4[i];
+      cntl[i] += use4[i] ? 1 : 0;
     }
     // a candidate is a member of the union when any of its four lanes (one per point group) uses it
     const unsigned long long anyb = __ballot(anyu);
@@ -238,22 +283,32 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
     pref[lane] = incl - mycnt;
     MIA_TL_SYNC();
     const int ncbi = (int)(ncb > 64 ? 64 : ncb);
-    // position of candidate q0 + cl in the bucket arrays (the last candidate again where there is none)
-    auto locate = [&](int q0) -> int64_t {
-      const int qi = q0 + cl;
-      const int qc = qi < total ? qi : total - 1;
-      int sel = 0;                                           // the cell of candidate qc: last cell whose prefix is <= qc
-      for (int i = 1; i < ncbi; ++i) sel += pref[i] <= qc ? 1 : 0;
-      const int cid = __shfl(mycid, sel, 64), pf = pref[sel];
-      return (int64_t)cid * cap + (qc - pf);
-    };
-    // (the candidates of trip t + 1 are requested before trip t is weighed: one memory round trip per tile instead of one per trip)
-    Cand nxt;
-    if (total > 0) nxt = fetch(locate(0));
-    for (int q0 = 0; q0 < total; q0 += 16) {
-      const Cand cur = nxt;
-      if (q0 + 16 < total) nxt = fetch(locate(q0 + 16));
-      weigh(q0 + cl < total, cur);
+    // The candidates are gathered ONCE, sixty-four per pass with lane = candidate (round 4 located and fetched the sixteen of a trip in
+    // all four point groups alike, every trip): position in the bucket arrays = the cell whose prefix range holds the candidate's
+    // place in the flat sequence; index and coordinates go to LDS, from where the trips of sixteen take them.  Same order of
+    // candidates as before -- same union, same ranks, same bits -- with one prefix search and one memory round trip per pass.
+    for (int qp = 0; qp < total; qp += 64) {
+      {
+        const int qi = qp + lane;
+        const int qc = qi < total ? qi : total - 1;          // (the last candidate again where there is none)
+        int sel = 0;                                         // the cell of candidate qc: last cell whose prefix is <= qc
+        for (int i = 1; i < ncbi; ++i) sel += pref[i] <= qc ? 1 : 0;
+        const int cid = __shfl(mycid, sel, 64), pf = pref[sel];
+        const Cand cd = fetch((int64_t)cid * cap + (qc - pf));
+        coj[lane] = cd.oj;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) cox[lane * NC + c] = cd.ox[c];
+      }
+      MIA_TL_SYNC();
+      const int npass = total - qp < 64 ? total - qp : 64;
+      for (int q0 = 0; q0 < npass; q0 += 16) {
+        Cand cur;
+        cur.oj = coj[q0 + cl];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) cur.ox[c] = cox[(q0 + cl) * NC + c];
+        weigh(q0 + cl < npass, cur);
+      }
+      MIA_TL_SYNC();                                         // (the next pass writes over the candidates)
     }
     MIA_TL_SYNC();
     for (int s_ = lane; s_ < kTlUmax; s_ += 64) uinv[s_] = -1;
@@ -284,7 +339,17 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
   }
   MIA_TL_SYNC();
   MIA_TL_SYNC();
-  // longest list of the tile (every lane of a point group holds the counts of its four points)
+  // longest list of the tile: a point's count is the sum over the sixteen candidate columns (lanes) of its group
+  int cnt4[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int v = cntl[i];
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);       // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);       // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);      // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);      // row_ror:8
+    cnt4[i] = v;
+  }
   int mx = cnt4[0] > cnt4[1] ? cnt4[0] : cnt4[1];
   mx = cnt4[2] > mx ? cnt4[2] : mx;
   mx = cnt4[3] > mx ? cnt4[3] : mx;

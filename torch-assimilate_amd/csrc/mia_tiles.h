@@ -157,6 +157,74 @@ __device__ __forceinline__ unsigned t2_max_h(unsigned u) {   // maximum of bit p
   r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
   return r.x > r.y ? r.x : r.y;
 }
+// x' = x - mean of one state row as scaled half pairs (one power of two per column): the values of member chunk b of this lane
+// (members 8 (4 b + sg) .. + 7 of column lr) arrive in xsb and leave as x' (unscaled); xm = the column's mean, inv_sx = 1 / scale.
+// SHARED by letkf_tile2_kernel.h and letkf_tile2p.hip so that the one- and the two-wavefront kernels produce the same bits.
+// Whole chunks of eight members (k a multiple of 8, wave-uniform test): a chunk beyond the ensemble, or a column beyond the tile, is
+// switched off by a FACTOR 0 / 1 per chunk -- one multiply-add per value where round 4 had a compare and two selects per value (a
+// select costs three multiply-adds' issue time, tools/micro/valu_rates.hip); the loads of such values are clamped to real data, so
+// 0 x is 0.  Any other k: the per-value selects.
+template <int NB, bool TIED>
+__device__ __forceinline__ void t2_split_x(float (&xsb)[NB][8], const bool colok, const int sg, const int k, const float inv_k,
+                                           float& xm, float& inv_sx, h8v (&xh)[NB], h8v (&xl)[NB]) {
+#pragma clang fp contract(off)      // (inlined into several kernels that must agree bit for bit: no multiply-add the source does not spell out)
+  float xs = 0.0f;
+  unsigned xmax = 0u;
+  if ((k & 7) == 0) {
+    float lm[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) lm[b] = (colok && 8 * (4 * b + sg) < k) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xs = __builtin_fmaf(xsb[b][i], lm[b], xs);
+    xm = t2_add_h(xs) * inv_k;
+    float xmaxf = 0.0f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float xml = xm * lm[b];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        xsb[b][i] = __builtin_fmaf(xsb[b][i], lm[b], -xml);
+        xmaxf = __builtin_fmaxf(xmaxf, __builtin_fabsf(xsb[b][i]));
+      }
+    }
+    xmax = __float_as_uint(xmaxf);
+  } else {
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bool live = colok && 8 * (4 * b + sg) + i < k;
+        xsb[b][i] = live ? xsb[b][i] : 0.0f;
+        xs += xsb[b][i];
+      }
+    xm = t2_add_h(xs) * inv_k;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bool live = colok && 8 * (4 * b + sg) + i < k;
+        xsb[b][i] = live ? xsb[b][i] - xm : 0.0f;
+        const unsigned a = __float_as_uint(xsb[b][i]) & 0x7fffffffu;
+        xmax = a > xmax ? a : xmax;
+      }
+  }
+  xmax = t2_max_h(xmax);
+  int esx;
+  const float sx = pow2_scale(xmax, 9, &esx);
+  inv_sx = __uint_as_float((unsigned)(127 - esx) << 23);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    float t8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t8[i] = xsb[b][i] * sx;
+    // (tied where the split follows matrix instructions closely -- the row loop, the pair kernel: there the fresh outputs of the untied
+    //  form could land on an accumulator still in flight, tools/check_mfma_hazards.py)
+    if constexpr (TIED) split8_tied(t8, xh[b], xl[b]);
+    else split8(t8, xh[b], xl[b]);
+  }
+}
 __device__ __forceinline__ unsigned t2_wave_max_u32(unsigned u) {     // wave-uniform maximum (DPP)
   unsigned t;
   t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0xB1, 0xf, 0xf, false); u = u > t ? u : t;
@@ -202,7 +270,7 @@ __device__ inline void pack_split_wave(const SplitPackJob& J, int64_t P, int64_t
   const bool real = j < P;                    // (j == P: the zero record; j > P: nothing)
   const int64_t jc = real ? j : (P > 0 ? P - 1 : 0);
   const float dj = (real && P > 0) ? J.d[jc] : 0.0f;                   // (requested with the first rows)
-  constexpr int kRowsInFlight = 24;                                    // (k = 40: two round trips instead of three)
+  constexpr int kRowsInFlight = 40;                                    // (k = 40: ONE round trip -- round 4: 24 rows, two trips)
   for (int i0 = 0; i0 < k; i0 += kRowsInFlight) {
     float v[kRowsInFlight];
 #pragma unroll
@@ -282,6 +350,7 @@ struct Tile2Params {
 };
 struct Tile2Housekeeping { int* counts; const int* n; unsigned* err; int32_t* err_out; };
 bool tile2_covers(int m, int k, int p_max, int extra_blocks, int64_t ldx, int64_t ldo, int64_t ng);
+bool tile2_records_addressable(int k, int64_t P);      // (P + 1) split records within 32-bit byte offsets
 int tile2_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const void* rec, int64_t P,
                           const void* tile_lists, int ut, float inf_factor, float* Xa, int64_t ldo, int64_t o0,
                           int32_t* flags, int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c,

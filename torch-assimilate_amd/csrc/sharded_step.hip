@@ -726,6 +726,21 @@ static void count_array_decision(void* ws, bool decide, bool bucket_step, bool f
   *use = e->cnt_use;
   *fused_out = e->fused;
 }
+// What a step decided where its preparation was enqueued (stage 1 / phase 0), CARRIED by the step -- the job of a step in flight, a
+// local of the one-call form -- to where its analysis is enqueued: the table above is only the workspace's memory BETWEEN steps (its
+// stamp, which count array comes next).  An entry pushed out of the table while a step is in flight costs that workspace's next
+// step a full rebuild (`unknown`), never the step in flight its decisions (round 4 looked them up again by pointer in stage 2).
+struct StepDecision { bool set = false, reuse = false, fused = false, must_clear = false; int cnt_use = 0; };
+
+// forget what the table holds about a workspace (its memory is about to be freed or handed to another runner: the next step on that
+// address starts from `unknown`)
+extern "C" int mia_letkf_step_workspace_release(void* ws) {
+  std::lock_guard<std::mutex> lock(g_stamp_mu);
+  for (auto it = g_stamps.begin(); it != g_stamps.end(); ++it)
+    if (it->ws == ws) { g_stamps.erase(it); break; }
+  return MIA_OK;
+}
+
 static bool count_arrays_clean_for_scan(void* ws) {
   std::lock_guard<std::mutex> lock(g_stamp_mu);
   for (auto& x : g_stamps)
@@ -743,7 +758,8 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
                      const double* gc_c, int n_r, double gc_eps, float inf_factor, float gamma, int method, int p_max_assumed,
                      mia_comm_t* comm, int n_chunks, int phase, float* Xa, int32_t* flags, int32_t* counters, void* ws,
                      size_t ws_bytes, void* stream, void* comm_stream, void* prep_stream, int step_flags, int stage,
-                     hipEvent_t* pe_io, uint32_t* seq_io, hipEvent_t t_start, hipEvent_t t_stop, hipEvent_t* kdone_out) {
+                     hipEvent_t* pe_io, uint32_t* seq_io, hipEvent_t t_start, hipEvent_t t_stop, hipEvent_t* kdone_out,
+                     StepDecision* dec_io) {
   const bool do1 = stage != 2, do2 = stage != 1;
   if (kdone_out) *kdone_out = nullptr;
   if (!X || !Xa || !flags || !counters || !ws || !grid_xyz || !coord_group || !gc_c) return MIA_ERR_NULL;
@@ -801,6 +817,7 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
                                       mia::cheb_primal_table((hipStream_t)(prep_stream ? prep_stream : stream), &tl_th, &tl_tc)
                                 : mia::option(MIA_OPT_TILE_SPLIT) != 0 &&
                                       mia::tile2_covers(m, k, pm_tl, (step_flags >> 4) & 7, G, exch ? L.nc : (no_gather ? blk : G), blk) &&
+                                      mia::tile2_records_addressable(k, P) &&
                                       mia::cheb_dual_table((hipStream_t)(prep_stream ? prep_stream : stream), &tl_th, &tl_tc));
   const bool tl_bucket = tl_route && mia::option(MIA_OPT_BUCKET_INDEX) != 0 && !(step_flags & MIA_STEP_SCAN_INDEX);
   // geometry epoch: the tile lists this workspace holds are used again (the caller vouches for unchanged coordinates, radii,
@@ -821,11 +838,18 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
   for (int i = 0; i < n_r && i < MIA_MAX_RADII; ++i) stamp_now.rc[i] = gc_c[i];
   for (int i = 0; i < n_coord && i < MIA_MAX_COORD; ++i) stamp_now.cg[i] = coord_group[i];
   // (decided once per step -- where its preparation is enqueued; the analysis stage and a redo of declined points read the decision)
-  const bool tl_reuse = geom_reuse_decision(ws, stamp_now, tl_route && (step_flags & MIA_STEP_REUSE_LISTS) != 0, phase == 0 && do1);
-  int cnt_use = 0;
-  bool tl_fused = false;
-  bool cnt_must_clear = false;
-  count_array_decision(ws, phase == 0 && do1, tl_bucket && !tl_reuse, want_fused && !tl_reuse, &cnt_use, &tl_fused, &cnt_must_clear);
+  StepDecision dec_local;
+  StepDecision& D = dec_io ? *dec_io : dec_local;
+  if (phase == 0 && do1) {
+    D.reuse = geom_reuse_decision(ws, stamp_now, tl_route && (step_flags & MIA_STEP_REUSE_LISTS) != 0, true);
+    count_array_decision(ws, true, tl_bucket && !D.reuse, want_fused && !D.reuse, &D.cnt_use, &D.fused, &D.must_clear);
+    D.set = true;
+  } else if (!D.set) {      // (a redo of declined points, phase 1: a call of its own -- what the table still knows)
+    D.reuse = geom_reuse_decision(ws, stamp_now, false, false);
+    count_array_decision(ws, false, false, false, &D.cnt_use, &D.fused, &D.must_clear);
+  }
+  const bool tl_reuse = D.reuse, tl_fused = D.fused, cnt_must_clear = D.must_clear;
+  const int cnt_use = D.cnt_use;
   // (the analysis launch puts the OTHER per-cell count array and the build's error word back to zero, see Tile2Params / GeomEntry)
   mia::Tile2Housekeeping tl_hk{nullptr, nullptr, nullptr, nullptr};
   int* tl_counts = nullptr;
@@ -1126,7 +1150,7 @@ extern "C" int mia_letkf_sharded_step_streams_f32(const float* X, int64_t G, int
   t_time_start = t_time_stop = nullptr;
   return step_impl(X, G, m, k, Yb, d, P, grid_xyz, obs_xyz, n_coord, coord_group, gc_c, n_r, gc_eps, inf_factor, gamma, method,
                    p_max_assumed, comm, n_chunks, phase, Xa, flags, counters, ws, ws_bytes, stream, comm_stream, prep_stream,
-                   step_flags, 0, &pe, &seq, t0, t1, nullptr);
+                   step_flags, 0, &pe, &seq, t0, t1, nullptr, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1148,6 +1172,7 @@ struct StepJob {
   int32_t* host8; void *after, *on; void** done_event; void *t0, *t1;
   hipEvent_t pe = nullptr; uint32_t seq = 0;
   hipEvent_t kdone = nullptr;      // completion event carried by the analysis launch itself (stage 2), if any
+  StepDecision dec;                // what stage 1 decided about the workspace's lists and count arrays, for stage 2
   int opts[MIA_OPT_COUNT_];        // the route options as they stood when the caller submitted the step
   int device = 0;
   int rc = 0;
@@ -1156,7 +1181,7 @@ struct StepJob {
     struct Scope { Scope(const int* o) { mia::option_override(o); } ~Scope() { mia::option_override(nullptr); } } scope(opts);
     return step_impl(X, G, m, k, Yb, d, P, grid, obs, n_coord, cg, rc_, n_r, eps, inf, gamma, method, hint, comm, n_chunks, phase,
                      Xa, flags, counters, ws, ws_bytes, stream, comm_stream, prep_stream, step_flags, stage, &pe, &seq,
-                     (hipEvent_t)t0, (hipEvent_t)t1, stage == 2 ? &kdone : nullptr);
+                     (hipEvent_t)t0, (hipEvent_t)t1, stage == 2 ? &kdone : nullptr, &dec);
   }
 };
 struct LaunchThreads {

@@ -70,6 +70,17 @@ class ShardedLetkf:
 
     @property
     def dominant_kernel_name(self):
+        """The analysis kernel of this runner's last completed step as the library launched it and as rocprofv3 names it
+        (mia_last_analysis_kernel: template arguments included); before the first step, a prediction from the route options."""
+        return self._last_kernel or self._predicted_kernel_name()
+
+    def _note_kernel(self):
+        from . import _cabi
+        name = _cabi.last_analysis_kernel()
+        if name:
+            self._last_kernel = name
+
+    def _predicted_kernel_name(self):
         if self.method == "eig":
             return "letkf_sys_kernel<20, 64>"
         import ctypes as C
@@ -90,8 +101,12 @@ class ShardedLetkf:
         return ("letkf_tile_kernel<2, 3, false, %s>" % ("true" if sp.value else "false")) if v.value else "letkf_cheb_kernel<20, 1, false>"
 
     def _fuse_now(self, pipelined: bool) -> bool:
+        # "auto" (the default) = fused wherever the library can (unions of at most 32 slots, bucket index, no geometry epoch --
+        # it decides per step and builds lists in memory otherwise), for steps one at a time and in flight alike: with three
+        # analysis streams the fused kernels of consecutive steps share the chip, 2.08e9 against 1.72e9 analyses/s at config 2
+        # (profiles/r05_stream_ab.txt; round 4 kept lists in memory for steps in flight to keep the analysis launch short)
         if self.fuse_tile_lists == "auto":
-            return not pipelined
+            return True
         return bool(self.fuse_tile_lists)
 
     @property
@@ -181,8 +196,8 @@ class ShardedLetkf:
                  rbf_gamma: Optional[float] = None, compute_shard: Optional[Callable] = None, group=None,
                  method: str = "auto", fused_localization: bool = False,
                  comm_chunks: int = 4, chunk_compute: Optional[Callable] = None, native_step: bool = True,
-                 max_in_flight: int = 3, peer_exchange: str = "auto", copy_results: bool = True, prep_streams: int = 5,
-                 analysis_streams: int = 1, gather: bool = True, fuse_tile_lists="auto"):
+                 max_in_flight: int = 3, peer_exchange: str = "auto", copy_results: bool = True, prep_streams: int = 3,
+                 analysis_streams: int = 3, gather: bool = True, fuse_tile_lists="auto"):
         self.device, self.rank, self.world = device, rank, world
         self.radii, self.inf_factor, self.coord_group, self.eps = list(radii), inf_factor, coord_group, eps
         self.rbf_gamma = rbf_gamma
@@ -192,11 +207,10 @@ class ShardedLetkf:
         self.gather = bool(gather)
         self.method = method
         self.fused_localization = fused_localization
-        # native step driver, tile route: True = the analysis wavefronts localise their tiles themselves (csrc/letkf_tile2f.hip, option
-        # "tile_fused": no list kernel, no lists in memory; same bits), False = tile lists in memory first, "auto" = fused for
-        # steps taken one at a time (assimilate(): one launch and ~10 us less per step) and lists first for steps in flight
-        # (submit(): the list kernel of the next step runs beside the analysis kernel of the previous one, which the fused kernel
-        # cannot -- measured 1.75e9 against 1.68e9 analyses/s at config 2)
+        # native step driver, tile route: True / "auto" = the analysis wavefronts localise their tiles themselves
+        # (csrc/letkf_tile2f.hip, option "tile_fused": no list kernel, no lists in memory; same bits) wherever the shape allows,
+        # False = tile lists in memory first (round 4's route for steps in flight: 1.72e9 against 2.08e9 analyses/s at config 2
+        # with three analysis and three preparation streams, profiles/r05_stream_ab.txt)
         self.fuse_tile_lists = fuse_tile_lists
         self.comm_chunks = int(comm_chunks)
         self._chunk_compute = chunk_compute
@@ -233,6 +247,7 @@ class ShardedLetkf:
         self._tile_extra = 0          # row blocks of sixteen slots added to the tiles' unions (MIA_STEP_TILE_EXTRA)
         self._fresh_box_once = False  # the next step recomputes the observations' bounding box (MIA_STEP_FRESH_BOX)
         self._scan_index = False      # scan-based observation index from now on (a cell overflowed its bucket: MIA_STEP_SCAN_INDEX)
+        self._last_kernel = None      # analysis kernel of the last completed step (mia_last_analysis_kernel)
 
     @property
     def engine(self):
@@ -273,6 +288,7 @@ class ShardedLetkf:
                 return xa
         xa, flags, finish = eng.analysis(X, Yb, d, nb, self.inf_factor, rbf_gamma=self.rbf_gamma,
                                          return_flags=True, method=self.method, defer_retry=True)
+        self._note_kernel()
         if not nb.confirm():
             nb = eng.localize(grid_xyz, obs_xyz, self.radii, self.coord_group, self.eps, g0, g1)
             xa, flags, finish = eng.analysis(X, Yb, d, nb, self.inf_factor, rbf_gamma=self.rbf_gamma,
@@ -311,6 +327,7 @@ class ShardedLetkf:
         if res is None:
             return None
         xa, flags, retry = res
+        self._note_kernel()
         n_retry = int(retry.item())
         if n_retry:
             if not nb.confirm():                                # (lists built on an assumed bound that did not hold)
@@ -427,6 +444,15 @@ class ShardedLetkf:
         """Release the library-owned communicator (idempotent)."""
         if self._native is not None:
             for slot in self._native.get("slots", []):
+                if slot.get("busy") is not None:                   # (a step never collected: its kernels still use the workspace)
+                    try:
+                        slot["busy"].result()
+                    except Exception:      # noqa: BLE001
+                        pass
+                if slot.get("ws") is not None:                     # what the library remembers about this address goes with it
+                    self.engine.lib.mia_letkf_step_workspace_release(slot["ws"].data_ptr())
+                    slot["ws"] = None
+                    slot["key"] = None
                 ev = slot.pop("in_event", None)
                 if ev is not None and ev.value:
                     self.engine.lib.mia_event_destroy(ev)
@@ -530,6 +556,8 @@ class ShardedLetkf:
             _cabi.check(lib.mia_letkf_sharded_step_workspace_bytes(G, m, k, P, nc, self.world, C_chunks, hint,
                                                                    C.byref(nbytes)), "sharded_step_workspace_bytes")
             if slot.get("ws") is None or slot["ws"].numel() < nbytes.value:
+                if slot.get("ws") is not None:                     # (the allocator may hand this address to anybody next)
+                    lib.mia_letkf_step_workspace_release(slot["ws"].data_ptr())
                 slot["ws"] = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=X.device)
             cg = [0] * nc if self.coord_group is None else [int(c) for c in self.coord_group]
             slot["cg"] = (C.c_int32 * nc)(*cg)
@@ -741,6 +769,8 @@ class ShardedLetkf:
             h._out = self._assimilate_native(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1)
             h._st = None
             return h._out
+        if self._last_kernel is None or self.native_steps % 64 == 0:
+            self._note_kernel()                                # (a ctypes call: not on every step of a timed loop)
         if n_retry:
             self.engine.lib.mia_letkf_step_drain()             # (after the steps already handed to the launch thread)
             p["call"](1)                                       # eigensolver redoes declined points; re-exchange
