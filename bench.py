@@ -519,6 +519,7 @@ def main():
                           prep_streams=int(os.environ.get("MIA_PREP_STREAMS", "3")),
                           analysis_streams=int(os.environ.get("MIA_ANALYSIS_STREAMS", "3")),
                           fuse_tile_lists={"auto": "auto", "1": True, "0": False}[os.environ.get("MIA_FUSE_TILE_LISTS", "auto")],
+                          prep_priority=int(os.environ.get("MIA_PREP_PRIORITY", "0")),
                           # N > 1: direct peer writes into IPC-mapped result buffers when the node allows it (self-tested
                           # at set-up, RCCL all-gather otherwise); the result is consumed from the slot buffer, no copy
                           peer_exchange=os.environ.get("MIA_PEER_EXCHANGE", "auto"), copy_results=False)

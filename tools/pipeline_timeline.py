@@ -6,9 +6,9 @@ d = sys.argv[1]
 rows = []
 for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("mia::", "")[:44], r.get("Queue_Id", "?")))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("mia::", "").replace("void ", "")[:44], r.get("Queue_Id", "?")))
 rows.sort()
-cheb = [i for i, r in enumerate(rows) if "letkf_cheb_kernel" in r[2] or "letkf_tile_kernel" in r[2] or "letkf_tile2_kernel" in r[2]]
+cheb = [i for i, r in enumerate(rows) if "letkf_cheb_kernel" in r[2] or "letkf_tile_kernel" in r[2] or "letkf_tile2" in r[2]]
 mid = cheb[int(sys.argv[2]) if len(sys.argv) > 2 else 60]      # inside the timed (pipelined) loop of the default bench
 t0 = rows[mid][0]
 print("window of ~3 steps around the middle of the run (t in us relative to an analysis-kernel start)")

@@ -21,7 +21,7 @@ for G in [int(a) for a in sys.argv[1:]] or [16, 100000]:
         eng.analysis_tiles(X, rec, Yb.shape[1], tiles, 1.1)
     torch.cuda.synchronize()
     nt = min((G + 15) // 16, 8192)
-    buf = np.zeros((nt, 12), dtype=np.int64)
+    buf = np.zeros((nt, 20), dtype=np.int64)
     assert lib.mia_debug_tile2_stamps(buf.ctypes.data_as(C.c_void_p), nt) == 0
     dt = np.diff(buf[:, :9], axis=1).astype(np.float64)
     print("G = %d: %d tiles; wave lifetime median %.0f cycles, p90 %.0f" % (G, nt, np.median(buf[:, 8] - buf[:, 0]), np.percentile(buf[:, 8] - buf[:, 0], 90)))

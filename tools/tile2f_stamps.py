@@ -20,12 +20,15 @@ for G in [int(a) for a in sys.argv[1:]] or [16, 100000]:
         r.assimilate(*case)
     torch.cuda.synchronize()
     nt = min((G + 15) // 16, 8192)
-    buf = np.zeros((nt, 12), dtype=np.int64)
+    buf = np.zeros((nt, 20), dtype=np.int64)
     assert lib.mia_debug_tile2f_stamps(buf.ctypes.data_as(C.c_void_p), nt) == 0
     dt = np.diff(buf[:, :9], axis=1).astype(np.float64)
     print("G = %d (%s): %d tiles; wave lifetime median %.0f cycles, p90 %.0f" % (G, r.dominant_kernel_name, nt, np.median(buf[:, 8] - buf[:, 0]), np.percentile(buf[:, 8] - buf[:, 0], 90)))
     for i, n in enumerate(names):
         print("  %-72s median %8.0f   p90 %8.0f" % (n, np.median(dt[:, i]), np.percentile(dt[:, i], 90)))
+    lt = np.diff(buf[:, 12:18], axis=1).astype(np.float64)      # (rows indexed by tile, not by block: medians only)
+    for i, n in enumerate(["grid coordinates -> cells (LDS)", "box, per-cell counts -> prefix", "candidates located, fetched -> LDS", "trips: tapers, union, sqrt(rho)", "ranks -> slots"]):
+        print("      localisation: %-44s median %8.0f   p90 %8.0f" % (n, np.median(lt[:, i]), np.percentile(lt[:, i], 90)))
     t0, t1 = buf[:, 10], buf[:, 11]
     lo = t0.min()
     span = t1.max() - lo

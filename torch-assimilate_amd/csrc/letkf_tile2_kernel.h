@@ -7,6 +7,11 @@
 #include "mia_kernels.h"
 #include "mia_options.h"
 #include "mia_tiles.h"
+#ifdef MIA_TILE_STAMPS
+// (diagnostic builds: sub-phase stamps of the localisation, slots 12 .. 19 of the tile's row -- indexed by TILE there, by block here)
+namespace mia { constexpr int kT2StampN = 20, kT2StampTiles = 8192; static __device__ long long g_tile2_stamps[kT2StampTiles * kT2StampN]; }
+#define MIA_TL_STAMP(i) do { if (lane == 0 && tile < mia::kT2StampTiles) mia::g_tile2_stamps[tile * mia::kT2StampN + 12 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #include "mia_tile_localize.h"
 
 namespace mia {
@@ -15,8 +20,6 @@ namespace mia {
 // go to a buffer of their own that nothing else reads.  Slots 0 .. 8: s_memtime at the phase boundaries; 9: where the wave ran
 // (HW_ID low word, XCC_ID high word); 10, 11: the constant 100 MHz counter at start and end (comparable across CUs).
 #ifdef MIA_TILE_STAMPS
-constexpr int kT2StampN = 12, kT2StampTiles = 8192;
-static __device__ long long g_tile2_stamps[kT2StampTiles * kT2StampN];      // (one per translation unit)
 #define T2_STAMP(i) do { if (lane == 0 && bid < kT2StampTiles) g_tile2_stamps[bid * kT2StampN + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #define T2_STAMP_HWID() do { if (lane == 0 && bid < kT2StampTiles) g_tile2_stamps[bid * kT2StampN + 9] = \
     (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } while (0)
@@ -118,24 +121,38 @@ __device__ __forceinline__ void tile2_body(Tile2Params P, const Tile2Loc* loc, c
     const TileLocOut lo = tile_localize<true, LOC, MIA_TAPER_GC>(loc->scan, P.g0, P.ng, UT, tile, smem, lane);
     const TileLocLds LL(smem);
     hdU = lo.overflow ? -1 : lo.U;
+    // (two rounds of independent LDS reads, one wait each: slot -> member, then the member's key / weights -- an unused slot reads
+    //  the scratch's key -1 / zero row instead of branching: round 4's select-by-branch form was a chain of sixteen dependent reads)
+    int mu[(UMAX + 63) / 64], du[UT][4];
 #pragma unroll
     for (int r = 0; r < (UMAX + 63) / 64; ++r) {
       const int s = lane + 64 * r;
-      const int u = (s < UMAX && !lo.overflow) ? LL.uinv[s] : -1;
-      myidx[r] = u < 0 ? -1 : LL.ukey[u];
+      mu[r] = LL.uinv[s < UMAX ? s : 0];
+      mu[r] = (s < UMAX && !lo.overflow && mu[r] >= 0) ? mu[r] : kTlUmax;          // ukey[kTlUmax] = -1
     }
 #pragma unroll
-    for (int t = 0; t < UT; ++t) {
-      f4w v = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < UT; ++t)
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
-        const int u = lo.overflow ? -1 : LL.uinv[16 * t + 4 * h + qq];
-        v[qq] = u < 0 ? 0.0f : LL.Wt[u * 16 + lr];
+        du[t][qq] = LL.uinv[16 * t + 4 * h + qq];
+        du[t][qq] = (!lo.overflow && du[t][qq] >= 0) ? du[t][qq] * 16 + lr : LL.zrow_off + lr;   // the zero row
       }
+#pragma unroll
+    for (int r = 0; r < (UMAX + 63) / 64; ++r) myidx[r] = LL.ukey[mu[r]];
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      f4w v;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) v[qq] = LL.Wt[du[t][qq]];
       dreg[t] = v;
     }
     if (lane == 0) {
-      if (lo.longest > __hip_atomic_load(&loc->stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&loc->stats[0], lo.longest);
+      // longest list: reported when it exceeds the bound the step was sized for (rare: the host then redoes the step), and by one
+      // tile in 64 behind a guard load of the running maximum (see Tile2Loc::longest_bound)
+      if (lo.longest > loc->longest_bound) atomicMax(&loc->stats[0], lo.longest);
+      else if ((tile & 63) == 0 && lo.longest > __hip_atomic_load(&loc->stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(&loc->stats[0], lo.longest);
+      if (tile == 0) atomicOr(&loc->stats[3], kStepSampledLongest);
       if (lo.overflow) atomicAdd(&loc->stats[1], 1);
       if (lo.box_overflow) atomicOr(&loc->stats[1], MIA_TILE_BOX_OVERFLOW);
     }

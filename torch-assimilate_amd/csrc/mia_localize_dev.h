@@ -83,7 +83,13 @@ struct ScanParams {
 struct Tile2Loc {
   ScanParams scan;
   int32_t* stats;        // [0] longest list (running maximum), [1] tiles whose union did not fit (+ MIA_TILE_BOX_OVERFLOW)
+  // the list bound the step was sized for.  The fused kernel reports a tile's longest list when it EXCEEDS this bound (the step is
+  // then redone) and otherwise only for one tile in 64: stats[0] is a SAMPLED maximum on this route (bit kStepSampledLongest of the
+  // step's error word says so) -- every tile guarding its atomic with a load of the running maximum was a dependent round trip to
+  // ONE address of all resident wavefronts at once, 6 us of the kernel's 43 at config 2 (tools/tile2f_stamps.py)
+  int longest_bound;
 };
+constexpr int kStepSampledLongest = 64;      // status bit in counters[3] / [7] (include/mia_letkf.h: MIA_STEP_STATUS_SAMPLED)
 
 // One wavefront scans the 3^d cells around grid point g (the innermost coordinate's three cells are one
 // contiguous range), evaluates distance and taper in float64 and compacts the observations whose weight

@@ -9,6 +9,9 @@
 
 namespace mia {
 
+#ifndef MIA_TL_STAMP
+#define MIA_TL_STAMP(i) do { } while (0)
+#endif
 #define MIA_TL_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 // ---- tile lists ------------------------------------------------------------------------------------------------------
@@ -51,20 +54,21 @@ struct TileLocLds {
   int* uinv;        // [kTlUmax] member of slot s, -1 = unused
   double* cox;      // [64][3] coordinates of the candidates of one pass (bucket index: gathered once, lane = candidate)
   int* coj;         // [64] their observation indices
-  float* Wt;        // [16 ut][16] sqrt(rho) of (member, point), 0 = not local
+  float* Wt;        // [16 ut][16] sqrt(rho) of (member, point), 0 = not local; Wt[zrow_off .. + 15] (in FRONT of it) = zeros
+  static constexpr int zrow_off = -16;
   __device__ __forceinline__ explicit TileLocLds(unsigned char* base) {
     gxs = reinterpret_cast<double*>(base);
     cox = gxs + 16 * MIA_MAX_COORD;
     cgs = reinterpret_cast<int*>(cox + 64 * MIA_MAX_COORD);
-    ukey = cgs + 16 * MIA_MAX_COORD;
-    uinv = ukey + kTlUmax;
+    ukey = cgs + 16 * MIA_MAX_COORD;                 // [kTlUmax + 16]: ukey[kTlUmax] = -1 (the key of an unused slot)
+    uinv = ukey + kTlUmax + 16;
     coj = uinv + kTlUmax;
-    Wt = reinterpret_cast<float*>(coj + 64);
+    Wt = reinterpret_cast<float*>(coj + 64) + 16;
   }
 };
 static inline size_t tile_loc_lds(int ut) {
-  return (16 + 64) * MIA_MAX_COORD * sizeof(double) + 16 * MIA_MAX_COORD * sizeof(int) + (2 * kTlUmax + 64) * sizeof(int) +
-         (size_t)16 * ut * 16 * sizeof(float);
+  return (16 + 64) * MIA_MAX_COORD * sizeof(double) + 16 * MIA_MAX_COORD * sizeof(int) + (2 * kTlUmax + 16 + 64) * sizeof(int) +
+         (size_t)16 * (ut * 16 + 1) * sizeof(float);
 }
 
 struct TileLocOut {
@@ -95,6 +99,7 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
   constexpr int nc = NC;
   const int64_t p0 = tile << 4;
   const int npts = ng - p0 < 16 ? (int)(ng - p0) : 16;
+  MIA_TL_STAMP(0);
   if (lane < 16) {
     const int64_t pt = g0 + p0 + (lane < npts ? lane : npts - 1);
     for (int c = 0; c < MIA_MAX_COORD; ++c) {
@@ -109,7 +114,9 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
     }
   }
   for (int s = lane; s < kTlUmax; s += 64) uinv[s] = -1;
+  if (lane < 16) { Wt[TileLocLds::zrow_off + lane] = 0.0f; ukey[kTlUmax + lane] = -1; }
   MIA_TL_SYNC();
+  MIA_TL_STAMP(1);
   // the tile's cell box: [min cell - 1, max cell + 1] per coordinate, clipped to the cell grid
   int lo[MIA_MAX_COORD], hi[MIA_MAX_COORD];
   for (int c = 0; c < MIA_MAX_COORD; ++c) {
@@ -282,6 +289,7 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
     int* pref = uinv;                                        // (scratch until the ranks are formed: [<= 64] exclusive prefix | cell id)
     pref[lane] = incl - mycnt;
     MIA_TL_SYNC();
+    MIA_TL_STAMP(2);
     const int ncbi = (int)(ncb > 64 ? 64 : ncb);
     // The candidates are gathered ONCE, sixty-four per pass with lane = candidate (round 4 located and fetched the sixteen of a trip in
     // all four point groups alike, every trip): position in the bucket arrays = the cell whose prefix range holds the candidate's
@@ -300,6 +308,7 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
         for (int c = 0; c < NC; ++c) cox[lane * NC + c] = cd.ox[c];
       }
       MIA_TL_SYNC();
+      MIA_TL_STAMP(3);
       const int npass = total - qp < 64 ? total - qp : 64;
       for (int q0 = 0; q0 < npass; q0 += 16) {
         Cand cur;
@@ -328,6 +337,7 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
   const int U = ubase;
   overflow = overflow || U > UMAX;
   MIA_TL_SYNC();
+  MIA_TL_STAMP(4);
   // rank of every member by observation index -> slot
   if (!overflow) {
     for (int u = lane; u < U; u += 64) {
@@ -339,6 +349,7 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
   }
   MIA_TL_SYNC();
   MIA_TL_SYNC();
+  MIA_TL_STAMP(5);
   // longest list of the tile: a point's count is the sum over the sixteen candidate columns (lanes) of its group
   int cnt4[4];
 #pragma unroll

@@ -883,6 +883,7 @@ static int step_impl(const float* X, int64_t G, int m, int k, const float* Yb, c
     if (rc != MIA_OK) return rc;
     tl_loc.scan.start = tl_counts;
     tl_loc.stats = ctr;
+    tl_loc.longest_bound = pm_tl;
   }
   (void)hipGetLastError();
   if (exch || peer) {

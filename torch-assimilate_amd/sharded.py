@@ -18,6 +18,7 @@ __all__ = ["ShardedLetkf", "PendingStep", "block_partition", "gather_blocks"]
 
 
 TILE_BOX_OVERFLOW = 1 << 30        # MIA_TILE_BOX_OVERFLOW (include/mia_letkf.h)
+STATUS_SAMPLED = 64                # MIA_STEP_STATUS_SAMPLED: counters[0] / [4] of this step are a sampled maximum (fused kernel)
 
 
 def block_partition(G: int, world: int) -> List[Tuple[int, int]]:
@@ -197,7 +198,7 @@ class ShardedLetkf:
                  method: str = "auto", fused_localization: bool = False,
                  comm_chunks: int = 4, chunk_compute: Optional[Callable] = None, native_step: bool = True,
                  max_in_flight: int = 3, peer_exchange: str = "auto", copy_results: bool = True, prep_streams: int = 3,
-                 analysis_streams: int = 3, gather: bool = True, fuse_tile_lists="auto"):
+                 analysis_streams: int = 3, gather: bool = True, fuse_tile_lists="auto", prep_priority: int = 0):
         self.device, self.rank, self.world = device, rank, world
         self.radii, self.inf_factor, self.coord_group, self.eps = list(radii), inf_factor, coord_group, eps
         self.rbf_gamma = rbf_gamma
@@ -224,6 +225,7 @@ class ShardedLetkf:
         self.max_in_flight = max(1, min(int(max_in_flight), 8))
         self.prep_streams = max(0, min(int(prep_streams), 8))      # steps in flight: preparation streams taken in turn (0: none, tools)
         self.analysis_streams = max(1, min(int(analysis_streams), 4))
+        self.prep_priority = int(prep_priority)      # HIP stream priority of the preparation streams (0 normal, -1 high)
         # exchange of the analysis blocks at world > 1: "auto" = direct peer writes into library-owned, IPC-mapped result
         # buffers when the node allows it and a self-test of the mapping passes, RCCL all-gather otherwise; "off" = RCCL.
         # With the direct route a result lives in its pipeline slot's buffer: copy_results (default) hands out a copy,
@@ -606,7 +608,7 @@ class ShardedLetkf:
                 # (round 3 sorted fresh streams by the hardware queue the runtime had given them -- 1 ms spin-kernel probes at
                 #  set-up -- and took a fixed mix; under the driver's flags the plain set measures the same, 1.729e9 against
                 #  1.738e9 analyses/s, profiles/r04_stream_ab.txt: the probes are gone.  Fewer streams cost: 2: 1.55e9, 3: 1.69e9)
-                st["pstreams"] = [torch.cuda.Stream(device=X.device) for _ in range(max(1, self.prep_streams))]
+                st["pstreams"] = [torch.cuda.Stream(device=X.device, priority=self.prep_priority) for _ in range(max(1, self.prep_streams))]
             comp = st["astreams"][self._submitted % len(st["astreams"])] if not exch else st["astream"]
             # (a step on reused lists prepares with ONE short kernel: one preparation stream for all of them -- every further
             #  queue in use costs the analysis queue dispatch time: 0.041 against 0.049 ms per step with three)
@@ -717,6 +719,10 @@ class ShardedLetkf:
         X, grid_xyz, obs_xyz, Yb, d, G, g0, g1 = p["args"]
         if st["comm"] is None or (self.world == 1 and p["C_chunks"] == 1):
             cnt[4:8] = cnt[0:4]                                # no exchange route: the rank's own counters
+        # MIA_STEP_STATUS_SAMPLED: the step ran on the fused kernel, whose "longest list" is exact only when it EXCEEDS the bound
+        # the step was sized for (then the step is redone below); otherwise it is the maximum over one tile in 64
+        sampled = bool(cnt[7] & STATUS_SAMPLED)
+        cnt[7] &= ~STATUS_SAMPLED
         p_seen, n_over, n_retry = cnt[4], cnt[5], cnt[6]
         redo = None
         if cnt[7] & 24:
@@ -789,7 +795,13 @@ class ShardedLetkf:
         self.native_steps += 1
         self.last_retries = cnt[2]
         self.reused_steps += 1 if p.get("reused") else 0
-        if not p.get("reused"):                                # (a step on reused lists reports no list lengths)
+        if sampled:
+            # a sampled maximum never RAISES the bound (a longer list would have broken it: redo above) and lowers it only across
+            # a boundary of the tile format -- sixteen slots -- with a margin of four for what the sample may have missed
+            ut_of = lambda q: max(1, (int(q) + 8 + 15) // 16)      # noqa: E731  (tile_ut_for, csrc/mia_tiles.h)
+            if ut_of(p_seen + 4) < ut_of(p["hint"]):
+                self._p_max_hint = p_seen + 4
+        elif not p.get("reused"):                              # (a step on reused lists reports no list lengths)
             self._p_max_hint = p_seen if self.world > 1 else max(p_seen, 0)
         if not self._no_tile_lists:
             slot["geom"] = p.get("geom_key")                   # this slot's lists now belong to that geometry epoch
