@@ -594,6 +594,10 @@ void* mia_comm_peer_buffer(mia_comm_t* comm, int slot);
 void* mia_comm_peer_sync_area(mia_comm_t* comm);
 int mia_comm_peer_exchange(mia_comm_t* comm, int slot, int rows, int64_t G, int64_t b0, int64_t b1, int32_t* counters,
                            void* stream);
+/* A waiter of the last exchange on `slot` gave up (error bit 2 of counters[3] / [7]): wait again for the peers' flags of THAT
+ * exchange and fold the counters once more (enqueued on `stream`; clears error bit 2, which is set again if this wait gives up
+ * too).  A late peer costs its lateness, not the run; the caller bounds the number of re-waits. */
+int mia_comm_peer_rewait(mia_comm_t* comm, int slot, int32_t* counters, void* stream);
 int mia_comm_destroy(mia_comm_t* comm);
 const char* mia_comm_last_error(void);
 int mia_letkf_sharded_step_workspace_bytes(int64_t G, int m, int k, int64_t P, int n_coord, int world,

@@ -581,6 +581,60 @@ def test_direct_peer_exchange_layout_and_protocol_on_one_gpu(mia, G, strong, ran
         _cabi.lib().mia_comm_destroy(handle)
 
 
+def test_a_late_peer_is_waited_for_again_and_a_dead_one_reported(mia):
+    """Direct exchange, emulated peer: its ready flag for slot 0 has NOT arrived when the waiter's (shortened) bound runs out -- error
+    bit 2.  The host waits again (mia_comm_peer_rewait: the flags of that exchange, the counters folded once more) instead of
+    failing the run; the peer's flag arrives during the first re-wait here and the step completes with the right analysis.  A
+    peer that stays silent through every re-wait is an error that says so."""
+    import warnings
+    from torch_assimilate_amd import _cabi
+    dev = torch.device("cuda:0")
+    G, rank = 2000, 0
+    case = O.synthetic_case(G, 40, 2)
+    args = (torch.as_tensor(case["state"], dtype=torch.float32, device=dev), torch.as_tensor(case["grid_x"], device=dev),
+            torch.as_tensor(case["obs_x"], device=dev), torch.as_tensor(case["yb"], dtype=torch.float32, device=dev),
+            torch.as_tensor(case["d"], dtype=torch.float32, device=dev))
+    plain = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1, native_step=False)
+    ref = plain.assimilate(*args)
+    runner = mia.ShardedLetkf(dev, rank, 2, radii=[10.0], inf_factor=1.1, max_in_flight=3)
+    runner._p_max_hint = plain._p_max_hint
+    handle, keep, mine, stub_bufs, stub_sync, (lo, hi) = _peer_rank_stub(mia, runner, rank, ref, G)
+    lib = _cabi.lib()
+    _cabi.check(lib.mia_comm_peer_wait_bound(handle, 10), "mia_comm_peer_wait_bound")      # ~1 ms instead of a minute
+    runner._native = dict(comm=handle, custom=True, stream=torch.cuda.Stream(device=dev), slots=[{}, {}, {}],
+                          peer=mine, peer_shape=tuple(ref.shape))
+    my_sync = runner._wrap_device(lib.mia_comm_peer_sync_area(handle), (8 * 16 * 6,), dev).view(torch.int32)
+    peer = 1 - rank
+    try:
+        out = runner.assimilate(*args)                         # the peer is on time
+        assert torch.equal(out, ref)
+        my_sync[peer] = 0                                      # ready[slot 0][peer]: not yet
+        torch.cuda.synchronize()
+        calls = []
+
+        def late_peer(attempt):                                # the peer's flag lands while this rank prepares to wait again
+            calls.append(attempt)
+            my_sync[peer] = 1 << 20
+            torch.cuda.synchronize()
+        runner._peer_rewait_hook = late_peer
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            out = runner.assimilate(*args)
+        assert calls == [0] and any("waiting again" in str(x.message) for x in w)
+        assert torch.equal(out, ref) and runner.last_flags_ok()
+        my_sync[peer] = 0                                      # ... and a peer that never answers
+        torch.cuda.synchronize()
+        runner._peer_rewait_hook = lambda attempt: calls.append(attempt)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            with pytest.raises(_cabi.MiaError, match="did not deliver within 4 waits"):
+                runner.assimilate(*args)
+        assert calls == [0, 0, 1, 2]
+    finally:
+        runner._native = None
+        lib.mia_comm_destroy(handle)
+
+
 def _peer_ipc_worker(rank, port, G, out_path):
     """One of two PROCESSES sharing cuda:0: real hipIpcGetMemHandle / hipIpcOpenMemHandle mapping of the other process's result
     buffers and flag area, handle exchange over torch.distributed (gloo), the exchange self-test, then real steps of both

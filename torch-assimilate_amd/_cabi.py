@@ -119,6 +119,7 @@ _PROTOS = {
     "mia_comm_peer_buffer": ([vp, i32], vp),
     "mia_comm_peer_sync_area": ([vp], vp),
     "mia_comm_peer_exchange": ([vp, i32, i32, i64, i64, i64, vp, vp], i32),
+    "mia_comm_peer_rewait": ([vp, i32, vp, vp], i32),
     "mia_comm_destroy": ([vp], i32),
     "mia_comm_last_error": ([], C.c_char_p),
     "mia_letkf_sharded_step_workspace_bytes": ([i64, i32, i32, i64, i32, i32, i32, i32, C.POINTER(sz)], i32),

@@ -514,6 +514,28 @@ extern "C" int mia_comm_peer_exchange(mia_comm_t* c, int slot, int rows, int64_t
   return peer_finish(c, slot, seq, G, b0, b1, rows, counters, (hipStream_t)stream);
 }
 
+// A waiter of the last exchange on `slot` gave up (error bit 2 of counters[3] / [7]): wait AGAIN for the peers' ready flags of that
+// exchange and fold the counters once more -- a peer that has not raised its flag within the bound is late (a first-step table
+// build, I/O between two steps, a debugger), and its push does not depend on anything this rank does.  Clears error bit 2 first; it
+// is set again if this wait gives up too.  The caller decides how often to come back before it calls the peer dead.
+__global__ void __launch_bounds__(64) peer_clear_timeout_kernel(int32_t* counters) {
+  if (threadIdx.x == 0) { counters[3] &= ~2; counters[7] &= ~2; }
+}
+extern "C" int mia_comm_peer_rewait(mia_comm_t* c, int slot, int32_t* counters, void* stream) {
+  if (!c || !counters) return MIA_ERR_NULL;
+  if (!c->peer_ready || slot < 0 || slot >= c->peer_slots) return MIA_ERR_SIZE;
+  if (c->world == 1) return MIA_OK;
+  (void)hipGetLastError();
+  hipStream_t cs = (hipStream_t)stream;
+  const uint32_t* my = c->peer_sync[c->rank] + slot * kSyncSlotWords;
+  peer_clear_timeout_kernel<<<1, 64, 0, cs>>>(counters);
+  MIA_LAUNCH_CHECK();
+  peer_wait_kernel<<<1, 64, 0, cs>>>(my, c->world, c->rank, c->peer_seq[slot], counters + 3, c->peer_wait_polls,
+                                     reinterpret_cast<const int32_t*>(my + 2 * kMaxRanks), counters);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
 extern "C" int mia_comm_destroy(mia_comm_t* c) {
   if (!c) return MIA_OK;
   for (int r = 0; r < c->world && r < kMaxRanks; ++r) {

@@ -226,6 +226,8 @@ class ShardedLetkf:
         self.prep_streams = max(0, min(int(prep_streams), 8))      # steps in flight: preparation streams taken in turn (0: none, tools)
         self.analysis_streams = max(1, min(int(analysis_streams), 4))
         self.prep_priority = int(prep_priority)      # HIP stream priority of the preparation streams (0 normal, -1 high)
+        self.peer_rewaits = 3          # direct exchange: how often a waiter that gave up waits again before the peer is called dead
+        self._peer_rewait_hook = None  # (tests: called before every re-wait)
         # exchange of the analysis blocks at world > 1: "auto" = direct peer writes into library-owned, IPC-mapped result
         # buffers when the node allows it and a self-test of the mapping passes, RCCL all-gather otherwise; "off" = RCCL.
         # With the direct route a result lives in its pipeline slot's buffer: copy_results (default) hands out a copy,
@@ -725,6 +727,28 @@ class ShardedLetkf:
         cnt[7] &= ~STATUS_SAMPLED
         p_seen, n_over, n_retry = cnt[4], cnt[5], cnt[6]
         redo = None
+        if cnt[7] & 2 and p.get("peer"):
+            # direct exchange: a waiter of this step gave up -- a peer is LATE.  Its push does not depend on this rank, so nothing is
+            # redone: this rank waits AGAIN for the flags of that exchange (a late peer used to be a hard error),
+            # up to peer_rewaits times; only a peer that stays silent through all of them is called dead.  Nothing collective: the
+            # other ranks need not know, and the counters folded after the wait are the ones they decided on.
+            import warnings
+            slot_idx = st["slots"].index(slot)
+            for attempt in range(self.peer_rewaits):
+                warnings.warn("direct exchange: a peer had not delivered within the waiter's bound; waiting again (%d of %d)"
+                              % (attempt + 1, self.peer_rewaits), RuntimeWarning)
+                if self._peer_rewait_hook is not None:
+                    self._peer_rewait_hook(attempt)
+                stream = p["last"]
+                _cabi.check(self.engine.lib.mia_comm_peer_rewait(st["comm"], slot_idx, slot["counters"].data_ptr(), stream.cuda_stream),
+                            "mia_comm_peer_rewait")
+                stream.synchronize()
+                cnt = slot["counters"].tolist()
+                if not (cnt[7] & 2):
+                    break
+            sampled = sampled or bool(cnt[7] & STATUS_SAMPLED)
+            cnt[7] &= ~STATUS_SAMPLED
+            p_seen, n_over, n_retry = cnt[4], cnt[5], cnt[6]
         if cnt[7] & 24:
             # bucket index of the tile route: an observation outside the bounding box this slot's workspace held (or other
             # radii) -> this step again with a fresh box; a cell with more observations than a bucket holds -> the scan-based
@@ -736,7 +760,8 @@ class ShardedLetkf:
             slot["ws_clean"] = False                           # (this slot's box is stale: its next step rebuilds it)
             redo = "same"
         elif cnt[7] & 2:
-            raise _cabi.MiaError("direct exchange: a peer did not deliver within the waiter's bound (error bits %d)" % cnt[7])
+            raise _cabi.MiaError("direct exchange: a peer did not deliver within %d waits of the waiter's bound (error bits %d)"
+                                 % (self.peer_rewaits + 1, cnt[7]))
         elif cnt[7]:
             # a segment waiter gave up (the analysis launch and the exchange stream must be able to run
             # concurrently: e.g. more HIP streams than hardware queues): all ranks switch to one launch + one
