@@ -6,7 +6,7 @@ import re, sys
 path, want = sys.argv[1], sys.argv[2]
 lines = open(path).read().splitlines()
 start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l) and want in l)
-end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end")) - 1      # (a kernel may hold several s_endpgm)
 cls = lambda op: ("mfma" if op.startswith("v_mfma") else "valu" if op.startswith("v_") else "lds" if op.startswith("ds_") else
                   "vmem" if op.startswith(("global_", "buffer_", "flat_", "scratch_")) else "smem" if op.startswith("s_load") or op.startswith("s_buffer_load") else
                   "wait" if op.startswith(("s_waitcnt", "s_nop", "s_barrier", "s_sleep")) else "branch" if op.startswith(("s_cbranch", "s_branch")) else

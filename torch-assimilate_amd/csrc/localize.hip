@@ -759,6 +759,11 @@ int make_scan_params(ScanParams* sp, const double* grid_xyz, int64_t P, int n_co
   for (int r = 0; r < MIA_MAX_RADII; ++r) { sp->inv_c[r] = r < n_r ? 1.0 / gc_c[r] : 1.0; sp->cc[r] = r < n_r ? gc_c[r] : 1.0; }
   sp->eps = gc_eps;
   sp->taper = taper;
+  for (int r = 0; r < MIA_MAX_RADII; ++r) {
+    sp->four_c2[r] = 4.0 * sp->cc[r] * sp->cc[r];
+    sp->inv_c_f[r] = (float)sp->inv_c[r]; sp->c_f[r] = (float)sp->cc[r]; sp->inv_c2_f[r] = (float)(sp->inv_c[r] * sp->inv_c[r]);
+  }
+  sp->eps_f = (float)gc_eps;
   return MIA_OK;
 }
 

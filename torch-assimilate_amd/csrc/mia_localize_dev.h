@@ -77,6 +77,9 @@ struct ScanParams {
   double cc[MIA_MAX_RADII];
   double eps;
   int taper;            // MIA_TAPER_*
+  // the float32 tile taper's constants, formed on the host (every wavefront used to convert them itself): 4 c^2, 1 / c, c, 1 / c^2
+  double four_c2[MIA_MAX_RADII];
+  float inv_c_f[MIA_MAX_RADII], c_f[MIA_MAX_RADII], inv_c2_f[MIA_MAX_RADII], eps_f;
 };
 // what the analysis kernel's fused variant (letkf_tile2f.hip) needs to localise its tiles itself: the scan over the step's bucket
 // index and the step's counters

@@ -155,14 +155,11 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
   for (int c = 0; c < NC; ++c) grp[c] = NC == 1 ? 0 : q.group[c];
   const int n_r = NC == 1 ? 1 : q.n_r;
   // (float32 copies of the taper's constants, float64 4 c^2)
-  const float epsf = (float)q.eps;
+  const float epsf = q.eps_f;
   double fc2[MIA_MAX_RADII];
   float icf[MIA_MAX_RADII], ccf[MIA_MAX_RADII], ic2f[MIA_MAX_RADII];
 #pragma unroll
-  for (int r = 0; r < MIA_MAX_RADII; ++r) {
-    fc2[r] = 4.0 * q.cc[r] * q.cc[r];
-    icf[r] = (float)q.inv_c[r]; ccf[r] = (float)q.cc[r]; ic2f[r] = (float)(q.inv_c[r] * q.inv_c[r]);
-  }
+  for (int r = 0; r < MIA_MAX_RADII; ++r) { fc2[r] = q.four_c2[r]; icf[r] = q.inv_c_f[r]; ccf[r] = q.c_f[r]; ic2f[r] = q.inv_c2_f[r]; }
   // a candidate: its observation index and coordinates (requested one trip ahead of their use by the bucket loop below)
   struct Cand { int oj; double ox[NC]; };
   auto fetch = [&](int64_t pos) {
@@ -275,7 +272,7 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
     overflow = overflow || ncb > 64;
     int mycid = 0, mycnt = 0;
     if (!overflow && lane < (int)ncb) {
-      const int row = lane / nlast, cc = lane - row * nlast;
+      const int row = NC == 1 ? 0 : lane / nlast, cc = lane - row * nlast;      // (one coordinate: one row of cells, no division)
       int base_cell = 0;
       if (nc == 2) base_cell = (lo[0] + row) * hd->n[1];
       else if (nc == 3) base_cell = ((lo[0] + row / n1) * hd->n[1] + (lo[1] + row % n1)) * hd->n[2];
@@ -283,8 +280,16 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
       mycnt = q.start[mycid];
       mycnt = mycnt > cap ? cap : mycnt;
     }
-    int incl = mycnt;                                        // inclusive prefix over the box's cells (lane = cell)
-    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+    // inclusive prefix over the box's cells (lane = cell): shifts inside the rows of sixteen lanes (zero comes in from the left),
+    // then each row's total into the rows above it -- six DPP additions (round 4: six shuffles through LDS with a compare and a
+    // select each)
+    int incl = mycnt;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);      // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);      // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);      // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);      // row_shr:8
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3 (lane 63: the total)
     const int total = overflow ? 0 : __builtin_amdgcn_readfirstlane(__shfl(incl, 63, 64));
     int* pref = uinv;                                        // (scratch until the ranks are formed: [<= 64] exclusive prefix | cell id)
     pref[lane] = incl - mycnt;
