@@ -114,6 +114,11 @@ def algorithmic_bytes(k, m, P_over_G, n_coord=1):
     return 4.0 * (2 * k * m + (k + 1) * P_over_G + 2 * n_coord * (1 + P_over_G))
 
 
+def _cabi_stats():
+    from torch_assimilate_amd import _cabi
+    return _cabi.step_coalesce_stats()
+
+
 def kernel_base_name(name):
     """'void mia::letkf_tile2f_kernel<2, 3, 1, false, 4>(mia::Tile2FParams)' -> 'letkf_tile2f_kernel<2, 3, 1, false, 4>'."""
     if not name:
@@ -584,12 +589,15 @@ def main():
     warm = args.warmup
     run(warm, depth)
     runner.kernel_timings.clear()
+    co_l0, co_s0 = _cabi_stats()
     regions = []
     for _ in range(repeats):
         el_i, out = timed(args.steps, depth)
         regions.append(el_i)
     elapsed = float(np.median(regions))
-    loop_kernel_ms = runner.kernel_ms()      # the dominant kernel inside the timed loop (every 4th step)
+    loop_kernel_ms = runner.kernel_ms()      # the dominant kernel's LAUNCHES inside the timed loop (every 4th step opens one)
+    spl = runner.kernel_steps_per_launch() if loop_kernel_ms else 1.0      # launch coalescing: steps whose tiles one launch holds
+    co_l1, co_s1 = _cabi_stats()
     runner._note_kernel()                    # ... and its name as the library launched it (before the other routes below run)
     kname = runner.dominant_kernel_name
     n_timed = len(runner.kernel_timings)
@@ -669,8 +677,9 @@ def main():
         tf = lambda f: None if f is None else f * n_pts / (ms * 1e-3) / 1e12
         return ex, us, tf(ex), tf(us), tf(algorithmic_flops(k, p, m)), f16, tf(f16)
 
-    ex_f, us_f, ex_tf, us_tf, credit_tf, f16_f, f16_tf = rates(K_ENS, 20, 1, deg, gpg, kern_ms, kkind)
-    hbm_alg = algorithmic_bytes(K_ENS, 1, P / G) * gpg / (kern_ms * 1e-3) / 1e9
+    gpl = gpg * spl                          # analyses per launch of the dominant kernel
+    ex_f, us_f, ex_tf, us_tf, credit_tf, f16_f, f16_tf = rates(K_ENS, 20, 1, deg, gpl, kern_ms, kkind)
+    hbm_alg = algorithmic_bytes(K_ENS, 1, P / G) * gpl / (kern_ms * 1e-3) / 1e9
 
     # secondary figure: the fused Jacobi-eigensolver route on the same shard (kernel only)
     eig_ms = None
@@ -938,16 +947,24 @@ def main():
             # governing algorithmic roof; the ceilings that bind in practice -- vector issue, the matrix pipe -- are listed beside it.
             "roofline": {"bound": "hbm",
                          "achieved": hbm_alg, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_alg / PEAK_HBM_GBS,
-                         "frac_basis": "%.0f algorithmic bytes per analysis (SURVEY 8(d): 4 (2 k m + (k + 1) P / G + 2 n_coord (1 + P / G))) x %d "
-                                       "analyses per launch / kernel_ms / 8 TB/s" % (algorithmic_bytes(K_ENS, 1, P / G), gpg),
-                         "algorithmic_bytes_per_launch": algorithmic_bytes(K_ENS, 1, P / G) * gpg,
+                         "frac_basis": "%.0f algorithmic bytes per analysis (SURVEY 8(d): 4 (2 k m + (k + 1) P / G + 2 n_coord (1 + P / G))) x %.0f "
+                                       "analyses per launch (%d per step x %.2f steps per launch) / kernel_ms / 8 TB/s"
+                                       % (algorithmic_bytes(K_ENS, 1, P / G), gpl, gpg, spl),
+                         "algorithmic_bytes_per_launch": algorithmic_bytes(K_ENS, 1, P / G) * gpl,
+                         "steps_per_launch": spl, "analyses_per_launch": gpl, "kernel_ms_per_step": kern_ms / spl,
+                         "steps_per_launch_note": "launch coalescing (option step_coalesce): the launch thread hands the tiles of up to four "
+                                                  "steps in flight whose preparation has finished to ONE grid of the fused kernel; mean over "
+                                                  "the timed launches; over the whole timed loop %s launches carried %s steps"
+                                                  % (co_l1 - co_l0, co_s1 - co_s0),
                          "step_frac": algorithmic_bytes(K_ENS, 1, P / G) * gpg / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBS,
                          "step_frac_note": "the same bytes / ms_per_step / peak: the whole step (index + packing + fused analysis) "
                                            "against the HBM roof",
                          "frac_alone": algorithmic_bytes(K_ENS, 1, P / G) * gpg / (alone_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if alone_ms else None,
+                         "frac_alone_note": "one step's launch alone on an idle GPU (kernel_ms_alone)",
                          "kernel": kernel_base_name(kname), "kernel_ms": kern_ms,
                          "kernel_ms_source": ("start / stop HIP events of the kernel's own dispatch (hipExtLaunchKernel, on the analysis "
-                                              "stream it is launched on) on every 4th step of the timed loop (%d launches); with %d "
+                                              "stream it is launched on) on every 4th step of the timed loop (%d launches, each opened by the "
+                                              "timed step and holding steps_per_launch steps); with %d "
                                               "analysis streams up to that many of these launches share the chip, so a launch lasts "
                                               "longer than it does alone (kernel_ms_alone: letkf_tile2_kernel on lists in memory, burst "
                                               "of launches on an idle GPU)" % (n_timed, runner.analysis_streams))
@@ -972,7 +989,7 @@ def main():
                                               "issues on a quarter of its cycles), not by bytes or matrix flops: every fraction "
                                               "here is far from 1, the largest is the vector unit's"},
                          "compute_view": {
-                             "frac_useful_shared": None if not deg else useful_flops_shared(K_ENS, 20, 1, deg) * gpg / (kern_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                             "frac_useful_shared": None if not deg else useful_flops_shared(K_ENS, 20, 1, deg) * gpl / (kern_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
                              "frac_useful_shared_basis": "useful f32 flops with the Gram matrix counted ONCE per tile of sixteen points "
                                                          "(k U (U+1) / 16 per analysis, U = 28) + per state row 4 k p + 2 deg p^2 + taper "
                                                          "25 p, no padding / kernel_ms / FP32 peak 157.3 TFLOP/s",

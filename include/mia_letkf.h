@@ -92,6 +92,12 @@ const char* mia_status_string(int status);
  *   "tile_fused"       1  step driver, tile route over the bucket index, unions of at most 32 slots, no
  *                         geometry epoch declared: every analysis wavefront localises its own tile first (csrc/letkf_tile2f.hip -- the
  *                         list kernel's code, bit-identical results; no list kernel, no tile lists in memory) / 0: lists first
+ *   "step_coalesce"    0  steps in flight (mia_letkf_step_submit) on the fused kernel: 1 .. 4: the launch thread keeps at most this many
+ *                         analysis launches of its own running and hands the tiles of the steps that become ready meanwhile -- up to
+ *                         four steps -- to ONE grid (letkf_tile2fb_kernel: every block takes its own step's parameters; same code per
+ *                         tile, bit-identical results; a timed step always opens a launch) / 0 (default): one launch per step.  The
+ *                         merged launch is cheaper per step (31 against 47 us) but the held-back steps lengthen the pipeline's loop by
+ *                         more: 0.050-0.052 against 0.047 ms per step at config 2 (profiles/r05_coalesce.txt)
  * Scope: process-wide defaults, read when a call ENQUEUES its work -- for steps handed to the launch threads
  * (mia_letkf_step_submit) at submission: a step runs with the routes that were in force when it was submitted, whatever is
  * set afterwards.  What differs per runner of one process travels in the call's own arguments (method, step_flags:
@@ -559,6 +565,33 @@ int mia_letkf_step_submit(const float* X, int64_t G, int m, int k, const float* 
                           int step_flags, int32_t* host8, void* after_stream, void* on_stream, void** done_event,
                           void* time_start_event, void* time_stop_event, void** job_out);
 int mia_letkf_step_join(void* job);
+/* The same submission through ONE argument block (a caller that keeps one block per pipeline slot rewrites only what changes from
+ * step to step: for a Python caller the 37-argument call above is ~8 us of argument conversion per step, and at config 2 the caller's
+ * ~37 us per step, not the GPU, bounded the pipeline).  in_event != NULL: prep_stream first waits for what caller_stream holds
+ * (mia_stream_wait_stream(prep_stream, caller_stream, in_event)) -- the inputs are ready.  The fields are mia_letkf_step_submit's
+ * arguments, in its order. */
+typedef struct mia_step_args {
+  const float* X; int64_t G; int32_t m, k; const float* Yb; const float* d; int64_t P;
+  const double* grid_xyz; const double* obs_xyz; int32_t n_coord; int32_t coord_group[MIA_MAX_COORD];
+  double gc_c[MIA_MAX_RADII]; int32_t n_r; double gc_eps; float inf_factor, gamma; int32_t method, p_max_assumed;
+  mia_comm_t* comm; int32_t n_chunks, phase; float* Xa; int32_t* flags; int32_t* counters; void* ws; size_t ws_bytes;
+  void* stream; void* comm_stream; void* prep_stream; int32_t step_flags; int32_t* host8; void* after_stream; void* on_stream;
+  void** done_event; void* time_start_event; void* time_stop_event;
+  void* caller_stream; void** in_event;
+} mia_step_args_t;
+int mia_letkf_step_submit_args(const mia_step_args_t* a, void** job_out);
+/* Collects a submitted step in one call: mia_letkf_step_join_info(job, batch_n), then waits on the host for *done_event (the event
+ * the step's read-back recorded -- the pointer handed to the submission, read after the join), copies the eight counters from host8
+ * to out8 and, if consumer_stream_valid, makes consumer_stream wait for that event (work enqueued there afterwards sees the step's
+ * result).  Returns the step call's status. */
+int mia_letkf_step_collect(void* job, void** done_event, const int32_t* host8, void* consumer_stream, int consumer_stream_valid,
+                           int32_t* out8, int* batch_n);
+/* Timing events for mia_letkf_step_submit's time_start_event / time_stop_event without a torch.cuda.Event per step: from a pool
+ * that is never freed (an event handed back with mia_timing_event_release is reused, not destroyed: a launch thread that still
+ * holds it touches a live event).  mia_timing_event_elapsed_ms: hipEventElapsedTime. */
+int mia_timing_event_acquire(void** event);
+int mia_timing_event_release(void* event);
+int mia_timing_event_elapsed_ms(void* start_event, void* stop_event, float* ms);
 int mia_letkf_step_drain(void);
 int mia_letkf_step_readback(const int32_t* counters, int32_t* host8, void* after_stream, void* on_stream, void** done_event);
 int mia_event_synchronize(void* event);
@@ -607,6 +640,11 @@ int mia_letkf_sharded_step_workspace_bytes(int64_t G, int m, int k, int64_t P, i
  * another geometry's steps: the next step on that address then starts from scratch (full clear, lists rebuilt), whatever its
  * flags say.  A step in flight is not affected (its decisions travel with it).  Always MIA_OK. */
 int mia_letkf_step_workspace_release(void* ws);
+/* Launch coalescing (option "step_coalesce", default on): the launch thread puts up to four steps in flight whose preparation has
+ * finished into ONE launch of the fused kernel.  mia_letkf_step_join_info is mia_letkf_step_join that also says how many steps shared
+ * the step's analysis launch; mia_letkf_step_coalesce_stats counts such launches and the steps in them since the process began. */
+int mia_letkf_step_join_info(void* job, int* batch_n);
+int mia_letkf_step_coalesce_stats(long long* launches, long long* steps);
 int mia_letkf_sharded_step_f32(const float* X /* [m][k][G] */, int64_t G, int m, int k,
                                const float* Yb /* [k][P] */, const float* d /* [P] */, int64_t P,
                                const double* grid_xyz /* [G][n_coord] */, const double* obs_xyz /* [P][n_coord] */,

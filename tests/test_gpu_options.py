@@ -1,6 +1,6 @@
 """Every route option of mia_set_option (include/mia_letkf.h) at its NON-DEFAULT value against the float64 oracle (the
 option table and the test matrix one to one).  The options not exercised elsewhere are exercised here; the table at the end of this
-file says where each of the fourteen is tested."""
+file says where each of the fifteen is tested."""
 import numpy as np
 import pytest
 import torch
@@ -27,6 +27,7 @@ OPTION_TESTS = {
     "bucket_index": (0, "tests/test_gpu_step_tiles.py::test_bucket_index_equals_scan_index_and_engine_calls"),
     "tile_pair": (0, "tests/test_gpu_tile2.py (one wavefront per tile for unions of more than 32 slots)"),
     "tile_fused": (0, "tests/test_gpu_options.py::test_step_driver_options[tile_fused]"),
+    "step_coalesce": (1, "tests/test_gpu_options.py::test_coalesced_launches_equal_one_launch_per_step"),
 }
 
 
@@ -113,3 +114,59 @@ def test_localize_one_lane_per_point(mia):
     xa = eng.analysis(X, torch.as_tensor(case["yb"], dtype=torch.float32), torch.as_tensor(case["d"], dtype=torch.float32), nb1, 1.1)
     oracle = O.letkf_analysis(case["state"], case["grid_x"], case["obs_x"], case["yb"], case["d"], 10.0, 1.1)[0]
     assert rel_fro(xa.cpu().numpy(), oracle) < TOL32
+
+
+def test_coalesced_launches_equal_one_launch_per_step(mia):
+    """Launch coalescing (option step_coalesce, default off): steps in flight whose preparation has finished share ONE launch of the
+    fused kernel.  Thirty-two steps with four different inputs, some of them timed (a timed step opens a launch): some launches hold
+    more than one step, every step returns its OWN result, bit for bit what one launch per step (step_coalesce = 0) returns, and the
+    result is the oracle's."""
+    from torch_assimilate_amd import _cabi
+    dev = torch.device("cuda:0")
+    G, k, depth = 100000, 40, 8
+    cases = [O.synthetic_case(G, k, 2, seed=40 + i) for i in range(4)]
+    args = [_args(c, dev) for c in cases]
+
+    def run(timed_every):
+        r = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1, max_in_flight=depth)
+        for i in range(depth + 2):
+            r.assimilate(*args[i % 4])
+        l0, s0 = _cabi.step_coalesce_stats()
+        pend, outs, batch = [], [], []
+        for i in range(32):
+            if timed_every and i % timed_every == 0:
+                r.time_next_step()
+            pend.append(r.submit(*args[i % 4]))
+            if len(pend) == depth:
+                h = pend.pop(0)
+                outs.append(h.result())          # (every step has a result tensor of its own: no copy, the loop stays GPU-bound)
+                batch.append(h.batch_n)
+        for h in pend:
+            outs.append(h.result())
+            batch.append(h.batch_n)
+        l1, s1 = _cabi.step_coalesce_stats()
+        r._note_kernel()
+        kern, tb = r.dominant_kernel_name, [r.kernel_batch.get(t, 1) for t in r.kernel_timings]
+        assert r.last_flags_ok()
+        r.close()
+        return outs, batch, (l1 - l0, s1 - s0), kern, tb
+
+    set_option("step_coalesce", OPTION_TESTS["step_coalesce"][0])             # (one launch running at a time: the others wait, and merge)
+    on, b_on, (launches, steps), kern, tb = run(3)
+    assert steps == 32 and launches <= steps
+    assert max(b_on) >= 2 and launches < steps, (b_on, launches)          # (some launch held more than one step ...)
+    assert max(b_on) <= 4 and len(tb) == 11 and all(1 <= t <= 4 for t in tb)
+    assert kern.startswith("letkf_tile2fb_kernel<"), kern
+    set_option("step_coalesce", 0)
+    off, b_off, (l_off, s_off), kern_off, _ = run(3)
+    assert b_off == [1] * 32 and l_off == 0 and s_off == 0
+    assert kern_off.startswith("letkf_tile2f_kernel<"), kern_off
+    for i in range(32):
+        assert torch.equal(on[i], off[i]), i                               # (... and every step got its own result)
+    for i in range(4):
+        c = cases[i]
+        if i == 0:
+            idx = np.arange(0, G, 97)
+            oracle = O.letkf_analysis(c["state"][..., idx], c["grid_x"][idx], c["obs_x"], c["yb"], c["d"], 10.0, 1.1)[0]
+            assert rel_fro(on[i].cpu().numpy()[..., idx], oracle) < TOL32
+        assert not torch.equal(on[i], on[(i + 1) % 4])

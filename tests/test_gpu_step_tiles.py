@@ -376,3 +376,62 @@ def test_fused_localisation_with_several_state_rows(mia):
             r.close()
         assert torch.equal(outs[True], outs[False]), (k, m)
         assert rel_fro(outs[True].cpu().numpy(), oracle) < 1e-5
+
+
+def test_the_steady_state_submit_path_equals_the_general_one(mia):
+    """ShardedLetkf.submit takes a short path (_submit_fast) once a steady state exists: same argument block, same streams, same flags.
+    Steps through it -- new input tensors every step, a timed step, inputs the short path must refuse (another dtype, another
+    shape, a non-contiguous state), observations that leave the stored box (step repeated on the general path) -- return what the
+    general path returns bit for bit, and the short path is really taken."""
+    dev = torch.device("cuda:0")
+    cases = [O.synthetic_case(4000, 40, 2, seed=60 + i) for i in range(3)]
+    args = [args_of(c, dev) for c in cases]
+    ref = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1, max_in_flight=4)
+    ref._submit_fast = lambda *a, **k: None                       # the general path for every step
+    want = [ref.assimilate(*a).clone() for a in args]
+    want_shift = ref.assimilate(*args_of(cases[0], dev, shift=5000.0)).clone()
+    ref.close()
+    r = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1, max_in_flight=4)
+    taken = []
+    orig = r._submit_fast
+
+    def spy(f, *a):
+        h = orig(f, *a)
+        taken.append(h is not None)
+        return h
+    r._submit_fast = spy
+    for a in args:
+        r.assimilate(*a)
+    pend = []
+    for i in range(13):
+        if i == 5:
+            r.time_next_step()
+        pend.append((i % 3, r.submit(*[t.clone() for t in args[i % 3]])))
+    for j, h in pend:
+        assert torch.equal(h.result(), want[j]), j
+    assert sum(taken) >= 8, taken                                  # (the first submissions set the state up)
+    assert len(r.kernel_timings) == 1 and r.kernel_timings[0][0].elapsed_time(r.kernel_timings[0][1]) > 0.0
+    n0 = len(taken)
+    X, g, o, Yb, d = args[1]
+    refused = [
+        (X.double(), g, o, Yb, d), (X, g.float(), o, Yb, d), (X, g, o, Yb.double(), d),
+        (X.transpose(1, 2).contiguous().transpose(1, 2), g, o, Yb, d),
+    ]
+    for a in refused:
+        out = r.submit(*a).result()
+        assert float(torch.linalg.norm(out.float() - want[1]) / torch.linalg.norm(want[1])) < 1e-5
+    assert not any(taken[n0:]), taken[n0:]
+    # a smaller problem, then the first one again: the state is re-recorded, the results stay right
+    small = args_of(O.synthetic_case(1500, 40, 2, seed=70), dev)
+    oracle = O.letkf_analysis(*[O.synthetic_case(1500, 40, 2, seed=70)[k] for k in ("state", "grid_x", "obs_x", "yb", "d")], 10.0, 1.1)[0]
+    for _ in range(3):
+        out = r.submit(*small).result()
+    assert rel_fro(out.cpu().numpy(), oracle) < 1e-5
+    for _ in range(3):
+        assert torch.equal(r.submit(*args[2]).result(), want[2])
+    # observations outside the box the workspaces hold: noticed at collection, the step is repeated (general path), right result
+    outs = [r.submit(*args_of(cases[0], dev, shift=5000.0)) for _ in range(3)]
+    for h in outs:
+        assert torch.equal(h.result(), want_shift)
+    assert r.last_flags_ok()
+    r.close()

@@ -7,6 +7,6 @@ for setting in "$@"; do
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        j = json.loads(l); print('   value %.3e  ms_per_step %.4f  kernel_ms %.4f  serial %.4f' % (j['value'], j['ms_per_step'], j['roofline'].get('kernel_ms', 0), j['pipeline']['serial_ms_per_step']))
+        j = json.loads(l); print('   value %.3e  ms_per_step %.4f  kernel_ms %.4f  steps/launch %.2f  serial %.4f' % (j['value'], j['ms_per_step'], j['roofline'].get('kernel_ms', 0), j['roofline'].get('steps_per_launch', 1), j['pipeline']['serial_ms_per_step']))
 "
 done

@@ -13,8 +13,11 @@ ap.add_argument("--depth", type=int, default=8)
 ap.add_argument("--steps", type=int, default=2000)
 ap.add_argument("--grid", type=int, default=100000)
 ap.add_argument("--prep-streams", type=int, default=3)
+ap.add_argument("--options", default="", help="name=value ... for mia_set_option")
 a = ap.parse_args()
 mia.build()
+for o in a.options.split():
+    _cabi.set_option(o.split("=")[0], int(o.split("=")[1]))
 dev = torch.device("cuda:0")
 X, gx, ox, Yb, d = bench.make_case(a.grid, 40, 2, dev)
 runner = ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1, method="auto", comm_chunks=1, native_step=True,
@@ -50,12 +53,14 @@ gc.collect(); gc.freeze()
 run(200)
 torch.cuda.synchronize()
 s0 = stats()
+co0 = _cabi.step_coalesce_stats()
 t0 = time.perf_counter()
 t_sub, t_res = run(a.steps)
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
 s1 = stats()
 n = s1[2] - s0[2]
+print(a.options, "depth", a.depth, "steps/launch %.2f" % ((lambda l0, l1: (l1[1] - l0[1]) / max(1, l1[0] - l0[0]))(co0, _cabi.step_coalesce_stats())))
 print("period %.1f us/step;  caller: submit %.1f us, result() %.1f us;  launch thread A (preparation) %.1f us, thread B "
       "(analysis + read-back, excluding its wait for the preparation) %.1f us  [%d jobs]"
       % (1e6 * el / a.steps, 1e6 * t_sub / a.steps, 1e6 * t_res / a.steps, (s1[0] - s0[0]) / n, (s1[1] - s0[1]) / n, n))

@@ -104,7 +104,14 @@ _PROTOS = {
     "mia_letkf_step_submit": ([vp, i64, i32, i32, vp, vp, i64, vp, vp, i32, C.POINTER(C.c_int32), C.POINTER(f64), i32, f64,
                                f32, f32, i32, i32, vp, i32, i32, vp, vp, vp, vp, sz, vp, vp, vp, i32,
                                vp, vp, vp, C.POINTER(vp), vp, vp, C.POINTER(vp)], i32),
+    "mia_letkf_step_submit_args": ([vp, vp], i32),
+    "mia_letkf_step_collect": ([vp, vp, vp, vp, i32, vp, vp], i32),
+    "mia_timing_event_acquire": ([C.POINTER(vp)], i32),
+    "mia_timing_event_release": ([vp], i32),
+    "mia_timing_event_elapsed_ms": ([vp, vp, C.POINTER(C.c_float)], i32),
     "mia_letkf_step_join": ([vp], i32),
+    "mia_letkf_step_join_info": ([vp, C.POINTER(C.c_int)], i32),
+    "mia_letkf_step_coalesce_stats": ([C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], i32),
     "mia_letkf_step_drain": ([], i32),
     "mia_letkf_step_readback": ([vp, vp, vp, vp, C.POINTER(vp)], i32),
     "mia_event_synchronize": ([vp], i32),
@@ -167,6 +174,50 @@ def set_option(name: str, value: int) -> int:
     check(lib().mia_get_option(name.encode(), C.byref(old)), "mia_get_option(%s)" % name)
     check(lib().mia_set_option(name.encode(), int(value)), "mia_set_option(%s)" % name)
     return old.value
+
+
+class StepArgs(C.Structure):
+    """mia_step_args_t (include/mia_letkf.h): mia_letkf_step_submit's arguments as one block a pipeline slot keeps."""
+    _fields_ = [("X", C.c_void_p), ("G", C.c_int64), ("m", C.c_int32), ("k", C.c_int32), ("Yb", C.c_void_p), ("d", C.c_void_p),
+                ("P", C.c_int64), ("grid_xyz", C.c_void_p), ("obs_xyz", C.c_void_p), ("n_coord", C.c_int32),
+                ("coord_group", C.c_int32 * 3), ("gc_c", C.c_double * 3), ("n_r", C.c_int32), ("gc_eps", C.c_double),
+                ("inf_factor", C.c_float), ("gamma", C.c_float), ("method", C.c_int32), ("p_max_assumed", C.c_int32),
+                ("comm", C.c_void_p), ("n_chunks", C.c_int32), ("phase", C.c_int32), ("Xa", C.c_void_p), ("flags", C.c_void_p),
+                ("counters", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("stream", C.c_void_p),
+                ("comm_stream", C.c_void_p), ("prep_stream", C.c_void_p), ("step_flags", C.c_int32), ("host8", C.c_void_p),
+                ("after_stream", C.c_void_p), ("on_stream", C.c_void_p), ("done_event", C.POINTER(C.c_void_p)),
+                ("time_start_event", C.c_void_p), ("time_stop_event", C.c_void_p), ("caller_stream", C.c_void_p),
+                ("in_event", C.POINTER(C.c_void_p))]
+
+
+class TimingEvent:
+    """A timing event from the library's pool (mia_timing_event_acquire): what ShardedLetkf.time_next_step hands to the step's
+    launch.  ``elapsed_time`` as torch.cuda.Event's; released to the pool, never destroyed, when the object goes away."""
+    __slots__ = ("cuda_event",)
+
+    def __init__(self):
+        ev = C.c_void_p()
+        check(lib().mia_timing_event_acquire(C.byref(ev)), "mia_timing_event_acquire")
+        self.cuda_event = ev.value
+
+    def elapsed_time(self, other) -> float:
+        ms = C.c_float(0.0)
+        check(lib().mia_timing_event_elapsed_ms(self.cuda_event, other.cuda_event, C.byref(ms)), "mia_timing_event_elapsed_ms")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.cuda_event:
+                lib().mia_timing_event_release(self.cuda_event)
+        except Exception:       # (interpreter shutdown)
+            pass
+
+
+def step_coalesce_stats():
+    """mia_letkf_step_coalesce_stats: (analysis launches made by the launch thread's collector, steps they carried) so far."""
+    a, b = C.c_longlong(0), C.c_longlong(0)
+    check(lib().mia_letkf_step_coalesce_stats(C.byref(a), C.byref(b)), "mia_letkf_step_coalesce_stats")
+    return int(a.value), int(b.value)
 
 
 def last_analysis_kernel() -> str:

@@ -24,7 +24,7 @@ extern "C" const char* mia_status_string(int status) {
 #include "mia_options.h"
 
 namespace mia {
-static std::atomic<int> g_opt[MIA_OPT_COUNT_] = {62, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+static std::atomic<int> g_opt[MIA_OPT_COUNT_] = {62, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0};
 // A thread may run under a SNAPSHOT of the options (the step driver's launch threads: a job is enqueued with the routes that
 // were in force when the caller submitted it, whatever mia_set_option does in the meantime)
 static thread_local const int* t_override = nullptr;
@@ -63,14 +63,16 @@ extern "C" int mia_last_analysis_kernel(char* buf, int n) {
 
 static const char* const kOptNames[MIA_OPT_COUNT_] = {"cheb_dmax", "cheb_table", "cheb_rowbatch", "cheb_big", "tile",
                                                       "tile_split", "localize_quad", "step_hostwait", "step_lazy_sort",
-                                                      "segment_signal", "tile_lists", "bucket_index", "tile_pair", "tile_fused"};
-static const int kOptDefault[MIA_OPT_COUNT_] = {62, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+                                                      "segment_signal", "tile_lists", "bucket_index", "tile_pair", "tile_fused",
+                                                      "step_coalesce"};
+static const int kOptDefault[MIA_OPT_COUNT_] = {62, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0};
 
 extern "C" int mia_set_option(const char* name, int value) {
   if (!name) return MIA_ERR_NULL;
   for (int i = 0; i < MIA_OPT_COUNT_; ++i)
     if (!strcmp(name, kOptNames[i])) {
       if (i == MIA_OPT_CHEB_DMAX) { if (value < 0) value = kOptDefault[i]; if (value < 3 || value > 62) return MIA_ERR_SIZE; }
+      else if (i == MIA_OPT_STEP_COALESCE) { if (value < 0) value = kOptDefault[i]; if (value > 4) return MIA_ERR_SIZE; }
       else value = value < 0 ? kOptDefault[i] : (value != 0);
       mia::g_opt[i].store(value, std::memory_order_relaxed);
       return MIA_OK;

@@ -18,6 +18,9 @@ enum {
   MIA_OPT_TILE_PAIR,         // tile route, unions of more than 32 slots: two wavefronts per tile (letkf_tile2p.hip) (1) or one (0)
   MIA_OPT_TILE_FUSED,        // step driver, tile route, unions of at most 32 slots: the analysis wavefronts localise their
                              // tiles themselves (letkf_tile2f.hip: no list kernel, no lists in memory) (1) or lists first (0)
+  MIA_OPT_STEP_COALESCE,     // steps in flight on the fused kernel: 0 (default): every step is launched on its own the moment it is ready;
+                             // 1 .. 4: the launch thread keeps at most this many launches of its own running and puts the steps that
+                             // become ready meanwhile -- up to four -- into ONE launch (measured slower per step: sharded_step.hip)
   MIA_OPT_COUNT_
 };
 

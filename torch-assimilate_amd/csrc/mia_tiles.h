@@ -359,6 +359,14 @@ int tile2_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0,
 // letkf_tile2f.hip: the same analysis with the localisation of each tile done by its own wavefront (loc: mia_localize_dev.h) --
 // shapes: unions of at most 32 slots, any number of state rows
 bool tile2f_covers(int m, int k, int ut, int n_coord);
+// launch coalescing (letkf_tile2f.hip): on the calling thread, tile2f_launch collects the steps' parameters instead of launching
+// until tile2f_collect_launch puts them on `stream` as one grid (kT2fBatchMax steps at most; a step that does not fit the batch
+// ends the collection and is launched on its own)
+constexpr int kT2fBatchMax = 4;
+void tile2f_collect_begin();
+int tile2f_collected();
+bool tile2f_collecting();
+int tile2f_collect_launch(hipStream_t stream);
 int tile2f_launch(const Tile2Params& tp, const struct Tile2Loc& loc, int ut, int kt, hipStream_t stream);
 size_t tile2_lds_bytes(int ut, int k);
 

@@ -18,6 +18,7 @@
 #include <deque>
 #include <mutex>
 #include <thread>
+#include <vector>
 #include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1197,6 +1198,7 @@ struct StepJob {
   hipEvent_t kdone = nullptr;      // completion event carried by the analysis launch itself (stage 2), if any
   StepDecision dec;                // what stage 1 decided about the workspace's lists and count arrays, for stage 2
   int opts[MIA_OPT_COUNT_];        // the route options as they stood when the caller submitted the step
+  int batch_n = 1;                 // steps in the analysis launch this step was part of (launch coalescing)
   int device = 0;
   int rc = 0;
   bool done = false;
@@ -1216,6 +1218,8 @@ struct LaunchThreads {
   bool stop = false, started = false;
   int busy = 0;          // jobs handed in and not yet finished by thread B
   std::atomic<long long> ns_a{0}, ns_b{0}, n_jobs{0};     // host time spent enqueueing (mia_letkf_step_launch_stats)
+  std::atomic<long long> n_launches{0}, n_launch_steps{0};      // analysis launches made with the collector on, and the steps in them
+  static int i_rc_first(int a, int b) { return a != MIA_OK ? a : b; }
   void run_a() {
     int cur_a = device;
     (void)hipSetDevice(device);
@@ -1244,6 +1248,11 @@ struct LaunchThreads {
   void run_b() {
     int cur_b = device;
     (void)hipSetDevice(device);
+    std::deque<hipEvent_t> running;      // completion events of this thread's coalesced launches that may still be running
+    void* last_stream = nullptr;
+    hipEvent_t own_ev[8] = {};
+    bool own_init = false;
+    unsigned own_next = 0;
     for (;;) {
       StepJob* j;
       {
@@ -1253,7 +1262,7 @@ struct LaunchThreads {
         j = qb.front();
         qb.pop_front();
       }
-      if (j->device != cur_b) { (void)hipSetDevice(j->device); cur_b = j->device; }
+      if (j->device != cur_b) { (void)hipSetDevice(j->device); cur_b = j->device; running.clear(); own_init = false; }
       int rc = j->rc;
       // Steps in flight: wait for the step's preparation HERE, on the host, and enqueue the analysis kernel with nothing in
       // front of it.  A stream-wait in the analysis queue is a barrier packet between every two analysis kernels (11-16 us
@@ -1266,19 +1275,103 @@ struct LaunchThreads {
         if (q == hipSuccess) j->step_flags |= kStepPrepDone;
         else (void)hipGetLastError();         // (leave the ordering to the stream wait)
       }
-      const auto tb0 = std::chrono::steady_clock::now();
+      auto tb0 = std::chrono::steady_clock::now();
+      // Launch coalescing: a launch of one step's 6250 tiles spends a quarter of its time filling and draining the chip, and kernels
+      // of different streams overlap badly (letkf_tile2f.hip).  Steps in flight are independent: while this step's analysis is being
+      // put together, the FOLLOWING steps of the queue whose preparation has already finished are put together too, and their tiles
+      // go to the GPU as one grid (up to kT2fBatchMax steps, the fused kernel only; a timed step always opens a launch).  Every
+      // step keeps its own workspace, counters, flags, result, read-back and completion event.
+      // A launch thread that enqueues every step the moment it is ready never finds a second one waiting: the queue in front of the
+      // GPU would be the hardware's, where it cannot be merged.  So with the option on the thread holds a step back while
+      // `step_coalesce` launches of its own are still running, and the steps that become ready meanwhile join it.
+      // MEASURED (profiles/r05_coalesce.txt) and therefore OFF by default: the merged launch is cheaper per step as predicted (90 us
+      // for 2.9 steps = 31 us per step against 47-55 us for a launch of one step beside its neighbours), but holding steps back
+      // lengthens the loop step -> result -> next submission of a pipeline with eight slots by more than the launch saves:
+      // 0.052 ms per step with one launch running at a time, 0.048-0.050 with two, against 0.047 without.
+      StepJob* batch[mia::kT2fBatchMax] = {j, nullptr, nullptr, nullptr};
+      int nb = 1;
+      const bool may = rc == MIA_OK && (j->step_flags & kStepPrepDone) && j->phase == 0 && !j->comm && j->n_chunks == 1 && j->method != 1 &&
+                       j->opts[MIA_OPT_STEP_COALESCE] != 0 && j->host8;
+      if (may) {
+        tb0 = std::chrono::steady_clock::now();
+        mia::tile2f_collect_begin();
+      }
       if (rc == MIA_OK) rc = j->run(2);
-      if (rc == MIA_OK && j->host8) {
-        // (the read-back waits for the kernel's own completion event when the launch carried one: no marker on the stream)
-        if (j->kdone && j->after == j->stream) rc = readback_after_event(j->counters, j->host8, j->kdone, j->on, j->done_event);
-        else rc = mia_letkf_step_readback(j->counters, j->host8, j->after, j->on, j->done_event);
+      if (may) {
+        const size_t w = (size_t)j->opts[MIA_OPT_STEP_COALESCE];
+        bool open = mia::tile2f_collecting() && mia::tile2f_collected() == 1;
+        long long waited = 0;
+        // the step is put together; it goes to the GPU when fewer than w launches of this thread are still running, and the steps
+        // that become ready until then join it
+        for (;;) {
+          while (open && nb < mia::kT2fBatchMax) {
+            StepJob* c = nullptr;
+            {
+              std::lock_guard<std::mutex> lk(mu);
+              if (!qb.empty()) c = qb.front();
+              const bool ok = c && c->rc == MIA_OK && c->device == j->device && c->pe && (c->step_flags & MIA_STEP_NO_JOIN) && c->phase == 0 &&
+                              !c->comm && c->n_chunks == 1 && c->method != 1 && c->host8 && !c->t0 && !c->t1 &&
+                              c->opts[MIA_OPT_STEP_COALESCE] != 0 && c->opts[MIA_OPT_STEP_HOSTWAIT] != 0;
+              if (ok && hipEventQuery(c->pe) == hipSuccess) qb.pop_front();      // (its preparation has finished: no waiting for it)
+              else { (void)hipGetLastError(); c = nullptr; }
+            }
+            if (!c) break;
+            c->step_flags |= kStepPrepDone;
+            const int had = mia::tile2f_collected();
+            c->rc = c->run(2);
+            batch[nb++] = c;
+            if (!mia::tile2f_collecting() || mia::tile2f_collected() == had) open = false;      // (went another way: launched by itself)
+          }
+          while (!running.empty() && hipEventQuery(running.front()) != hipErrorNotReady) { (void)hipGetLastError(); running.pop_front(); }
+          if (running.size() < w) break;
+          const auto tw = std::chrono::steady_clock::now();
+          std::this_thread::yield();
+          waited += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tw).count();
+        }
+        ns_b -= waited;      // (the host-time statistic: enqueueing, not waiting)
+      }
+      if (may) {
+        const int n_in = mia::tile2f_collected();
+        // on a stream other than the previous launch's where the steps offer one: the head of this launch overlaps the tail of that
+        // (one stream for all these launches measured the same: profiles/r05_coalesce.txt)
+        void* ls = j->stream;
+        for (int i = 0; i < n_in; ++i)
+          if (batch[i]->stream != last_stream) { ls = batch[i]->stream; break; }
+        int lrc = mia::tile2f_collect_launch((hipStream_t)ls);
+        if (lrc == MIA_OK && n_in > 0) {
+          last_stream = ls;
+          hipEvent_t done = n_in > 1 ? batch[n_in - 1]->kdone : (j->t1 ? nullptr : j->kdone);
+          if (!done) {        // (a timed step alone: its stop event is the caller's, which may not outlive the step)
+            if (!own_init) {
+              for (auto& e : own_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+              own_init = true;
+            }
+            done = own_ev[own_next++ & 7];
+            if (done && hipEventRecord(done, (hipStream_t)ls) != hipSuccess) { (void)hipGetLastError(); done = nullptr; }
+          }
+          if (done) running.push_back(done);
+        }
+        if (lrc != MIA_OK)
+          for (int i = 0; i < nb; ++i) if (i < n_in && batch[i]->rc == MIA_OK) batch[i]->rc = lrc;
+        rc = i_rc_first(rc, batch[0]->rc);
+        for (int i = 0; i < nb; ++i) batch[i]->batch_n = i < n_in ? n_in : 1;
+        n_launches += 1;
+        n_launch_steps += n_in > 0 ? n_in : 1;
+      }
+      for (int i = 0; i < nb; ++i) {
+        StepJob* b = batch[i];
+        int brc = i == 0 ? rc : b->rc;
+        if (brc == MIA_OK && b->host8) {
+          // (the read-back waits for the kernel's own completion event when the launch carried one: no marker on the stream)
+          if (b->kdone && b->after == b->stream) brc = readback_after_event(b->counters, b->host8, b->kdone, b->on, b->done_event);
+          else brc = mia_letkf_step_readback(b->counters, b->host8, b->after, b->on, b->done_event);
+        }
+        b->rc = brc;
       }
       ns_b += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tb0).count();
       {
         std::lock_guard<std::mutex> lk(mu);
-        j->rc = rc;
-        j->done = true;
-        --busy;
+        for (int i = 0; i < nb; ++i) { batch[i]->done = true; --busy; }
       }
       cv_done.notify_all();
     }
@@ -1330,6 +1423,59 @@ extern "C" int mia_letkf_step_submit(const float* X, int64_t G, int m, int k, co
   return MIA_OK;
 }
 
+extern "C" int mia_letkf_step_submit_args(const mia_step_args_t* a, void** job_out) {
+  if (!a) return MIA_ERR_NULL;
+  if (a->in_event) {
+    const int rc = mia_stream_wait_stream(a->prep_stream, a->caller_stream, a->in_event);
+    if (rc != MIA_OK) return rc;
+  }
+  return mia_letkf_step_submit(a->X, a->G, a->m, a->k, a->Yb, a->d, a->P, a->grid_xyz, a->obs_xyz, a->n_coord, a->coord_group, a->gc_c,
+                               a->n_r, a->gc_eps, a->inf_factor, a->gamma, a->method, a->p_max_assumed, a->comm, a->n_chunks, a->phase,
+                               a->Xa, a->flags, a->counters, a->ws, a->ws_bytes, a->stream, a->comm_stream, a->prep_stream, a->step_flags,
+                               a->host8, a->after_stream, a->on_stream, a->done_event, a->time_start_event, a->time_stop_event, job_out);
+}
+
+extern "C" int mia_letkf_step_collect(void* job, void** done_event, const int32_t* host8, void* consumer_stream, int consumer_stream_valid,
+                                      int32_t* out8, int* batch_n) {
+  if (!job || !done_event || !host8 || !out8) return MIA_ERR_NULL;
+  const int rc = mia_letkf_step_join_info(job, batch_n);
+  if (rc != MIA_OK) return rc;
+  const hipEvent_t ev = (hipEvent_t)*done_event;      // (made by the step's read-back on the launch thread: read after the join)
+  if (!ev) return MIA_ERR_NULL;
+  MIA_HIP_TRY(hipEventSynchronize(ev));
+  for (int i = 0; i < 8; ++i) out8[i] = host8[i];
+  if (consumer_stream_valid) MIA_HIP_TRY(hipStreamWaitEvent((hipStream_t)consumer_stream, ev, 0));
+  return MIA_OK;
+}
+
+namespace {
+std::mutex g_tev_mutex;
+std::vector<hipEvent_t> g_tev_free;
+}
+extern "C" int mia_timing_event_acquire(void** event) {
+  if (!event) return MIA_ERR_NULL;
+  {
+    std::lock_guard<std::mutex> lk(g_tev_mutex);
+    if (!g_tev_free.empty()) { *event = (void*)g_tev_free.back(); g_tev_free.pop_back(); return MIA_OK; }
+  }
+  hipEvent_t e = nullptr;
+  MIA_HIP_TRY(hipEventCreate(&e));
+  *event = (void*)e;
+  return MIA_OK;
+}
+extern "C" int mia_timing_event_release(void* event) {
+  if (!event) return MIA_ERR_NULL;
+  std::lock_guard<std::mutex> lk(g_tev_mutex);
+  g_tev_free.push_back((hipEvent_t)event);
+  return MIA_OK;
+}
+extern "C" int mia_timing_event_elapsed_ms(void* start_event, void* stop_event, float* ms) {
+  if (!start_event || !stop_event || !ms) return MIA_ERR_NULL;
+  MIA_HIP_TRY(hipEventSynchronize((hipEvent_t)stop_event));
+  MIA_HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start_event, (hipEvent_t)stop_event));
+  return MIA_OK;
+}
+
 // host time the two launch threads have spent enqueueing so far (microseconds: preparation stage, analysis / exchange /
 // read-back stage) and the number of steps: tells a pipeline that waits for its launches from one that waits for the GPU
 extern "C" int mia_letkf_step_launch_stats(double* prep_us, double* rest_us, long long* steps) {
@@ -1350,6 +1496,26 @@ extern "C" int mia_letkf_step_join(void* job) {
   lk.unlock();
   delete j;
   return rc;
+}
+
+// ... and how many steps shared this step's analysis launch (1: its own launch)
+extern "C" int mia_letkf_step_join_info(void* job, int* batch_n) {
+  if (!job) return MIA_ERR_NULL;
+  StepJob* j = (StepJob*)job;
+  std::unique_lock<std::mutex> lk(g_launcher.mu);
+  g_launcher.cv_done.wait(lk, [&] { return j->done; });
+  const int rc = j->rc;
+  if (batch_n) *batch_n = j->batch_n;
+  lk.unlock();
+  delete j;
+  return rc;
+}
+// analysis launches of steps in flight so far and the steps they carried (launch coalescing: steps / launches > 1)
+extern "C" int mia_letkf_step_coalesce_stats(long long* launches, long long* steps) {
+  if (!launches || !steps) return MIA_ERR_NULL;
+  *launches = g_launcher.n_launches.load();
+  *steps = g_launcher.n_launch_steps.load();
+  return MIA_OK;
 }
 
 // waits until nothing is queued or running on the launch thread (before a synchronous call that must not overtake it)

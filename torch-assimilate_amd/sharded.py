@@ -48,11 +48,18 @@ def gather_blocks(shard: torch.Tensor, G: int, world: int, group=None) -> torch.
     return gathered.view(world, m, k, n).permute(1, 2, 0, 3).reshape(m, k, world * n)[:, :, :G].contiguous()
 
 
+from . import _cabi          # (ctypes declarations only: the library itself is loaded on first use)
+
+_F32, _F64 = torch.float32, torch.float64
+_METHODS = {"auto": 0, "eig": 1, "matfun": 2}
+
+
 class PendingStep:
     """Handle of a step enqueued by :meth:`ShardedLetkf.submit`."""
 
     def __init__(self, runner, state, out=None):
         self._runner, self._st, self._out = runner, state, out
+        self.batch_n = 1        # steps that shared this step's analysis launch (known once the step has been joined)
 
     def result(self) -> torch.Tensor:
         """The (m, k, G) analysis; performs the step's host read-back the first time it is called."""
@@ -68,6 +75,18 @@ class ShardedLetkf:
     gfx950 engine; the multi-process CPU tests inject a stand-in to exercise the sharding /
     collective logic under the gloo backend.
     """
+
+    @property
+    def _last_flags(self):
+        """Per-point flags of the last completed step (None before the first)."""
+        lz = self._last_flags_lazy
+        if lz is not None:
+            self._last_flags_val, self._last_flags_lazy = lz[0][:lz[1]], None
+        return self._last_flags_val
+
+    @_last_flags.setter
+    def _last_flags(self, value):
+        self._last_flags_val, self._last_flags_lazy = value, None
 
     @property
     def dominant_kernel_name(self):
@@ -222,6 +241,8 @@ class ShardedLetkf:
         self._in_flight = []
         self._time_next = False        # time_next_step(): the next native step brackets its analysis kernel with events
         self.kernel_timings = []       # [(start, stop)] torch events recorded on the analysis stream by the library
+        self.kernel_batch = {}         # (start, stop) -> steps in the launch those events bracket (launch coalescing; absent: 1)
+        self.last_batch_n = 1          # steps that shared the analysis launch of the step finished last
         self.max_in_flight = max(1, min(int(max_in_flight), 8))
         self.prep_streams = max(0, min(int(prep_streams), 8))      # steps in flight: preparation streams taken in turn (0: none, tools)
         self.analysis_streams = max(1, min(int(analysis_streams), 4))
@@ -244,7 +265,8 @@ class ShardedLetkf:
         self._compute = compute_shard or self._engine_shard
         self.last_p_max = 0
         self._p_max_hint = None
-        self._last_flags = None
+        self._last_flags_val, self._last_flags_lazy = None, None
+        self._fast = None              # what _submit_fast needs: recorded by _native_submit once a steady state exists
         # tile route of the native step driver (tile-shaped lists + split records, csrc/letkf_tile2.hip): switched off for this
         # object once a step reports tiles whose union does not fit their slots (scattered grids) -- per-point lists then
         self._no_tile_lists = False
@@ -492,6 +514,11 @@ class ShardedLetkf:
         every earlier step submitted with the same id (a fixed observing network in a cycled filter).  Steps on the tile
         route then use the tile lists their pipeline slot already holds and rebuild only the split records
         (MIA_STEP_REUSE_LISTS); results are identical to a full rebuild, which is what the reference does on every call."""
+        f = self._fast
+        if f is not None and geometry_id is None:
+            h = self._submit_fast(f, X, grid_xyz, obs_xyz, Yb, d)
+            if h is not None:
+                return h
         G = X.shape[-1]
         g0, g1 = block_partition(G, self.world)[self.rank]
         if not (self.native_step and self._compute == self._engine_shard and self._chunk_compute is None
@@ -499,6 +526,68 @@ class ShardedLetkf:
                 and not self.fused_localization):
             return PendingStep(self, None, out=self.assimilate(X, grid_xyz, obs_xyz, Yb, d))
         return self._native_submit(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, pipelined=True, geometry_id=geometry_id)
+
+    def _submit_fast(self, f, X, grid_xyz, obs_xyz, Yb, d):
+        """The steady state of :meth:`submit` on one GPU: the SAME step as ``_native_submit`` enqueues -- same argument block, same
+        streams in the same rotation, same flags -- for inputs that already are what the library reads (device, dtype, contiguous,
+        the shapes of the previous step), without the general path's set-up code.  At config 2 the caller's host time per step,
+        not the GPU, bounded the pipeline (tools/host_bound.py: submit 25 us + result 12 us = the 37 us period).  Returns None
+        whenever anything differs from the state ``_native_submit`` recorded: the general path then takes the step."""
+        try:
+            ok = (X.dtype is _F32 and Yb.dtype is _F32 and d.dtype is _F32 and grid_xyz.dtype is _F64 and obs_xyz.dtype is _F64
+                  and X.shape == f["xs"] and Yb.shape == f["ys"] and d.shape == f["ds"] and grid_xyz.shape == f["gs"]
+                  and obs_xyz.shape == f["os"] and X.is_contiguous() and Yb.is_contiguous() and d.is_contiguous()
+                  and grid_xyz.is_contiguous() and obs_xyz.is_contiguous())
+            dev = f["device"]
+            ok = ok and X.device == dev and Yb.device == dev and d.device == dev and grid_xyz.device == dev and obs_xyz.device == dev
+        except AttributeError:
+            return None
+        if not ok or self._native is not f["st"] or not self.native_step or self.fused_localization:
+            return None
+        n_sub = self._submitted
+        slot = f["slots"][n_sub % f["n"]]
+        busy = slot.get("busy")
+        if busy is not None:                                      # its previous step was never collected
+            busy.result()
+        hint = self._p_max_hint
+        if hint is None or slot.get("args_key") != (f["G"], f["m"], f["k"], f["P"], f["nc"], int(hint), 1) or self._fast is not f:
+            return None
+        a = slot["args"]
+        out = torch.empty(f["xs"], dtype=_F32, device=dev)
+        step_flags = (1 | (4 if slot.get("ws_clean") else 0) | (8 if self._no_tile_lists else 0) | (self._tile_extra << 4) |
+                      (0x400 if self._fresh_box_once else 0) | (0x800 if self._scan_index else 0) |
+                      (0 if self._fuse_now(True) else 0x4000))
+        self._fresh_box_once = False
+        slot["ws_clean"] = False
+        timing = None
+        if self._time_next:
+            self._time_next = False
+            timing = (_cabi.TimingEvent(), _cabi.TimingEvent())
+            self.kernel_timings.append(timing)
+            a.time_start_event, a.time_stop_event = timing[0].cuda_event, timing[1].cuda_event
+        elif a.time_start_event:
+            a.time_start_event, a.time_stop_event = None, None
+        comp = f["astreams"][n_sub % f["na"]]
+        prep = f["pstreams"][n_sub % f["np"]] if f["np"] else comp
+        cur_raw = torch._C._cuda_getCurrentRawStream(f["dev_index"])
+        a.X, a.Yb, a.d, a.grid_xyz, a.obs_xyz, a.Xa = X.data_ptr(), Yb.data_ptr(), d.data_ptr(), grid_xyz.data_ptr(), obs_xyz.data_ptr(), out.data_ptr()
+        a.gc_eps, a.inf_factor, a.gamma = float(self.eps), float(self.inf_factor), float(self.rbf_gamma) if self.rbf_gamma is not None else 0.0
+        a.method, a.p_max_assumed, a.step_flags = _METHODS[self.method], int(hint), step_flags
+        a.comm, a.n_chunks = None, 1
+        a.stream, a.comm_stream, a.prep_stream = comp.cuda_stream, f["side"], prep.cuda_stream
+        a.after_stream, a.on_stream, a.caller_stream = comp.cuda_stream, f["side"], cur_raw
+        rc = f["lib"].mia_letkf_step_submit_args(slot["args_ref"], slot["job_ref"])
+        if rc != 0:
+            _cabi.check(rc, "mia_letkf_step_submit_args")
+        G = f["G"]
+        h = PendingStep(self, dict(slot=slot, call=None, comp=comp, cur=None, cur_raw=cur_raw, dev_index=f["dev_index"], ev=slot["event"],
+                                   job=slot["job"].value, out=out, flags=slot["flags"], hint=int(hint), last=f["last"], peer=False,
+                                   timing=timing, C_chunks=1, args=(X, grid_xyz, obs_xyz, Yb, d, G, 0, G),
+                                   keep=(X, grid_xyz, obs_xyz, Yb, d), geom_key=None, reused=False, geometry_id=None))
+        slot["busy"] = h
+        self._in_flight.append(h)
+        self._submitted = n_sub + 1
+        return h
 
     def _native_submit(self, X, grid_xyz, obs_xyz, Yb, d, G, g0, g1, pipelined, geometry_id=None):
         import ctypes as C
@@ -571,6 +660,7 @@ class ShardedLetkf:
             slot["flags"] = torch.empty(max(g1 - g0, 1), dtype=torch.int32, device=X.device)
             slot["event"] = slot.get("event") or C.c_void_p()          # completion event of the read-back (library-made)
             slot["key"] = key
+            slot["args"] = None                                        # (the argument block of steps in flight points at the old buffers)
             slot["ws_clean"] = False                                   # fresh workspace: the first step clears the index header
         # direct exchange: the result IS the slot's peer-mapped buffer (every rank uses the same slot for the same step)
         part = st.get("part")                       # gather=False: partition-only communicator, the result is this rank's block
@@ -595,7 +685,7 @@ class ShardedLetkf:
         #  per step; the Stream object is built only on the paths that need one)
         dev_index = X.device.index if X.device.index is not None else torch.cuda.current_device()
         cur_raw = torch._C._cuda_getCurrentRawStream(dev_index)
-        cur = None if pipelined and not self._time_next else torch.cuda.current_stream(X.device)
+        cur = None if pipelined else torch.cuda.current_stream(X.device)
         side = st["stream"].cuda_stream if st["stream"] is not None else None
         exch = st["comm"] is not None and (self.world > 1 or C_chunks > 1)
         if pipelined:
@@ -621,43 +711,37 @@ class ShardedLetkf:
                 # analyses/s at config 2 against 1.73e9, at 51 us per analysis launch instead of 35 -- WHEN the two streams get
                 # hardware queues of their own: as the third runner of a process the same set-up ran at 1.24e9 (HISTORY.md)
                 prep = comp
-            if "in_event" not in slot:
-                slot["in_event"] = C.c_void_p()
-            _cabi.check(lib.mia_stream_wait_stream(prep.cuda_stream, cur_raw, C.byref(slot["in_event"])),
-                        "mia_stream_wait_stream")                  # inputs (and `out`'s memory) are ready
             # where the step's last work is enqueued: the placement stream when there is one, else the exchange stream
             last = ((st["stream"] if peer else (st.get("xstream") or st["stream"])) if exch else comp)
         else:
             comp, prep, last = cur, None, cur
 
-        # (plain integers for the pointer arguments: ctypes converts them itself, a C.c_void_p object per argument was a
-        #  third of this function's host time)
-        cargs = [X.data_ptr(), G, m, k, Yb.data_ptr(), d.data_ptr(), P, grid.data_ptr(), obs.data_ptr(), nc, slot["cg"],
-                 slot["rc"], len(self.radii), float(self.eps), float(self.inf_factor), gamma, method, hint,
-                 st["comm"] if part is None else part,
-                 C_chunks, 0, out.data_ptr(), flags.data_ptr(), slot["counters"].data_ptr(), slot["ws"].data_ptr(),
-                 slot["ws"].numel(), comp.cuda_stream, side, prep.cuda_stream if prep is not None else None,
-                 # MIA_STEP_NO_JOIN for steps in flight; MIA_STEP_WS_CLEAN: this slot's workspace was last used by a step that
-                 # ran to completion (its index kernels leave the header zeroed)
-                 (1 if pipelined else 0) | (4 if slot.get("ws_clean") else 0) | (8 if self._no_tile_lists else 0) | (self._tile_extra << 4) |
-                 (0x400 if self._fresh_box_once else 0) | (0x800 if self._scan_index else 0) | (0x1000 if reuse else 0) | (0x4000 if (geom_key is not None or not self._fuse_now(pipelined)) else 0) |
-                 (0x2000 if part is not None else 0)]
-        self._fresh_box_once = False
-        slot["ws_clean"] = False            # (until this step has been collected without an error)
-        step_fn = lib.mia_letkf_sharded_step_streams_f32
+        step_flags = ((1 if pipelined else 0) | (4 if slot.get("ws_clean") else 0) | (8 if self._no_tile_lists else 0) | (self._tile_extra << 4) |
+                      (0x400 if self._fresh_box_once else 0) | (0x800 if self._scan_index else 0) | (0x1000 if reuse else 0) |
+                      (0x4000 if (geom_key is not None or not self._fuse_now(pipelined)) else 0) | (0x2000 if part is not None else 0))
+        # MIA_STEP_NO_JOIN for steps in flight; MIA_STEP_WS_CLEAN: this slot's workspace was last used by a step that
+        # ran to completion (its index kernels leave the header zeroed)
+        comm_arg = st["comm"] if part is None else part
+        comm_val = getattr(comm_arg, "value", comm_arg)          # (a plain integer / None for the argument block)
+        eps, inf = float(self.eps), float(self.inf_factor)
 
         def call(phase):
-            cargs[20] = phase
-            rc = step_fn(*cargs)
+            # (plain integers for the pointer arguments: ctypes converts them itself, a C.c_void_p object per argument was a
+            #  third of this function's host time)
+            rc = lib.mia_letkf_sharded_step_streams_f32(
+                X.data_ptr(), G, m, k, Yb.data_ptr(), d.data_ptr(), P, grid.data_ptr(), obs.data_ptr(), nc, slot["cg"],
+                slot["rc"], len(self.radii), eps, inf, gamma, method, hint, comm_arg,
+                C_chunks, phase, out.data_ptr(), flags.data_ptr(), slot["counters"].data_ptr(), slot["ws"].data_ptr(),
+                slot["ws"].numel(), comp.cuda_stream, side, prep.cuda_stream if prep is not None else None, step_flags)
             if rc != 0:
                 _cabi.check(rc, "mia_letkf_sharded_step_streams_f32")
 
+        self._fresh_box_once = False
+        slot["ws_clean"] = False            # (until this step has been collected without an error)
         timing = None
         if self._time_next:                                        # bench: bracket this step's analysis kernel
             self._time_next = False
-            timing = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            for e in timing:
-                e.record(cur)                                      # creates the underlying hipEvent_t
+            timing = (_cabi.TimingEvent(), _cabi.TimingEvent())    # (pooled events of the library: no torch.cuda.Event, no record)
             self.kernel_timings.append(timing)
         ev = job = None
         if pipelined:
@@ -667,17 +751,39 @@ class ShardedLetkf:
                 # stream sits between two analysis kernels and costs ~15 us of dispatch gaps per step
                 after, last = comp, st["stream"]
             # The step call and its read-back (wait for `after`, copy the counters to pinned memory on `last`, record the
-            # slot's event) run on the library's launch thread, in submission order: their ~65 us of HIP runtime calls
-            # overlap this thread's own per-step work instead of adding to it: submit() 80 -> 24 us of the caller's time.
-            # (No throughput gain at N = 1, where the analysis stream is the bound: 83 us of kernel per step beside the
-            # preparation kernels + ~15 us of event / barrier packets between two kernels of one queue = the 0.102 ms
-            # measured; the whole step on per-step streams instead was slower, 0.111 ms.)
-            job = C.c_void_p()
-            rc = lib.mia_letkf_step_submit(*cargs, slot["host"].data_ptr(), after.cuda_stream, last.cuda_stream,
-                                           C.byref(slot["event"]), timing[0].cuda_event if timing else None,
-                                           timing[1].cuda_event if timing else None, C.byref(job))
+            # slot's event) run on the library's launch threads, in submission order: their ~65 us of HIP runtime calls
+            # overlap this thread's own per-step work instead of adding to it.  The arguments travel in the slot's argument
+            # block (mia_step_args_t): what a slot keeps from step to step is written once, and the wait of the preparation
+            # stream for the caller's stream (inputs and `out`'s memory are ready) is part of the same call
+            a = slot.get("args")
+            if a is None or slot.get("args_key") != key:
+                a = slot["args"] = _cabi.StepArgs()
+                slot["args_key"] = key
+                if "in_event" not in slot:
+                    slot["in_event"] = C.c_void_p()
+                a.G, a.m, a.k, a.P, a.n_coord, a.n_r = G, m, k, P, nc, len(self.radii)
+                for i_ in range(nc):
+                    a.coord_group[i_] = slot["cg"][i_]
+                for i_ in range(len(self.radii)):
+                    a.gc_c[i_] = slot["rc"][i_]
+                a.flags, a.counters, a.ws, a.ws_bytes = flags.data_ptr(), slot["counters"].data_ptr(), slot["ws"].data_ptr(), slot["ws"].numel()
+                a.host8 = slot["host"].data_ptr()
+                a.done_event = C.pointer(slot["event"])
+                a.in_event = C.pointer(slot["in_event"])
+                a.phase = 0
+                slot["job"] = C.c_void_p()
+                slot["job_ref"] = C.byref(slot["job"])
+                slot["args_ref"] = C.byref(a)
+            a.X, a.Yb, a.d, a.grid_xyz, a.obs_xyz, a.Xa = X.data_ptr(), Yb.data_ptr(), d.data_ptr(), grid.data_ptr(), obs.data_ptr(), out.data_ptr()
+            a.gc_eps, a.inf_factor, a.gamma, a.method, a.p_max_assumed = eps, inf, gamma, method, hint
+            a.comm, a.n_chunks, a.step_flags = comm_val, C_chunks, step_flags
+            a.stream, a.comm_stream, a.prep_stream = comp.cuda_stream, side, prep.cuda_stream
+            a.after_stream, a.on_stream, a.caller_stream = after.cuda_stream, last.cuda_stream, cur_raw
+            a.time_start_event, a.time_stop_event = (timing[0].cuda_event, timing[1].cuda_event) if timing else (None, None)
+            rc = lib.mia_letkf_step_submit_args(slot["args_ref"], slot["job_ref"])
             if rc != 0:
-                _cabi.check(rc, "mia_letkf_step_submit")
+                _cabi.check(rc, "mia_letkf_step_submit_args")
+            job = slot["job"].value
             ev = slot["event"]
         else:
             lib.mia_letkf_step_drain()                             # (a synchronous step must not overtake queued ones)
@@ -691,27 +797,67 @@ class ShardedLetkf:
             if lib.mia_letkf_step_readback(slot["counters"].data_ptr(), slot["host"].data_ptr(), raw, raw, C.byref(slot["event"])) == 0:
                 ev = slot["event"]
         h = PendingStep(self, dict(slot=slot, call=call, comp=comp, cur=cur, cur_raw=cur_raw, dev_index=dev_index, ev=ev, job=job, out=out, flags=flags, hint=hint,
-                                   last=last, peer=bool(peer),
+                                   last=last, peer=bool(peer), timing=timing,
                                    C_chunks=C_chunks, args=(X, grid_xyz, obs_xyz, Yb, d, G, g0, g1),
                                    keep=(X, grid, obs, Yb, d), geom_key=geom_key, reused=reuse, geometry_id=geometry_id))
         slot["busy"] = h
         self._in_flight.append(h)
         self._submitted += 1
+        # the steady state for _submit_fast: one GPU, no exchange, no geometry epoch, steps in flight
+        if (pipelined and st["comm"] is None and part is None and not peer and C_chunks == 1 and self.world == 1 and not exch
+                and geometry_id is None and g0 == 0 and g1 == G):
+            f = self._fast
+            if f is None or f["st"] is not st or (f["G"], f["m"], f["k"], f["P"], f["nc"]) != (G, m, k, P, nc) or f["device"] != X.device:
+                self._fast = dict(st=st, lib=lib, slots=st["slots"], n=len(st["slots"]), G=G, m=m, k=k, P=P, nc=nc, device=X.device,
+                                  xs=X.shape, ys=Yb.shape, ds=d.shape, gs=grid_xyz.shape if torch.is_tensor(grid_xyz) else None,
+                                  os=obs_xyz.shape if torch.is_tensor(obs_xyz) else None, dev_index=dev_index,
+                                  astreams=st["astreams"], na=len(st["astreams"]), pstreams=st["pstreams"],
+                                  np=len(st["pstreams"]) if self.prep_streams else 0, side=st["stream"].cuda_stream, last=st["stream"],
+                                  )
+        else:
+            self._fast = None
         return h
 
-    def _native_finish(self, h: "PendingStep"):
+    def _call_from_args(self, a):
+        """The step call of a step submitted through an argument block (mia_step_args_t), for its rare second phase."""
         from . import _cabi
+        lib = self.engine.lib
+
+        def call(phase):
+            rc = lib.mia_letkf_sharded_step_streams_f32(a.X, a.G, a.m, a.k, a.Yb, a.d, a.P, a.grid_xyz, a.obs_xyz, a.n_coord, a.coord_group,
+                                                        a.gc_c, a.n_r, a.gc_eps, a.inf_factor, a.gamma, a.method, a.p_max_assumed, a.comm,
+                                                        a.n_chunks, phase, a.Xa, a.flags, a.counters, a.ws, a.ws_bytes, a.stream,
+                                                        a.comm_stream, a.prep_stream, a.step_flags)
+            if rc != 0:
+                _cabi.check(rc, "mia_letkf_sharded_step_streams_f32")
+        return call
+
+    def _native_finish(self, h: "PendingStep"):
         if h._out is not None or h._st is None:
             return h._out
         p = h._st
         slot, st = p["slot"], self._native_state()
         if p["ev"] is not None:
             if p["job"] is not None:
-                rc = self.engine.lib.mia_letkf_step_join(p["job"])  # the launch thread has enqueued this step ...
+                # ONE call: the launch thread has enqueued this step (join), the host waits for its read-back event -- the one host
+                # wait for the GPU --, the counters come back, and torch's current stream waits for that event too (consumers see
+                # the result; THIS step's event only: the analysis stream as a whole also holds the later steps)
+                import ctypes as C
+                if "out8" not in slot:
+                    slot["out8"], slot["bn"] = (C.c_int32 * 8)(), C.c_int(1)
+                    slot["bn_ref"] = C.byref(slot["bn"])
+                rc = self.engine.lib.mia_letkf_step_collect(p["job"], C.byref(p["ev"]), slot["host"].data_ptr(),
+                                                            torch._C._cuda_getCurrentRawStream(p["dev_index"]), 1, slot["out8"], slot["bn_ref"])
                 if rc != 0:
                     _cabi.check(rc, "mia_letkf_sharded_step_streams_f32 (launch thread)")
-            self.engine.lib.mia_event_synchronize(p["ev"])     # ... and this is the one host wait for the GPU
-            cnt = slot["host"].tolist()
+                self.last_batch_n = h.batch_n = slot["bn"].value
+                if p["timing"] is not None:
+                    self.kernel_batch[p["timing"]] = h.batch_n
+                cnt = list(slot["out8"])
+                p["waited"] = True
+            else:
+                self.engine.lib.mia_event_synchronize(p["ev"])     # ... and this is the one host wait for the GPU
+                cnt = slot["host"].tolist()
         else:
             cnt = slot["counters"].tolist()                    # serial route: synchronous read-back
         slot["busy"] = None
@@ -804,7 +950,7 @@ class ShardedLetkf:
             self._note_kernel()                                # (a ctypes call: not on every step of a timed loop)
         if n_retry:
             self.engine.lib.mia_letkf_step_drain()             # (after the steps already handed to the launch thread)
-            p["call"](1)                                       # eigensolver redoes declined points; re-exchange
+            (p["call"] or self._call_from_args(slot["args"]))(1)      # eigensolver redoes declined points; re-exchange
         if p["job"] is not None or p["comp"] is not p["cur"]:     # (a step taken one at a time ran on torch's stream itself)
             # consumers on torch's stream see the result.  Wait for THIS step's completion event only: waiting for
             # the analysis stream as a whole would also wait for the later steps already enqueued on it, and the
@@ -815,7 +961,7 @@ class ShardedLetkf:
                     e2 = torch.cuda.Event()
                     e2.record(strm)
                     now.wait_event(e2)
-            else:
+            elif not p.get("waited"):
                 self.engine.lib.mia_stream_wait_event(torch._C._cuda_getCurrentRawStream(p["dev_index"]), p["ev"])
         self.native_steps += 1
         self.last_retries = cnt[2]
@@ -831,7 +977,7 @@ class ShardedLetkf:
         if not self._no_tile_lists:
             slot["geom"] = p.get("geom_key")                   # this slot's lists now belong to that geometry epoch
         self.last_p_max = p["hint"]
-        self._last_flags = p["flags"][:g1 - g0]
+        self._last_flags_lazy = (p["flags"], g1 - g0)       # (sliced when somebody asks: a tensor view per step is ~2 us)
         h._out, h._st = (p["out"].clone() if p.get("peer") and self.copy_results else p["out"]), None
         return h._out
 
@@ -1004,11 +1150,18 @@ class ShardedLetkf:
         self._time_next = True
 
     def kernel_ms(self):
-        """Mean duration (ms) of the analysis kernels timed so far inside real steps, or None."""
+        """Mean duration (ms) of the analysis LAUNCHES timed so far inside real steps, or None.  With launch coalescing
+        (option ``step_coalesce``) a launch holds the tiles of :meth:`kernel_steps_per_launch` steps."""
         if not self.kernel_timings:
             return None
         torch.cuda.synchronize(self.device)
         return sum(a.elapsed_time(b) for a, b in self.kernel_timings) / len(self.kernel_timings)
+
+    def kernel_steps_per_launch(self):
+        """Mean number of steps in the launches :meth:`kernel_ms` averages over (1.0 without coalescing)."""
+        if not self.kernel_timings:
+            return 1.0
+        return sum(self.kernel_batch.get(t, 1) for t in self.kernel_timings) / len(self.kernel_timings)
 
     def mean_degree(self):
         """Mean Chebyshev degree of the last matfun launch (flags bits 8-15), None for the eigensolver route."""
