@@ -12,7 +12,8 @@ cheb = [i for i, r in enumerate(rows) if "letkf_cheb_kernel" in r[2] or "letkf_t
 mid = cheb[int(sys.argv[2]) if len(sys.argv) > 2 else 60]      # inside the timed (pipelined) loop of the default bench
 t0 = rows[mid][0]
 print("window of ~3 steps around the middle of the run (t in us relative to an analysis-kernel start)")
-for s, e, name, q in rows[mid - 8:mid + 22]:
+import os
+for s, e, name, q in rows[mid - 8:mid + int(os.environ.get('TIMELINE_ROWS', '22'))]:
     print("%9.1f  +%7.1f  q%-3s %s" % ((s - t0) / 1e3, (e - s) / 1e3, q, name))
 lo_i, hi_i = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (20, 100)
 st = [rows[i][0] for i in cheb[lo_i:hi_i]]
