@@ -645,6 +645,10 @@ int mia_letkf_step_workspace_release(void* ws);
  * the step's analysis launch; mia_letkf_step_coalesce_stats counts such launches and the steps in them since the process began. */
 int mia_letkf_step_join_info(void* job, int* batch_n);
 int mia_letkf_step_coalesce_stats(long long* launches, long long* steps);
+/* Diagnostics: host time stamps of the last steps handed to the launch threads (8 per step, ns of the steady clock: submitted,
+ * preparation thread begins / has enqueued, analysis thread takes the step / has seen the preparation finished / has enqueued the
+ * analysis / the read-back, 0), oldest first.  Returns the number of steps written. */
+int mia_debug_step_trace(long long* out, int max_steps);
 int mia_letkf_sharded_step_f32(const float* X /* [m][k][G] */, int64_t G, int m, int k,
                                const float* Yb /* [k][P] */, const float* d /* [P] */, int64_t P,
                                const double* grid_xyz /* [G][n_coord] */, const double* obs_xyz /* [P][n_coord] */,

@@ -14,6 +14,7 @@ ap.add_argument("--steps", type=int, default=2000)
 ap.add_argument("--grid", type=int, default=100000)
 ap.add_argument("--prep-streams", type=int, default=3)
 ap.add_argument("--options", default="", help="name=value ... for mia_set_option")
+ap.add_argument("--no-in-event", action="store_true", help="experiment: the preparation stream does not wait for the caller's stream")
 a = ap.parse_args()
 mia.build()
 for o in a.options.split():
@@ -48,6 +49,11 @@ def run(n):
 
 
 run(200)
+if a.no_in_event:
+    import ctypes
+    for slot in runner._native["slots"]:
+        if slot.get("args") is not None:
+            slot["args"].in_event = ctypes.POINTER(ctypes.c_void_p)()
 import gc
 gc.collect(); gc.freeze()
 run(200)

@@ -13,7 +13,7 @@ src_path = sharded.__file__
 src = open(src_path).read()
 lines = src.split("\n")
 tree = ast.parse(src)
-ACC = collections.defaultdict(lambda: [0, 0])      # (function, line) -> [ns, calls]
+ACC = collections.defaultdict(lambda: [0, 0, 0])      # (function, line) -> [ns, calls, max ns]
 _last = [None, 0]
 
 
@@ -23,6 +23,7 @@ def _pp(fn, ln):
         a = ACC[_last[0]]
         a[0] += now - _last[1]
         a[1] += 1
+        a[2] = max(a[2], now - _last[1])
     _last[0], _last[1] = (fn, ln), time.perf_counter_ns()
 
 
@@ -32,6 +33,7 @@ def _end(fn):
         a = ACC[_last[0]]
         a[0] += now - _last[1]
         a[1] += 1
+        a[2] = max(a[2], now - _last[1])
     _last[0] = None
 
 
@@ -63,6 +65,9 @@ instrument("_submit_fast")
 instrument("_native_submit")
 instrument("_native_finish")
 mia.build()
+from torch_assimilate_amd import _cabi
+for o in os.environ.get("OPTIONS", "").split():
+    _cabi.set_option(o.split("=")[0], int(o.split("=")[1]))
 dev = torch.device("cuda:0")
 X, gx, ox, Yb, d = bench.make_case(100000, 40, 2, dev)
 depth = int(os.environ.get("DEPTH", "8"))
@@ -95,4 +100,4 @@ for fn in ("_submit_fast", "_native_submit", "_native_finish"):
     print("%s: %.1f us per step in total; statements over 0.25 us:" % (fn, tot / N / 1e3))
     for (f, ln), v in sorted(ACC.items(), key=lambda kv: kv[0][1]):
         if f == fn and v[0] / N / 1e3 >= 0.25:
-            print("  line %4d  %6.2f us  x%5d   %s" % (ln, v[0] / N / 1e3, v[1], lines[ln - 1].strip()[:110]))
+            print("  line %4d  %6.2f us  (max %7.1f)  x%5d   %s" % (ln, v[0] / N / 1e3, v[2] / 1e3, v[1], lines[ln - 1].strip()[:100]))

@@ -112,6 +112,7 @@ _PROTOS = {
     "mia_letkf_step_join": ([vp], i32),
     "mia_letkf_step_join_info": ([vp, C.POINTER(C.c_int)], i32),
     "mia_letkf_step_coalesce_stats": ([C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], i32),
+    "mia_debug_step_trace": ([C.POINTER(C.c_longlong), i32], i32),
     "mia_letkf_step_drain": ([], i32),
     "mia_letkf_step_readback": ([vp, vp, vp, vp, C.POINTER(vp)], i32),
     "mia_event_synchronize": ([vp], i32),

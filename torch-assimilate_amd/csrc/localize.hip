@@ -661,41 +661,49 @@ int index_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_
 __global__ __launch_bounds__(64) void index_bucket_kernel(IndexParams p) {
   MIA_PREP_PRIORITY();
   MIA_PREP_PRIORITY();
-  if (blockIdx.x >= p.nb_main) {      // independent passenger: the split records of the analysis kernel (only it needs them)
-    extern __shared__ __attribute__((aligned(16))) float bk_lds[];
-    pack_split_wave(p.spack, p.P, (int64_t)(blockIdx.x - p.nb_main), bk_lds);
-    return;
-  }
-  const int64_t stride = (int64_t)p.nb_main * blockDim.x;
+  // Workgroup b bins observations 64 b .. 64 b + 63 AND packs their split records (the analysis kernel's, only it needs them): the
+  // rows of Yb are requested first, straight into LDS; the binning runs while they travel.  One lean wavefront per 64 observations
+  // -- at most 32 registers, k x 256 bytes of LDS -- so that it is placed BESIDE the five wavefronts per SIMD of the previous
+  // steps' analysis kernels (96 of 512 registers each) instead of waiting for one of them to retire: with two kinds of workgroup,
+  // 50 registers and 10.7 KB each, a preparation kernel took 24-45 us in the loop instead of 11 and the launch thread waited for it
+  // a third of the time (profiles/r05_step_trace.txt)
+  extern __shared__ __attribute__((aligned(16))) float bk_lds[];
+  const bool packs = p.spack.rec != nullptr;
+  if (packs) pack_split_lean_request(p.spack, p.P, (int64_t)blockIdx.x, bk_lds);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int q = 0; q < 3; ++q)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < p.zero.n[q]; i += stride) p.zero.ptr[q][i] = 0;
   const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (j >= p.P) return;
-  IndexHeader* h = p.hdr;
-  const bool grid_ok = h->magic == kIndexMagic;
-  bool ok = grid_ok && h->bucket_cap > 0;
-  for (int c = 0; c < p.nc; ++c) ok = ok && h->cutoff[c] == p.cutoff[c];
-  const int cap = h->bucket_cap;
-  int id = 0;
-  bool skip = false;
-  double x[MIA_MAX_COORD] = {0.0, 0.0, 0.0};
-  for (int c = 0; c < p.nc; ++c) {
-    x[c] = p.obs[j * p.nc + c];
-    const double f = floor((x[c] - h->mn[c]) * h->invh[c]);
-    if (!(x[c] == x[c])) { skip = true; continue; }         // NaN coordinate: no cell (its weight is 0 everywhere)
-    if (!(f >= 0.0 && f < double(h->n[c]))) { ok = false; continue; }
-    id = id * h->n[c] + int(f);
+  if (j < p.P) {
+    IndexHeader* h = p.hdr;
+    const bool grid_ok = h->magic == kIndexMagic;
+    bool ok = grid_ok && h->bucket_cap > 0;
+    for (int c = 0; c < p.nc; ++c) ok = ok && h->cutoff[c] == p.cutoff[c];
+    const int cap = h->bucket_cap;
+    int id = 0;
+    bool skip = false;
+    double x[MIA_MAX_COORD] = {0.0, 0.0, 0.0};
+    for (int c = 0; c < p.nc; ++c) {
+      x[c] = p.obs[j * p.nc + c];
+      const double f = floor((x[c] - h->mn[c]) * h->invh[c]);
+      if (!(x[c] == x[c])) { skip = true; continue; }         // NaN coordinate: no cell (its weight is 0 everywhere)
+      if (!(f >= 0.0 && f < double(h->n[c]))) { ok = false; continue; }
+      id = id * h->n[c] + int(f);
+    }
+    if (!ok) {
+      atomicOr(&h->err, (grid_ok && cap == 0) ? kIndexErrFull : kIndexErrBox);
+    } else if (!skip) {
+      const int pos = atomicAdd(&p.cursor[id], 1);
+      if (pos >= cap) {
+        atomicOr(&h->err, kIndexErrFull);
+      } else {
+        const int64_t e = (int64_t)id * cap + pos;
+        p.bidx[e] = int(j);
+        for (int c = 0; c < p.nc; ++c) p.bxyz[e * p.nc + c] = x[c];
+      }
+    }
   }
-  if (!ok) {
-    atomicOr(&h->err, (grid_ok && cap == 0) ? kIndexErrFull : kIndexErrBox);
-    return;
-  }
-  if (skip) return;
-  const int pos = atomicAdd(&p.cursor[id], 1);
-  if (pos >= cap) { atomicOr(&h->err, kIndexErrFull); return; }
-  const int64_t e = (int64_t)id * cap + pos;
-  p.bidx[e] = int(j);
-  for (int c = 0; c < p.nc; ++c) p.bxyz[e * p.nc + c] = x[c];
+  if (packs) pack_split_lean_finish(p.spack, p.P, (int64_t)blockIdx.x, bk_lds);
 }
 
 int index_bucket_build_impl(const double* obs_xyz, int64_t P, int n_coord, const int32_t* coord_group, const double* gc_c, int n_r,
@@ -731,16 +739,16 @@ int index_bucket_build_impl(const double* obs_xyz, int64_t P, int n_coord, const
   ip.zero = zero ? *zero : ZeroJob{{nullptr, nullptr, nullptr}, {0, 0, 0}};
   ip.nb_main = nbP;
   ip.spack = SplitPackJob{nullptr, nullptr, nullptr, 0};
-  unsigned nb_pack = 0;
+  unsigned nb = nbP;
   size_t lds = 0;
   if (spack && spack->rec) {
     ip.spack = *spack;
-    nb_pack = (unsigned)((P + 1 + 63) / 64);
-    lds = split_pack_lds(spack->k);
+    nb = (unsigned)((P + 1 + 63) / 64);      // (record P is the all-zero record)
+    lds = split_pack_lean_lds(spack->k);
     if (lds > kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
     if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)index_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  index_bucket_kernel<<<dim3(nbP + nb_pack), dim3(kPrepThreads), lds, stream>>>(ip);
+  index_bucket_kernel<<<dim3(nb), dim3(kPrepThreads), lds, stream>>>(ip);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

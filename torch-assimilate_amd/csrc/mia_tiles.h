@@ -319,6 +319,54 @@ __device__ inline void pack_split_wave(const SplitPackJob& J, int64_t P, int64_t
 
 static inline size_t split_pack_lds(int k) { return ((size_t)64 * ((k + 1) | 1) + 64) * sizeof(float); }
 
+// The same records from a wavefront that must fit BESIDE the analysis kernel's five 96-register wavefronts per SIMD (32 registers
+// are left; the bucket kernel of the step driver, localize.hip): lane = record.  The 64 entries of every row of Yb go straight
+// into LDS with global_load_lds_dword (no registers, all k rows in flight), image [k][64]; each lane then reads ITS column
+// (conflict-free), finds its scale, and converts and stores its own record chunk by chunk.  Same arithmetic as pack_split_wave:
+// the records are the same bit for bit.  lds: 64 k floats.  Two halves so that the caller can put work between request and use.
+__device__ __forceinline__ void pack_split_lean_request(const SplitPackJob& J, int64_t P, int64_t block, float* lds) {
+  const int lane = threadIdx.x & 63;
+  const int64_t j = block * 64 + lane;
+  const int64_t jc = j < P ? j : (P > 0 ? P - 1 : 0);
+  if (P > 0)
+    for (int i = 0; i < J.k; ++i)
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>(J.Yb + (int64_t)i * P + jc),
+                                       (__attribute__((address_space(3))) void*)(lds + i * 64), 4, 0, 0);
+}
+__device__ __forceinline__ void pack_split_lean_finish(const SplitPackJob& J, int64_t P, int64_t block, const float* lds) {
+  const int lane = threadIdx.x & 63;
+  const int k = J.k, nc8 = (k + 7) >> 3, rb = 32 * nc8 + 16;
+  const int64_t j = block * 64 + lane;
+  const bool real = j < P;                    // (j == P: the zero record; j > P: nothing)
+  const float dj = (real && P > 0) ? J.d[j] : 0.0f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  unsigned mx = 0u;
+  if (real)
+    for (int i = 0; i < k; ++i) {
+      const unsigned a = __float_as_uint(lds[i * 64 + lane]) & 0x7fffffffu;
+      mx = a > mx ? a : mx;
+    }
+  int es;
+  const float sc = pow2_scale(mx, 9, &es);
+  const float wd = dj * sc;
+  const bool bad = mx >= 0x7f800000u || !(fabsf(wd) < 3.0e38f);
+  if (j > P) return;
+  unsigned char* o = J.rec + j * rb;
+  const float E = bad ? __builtin_nanf("") : __uint_as_float((unsigned)(127 - es) << 23);
+  *reinterpret_cast<f4w*>(o + 32 * nc8) = f4w{wd, E, 0.0f, 0.0f};
+  for (int c = 0; c < nc8; ++c) {
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = (real && 8 * c + i < k) ? lds[(8 * c + i) * 64 + lane] * sc : 0.0f;
+    h8v hi, lo;
+    split8(x, hi, lo);
+    *reinterpret_cast<h8v*>(o + 32 * c) = hi;
+    *reinterpret_cast<h8v*>(o + 32 * c + 16) = lo;
+  }
+}
+static inline size_t split_pack_lean_lds(int k) { return (size_t)64 * k * sizeof(float); }
+
 // host side (tile_lists.hip)
 struct ScanParams;
 int split_pack_launch(const float* Yb, const float* d, int k, int64_t P, void* rec, hipStream_t stream);

@@ -12,6 +12,7 @@
 // librccl.so) so that this library keeps loading on machines without RCCL and never pulls in a second
 // HIP runtime.
 #include <dlfcn.h>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -1199,6 +1200,8 @@ struct StepJob {
   StepDecision dec;                // what stage 1 decided about the workspace's lists and count arrays, for stage 2
   int opts[MIA_OPT_COUNT_];        // the route options as they stood when the caller submitted the step
   int batch_n = 1;                 // steps in the analysis launch this step was part of (launch coalescing)
+  long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // host time stamps (ns): submitted, A begins, A done, B has it, its preparation seen done,
+                                                   // analysis enqueued, read-back enqueued (mia_debug_step_trace)
   int device = 0;
   int rc = 0;
   bool done = false;
@@ -1218,6 +1221,34 @@ struct LaunchThreads {
   bool stop = false, started = false;
   int busy = 0;          // jobs handed in and not yet finished by thread B
   std::atomic<long long> ns_a{0}, ns_b{0}, n_jobs{0};     // host time spent enqueueing (mia_letkf_step_launch_stats)
+  // entries of the two queues, readable without the lock: a thread whose queue has run dry polls its counter for kSpinUs before
+  // it sleeps on the condition variable.  Waking a sleeping thread costs 30-60 us on this host (a step's whole GPU time): the
+  // first analysis launch of a burst of steps came 80 us after the first preparation kernel had finished
+  // (profiles/r05_timeline_steps20.txt); a caller that submits its next step within kSpinUs finds both threads awake
+  std::atomic<int> na{0}, nb_q{0};
+  static constexpr int kTraceN = 256;
+  std::array<long long, 8> trace[kTraceN];      // the stamps of the last kTraceN steps (mia_debug_step_trace)
+  unsigned long long trace_n = 0;
+  static long long now_ns() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
+  static constexpr long long kSpinUs = 400;
+  void spin_for(const std::atomic<int>& n) {
+    if (n.load(std::memory_order_acquire) > 0) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      for (int i = 0; i < 64; ++i) {
+        if (n.load(std::memory_order_acquire) > 0) return;
+        __builtin_ia32_pause();
+      }
+      if (stop_flag.load(std::memory_order_relaxed)) return;
+      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > kSpinUs) return;
+    }
+  }
+  std::atomic<bool> stop_flag{false};
+  static void relax(int n = 40) {
+    for (int i = 0; i < n; ++i) __builtin_ia32_pause();      // 40: ~1 us
+  }
   std::atomic<long long> n_launches{0}, n_launch_steps{0};      // analysis launches made with the collector on, and the steps in them
   static int i_rc_first(int a, int b) { return a != MIA_OK ? a : b; }
   void run_a() {
@@ -1225,22 +1256,27 @@ struct LaunchThreads {
     (void)hipSetDevice(device);
     for (;;) {
       StepJob* j;
+      spin_for(na);
       {
         std::unique_lock<std::mutex> lk(mu);
         cv_a.wait(lk, [&] { return stop || !qa.empty(); });
         if (qa.empty()) return;
         j = qa.front();
         qa.pop_front();
+        --na;
       }
       if (j->device != cur_a) { (void)hipSetDevice(j->device); cur_a = j->device; }
       const auto ta0 = std::chrono::steady_clock::now();
+      j->ts[1] = now_ns();
       const int rc = j->run(1);
+      j->ts[2] = now_ns();
       ns_a += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - ta0).count();
       ++n_jobs;
       {
         std::lock_guard<std::mutex> lk(mu);
         j->rc = rc;
         qb.push_back(j);
+        ++nb_q;
       }
       cv_b.notify_one();
     }
@@ -1255,14 +1291,17 @@ struct LaunchThreads {
     unsigned own_next = 0;
     for (;;) {
       StepJob* j;
+      spin_for(nb_q);
       {
         std::unique_lock<std::mutex> lk(mu);
         cv_b.wait(lk, [&] { return stop || !qb.empty(); });
         if (qb.empty()) return;
         j = qb.front();
         qb.pop_front();
+        --nb_q;
       }
       if (j->device != cur_b) { (void)hipSetDevice(j->device); cur_b = j->device; running.clear(); own_init = false; }
+      j->ts[3] = now_ns();
       int rc = j->rc;
       // Steps in flight: wait for the step's preparation HERE, on the host, and enqueue the analysis kernel with nothing in
       // front of it.  A stream-wait in the analysis queue is a barrier packet between every two analysis kernels (11-16 us
@@ -1271,11 +1310,13 @@ struct LaunchThreads {
       // preparation runs two steps ahead, so the wait is short; query + yield rather than a spinning synchronise.
       if (rc == MIA_OK && j->pe && (j->step_flags & MIA_STEP_NO_JOIN) && mia::option(MIA_OPT_STEP_HOSTWAIT) != 0) {
         hipError_t q;
-        while ((q = hipEventQuery(j->pe)) == hipErrorNotReady) std::this_thread::yield();
+        while ((q = hipEventQuery(j->pe)) == hipErrorNotReady) relax();      // (a microsecond between two queries: the runtime's locks are
+                                                                             //  the caller's and the other launch thread's too)
         if (q == hipSuccess) j->step_flags |= kStepPrepDone;
         else (void)hipGetLastError();         // (leave the ordering to the stream wait)
       }
       auto tb0 = std::chrono::steady_clock::now();
+      j->ts[4] = now_ns();
       // Launch coalescing: a launch of one step's 6250 tiles spends a quarter of its time filling and draining the chip, and kernels
       // of different streams overlap badly (letkf_tile2f.hip).  Steps in flight are independent: while this step's analysis is being
       // put together, the FOLLOWING steps of the queue whose preparation has already finished are put together too, and their tiles
@@ -1304,7 +1345,9 @@ struct LaunchThreads {
         // the step is put together; it goes to the GPU when fewer than w launches of this thread are still running, and the steps
         // that become ready until then join it
         for (;;) {
-          while (open && nb < mia::kT2fBatchMax) {
+          // (the queue's atomic count first: a spinning thread that takes the queue's mutex on every turn starves the caller's
+          //  submit() of it -- submissions of 60-140 us were measured, profiles/r05_step_trace_coalesce.txt)
+          while (open && nb < mia::kT2fBatchMax && nb_q.load(std::memory_order_acquire) > 0) {
             StepJob* c = nullptr;
             {
               std::lock_guard<std::mutex> lk(mu);
@@ -1312,7 +1355,7 @@ struct LaunchThreads {
               const bool ok = c && c->rc == MIA_OK && c->device == j->device && c->pe && (c->step_flags & MIA_STEP_NO_JOIN) && c->phase == 0 &&
                               !c->comm && c->n_chunks == 1 && c->method != 1 && c->host8 && !c->t0 && !c->t1 &&
                               c->opts[MIA_OPT_STEP_COALESCE] != 0 && c->opts[MIA_OPT_STEP_HOSTWAIT] != 0;
-              if (ok && hipEventQuery(c->pe) == hipSuccess) qb.pop_front();      // (its preparation has finished: no waiting for it)
+              if (ok && hipEventQuery(c->pe) == hipSuccess) { qb.pop_front(); --nb_q; }      // (its preparation has finished: no waiting for it)
               else { (void)hipGetLastError(); c = nullptr; }
             }
             if (!c) break;
@@ -1325,7 +1368,7 @@ struct LaunchThreads {
           while (!running.empty() && hipEventQuery(running.front()) != hipErrorNotReady) { (void)hipGetLastError(); running.pop_front(); }
           if (running.size() < w) break;
           const auto tw = std::chrono::steady_clock::now();
-          std::this_thread::yield();
+          relax(240);
           waited += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tw).count();
         }
         ns_b -= waited;      // (the host-time statistic: enqueueing, not waiting)
@@ -1358,6 +1401,7 @@ struct LaunchThreads {
         n_launches += 1;
         n_launch_steps += n_in > 0 ? n_in : 1;
       }
+      j->ts[5] = now_ns();
       for (int i = 0; i < nb; ++i) {
         StepJob* b = batch[i];
         int brc = i == 0 ? rc : b->rc;
@@ -1369,15 +1413,19 @@ struct LaunchThreads {
         b->rc = brc;
       }
       ns_b += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tb0).count();
+      j->ts[6] = now_ns();
       {
         std::lock_guard<std::mutex> lk(mu);
-        for (int i = 0; i < nb; ++i) { batch[i]->done = true; --busy; }
+        for (int i = 0; i < nb; ++i) {
+          trace[trace_n++ % kTraceN] = *reinterpret_cast<std::array<long long, 8>*>(batch[i]->ts);
+          batch[i]->done = true; --busy;
+        }
       }
       cv_done.notify_all();
     }
   }
   ~LaunchThreads() {
-    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    { std::lock_guard<std::mutex> lk(mu); stop = true; stop_flag = true; }
     cv_a.notify_all();
     cv_b.notify_all();
     if (ta.joinable()) ta.join();
@@ -1387,6 +1435,7 @@ struct LaunchThreads {
 LaunchThreads g_launcher;
 }  // namespace
 
+static thread_local long long t_submit_entry = 0, t_submit_waited = 0;
 extern "C" int mia_letkf_step_submit(const float* X, int64_t G, int m, int k, const float* Yb, const float* d, int64_t P,
                                      const double* grid_xyz, const double* obs_xyz, int n_coord, const int32_t* coord_group,
                                      const double* gc_c, int n_r, double gc_eps, float inf_factor, float gamma, int method,
@@ -1406,6 +1455,9 @@ extern "C" int mia_letkf_step_submit(const float* X, int64_t G, int m, int k, co
   j->prep_stream = prep_stream; j->step_flags = step_flags; j->host8 = host8; j->after = after_stream; j->on = on_stream;
   j->done_event = done_event; j->t0 = time_start_event; j->t1 = time_stop_event;
   mia::option_snapshot(j->opts);
+  j->ts[0] = LaunchThreads::now_ns();
+  j->ts[7] = t_submit_entry;            // (diagnostics: entry of the argument-block submission; 0 through the plain entry)
+  t_submit_entry = 0;
   if (hipGetDevice(&j->device) != hipSuccess) { (void)hipGetLastError(); delete j; return MIA_ERR_UNSUPPORTED; }
   {
     std::lock_guard<std::mutex> lk(g_launcher.mu);
@@ -1416,6 +1468,7 @@ extern "C" int mia_letkf_step_submit(const float* X, int64_t G, int m, int k, co
       g_launcher.tb = std::thread([] { g_launcher.run_b(); });
     }
     g_launcher.qa.push_back(j);
+    ++g_launcher.na;
     ++g_launcher.busy;
   }
   g_launcher.cv_a.notify_one();
@@ -1425,10 +1478,12 @@ extern "C" int mia_letkf_step_submit(const float* X, int64_t G, int m, int k, co
 
 extern "C" int mia_letkf_step_submit_args(const mia_step_args_t* a, void** job_out) {
   if (!a) return MIA_ERR_NULL;
+  t_submit_entry = LaunchThreads::now_ns();
   if (a->in_event) {
     const int rc = mia_stream_wait_stream(a->prep_stream, a->caller_stream, a->in_event);
     if (rc != MIA_OK) return rc;
   }
+  t_submit_waited = LaunchThreads::now_ns();
   return mia_letkf_step_submit(a->X, a->G, a->m, a->k, a->Yb, a->d, a->P, a->grid_xyz, a->obs_xyz, a->n_coord, a->coord_group, a->gc_c,
                                a->n_r, a->gc_eps, a->inf_factor, a->gamma, a->method, a->p_max_assumed, a->comm, a->n_chunks, a->phase,
                                a->Xa, a->flags, a->counters, a->ws, a->ws_bytes, a->stream, a->comm_stream, a->prep_stream, a->step_flags,
@@ -1474,6 +1529,22 @@ extern "C" int mia_timing_event_elapsed_ms(void* start_event, void* stop_event, 
   MIA_HIP_TRY(hipEventSynchronize((hipEvent_t)stop_event));
   MIA_HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start_event, (hipEvent_t)stop_event));
   return MIA_OK;
+}
+
+// the host time stamps of the last steps handed to the launch threads, oldest first: 8 values per step (ns of the steady clock:
+// submitted, thread A begins / has enqueued the preparation, thread B takes the step / has seen its preparation finished / has
+// enqueued the analysis / the read-back, 0).  Returns the number of steps written (tools/step_trace.py)
+extern "C" int mia_debug_step_trace(long long* out, int max_steps) {
+  if (!out || max_steps <= 0) return 0;
+  std::lock_guard<std::mutex> lk(g_launcher.mu);
+  const unsigned long long n = g_launcher.trace_n;
+  const int have = (int)(n < (unsigned long long)LaunchThreads::kTraceN ? n : LaunchThreads::kTraceN);
+  const int take = have < max_steps ? have : max_steps;
+  for (int i = 0; i < take; ++i) {
+    const auto& t = g_launcher.trace[(n - take + i) % LaunchThreads::kTraceN];
+    for (int q = 0; q < 8; ++q) out[8 * i + q] = t[q];
+  }
+  return take;
 }
 
 // host time the two launch threads have spent enqueueing so far (microseconds: preparation stage, analysis / exchange /
