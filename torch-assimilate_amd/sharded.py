@@ -243,7 +243,9 @@ class ShardedLetkf:
         self.kernel_timings = []       # [(start, stop)] torch events recorded on the analysis stream by the library
         self.kernel_batch = {}         # (start, stop) -> steps in the launch those events bracket (launch coalescing; absent: 1)
         self.last_batch_n = 1          # steps that shared the analysis launch of the step finished last
-        self.max_in_flight = max(1, min(int(max_in_flight), 8))
+        # (eight measured best at config 2: 2.61e9 analyses/s against 2.41e9 with sixteen -- more steps in flight are more kernels sharing
+        #  the chip, profiles/r05_coalesce.txt; rounds 1-4 capped the argument at eight silently)
+        self.max_in_flight = max(1, min(int(max_in_flight), 16))
         self.prep_streams = max(0, min(int(prep_streams), 8))      # steps in flight: preparation streams taken in turn (0: none, tools)
         self.analysis_streams = max(1, min(int(analysis_streams), 4))
         self.prep_priority = int(prep_priority)      # HIP stream priority of the preparation streams (0 normal, -1 high)
