@@ -36,7 +36,7 @@ struct Problem {
 };
 
 struct Slot {
-  void* ws = nullptr; size_t ws_bytes = 0; int32_t* counters; int32_t* flags; float* Xa; int32_t* host8; void* event = nullptr; void* job = nullptr;
+  void* ws = nullptr; size_t ws_bytes = 0; int32_t* counters; int32_t* flags; float* Xa; int32_t* host8; void* event = nullptr; void* job = nullptr; void* in_event = nullptr;
 };
 
 static int allgather_cb(void* ctx, const void* send, void* recv, size_t bytes, void*) {
@@ -87,12 +87,37 @@ static void caller(int id, int n_steps) {
       }
       continue;
     }
-    int rc2 = mia_letkf_step_submit(pr.X, pr.G, pr.m, pr.k, pr.Yb, pr.d, pr.P, pr.grid, pr.obs, 1, cg, rc, 1, 1e-5, 1.1f, id == 4 ? 0.5f : 0.0f, 0, 20,
-                                    comm, chunks, 0, s.Xa, s.flags, s.counters, s.ws, s.ws_bytes, streams[0], streams[1], streams[2 + (it & 1)], flags,
-                                    s.host8, comm ? streams[1] : streams[0], streams[1], &s.event, nullptr, nullptr, &s.job);
-    CHECK(rc2 == MIA_OK);
+    int rc2;
+    if (id == 0 || id == 5) {
+      // the argument-block submission + one-call collection of ShardedLetkf's steady-state path, every third step timed
+      mia_step_args_t a;
+      memset(&a, 0, sizeof(a));
+      a.X = pr.X; a.G = pr.G; a.m = pr.m; a.k = pr.k; a.Yb = pr.Yb; a.d = pr.d; a.P = pr.P; a.grid_xyz = pr.grid; a.obs_xyz = pr.obs;
+      a.n_coord = 1; a.coord_group[0] = 0; a.gc_c[0] = 10.0; a.n_r = 1; a.gc_eps = 1e-5; a.inf_factor = 1.1f; a.gamma = 0.0f; a.method = 0;
+      a.p_max_assumed = 20; a.comm = nullptr; a.n_chunks = 1; a.phase = 0; a.Xa = s.Xa; a.flags = s.flags; a.counters = s.counters;
+      a.ws = s.ws; a.ws_bytes = s.ws_bytes; a.stream = streams[it % 3 == 0 ? 0 : 3]; a.comm_stream = streams[1]; a.prep_stream = streams[2];
+      a.step_flags = flags; a.host8 = s.host8; a.after_stream = a.stream; a.on_stream = streams[1]; a.done_event = &s.event;
+      a.caller_stream = nullptr; a.in_event = &s.in_event;
+      void *t0 = nullptr, *t1 = nullptr;
+      if (it % 3 == 1) { CHECK(mia_timing_event_acquire(&t0) == MIA_OK); CHECK(mia_timing_event_acquire(&t1) == MIA_OK); }
+      a.time_start_event = t0; a.time_stop_event = t1;
+      rc2 = mia_letkf_step_submit_args(&a, &s.job);
+      CHECK(rc2 == MIA_OK);
+      if (it % 2 == 0) {          // collected at once, in one call
+        int32_t out8[8]; int bn = 0;
+        CHECK(mia_letkf_step_collect(s.job, &s.event, s.host8, streams[0], 1, out8, &bn) == MIA_OK); s.job = nullptr;
+        CHECK(bn >= 1 && bn <= 4);
+      }
+      if (t0) { float ms = 0; (void)mia_timing_event_elapsed_ms(t0, t1, &ms); CHECK(mia_timing_event_release(t0) == MIA_OK); CHECK(mia_timing_event_release(t1) == MIA_OK); }
+    } else {
+      rc2 = mia_letkf_step_submit(pr.X, pr.G, pr.m, pr.k, pr.Yb, pr.d, pr.P, pr.grid, pr.obs, 1, cg, rc, 1, 1e-5, 1.1f, id == 4 ? 0.5f : 0.0f, 0, 20,
+                                  comm, chunks, 0, s.Xa, s.flags, s.counters, s.ws, s.ws_bytes, streams[0], streams[1], streams[2 + (it & 1)], flags,
+                                  s.host8, comm ? streams[1] : streams[0], streams[1], &s.event, nullptr, nullptr, &s.job);
+      CHECK(rc2 == MIA_OK);
+    }
+    if (id == 1 && it % 6 == 1) { CHECK(mia_set_option("step_coalesce", (it / 6) % 3) == MIA_OK); }      // launch coalescing on / off while steps are in flight
     if (it % 13 == 6) {          // the caller gives a workspace up between steps (a new geometry): release, then reuse the address
-      CHECK(mia_letkf_step_join(s.job) == MIA_OK); s.job = nullptr;
+      if (s.job) { CHECK(mia_letkf_step_join(s.job) == MIA_OK); } s.job = nullptr;
       CHECK(mia_letkf_step_workspace_release(s.ws) == MIA_OK);
     }
     if (id == 0 && it % 9 == 2) { CHECK(mia_set_option("tile_fused", it & 1) == MIA_OK); }      // route switches while steps are in flight
@@ -102,13 +127,14 @@ static void caller(int id, int n_steps) {
     if (s.event) CHECK(mia_event_synchronize(s.event) == MIA_OK);
     CHECK(mia_letkf_step_workspace_release(s.ws) == MIA_OK);
     if (s.event) mia_event_destroy(s.event);
+    if (s.in_event) mia_event_destroy(s.in_event);
     hipFree(s.ws); hipFree(s.counters); hipFree(s.flags); hipFree(s.Xa); free(s.host8);
   }
   if (comm) { CHECK(cb_calls.load() > 0); CHECK(mia_comm_destroy(comm) == MIA_OK); }
 }
 
 int main(int argc, char** argv) {
-  const int n_threads = argc > 1 ? atoi(argv[1]) : 5, n_steps = argc > 2 ? atoi(argv[2]) : 60;
+  const int n_threads = argc > 1 ? atoi(argv[1]) : 6, n_steps = argc > 2 ? atoi(argv[2]) : 60;
   CHECK(mia_version() == 100);
   char name[160];
   std::vector<std::thread> th;
@@ -116,6 +142,10 @@ int main(int argc, char** argv) {
   for (auto& t : th) t.join();
   CHECK(mia_letkf_step_drain() == MIA_OK);
   CHECK(mia_set_option("tile_fused", -1) == MIA_OK);
+  CHECK(mia_set_option("step_coalesce", -1) == MIA_OK);
+  long long co_l = 0, co_s = 0, trace[8 * 16];
+  CHECK(mia_letkf_step_coalesce_stats(&co_l, &co_s) == MIA_OK && co_s >= co_l);
+  CHECK(mia_debug_step_trace(trace, 16) == 16);
   CHECK(mia_last_analysis_kernel(name, (int)sizeof name) == MIA_OK);
   double a = 0, b = 0; long long n = 0;
   CHECK(mia_letkf_step_launch_stats(&a, &b, &n) == MIA_OK);

@@ -47,6 +47,8 @@ hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t
   return hipSuccess;
 }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = reinterpret_cast<hipEvent_t>(new StubEvent()); ++g_events; return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) { return hipEventCreateWithFlags(e, 0); }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { if (!a || !b || !ms) return hipErrorInvalidHandle; *ms = 0.01f; return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { delete reinterpret_cast<StubEvent*>(e); --g_events; return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { if (!e) return hipErrorInvalidHandle; ++reinterpret_cast<StubEvent*>(e)->recorded; return hipSuccess; }
 hipError_t hipEventQuery(hipEvent_t e) { if (!e) return hipErrorInvalidHandle; (void)reinterpret_cast<StubEvent*>(e)->recorded.load(); return hipSuccess; }

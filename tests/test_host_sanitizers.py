@@ -1,7 +1,7 @@
 """Host-side sanitizer pass ("race detection / sanitizers"): every source of the library compiled
 HOST-ONLY (`hipcc --cuda-host-only`: the kernels become launch stubs) with AddressSanitizer + UBSan and, separately, ThreadSanitizer,
 linked against a stand-in HIP runtime (tests/host_sanitize/hip_stub.cc: device memory = host memory, kernels do nothing) and driven by
-tests/host_sanitize/driver.cc -- five caller threads with rotating pipeline slots submitting steps to the library's two launch
+tests/host_sanitize/driver.cc -- six caller threads with rotating pipeline slots submitting steps to the library's two launch
 threads, synchronous steps, phase-1 redos, geometry epochs, the list route, a custom communicator with pieces, option changes and
 workspace releases while steps are in flight.  No GPU, no GPU sanitizer: the device code is not compiled at all."""
 import os
@@ -66,7 +66,7 @@ def test_step_driver_host_logic_under_sanitizers(tmp_path, name, flags, env):
     if not _sanitizer_runtime(name):
         pytest.skip("clang's %s runtime is not installed" % name)
     exe = _build(str(tmp_path), flags)
-    res = subprocess.run([exe, "5", "60"], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+    res = subprocess.run([exe, "6", "60"], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
     out = res.stdout + res.stderr
     assert res.returncode == 0, out[-6000:]
     assert "failed checks" in out and ", 0 failed checks" in out, out[-3000:]

@@ -1289,6 +1289,10 @@ struct LaunchThreads {
     hipEvent_t own_ev[8] = {};
     bool own_init = false;
     unsigned own_next = 0;
+    struct OwnEvents {      // (destroyed when the thread ends)
+      hipEvent_t (&ev)[8]; bool& init;
+      ~OwnEvents() { if (init) for (auto e : ev) if (e) (void)hipEventDestroy(e); }
+    } own_guard{own_ev, own_init};
     for (;;) {
       StepJob* j;
       spin_for(nb_q);
@@ -1300,7 +1304,7 @@ struct LaunchThreads {
         qb.pop_front();
         --nb_q;
       }
-      if (j->device != cur_b) { (void)hipSetDevice(j->device); cur_b = j->device; running.clear(); own_init = false; }
+      if (j->device != cur_b) { (void)hipSetDevice(j->device); cur_b = j->device; running.clear(); if (own_init) { for (auto& e : own_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; } } own_init = false; }
       j->ts[3] = now_ns();
       int rc = j->rc;
       // Steps in flight: wait for the step's preparation HERE, on the host, and enqueue the analysis kernel with nothing in
