@@ -409,13 +409,18 @@ void letkf_tile2w_kernel(Tile2wParams P) {
     auto coef = [&](int j) -> float {      // (uniform address: scalar loads); 2^-10 keeps M inside the half range for P
       return t2_ld<float2>(P.tab_c, cbase + (unsigned)(j < kTabDeg ? j : kTabDeg - 1) * 8u).x * 0x1p-10f;
     };
-    f4w d2[UT], ad2[UT];
+    // The recurrence as ONE matrix per point: V_{j+1} = A' V_j - V_{j-1} with A' = 2 alpha_g D_hat^2 Ghat - 2 I, whose A fragments are
+    // formed once per point (rows scaled by this lane's row factor, the diagonal in place) -- then the matrix instruction does the
+    // whole step: its accumulator input IS V_{j-1}, carried with signs W_j = sigma_j V_j, sigma = + + - - + + ..., so that the
+    // subtraction becomes an addition and the sign that leaves on A' rides in the split of the right-hand side (split8n: source
+    // modifiers, no instruction).  Per column block and step 12 (split) + 8 (accumulate c_j V_j) vector instructions where the
+    // elementwise form had 44: the kernel was bound by vector issue (82 % busy, profiles/r04_w_pmc.json).
+    f4w d2[UT];
     unsigned dmx = 0u;
 #pragma unroll
     for (int t = 0; t < UT; ++t) {
       const f4w d4 = *reinterpret_cast<const f4w*>(Dl + i * UMAX + 16 * t + 4 * h);
       d2[t] = d4 * d4;
-      ad2[t] = alpha_g * d2[t];
 #pragma unroll
       for (int q = 0; q < 4; ++q) { const unsigned a = __float_as_uint(d2[t][q]); dmx = a > dmx ? a : dmx; }
     }
@@ -423,8 +428,27 @@ void letkf_tile2w_kernel(Tile2wParams P) {
     int es;
     const float s = pow2_scale(dmx, 8, &es);
     const float inv_s = __uint_as_float((unsigned)(127 - es) << 23);
+    h8v APh[UT][NKB], APl[UT][NKB];
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      const float dr = Dl[i * UMAX + 16 * t + lr];                 // D_hat of row 16 t + lr (A layout: lane = row)
+      const float r2 = 2.0f * alpha_g * dr * dr;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        float av[8];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float gq = (float)GAh[t][kb][4 * tt + q] + (float)GAl[t][kb][4 * tt + q];      // 2^-16 Ghat (alpha carries 2^16)
+            const bool dg = 2 * kb + tt == t && 4 * h + q == lr;
+            av[4 * tt + q] = __builtin_fmaf(r2, gq, dg ? -2.0f : 0.0f);
+          }
+        split8_tied(av, APh[t][kb], APl[t][kb]);
+      }
+    }
     // V[cb][t][q] = V[slot 16 t + 4 h + q][slot 16 cb + lr]
-    f4w va[UT][UT], vb[UT][UT], am[UT][UT], y[UT];
+    f4w va[UT][UT], vb[UT][UT], am[UT][UT];
     const float c0 = coef(0), c1 = coef(1);
     float cn0 = coef(2), cn1 = coef(3);
 #pragma unroll
@@ -433,44 +457,65 @@ void letkf_tile2w_kernel(Tile2wParams P) {
       for (int t = 0; t < UT; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) va[cb][t][q] = (t == cb && 4 * h + q == lr) ? d2[t][q] * s : 0.0f;
-    // (the second column block's split follows the first block's products closely: tied form, see mia_tiles.h)
+    // acc += (+-) A' tv (one column block); neg: the right-hand side enters negated
+    auto product_acc = [&](const f4w (&tv)[UT], f4w (&acc)[UT], auto neg, auto tied) {
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+        if (kb == 0 || 32 * kb < U) {
+          float bv[8];
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int tk = 2 * kb + tt < UT ? 2 * kb + tt : 0;
+              bv[4 * tt + q] = 2 * kb + tt < UT ? tv[tk][q] : 0.0f;
+            }
+          h8v bh, bl;
+          if constexpr (decltype(neg)::value) {
+            if constexpr (decltype(tied)::value) split8n_tied(bv, bh, bl); else split8n(bv, bh, bl);
+          } else {
+            if constexpr (decltype(tied)::value) split8_tied(bv, bh, bl); else split8(bv, bh, bl);
+          }
+#pragma unroll
+          for (int t = 0; t < UT; ++t) acc[t] = t2_mfma3(acc[t], APh[t][kb], APl[t][kb], bh, bl);
+        }
+    };
+    // V_1 = X V_0 = A' V_0 / 2 (sigma_0 = sigma_1 = +)
     auto first_block = [&](int cb, auto tied) {
-      product(va[cb], y, tied);
+#pragma unroll
+      for (int t = 0; t < UT; ++t) vb[cb][t] = f4w{0.f, 0.f, 0.f, 0.f};
+      product_acc(va[cb], vb[cb], fresh_t{}, tied);
 #pragma unroll
       for (int t = 0; t < UT; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float vq = __builtin_fmaf(ad2[t][q], y[t][q], -va[cb][t][q]);
+          const float vq = 0.5f * vb[cb][t][q];
           vb[cb][t][q] = vq;
           am[cb][t][q] = __builtin_fmaf(c1, vq, c0 * va[cb][t][q]);
         }
     };
     first_block(0, fresh_t{});
     if constexpr (UT > 1) first_block(1, tied_t{});
-    auto advance_block = [&](f4w (&vold)[UT][UT], const f4w (&vcur)[UT][UT], const float cj, int cb, auto tied) {
-      product(vcur[cb], y, tied);
+    // W_new = (+-) A' W_cur + W_old, in place over W_old; am += (sigma c_j) W_new
+    auto advance = [&](f4w (&vold)[UT][UT], const f4w (&vcur)[UT][UT], const float cjs, auto neg) {
 #pragma unroll
-      for (int t = 0; t < UT; ++t)
+      for (int cb = 0; cb < UT; ++cb) {
+        if (cb == 0) product_acc(vcur[cb], vold[cb], neg, fresh_t{}); else product_acc(vcur[cb], vold[cb], neg, tied_t{});
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float tq_ = __builtin_fmaf(ad2[t][q], y[t][q], -vcur[cb][t][q]);
-          const float vn = __builtin_fmaf(2.0f, tq_, -vold[cb][t][q]);
-          vold[cb][t][q] = vn;
-          am[cb][t][q] = __builtin_fmaf(cj, vn, am[cb][t][q]);
-        }
-    };
-    auto advance = [&](f4w (&vold)[UT][UT], const f4w (&vcur)[UT][UT], const float cj) {
-      advance_block(vold, vcur, cj, 0, fresh_t{});
-      if constexpr (UT > 1) advance_block(vold, vcur, cj, 1, tied_t{});
+        for (int t = 0; t < UT; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) am[cb][t][q] = __builtin_fmaf(cjs, vold[cb][t][q], am[cb][t][q]);
+      }
     };
     int j = 2;
     for (; j + 1 <= deg_g; j += 2) {
-      const float cj = cn0, cj1 = cn1;
+      const float sg_ = (j & 2) ? -1.0f : 1.0f;            // sigma_j = sigma_{j+1} (j even)
+      const float cj = cn0 * sg_, cj1 = cn1 * sg_;
       cn0 = coef(j + 2); cn1 = coef(j + 3);
-      advance(va, vb, cj);
-      advance(vb, va, cj1);
+      advance(va, vb, cj, tied_t{});        // W_j     = -A' W_{j-1} + W_{j-2}   (tied_t = "true": negated right-hand side)
+      advance(vb, va, cj1, fresh_t{});      // W_{j+1} =  A' W_j     + W_{j-1}
     }
-    if (j <= deg_g) advance(va, vb, cn0);
+    if (j <= deg_g) advance(va, vb, cn0 * ((j & 2) ? -1.0f : 1.0f), tied_t{});
     // ---- P = M Yhat^T: A fragments of M (row block rb) = the registers of its column block rb (M is symmetric)
     h8v mh[UT][NKB], ml[UT][NKB];
 #pragma unroll
@@ -507,21 +552,27 @@ void letkf_tile2w_kernel(Tile2wParams P) {
             yfrag(ti, kb, yh, yl);
             acc = t2_mfma3(acc, yh, yl, ph_[kb], pl_[kb]);
           }
-        const f4w wm = *reinterpret_cast<const f4w*>(wbl + i * (16 * KT) + 16 * ti + 4 * h);
+        // W_pert is symmetric: this lane's four values W_pert[16 ti + 4 h + q][16 tj + lr] are stored as W[16 tj + lr][16 ti + 4 h + q],
+        // q = 0..3 -- FOUR CONSECUTIVE floats of one row, one 16-byte store per lane (round 4: four 4-byte stores per lane, 36 store
+        // instructions per point instead of 9); w_mean is the ROW's: one value per lane
+        const float wm = wbl[i * (16 * KT) + 16 * tj + lr];
         // (the values are formed outside the store's branch: the compiler pads the wait states between a matrix instruction
         //  and the first vector read of its result on the fall-through side of a branch only -- tools/check_mfma_hazards.py)
-        float vq[4];
+        f4w vq;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          vq[q] = __builtin_fmaf(acc[q], wsc, wm[q]);
+          vq[q] = __builtin_fmaf(acc[q], wsc, wm);
           if (ti == tj) vq[q] += (4 * h + q == lr ? P.f0 : 0.0f);      // (the diagonal lives in the diagonal blocks)
           chk = __builtin_fmaf(vq[q], 0.0f, chk);                      // NaN once any value is NaN or infinite: one test per point
-          asm volatile("" : "+v"(vq[q]));
         }
+        asm volatile("" : "+v"(vq));
+        const int row = col, c0_ = 16 * ti + 4 * h;                    // (col = 16 tj + lr: the stored ROW)
+        if ((k & 3) == 0) {
+          if (row < k && c0_ < k) *reinterpret_cast<f4w*>(Wg + (unsigned)(row * k + c0_)) = vq;
+        } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int row = 16 * ti + 4 * h + q;
-          if (row < k && col < k) Wg[(unsigned)(row * k + col)] = vq[q];
+          for (int q = 0; q < 4; ++q)
+            if (row < k && c0_ + q < k) Wg[(unsigned)(row * k + c0_ + q)] = vq[q];
         }
       }
     }

@@ -130,6 +130,55 @@ __device__ __forceinline__ void split8_tied(const float (&x)[8], h8v& hi, h8v& l
   hi = __builtin_bit_cast(h8v, hu);
   lo = __builtin_bit_cast(h8v, lu);
 }
+// ... and of -x (the weights kernel's recurrence alternates the sign of its right-hand sides, letkf_tile2w.hip): the negation rides
+// in the source modifiers of the conversions and of the mixed multiply-adds, hi = f16(-x), lo = f16(-x - hi): no instruction more.
+__device__ __forceinline__ void split8n(const float (&x)[8], h8v& hi, h8v& lo) {
+  u4w hu, lu;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f2w v = {-x[2 * i], -x[2 * i + 1]};
+    const h2v a = __builtin_convertvector(v, h2v);
+    hu[i] = __builtin_bit_cast(unsigned, a);
+  }
+  asm("s_nop 2\n\t"
+      "v_fma_mixlo_f16 %0, %4, -1.0, -%8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %4, -1.0, -%9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %1, %5, -1.0, -%10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %1, %5, -1.0, -%11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %2, %6, -1.0, -%12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %2, %6, -1.0, -%13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %3, %7, -1.0, -%14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %3, %7, -1.0, -%15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "s_nop 1"
+      : "=&v"(lu[0]), "=&v"(lu[1]), "=&v"(lu[2]), "=&v"(lu[3])
+      : "v"(hu[0]), "v"(hu[1]), "v"(hu[2]), "v"(hu[3]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]),
+        "v"(x[6]), "v"(x[7]));
+  hi = __builtin_bit_cast(h8v, hu);
+  lo = __builtin_bit_cast(h8v, lu);
+}
+__device__ __forceinline__ void split8n_tied(const float (&x)[8], h8v& hi, h8v& lo) {
+  u4w hu, lu;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f2w v = {-x[2 * i], -x[2 * i + 1]};
+    const h2v a = __builtin_convertvector(v, h2v);
+    hu[i] = __builtin_bit_cast(unsigned, a);
+    lu[i] = hu[i];
+  }
+  asm("v_fma_mixlo_f16 %0, %0, -1.0, -%4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %0, -1.0, -%5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %1, %1, -1.0, -%6 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %1, %1, -1.0, -%7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %2, %2, -1.0, -%8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %2, %2, -1.0, -%9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %3, %3, -1.0, -%10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %3, %3, -1.0, -%11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "s_nop 1"
+      : "+v"(lu[0]), "+v"(lu[1]), "+v"(lu[2]), "+v"(lu[3])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+  hi = __builtin_bit_cast(h8v, hu);
+  lo = __builtin_bit_cast(h8v, lu);
+}
 __device__ __forceinline__ h8v hi8(const float (&x)[8]) {
   h8v hi;
 #pragma unroll
