@@ -230,3 +230,32 @@ def test_split_products_follow_the_magnitude_of_their_operands(eng):
         assert int((fl.cpu().numpy() & 0xff & ~8).max()) == 0
         ref, _ = O.letkf_analysis(scaled["state"], scaled["grid_x"], scaled["obs_x"], scaled["yb"], scaled["d"], 10.0, 1.1)
         assert rel_fro(xa.cpu().numpy(), ref) < TOL32, s
+
+
+@pytest.mark.parametrize("k", [2, 3, 5])
+def test_tiny_ensembles_with_large_innovations(eng, k):
+    """Two to five members, innovations hundreds of times the state's spread (the analysis mean moves by hundreds of spreads): the
+    engine's list route (round-2 tile kernel: split products from three members on, f32 products for two -- tools/small_k_sweep.py)
+    and the tile route (letkf_tile2_kernel) against the oracle."""
+    set_option("tile_split", 1)
+    rs = np.random.RandomState(100 + k)
+    G = 320
+    grid = np.arange(G, dtype=np.float64)
+    obs = np.arange(0, G, 3.0) + 0.1
+    P = obs.shape[0]
+    state = rs.normal(size=(1, k, G)) * 7e-4
+    hx = rs.normal(size=(k, P)) * 350.0
+    yb, d = hx - hx.mean(axis=0), rs.normal(size=P) * 350.0
+    nb = eng.localize(grid, obs, [0.75])
+    assert nb.p_max <= k
+    ref, _ = O.letkf_analysis(state, grid, obs, yb, d, 0.75, 1.0)
+    xa, fl, fin = eng.analysis(dev(state), dev(yb), dev(d), nb, 1.0, return_flags=True, method="matfun", defer_retry=True)
+    fin()
+    assert int((fl.cpu().numpy() & 0xff & ~8).max()) == 0
+    assert rel_fro(xa.cpu().numpy(), ref) < TOL32
+    tiles = eng.localize_tiles(grid, obs, [0.75], nb.p_max)
+    assert int(tiles.stats[1].item()) == 0
+    xa2, fl2, retry = eng.analysis_tiles(dev(state), eng.pack_split(dev(yb), dev(d)), P, tiles, 1.0)
+    if int(retry.item()):
+        eng.retry_points(dev(state), dev(yb), dev(d), nb, 1.0, xa2, fl2)
+    assert rel_fro(xa2.cpu().numpy(), ref) < TOL32

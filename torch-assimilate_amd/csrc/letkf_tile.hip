@@ -1205,8 +1205,12 @@ unsigned long long& tile_launch_count() {
   static thread_local unsigned long long n = 0;
   return n;
 }
+// Two members: the split-precision variant of this kernel loses three digits when the analysis mean moves by hundreds of spreads
+// (3e-4 against 4e-6 with f32 products, tools/small_k_sweep.py; three members and more: 2-3e-6 either way; the tile route's kernels
+// are not affected) -- such ensembles take the f32 products.
+static bool tile_split_for(int k) { return option(MIA_OPT_TILE_SPLIT) != 0 && k >= 3; }
 bool tile_launch_would_serve(int m, int k, int p_max, int p_cap, int64_t ldx, int64_t ldo, int64_t ng, int seg_len) {
-  return option(MIA_OPT_TILE) != 0 && tile_launch_args_ok(m, k, p_max, p_cap, ldx, ldo, ng, seg_len, option(MIA_OPT_TILE_SPLIT) != 0);
+  return option(MIA_OPT_TILE) != 0 && tile_launch_args_ok(m, k, p_max, p_cap, ldx, ldo, ng, seg_len, tile_split_for(k));
 }
 
 int tile_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, int64_t ng, const float* rec,
@@ -1214,7 +1218,7 @@ int tile_analysis_launch(const float* X, int64_t ldx, int m, int k, int64_t g0, 
                          int p_max, float inf_factor, float* Xa, int64_t ldo, int64_t o0, int32_t* flags,
                          int32_t* retry_count, int dmax, const int2* tab_hdr, const float2* tab_c, hipStream_t stream,
                          int seg_len, int64_t seg_stride, int32_t* done) {
-  if (option(MIA_OPT_TILE_SPLIT))
+  if (tile_split_for(k))
     return tile_split_analysis_launch(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, w_f32, p_cap, p_max, inf_factor, Xa, ldo,
                                       o0, flags, retry_count, dmax, tab_hdr, tab_c, stream, seg_len, seg_stride, done);
   return tile_launch_impl<false>(X, ldx, m, k, g0, ng, rec, nbr_cnt, nbr_idx, nbr_w, w_f32, p_cap, p_max, inf_factor, Xa, ldo, o0,
