@@ -580,6 +580,11 @@ typedef struct mia_step_args {
   void* caller_stream; void** in_event;
 } mia_step_args_t;
 int mia_letkf_step_submit_args(const mia_step_args_t* a, void** job_out);
+/* One step taken at once on the caller's thread through the same block (MIA_STEP_NO_JOIN is ignored): drain of the launch threads,
+ * the step call, the counters' read-back (after_stream / on_stream / done_event as in mia_letkf_step_readback) and, when out8 is
+ * given, the host's wait for it and the eight counters -- the whole of a cycled filter's step in one call (a Python caller's
+ * ~15 us of set-up code and argument conversion in front of the first launch were a fifth of the step's 80 us). */
+int mia_letkf_step_run_args(const mia_step_args_t* a, int32_t* out8);
 /* Collects a submitted step in one call: mia_letkf_step_join_info(job, batch_n), then waits on the host for *done_event (the event
  * the step's read-back recorded -- the pointer handed to the submission, read after the join), copies the eight counters from host8
  * to out8 and, if consumer_stream_valid, makes consumer_stream wait for that event (work enqueued there afterwards sees the step's

@@ -71,6 +71,19 @@ static void caller(int id, int n_steps) {
     if (id == 1 && it % 7 == 3) flags |= MIA_STEP_NO_TILE_LISTS;            // the per-point list route now and then
     if (id == 3) flags |= (it >= n_slots ? MIA_STEP_REUSE_LISTS : 0) | MIA_STEP_KEEP_LISTS;      // a geometry epoch
     if (id == 0 && it % 11 == 5) flags |= MIA_STEP_SCAN_INDEX;
+    if (it % 5 == 4 && id == 5) {
+      // the same through the argument block, in one call (ShardedLetkf._run_fast)
+      mia_step_args_t a;
+      memset(&a, 0, sizeof(a));
+      a.X = pr.X; a.G = pr.G; a.m = pr.m; a.k = pr.k; a.Yb = pr.Yb; a.d = pr.d; a.P = pr.P; a.grid_xyz = pr.grid; a.obs_xyz = pr.obs;
+      a.n_coord = 1; a.coord_group[0] = 0; a.gc_c[0] = 10.0; a.n_r = 1; a.gc_eps = 1e-5; a.inf_factor = 1.1f; a.method = 0;
+      a.p_max_assumed = 20; a.n_chunks = 1; a.Xa = s.Xa; a.flags = s.flags; a.counters = s.counters; a.ws = s.ws; a.ws_bytes = s.ws_bytes;
+      a.stream = a.after_stream = a.on_stream = streams[0]; a.comm_stream = streams[1]; a.step_flags = flags; a.host8 = s.host8;
+      a.done_event = &s.event;
+      int32_t out8[8];
+      CHECK(mia_letkf_step_run_args(&a, out8) == MIA_OK);
+      continue;
+    }
     if (it % 5 == 4) {
       // a synchronous step on this slot (what ShardedLetkf.assimilate does): the queued ones first
       CHECK(mia_letkf_step_drain() == MIA_OK);

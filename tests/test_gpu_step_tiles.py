@@ -435,3 +435,54 @@ def test_the_steady_state_submit_path_equals_the_general_one(mia):
         assert torch.equal(h.result(), want_shift)
     assert r.last_flags_ok()
     r.close()
+
+
+def test_the_steady_state_serial_path_equals_the_general_one(mia):
+    """ShardedLetkf.assimilate takes a short path (_run_fast: one library call per step) once a steady state exists for steps taken one
+    at a time: same results bit for bit as the general path, for new input tensors every step; inputs it must refuse, another problem
+    size, steps in flight in between, observations leaving the stored box and declined points all fall back to the general path
+    and come out right."""
+    dev = torch.device("cuda:0")
+    cases = [O.synthetic_case(4000, 40, 2, seed=80 + i) for i in range(3)]
+    args = [args_of(c, dev) for c in cases]
+    ref = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1)
+    ref._run_fast = lambda *a, **k: None
+    want = [ref.assimilate(*a).clone() for a in args]
+    want_shift = ref.assimilate(*args_of(cases[0], dev, shift=5000.0)).clone()
+    want_strong = ref.assimilate(*args_of(cases[1], dev, scale=300.0)).clone()        # (strong observations: declined points, float64 redo)
+    ref.close()
+    r = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1)
+    taken = []
+    orig = r._run_fast
+
+    def spy(f, *a):
+        out = orig(f, *a)
+        taken.append(out is not None)
+        return out
+    r._run_fast = spy
+    for rep in range(4):
+        for j, a in enumerate(args):
+            assert torch.equal(r.assimilate(*[t.clone() for t in a]), want[j]), (rep, j)
+    assert sum(taken) >= 9, taken
+    n0 = len(taken)
+    X, g, o, Yb, d = args[1]
+    out = r.assimilate(X.double(), g, o, Yb, d)
+    assert float(torch.linalg.norm(out.float() - want[1]) / torch.linalg.norm(want[1])) < 1e-5
+    pend = [r.submit(*args[2]) for _ in range(3)]                 # steps in flight, then one at a time again
+    for h in pend:
+        assert torch.equal(h.result(), want[2])
+    assert torch.equal(r.assimilate(*args[0]), want[0])
+    assert torch.equal(r.assimilate(*args_of(cases[0], dev, shift=5000.0)), want_shift)      # box rebuilt, step repeated
+    assert torch.equal(r.assimilate(*args_of(cases[0], dev, shift=5000.0)), want_shift)
+    strong = args_of(cases[1], dev, scale=300.0)
+    assert torch.equal(r.assimilate(*strong), want_strong)
+    assert torch.equal(r.assimilate(*strong), want_strong)
+    assert r.last_retries >= 0 and r.last_flags_ok()
+    small = args_of(O.synthetic_case(1500, 40, 2, seed=90), dev)
+    oracle = O.letkf_analysis(*[O.synthetic_case(1500, 40, 2, seed=90)[k] for k in ("state", "grid_x", "obs_x", "yb", "d")], 10.0, 1.1)[0]
+    for _ in range(3):
+        out = r.assimilate(*small)
+    assert rel_fro(out.cpu().numpy(), oracle) < 1e-5
+    assert torch.equal(r.assimilate(*args[2]), want[2])
+    assert any(taken[n0:])
+    r.close()

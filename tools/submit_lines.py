@@ -75,6 +75,10 @@ runner = ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1, max_in_flight=dep
 
 
 def run(n):
+    if os.environ.get("SERIAL"):
+        for it in range(n):
+            runner.assimilate(X, gx, ox, Yb, d)
+        return
     pend = collections.deque()
     for it in range(n):
         pend.append(runner.submit(X, gx, ox, Yb, d))

@@ -105,6 +105,7 @@ _PROTOS = {
                                f32, f32, i32, i32, vp, i32, i32, vp, vp, vp, vp, sz, vp, vp, vp, i32,
                                vp, vp, vp, C.POINTER(vp), vp, vp, C.POINTER(vp)], i32),
     "mia_letkf_step_submit_args": ([vp, vp], i32),
+    "mia_letkf_step_run_args": ([vp, vp], i32),
     "mia_letkf_step_collect": ([vp, vp, vp, vp, i32, vp, vp], i32),
     "mia_timing_event_acquire": ([C.POINTER(vp)], i32),
     "mia_timing_event_release": ([vp], i32),

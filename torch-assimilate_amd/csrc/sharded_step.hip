@@ -1494,6 +1494,31 @@ extern "C" int mia_letkf_step_submit_args(const mia_step_args_t* a, void** job_o
                                a->host8, a->after_stream, a->on_stream, a->done_event, a->time_start_event, a->time_stop_event, job_out);
 }
 
+// One step taken at once on the caller's thread through the argument block: what mia_letkf_step_drain + the step call +
+// mia_letkf_step_readback (+ mia_event_synchronize and a copy of the counters, when out8 is given) do, in one call.
+extern "C" int mia_letkf_step_run_args(const mia_step_args_t* a, int32_t* out8) {
+  if (!a || !a->done_event || !a->host8) return MIA_ERR_NULL;
+  int rc = mia_letkf_step_drain();       // (a synchronous step must not overtake queued ones)
+  if (rc != MIA_OK) return rc;
+  if (a->in_event) {
+    rc = mia_stream_wait_stream(a->prep_stream ? a->prep_stream : a->stream, a->caller_stream, a->in_event);
+    if (rc != MIA_OK) return rc;
+  }
+  if ((a->time_start_event == nullptr) != (a->time_stop_event == nullptr)) return MIA_ERR_NULL;
+  hipEvent_t pe = nullptr;
+  uint32_t seq = 0;
+  rc = step_impl(a->X, a->G, a->m, a->k, a->Yb, a->d, a->P, a->grid_xyz, a->obs_xyz, a->n_coord, a->coord_group, a->gc_c, a->n_r, a->gc_eps,
+                 a->inf_factor, a->gamma, a->method, a->p_max_assumed, a->comm, a->n_chunks, a->phase, a->Xa, a->flags, a->counters, a->ws,
+                 a->ws_bytes, a->stream, a->comm_stream, a->prep_stream, a->step_flags & ~MIA_STEP_NO_JOIN, 0, &pe, &seq,
+                 (hipEvent_t)a->time_start_event, (hipEvent_t)a->time_stop_event, nullptr, nullptr);
+  if (rc != MIA_OK) return rc;
+  rc = mia_letkf_step_readback(a->counters, a->host8, a->after_stream, a->on_stream, a->done_event);
+  if (rc != MIA_OK || !out8) return rc;
+  MIA_HIP_TRY(hipEventSynchronize((hipEvent_t)*a->done_event));
+  for (int i = 0; i < 8; ++i) out8[i] = a->host8[i];
+  return MIA_OK;
+}
+
 extern "C" int mia_letkf_step_collect(void* job, void** done_event, const int32_t* host8, void* consumer_stream, int consumer_stream_valid,
                                       int32_t* out8, int* batch_n) {
   if (!job || !done_event || !host8 || !out8) return MIA_ERR_NULL;
