@@ -294,6 +294,8 @@ int mia_letkf_weights_retry_f32(const float* X, int64_t ldx, int m, int k, int64
  * help such a tile -- use the per-point lists */
 #define MIA_TILE_BOX_OVERFLOW (1 << 30)
 #define MIA_STEP_STATUS_SAMPLED 64 /* counters[3] / [7] of a step: see mia_letkf_sharded_step_streams_f32 */
+#define MIA_STEP_STATUS_NONFINITE 128 /* with MIA_STEP_STATUS_SAMPLED (the fused kernel ran): some grid point's flags carry
+                                       * MIA_FLAG_NONFINITE; absent: none does -- no scan of the per-point flags needed */
 int mia_letkf_tile_lists_bytes(int64_t n_points, int p_max, int extra_blocks, size_t* bytes);
 int mia_letkf_localize_tiles_f64(int taper, const double* grid_xyz, int64_t g0, int64_t g1,
                                  const double* obs_xyz, int64_t P, int n_coord,

@@ -486,3 +486,41 @@ def test_the_steady_state_serial_path_equals_the_general_one(mia):
     assert torch.equal(r.assimilate(*args[2]), want[2])
     assert any(taken[n0:])
     r.close()
+
+
+def test_non_finite_points_are_reported_in_the_status_word(mia):
+    """The fused kernel says in the step's status word (MIA_STEP_STATUS_NONFINITE) whether any grid point carries MIA_FLAG_NONFINITE, so
+    that a caller need not scan the per-point flags after every step: clean inputs -> summary 0; a state column beyond the float
+    range -> summary 4 and exactly that point flagged; the drop-in class warns from the summary."""
+    import warnings
+    dev = torch.device("cuda:0")
+    case = O.synthetic_case(3000, 40, 2, seed=95)
+    X, g, o, Yb, d = args_of(case, dev)
+    r = mia.ShardedLetkf(dev, 0, 1, radii=[10.0], inf_factor=1.1)
+    for _ in range(3):
+        r.assimilate(X, g, o, Yb, d)
+    assert r.last_flags_summary == 0 and r.last_flags_ok()
+    Xb = X.clone()
+    Xb[0, 3, 1234] = 3.0e38
+    Xb[0, 4, 1234] = -3.0e38
+    for _ in range(2):                                   # (general path, then the short one)
+        out = r.assimilate(Xb, g, o, Yb, d)
+        assert r.last_flags_summary == 4
+        fl = (r._last_flags & 0xff).cpu().numpy()
+        assert fl[1234] & 4 and int((fl != 0).sum()) == 1
+        assert not bool(torch.isfinite(out[0, :, 1234]).all())
+    h = [r.submit(Xb, g, o, Yb, d) for _ in range(3)]
+    for x in h:
+        x.result()
+        assert r.last_flags_summary == 4
+    r.assimilate(X, g, o, Yb, d)
+    assert r.last_flags_summary == 0
+    r.close()
+    a = mia.LETKF(mia.GaspariCohn(10.0, mia.AbsoluteDistance()), inf_factor=1.1, dtype=torch.float32)
+    gx, ox = g[:, None], o[:, None]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for _ in range(3):
+            a.analyse_arrays(X, Yb, d, grid_coords=gx, obs_coords=ox)
+    with pytest.warns(RuntimeWarning, match="non-finite"):
+        a.analyse_arrays(Xb, Yb, d, grid_coords=gx, obs_coords=ox)

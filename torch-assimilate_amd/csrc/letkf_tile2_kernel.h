@@ -605,6 +605,9 @@ __device__ __forceinline__ void tile2_body(Tile2Params P, const Tile2Loc* loc, c
     const unsigned long long fb = __ballot(pflag != 0);
     const bool anyf = ((fb >> lr) & 0x0001000100010001ull) != 0ull;
     if (h == 0 && colok && !decl) P.flags[p0 + lr] = (anyf ? MIA_FLAG_NONFINITE : 0) | (deg << 8);
+    if constexpr (LOC > 0) {      // (the step's status word says so too: a host that trusts it need not scan 1e5 flags per step)
+      if (fb != 0ull && lane == 0) atomicOr(&loc->stats[3], kStepNonfinite);
+    }
   }
   T2_STAMP(8);
   T2_STAMP_REAL(11);

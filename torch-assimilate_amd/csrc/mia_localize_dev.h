@@ -93,6 +93,7 @@ struct Tile2Loc {
   int longest_bound;
 };
 constexpr int kStepSampledLongest = 64;      // status bit in counters[3] / [7] (include/mia_letkf.h: MIA_STEP_STATUS_SAMPLED)
+constexpr int kStepNonfinite = 128;          // ... MIA_STEP_STATUS_NONFINITE: some point of the fused kernel's launch carries MIA_FLAG_NONFINITE
 
 // One wavefront scans the 3^d cells around grid point g (the innermost coordinate's three cells are one
 // contiguous range), evaluates distance and taper in float64 and compacts the observations whose weight

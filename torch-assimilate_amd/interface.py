@@ -314,8 +314,10 @@ class LETKF(ETKF):
             self._step_runner, self._step_runner_key = runner, key
         dev = self.engine.device
         xa = runner.assimilate(x, grid.to(device=dev, dtype=torch.float64), obs.to(device=dev, dtype=torch.float64), yb, d)
-        fl = runner._last_flags
-        bad = int((fl & 0xff).max().item()) if fl is not None and fl.numel() else 0
+        bad = runner.last_flags_summary          # (known from the step's status word on the default route: no scan of 1e5 flags, no sync)
+        if bad is None:
+            fl = runner._last_flags
+            bad = int((fl & 0xff).max().item()) if fl is not None and fl.numel() else 0
         if bad & 1:
             raise RuntimeError("LETKF kernel: local observation list overflow (engine bug: lists are sized from counts)")
         if bad & 4:

@@ -18,6 +18,7 @@ __all__ = ["ShardedLetkf", "PendingStep", "block_partition", "gather_blocks"]
 
 
 TILE_BOX_OVERFLOW = 1 << 30        # MIA_TILE_BOX_OVERFLOW (include/mia_letkf.h)
+STATUS_NONFINITE = 128             # MIA_STEP_STATUS_NONFINITE: (with STATUS_SAMPLED) some point carries MIA_FLAG_NONFINITE
 STATUS_SAMPLED = 64                # MIA_STEP_STATUS_SAMPLED: counters[0] / [4] of this step are a sampled maximum (fused kernel)
 
 
@@ -87,6 +88,7 @@ class ShardedLetkf:
     @_last_flags.setter
     def _last_flags(self, value):
         self._last_flags_val, self._last_flags_lazy = value, None
+        self.last_flags_summary = None          # (a route that does not report through the status word)
 
     @property
     def dominant_kernel_name(self):
@@ -270,6 +272,7 @@ class ShardedLetkf:
         self._last_flags_val, self._last_flags_lazy = None, None
         self._fast = None              # what _submit_fast needs: recorded by _native_submit once a steady state exists
         self._fast_serial = None       # ... and what _run_fast needs (one step at a time)
+        self.last_flags_summary = None # OR of the flag bits (low byte) of the last step's points when known without a scan
         # tile route of the native step driver (tile-shaped lists + split records, csrc/letkf_tile2.hip): switched off for this
         # object once a step reports tiles whose union does not fit their slots (scattered grids) -- per-point lists then
         self._no_tile_lists = False
@@ -958,7 +961,8 @@ class ShardedLetkf:
         # MIA_STEP_STATUS_SAMPLED: the step ran on the fused kernel, whose "longest list" is exact only when it EXCEEDS the bound
         # the step was sized for (then the step is redone below); otherwise it is the maximum over one tile in 64
         sampled = bool(cnt[7] & STATUS_SAMPLED)
-        cnt[7] &= ~STATUS_SAMPLED
+        nonfinite = bool(cnt[7] & STATUS_NONFINITE)
+        cnt[7] &= ~(STATUS_SAMPLED | STATUS_NONFINITE)
         p_seen, n_over, n_retry = cnt[4], cnt[5], cnt[6]
         redo = None
         if cnt[7] & 2 and p.get("peer"):
@@ -981,7 +985,8 @@ class ShardedLetkf:
                 if not (cnt[7] & 2):
                     break
             sampled = sampled or bool(cnt[7] & STATUS_SAMPLED)
-            cnt[7] &= ~STATUS_SAMPLED
+            nonfinite = nonfinite or bool(cnt[7] & STATUS_NONFINITE)
+            cnt[7] &= ~(STATUS_SAMPLED | STATUS_NONFINITE)
             p_seen, n_over, n_retry = cnt[4], cnt[5], cnt[6]
         if cnt[7] & 24:
             # bucket index of the tile route: an observation outside the bounding box this slot's workspace held (or other
@@ -1054,6 +1059,10 @@ class ShardedLetkf:
             elif not p.get("waited"):
                 self.engine.lib.mia_stream_wait_event(torch._C._cuda_getCurrentRawStream(p["dev_index"]), p["ev"])
         self.native_steps += 1
+        # what the per-point flags of this step can hold, known WITHOUT reading them: the fused kernel (sampled bit) reports non-finite
+        # points in the status word, overflowing unions redo the step above, and only a float64 redo of declined points can add the
+        # eigensolver's own bits -- None: unknown, scan the flags (other kernels, a redo ran)
+        self.last_flags_summary = (4 if nonfinite else 0) if (sampled and not n_retry) else None
         self.last_retries = cnt[2]
         self.reused_steps += 1 if p.get("reused") else 0
         if sampled:
