@@ -524,10 +524,11 @@ int mia_obs_space_corr_f64(const double* hx, int64_t ldh, const double* y, const
  * method: 0 auto (= matfun, with the eigensolver redoing declined points), 1 eigensolver kernel, 2 matfun.   p_max_assumed: bound of the local
  * observation count the launch is sized for (lists capacity = round_up(., 8)).
  * counters [8] i32 (device): [0] longest list of the block, [1] lists longer than the capacity, [2] grid points
- * the matfun kernel declined, [3] error bits (bit 0: a segment waiter timed out) and ONE status bit, MIA_STEP_STATUS_SAMPLED (64):
+ * the matfun kernel declined, [3] error bits (bit 0: a segment waiter timed out) and TWO status bits: MIA_STEP_STATUS_SAMPLED (64):
  * the step ran on the fused kernel (csrc/letkf_tile2f.hip), whose [0] is exact only when it exceeds p_max_assumed -- otherwise
  * the maximum over one tile of sixteen points in 64 (a caller that carries the bound from step to step keeps it, or lowers it
- * with a margin); [4..7] the same, max- (or-)
+ * with a margin); and, with it, MIA_STEP_STATUS_NONFINITE (128): some grid point's flags carry MIA_FLAG_NONFINITE (absent: none
+ * does, the per-point flags need not be read to know); [4..7] the same, max- (or-)
  * reduced over all ranks (comm == NULL: left zero, [0..3] are the whole story).  The host reads them once
  * after the call (the only synchronisation of the step):
  *   [5] != 0 or [4] > p_max_assumed  -> the bound did not hold on some rank: repeat the step (phase 0) on ALL
