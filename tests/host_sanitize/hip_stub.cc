@@ -53,6 +53,7 @@ hipError_t hipEventDestroy(hipEvent_t e) { delete reinterpret_cast<StubEvent*>(e
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { if (!e) return hipErrorInvalidHandle; ++reinterpret_cast<StubEvent*>(e)->recorded; return hipSuccess; }
 hipError_t hipEventQuery(hipEvent_t e) { if (!e) return hipErrorInvalidHandle; (void)reinterpret_cast<StubEvent*>(e)->recorded.load(); return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t e) { if (!e) return hipErrorInvalidHandle; (void)reinterpret_cast<StubEvent*>(e)->recorded.load(); return hipSuccess; }
+hipError_t hipStreamQuery(hipStream_t s) { return (reinterpret_cast<uintptr_t>(s) & 4) ? hipErrorNotReady : hipSuccess; }      // (some streams busy, some idle)
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t e, unsigned) { if (!e) return hipErrorInvalidHandle; (void)reinterpret_cast<StubEvent*>(e)->recorded.load(); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* st) { *st = hipStreamCaptureStatusNone; return hipSuccess; }

@@ -1484,8 +1484,14 @@ extern "C" int mia_letkf_step_submit_args(const mia_step_args_t* a, void** job_o
   if (!a) return MIA_ERR_NULL;
   t_submit_entry = LaunchThreads::now_ns();
   if (a->in_event) {
-    const int rc = mia_stream_wait_stream(a->prep_stream, a->caller_stream, a->in_event);
-    if (rc != MIA_OK) return rc;
+    // (an idle caller stream has produced everything it ever will before this call: nothing to wait for -- no event, and no
+    //  barrier packet in front of the preparation kernel)
+    const hipError_t q = hipStreamQuery((hipStream_t)a->caller_stream);
+    if (q != hipSuccess) {
+      (void)hipGetLastError();
+      const int rc = mia_stream_wait_stream(a->prep_stream, a->caller_stream, a->in_event);
+      if (rc != MIA_OK) return rc;
+    }
   }
   t_submit_waited = LaunchThreads::now_ns();
   return mia_letkf_step_submit(a->X, a->G, a->m, a->k, a->Yb, a->d, a->P, a->grid_xyz, a->obs_xyz, a->n_coord, a->coord_group, a->gc_c,
