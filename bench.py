@@ -952,10 +952,12 @@ def main():
                                        % (algorithmic_bytes(K_ENS, 1, P / G), gpl, gpg, spl),
                          "algorithmic_bytes_per_launch": algorithmic_bytes(K_ENS, 1, P / G) * gpl,
                          "steps_per_launch": spl, "analyses_per_launch": gpl, "kernel_ms_per_step": kern_ms / spl,
-                         "steps_per_launch_note": "launch coalescing (option step_coalesce): the launch thread hands the tiles of up to four "
-                                                  "steps in flight whose preparation has finished to ONE grid of the fused kernel; mean over "
-                                                  "the timed launches; over the whole timed loop %s launches carried %s steps"
-                                                  % (co_l1 - co_l0, co_s1 - co_s0),
+                         "steps_per_launch_note": ("launch coalescing (option step_coalesce) is ON: the launch thread hands the tiles of up to four "
+                                                   "steps in flight whose preparation has finished to ONE grid of the fused kernel; mean over "
+                                                   "the timed launches; over the whole timed loop %s launches carried %s steps"
+                                                   % (co_l1 - co_l0, co_s1 - co_s0)) if co_l1 > co_l0 else
+                                                  "one launch per step (launch coalescing, option step_coalesce, is off: the default -- it measured "
+                                                  "slower per step, profiles/r05_coalesce.txt)",
                          "step_frac": algorithmic_bytes(K_ENS, 1, P / G) * gpg / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBS,
                          "step_frac_note": "the same bytes / ms_per_step / peak: the whole step (index + packing + fused analysis) "
                                            "against the HBM roof",
