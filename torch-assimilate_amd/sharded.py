@@ -55,6 +55,20 @@ _F32, _F64 = torch.float32, torch.float64
 _METHODS = {"auto": 0, "eig": 1, "matfun": 2}
 
 
+def _steady_inputs(f, X, grid_xyz, obs_xyz, Yb, d) -> bool:
+    """The inputs already are what the library reads -- device, dtype, contiguous -- and have the shapes of the state `f` a general
+    call recorded: what the short paths of ShardedLetkf (_submit_fast, _run_fast) require before they skip the general set-up."""
+    try:
+        dev = f["device"]
+        return (X.dtype is _F32 and Yb.dtype is _F32 and d.dtype is _F32 and grid_xyz.dtype is _F64 and obs_xyz.dtype is _F64
+                and X.shape == f["xs"] and Yb.shape == f["ys"] and d.shape == f["ds"] and grid_xyz.shape == f["gs"]
+                and obs_xyz.shape == f["os"] and X.is_contiguous() and Yb.is_contiguous() and d.is_contiguous()
+                and grid_xyz.is_contiguous() and obs_xyz.is_contiguous()
+                and X.device == dev and Yb.device == dev and d.device == dev and grid_xyz.device == dev and obs_xyz.device == dev)
+    except AttributeError:
+        return False
+
+
 class PendingStep:
     """Handle of a step enqueued by :meth:`ShardedLetkf.submit`."""
 
@@ -544,16 +558,10 @@ class ShardedLetkf:
         (mia_letkf_step_run_args: step, read-back, wait, counters).  The general path's ~15 us of set-up code ran before the step's
         first launch, i.e. on the step's critical path: 0.080 -> 0.068 ms per step at config 2.  None whenever anything differs from
         the recorded state (the general path then takes the step)."""
-        try:
-            ok = (X.dtype is _F32 and Yb.dtype is _F32 and d.dtype is _F32 and grid_xyz.dtype is _F64 and obs_xyz.dtype is _F64
-                  and X.shape == f["xs"] and Yb.shape == f["ys"] and d.shape == f["ds"] and grid_xyz.shape == f["gs"]
-                  and obs_xyz.shape == f["os"] and X.is_contiguous() and Yb.is_contiguous() and d.is_contiguous()
-                  and grid_xyz.is_contiguous() and obs_xyz.is_contiguous())
-            dev = f["device"]
-            ok = ok and X.device == dev and Yb.device == dev and d.device == dev and grid_xyz.device == dev and obs_xyz.device == dev
-        except AttributeError:
+        if not _steady_inputs(f, X, grid_xyz, obs_xyz, Yb, d):
             return None
-        if not ok or self._native is not f["st"] or self._in_flight:
+        dev = f["device"]
+        if self._native is not f["st"] or self._in_flight:
             return None
         slot = f["slot"]
         hint = self._p_max_hint
@@ -598,16 +606,10 @@ class ShardedLetkf:
         the shapes of the previous step), without the general path's set-up code.  At config 2 the caller's host time per step,
         not the GPU, bounded the pipeline (tools/host_bound.py: submit 25 us + result 12 us = the 37 us period).  Returns None
         whenever anything differs from the state ``_native_submit`` recorded: the general path then takes the step."""
-        try:
-            ok = (X.dtype is _F32 and Yb.dtype is _F32 and d.dtype is _F32 and grid_xyz.dtype is _F64 and obs_xyz.dtype is _F64
-                  and X.shape == f["xs"] and Yb.shape == f["ys"] and d.shape == f["ds"] and grid_xyz.shape == f["gs"]
-                  and obs_xyz.shape == f["os"] and X.is_contiguous() and Yb.is_contiguous() and d.is_contiguous()
-                  and grid_xyz.is_contiguous() and obs_xyz.is_contiguous())
-            dev = f["device"]
-            ok = ok and X.device == dev and Yb.device == dev and d.device == dev and grid_xyz.device == dev and obs_xyz.device == dev
-        except AttributeError:
+        if not _steady_inputs(f, X, grid_xyz, obs_xyz, Yb, d):
             return None
-        if not ok or self._native is not f["st"] or not self.native_step or self.fused_localization:
+        dev = f["device"]
+        if self._native is not f["st"] or not self.native_step or self.fused_localization:
             return None
         n_sub = self._submitted
         slot = f["slots"][n_sub % f["n"]]
