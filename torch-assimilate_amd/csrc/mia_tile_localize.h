@@ -344,7 +344,21 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
   MIA_TL_SYNC();
   MIA_TL_STAMP(4);
   // rank of every member by observation index -> slot
-  if (!overflow) {
+  if (!overflow && U <= 32) {
+    // at most 32 members (the fused kernel's shapes): BOTH halves of the wavefront count -- lane u and lane u + 32 take sixteen keys
+    // each and add up (one round of LDS reads and sixteen compare-adds instead of two; slots beyond U hold a key that counts for nobody)
+    if (lane >= U && lane < 32) ukey[lane] = 0x7fffffff;
+    MIA_TL_SYNC();
+    const int u = lane & 31, v0 = (lane >> 5) << 4;
+    const int key = ukey[u];
+    int rk = 0;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) rk += ukey[v0 + v] < key ? 1 : 0;
+    typedef unsigned u2v_ __attribute__((ext_vector_type(2)));
+    const u2v_ r2 = __builtin_amdgcn_permlane32_swap((unsigned)rk, (unsigned)rk, false, false);
+    rk = (int)(r2.x + r2.y);
+    if (lane < U) uinv[16 * (rk >> 4) + 4 * (rk & 3) + ((rk >> 2) & 3)] = u;
+  } else if (!overflow) {
     for (int u = lane; u < U; u += 64) {
       const int key = ukey[u];
       int rk = 0;
