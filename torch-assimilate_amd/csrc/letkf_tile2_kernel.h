@@ -2,6 +2,7 @@
 // translation units that instantiate it: letkf_tile2.hip (lists from memory) and letkf_tile2f.hip (the wavefront localises its
 // own tile first).
 #pragma once
+#include <type_traits>
 #include "mia_common.h"
 #include <hip/hip_ext.h>
 #include "mia_kernels.h"
@@ -211,32 +212,28 @@ __device__ __forceinline__ void tile2_body(Tile2Params P, const Tile2Loc* loc, c
         const int idx = ukey[16 * t + ((lr - 8 * par) & 15)];
         roff[t][par] = (unsigned)(idx < 0 ? (int)P.zero_rec : idx) * (unsigned)P.rb + 16u * (unsigned)hl;
       }
-    constexpr int NLmax = (UT * 2 * KT + 1) / 2;
+    // A record has 2 KT - 1 or 2 KT chunks of eight members (k in (16 (KT - 1), 16 KT]): with the count a compile-time constant
+    // the (row block, chunk) of every piece line is one too, and the lane's record offset is picked by INDEX -- as a run-time
+    // count it was picked by eight selects per load and lane group, forty-odd selects per tile, each the issue time of three
+    // multiply-adds (tools/micro/valu_rates.hip).  One wave-uniform branch instead.
+    auto gather = [&](auto nc8c) {
+      constexpr int NC8 = decltype(nc8c)::value;
+      constexpr int NL = (UT * NC8 + 1) / 2;
 #pragma unroll
-    for (int u = 0; u < NLmax; ++u) {
-      if (2 * u < UT * nc8) {                            // (wave-uniform)
-        // piece lines 2 u (lane groups 0, 1) and 2 u + 1 (groups 2, 3): (row block, chunk) of each -- scalar arithmetic
-        int tA = 0, cA = 2 * u, tB = 0, cB = 2 * u + 1;
-#pragma unroll
-        for (int i = 1; i < UT; ++i) {
-          if (cA >= nc8) { cA -= nc8; ++tA; }
-          if (cB >= nc8) { cB -= nc8; ++tB; }
-        }
-        unsigned roA = roff[0][0], roB = roff[0][0];
-#pragma unroll
-        for (int t = 0; t < UT; ++t)
-#pragma unroll
-          for (int par = 0; par < 2; ++par) {
-            roA = (tA == t && (cA & 1) == par) ? roff[t][par] : roA;
-            roB = (tB == t && (cB & 1) == par) ? roff[t][par] : roB;
-          }
-        const unsigned off = gh ? roB + 32u * (unsigned)cB : roA + 32u * (unsigned)cA;
-        const bool valid = 2 * u + gh < UT * nc8;
+      for (int u = 0; u < NL; ++u) {
+        // piece lines 2 u (lane groups 0, 1) and 2 u + 1 (groups 2, 3): (row block, chunk) of each
+        const int lA = 2 * u, lB = 2 * u + 1;
+        const int tA = lA / NC8, cA = lA % NC8, tB = (lB / NC8) < UT ? lB / NC8 : UT - 1, cB = lB % NC8;
+        const unsigned offA = roff[tA][cA & 1] + 32u * (unsigned)cA, offB = roff[tB][cB & 1] + 32u * (unsigned)cB;
+        const unsigned off = gh ? offB : offA;
+        const bool valid = 2 * u + gh < UT * NC8;
         if (valid)
           __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>(P.rec + off),
                                            (__attribute__((address_space(3))) void*)(smem + u * 1024), 16, 0, 0);
       }
-    }
+    };
+    if (nc8 == 2 * KT - 1) gather(std::integral_constant<int, 2 * KT - 1>{});
+    else gather(std::integral_constant<int, 2 * KT>{});
   }
   f2w tails[(UMAX + 63) / 64];
 #pragma unroll
