@@ -527,6 +527,7 @@ __device__ __forceinline__ void tile2_body(Tile2Params P, const Tile2Loc* loc, c
     // 16 tj + 4 p .. + 3 (chunk 2 tj + (p >> 1), byte 8 (p & 1)) and receives, for its member, the four slots q = 0 .. 3
     const int tq = (lane & 15) >> 2, tp = lane & 3;
     f4w acc[KT];
+    unsigned amax = 0u;        // largest |value| of this lane's results as a bit pattern: NaN > inf > every finite value
 #pragma unroll
     for (int tj = 0; tj < KT; ++tj) {
       acc[tj] = f4w{0.f, 0.f, 0.f, 0.f};
@@ -551,9 +552,13 @@ __device__ __forceinline__ void tile2_body(Tile2Params P, const Tile2Loc* loc, c
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         acc[tj][q] = acc[tj][q] * fo + (mterm + P.f0 * (xre[tj][q] - xm));
-        if (!(fabsf(acc[tj][q]) <= 1e30f) && (tj < KT - 1 || 16 * tj + 4 * h + q < k)) pflag |= MIA_FLAG_NONFINITE;
+        // (one integer maximum per value and ONE comparison per row instead of a comparison per value -- twelve comparisons were the
+        //  issue time of forty multiply-adds; rows beyond the ensemble hold the clamped member k - 1: the same magnitudes)
+        const unsigned ab = __float_as_uint(acc[tj][q]) & 0x7fffffffu;
+        amax = ab > amax ? ab : amax;
       }
     }
+    if (amax > 0x7149f2cau) pflag |= MIA_FLAG_NONFINITE;       // |value| > 1e30, infinite or NaN
     if (colok && !decl) {
       float* obase = P.Xa + (int64_t)mi * k * P.ldo + oc0;
       const unsigned olane = (unsigned)(4 * h) * ldob + (unsigned)lr * 4u;
