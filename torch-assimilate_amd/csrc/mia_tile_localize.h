@@ -43,6 +43,23 @@ __device__ __forceinline__ float gc_taper_fast(double d2, double four_c2, float 
   return r < 1.0f ? f1 : f2;
 }
 
+// ONE coordinate: the distance is |dx| itself -- no square, no square root -- and 2 - r = (2 c - |dx|) / c is formed in float64 where
+// it cancels and scaled in float32: no reciprocal either (two transcendental instructions per pair instead of four, each the issue
+// time of three and a half multiply-adds; two float64 operations instead of three).
+__device__ __forceinline__ float gc_taper_fast_1d(double dx, double two_c, float inv_c, float c) {
+#pragma clang fp contract(off)
+  const float a = __builtin_fabsf((float)dx);
+  const float r = a * inv_c;
+  const float rinv = c * __builtin_amdgcn_rcpf(a);                // (enters where r >= 1 only; inf at r = 0 is never selected)
+  const float h1 = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-0.25f, r, 0.5f), r, 0.625f), r, -5.0f / 3.0f);
+  const float f1 = __builtin_fmaf(h1 * r, r, 1.0f);
+  float t = (float)(two_c - __builtin_fabs(dx)) * inv_c;          // 2 - r
+  t = __builtin_fmaxf(t, 0.0f);                                   // r >= 2: zero (strict `<` at 2, gaspari_cohn.py:127-133)
+  const float t2 = t * t;
+  const float f2 = t2 * t2 * __builtin_fmaf(__builtin_fmaf(r, 1.0f / 12.0f, 1.0f / 6.0f), r, -1.0f / 24.0f) * rinv;
+  return r < 1.0f ? f1 : f2;
+}
+
 constexpr int kTlUmax = 96;           // largest union (UT = 6)
 constexpr int kTlMaxRows = 64;        // cell rows of a tile's box (outer coordinates); more = scattered points: no tile list
 
@@ -160,6 +177,7 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
   float icf[MIA_MAX_RADII], ccf[MIA_MAX_RADII], ic2f[MIA_MAX_RADII];
 #pragma unroll
   for (int r = 0; r < MIA_MAX_RADII; ++r) { fc2[r] = q.four_c2[r]; icf[r] = q.inv_c_f[r]; ccf[r] = q.c_f[r]; ic2f[r] = q.inv_c2_f[r]; }
+  const double twoc0 = 2.0 * q.cc[0];
   // a candidate: its observation index and coordinates (requested one trip ahead of their use by the bucket loop below)
   struct Cand { int oj; double ox[NC]; };
   auto fetch = [&](int64_t pos) {
@@ -198,9 +216,13 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
             if (grp[c] == r) d2[r] = __builtin_fma(dx, dx, d2[r]);
         }
         float wf = 1.0f;
+        if constexpr (NC == 1) {
+          wf = gc_taper_fast_1d(ox[0] - gxr[i][0], twoc0, icf[0], ccf[0]);
+        } else {
 #pragma unroll
-        for (int r = 0; r < (NC == 1 ? 1 : MIA_MAX_RADII); ++r)
-          if (r < n_r) wf *= gc_taper_fast(d2[r], fc2[r], icf[r], ccf[r], ic2f[r]);
+          for (int r = 0; r < MIA_MAX_RADII; ++r)
+            if (r < n_r) wf *= gc_taper_fast(d2[r], fc2[r], icf[r], ccf[r], ic2f[r]);
+        }
         wf4[i] = wf;
         amb4[i] = have && ptok[i] && fabsf(wf - epsf) < 1e-4f * epsf;
         anyamb = anyamb || amb4[i];
