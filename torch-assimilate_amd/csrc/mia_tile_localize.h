@@ -204,7 +204,8 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
       // float32 weights of the four pairs first; the (rare) pairs whose weight is within 1e-4 of eps are collected and weighed again
       // in float64 behind ONE wave-level test per trip (round 4: one test and one branch per pair)
       float wf4[4];
-      bool amb4[4], anyamb = false;
+      float dmin = 3.0e38f;          // smallest |weight - eps| of the lane's four pairs: ONE comparison per trip instead of one per pair
+      const float amb_thr = 1e-4f * epsf;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         double d2[MIA_MAX_RADII] = {0.0, 0.0, 0.0};
@@ -224,16 +225,15 @@ __device__ __forceinline__ TileLocOut tile_localize(const ScanParams& q, int64_t
             if (r < n_r) wf *= gc_taper_fast(d2[r], fc2[r], icf[r], ccf[r], ic2f[r]);
         }
         wf4[i] = wf;
-        amb4[i] = have && ptok[i] && fabsf(wf - epsf) < 1e-4f * epsf;
-        anyamb = anyamb || amb4[i];
+        dmin = __builtin_fminf(dmin, __builtin_fabsf(wf - epsf));
       }
-      if (__any(anyamb)) {
+      if (__any(dmin < amb_thr)) {      // (pairs that do not count may trigger it too: the test per pair follows)
         // the decision is the float64 one: where float32 put an ambiguous weight on the wrong side of eps, the weight moves to the
         // float value next to eps on the right side (a change of the order of its own rounding error, ~1e-6 relative, of a weight
         // of 1e-5) -- so that every decision below is ONE comparison of the float32 weight
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          if (amb4[i]) {
+          if (have && ptok[i] && __builtin_fabsf(wf4[i] - epsf) < amb_thr) {
             double wgt = 1.0;
             for (int r = 0; r < n_r; ++r) {
               double d2r = 0.0;
