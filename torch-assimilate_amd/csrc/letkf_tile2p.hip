@@ -23,6 +23,7 @@
 #include "mia_options.h"
 #include "mia_tiles.h"
 #include <cstdio>
+#include <type_traits>
 #include <cstdlib>
 
 #ifdef MIA_T2P_STAMPS
@@ -168,30 +169,43 @@ void letkf_tile2p_kernel(Tile2Params P) {
     return;
   }
   P_STAMP(1);
-  // ---- second round trip: the union's records straight into the LDS image (the waves take alternate kilobytes), tails
+  // ---- second round trip: the union's records straight into the LDS image (the waves take alternate kilobytes), tails.
+  //      As in letkf_tile2_kernel.h (round 5): every lane's pieces belong to at most 2 UT records, whose 32-bit byte offsets are formed
+  //      once; with the record's chunk count (2 KT - 1 or 2 KT) and the wave's index as compile-time constants behind wave-uniform
+  //      branches the (row block, chunk) of every piece line is a constant too -- as run-time values every one of the thirteen loads
+  //      of a wave cost 45 vector instructions, fifteen of them compares and selects (a sixth of the kernel's instructions).
   {
-    const int g = lane >> 4, hl = g & 1;
-    int tc = (g >> 1) + 2 * wv;
-    constexpr int NLmax = (UT * 2 * KT + 1) / 2;
+    const int g = lane >> 4, hl = g & 1, gh = g >> 1;
+    unsigned roff[UT][2];
 #pragma unroll
-    for (int u0 = 0; u0 < NLmax; u0 += NW) {
-      const int u = u0 + wv;                             // (wave-uniform)
-      if (2 * u < UT * nc8) {
-        int t = 0, c = tc;
+    for (int t = 0; t < UT; ++t)
 #pragma unroll
-        for (int i = 1; i < UT; ++i)
-          if (c >= nc8) { c -= nc8; ++t; }
-        const bool valid = tc < UT * nc8;
-        const int r = 16 * t + ((lr - 8 * (c & 1)) & 15);
-        const int idx = valid ? ukey[r] : -1;
-        const int64_t j = idx < 0 ? P.zero_rec : (int64_t)idx;
-        const unsigned char* src = P.rec + j * P.rb + (32 * c + 16 * hl);
+      for (int par = 0; par < 2; ++par) {
+        const int idx = ukey[16 * t + ((lr - 8 * par) & 15)];
+        roff[t][par] = (unsigned)(idx < 0 ? (int)P.zero_rec : idx) * (unsigned)P.rb + 16u * (unsigned)hl;
+      }
+    auto gather = [&](auto nc8c, auto wvc) {
+      constexpr int NC8 = decltype(nc8c)::value, WV = decltype(wvc)::value;
+      constexpr int NL = (UT * NC8 + 1) / 2;
+#pragma unroll
+      for (int u = WV; u < NL; u += NW) {
+        const int lA = 2 * u, lB = 2 * u + 1;
+        const int tA = lA / NC8, cA = lA % NC8, tB = (lB / NC8) < UT ? lB / NC8 : UT - 1, cB = lB % NC8;
+        const unsigned offA = roff[tA][cA & 1] + 32u * (unsigned)cA, offB = roff[tB][cB & 1] + 32u * (unsigned)cB;
+        const unsigned off = gh ? offB : offA;
+        const bool valid = 2 * u + gh < UT * NC8;
         if (valid)
-          __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>(src),
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>(P.rec + off),
                                            (__attribute__((address_space(3))) void*)(smem + u * 1024), 16, 0, 0);
       }
-      tc += 2 * NW;
-    }
+    };
+    auto gather_w = [&](auto nc8c) {
+      if (wv == 0) gather(nc8c, std::integral_constant<int, 0>{});
+      else if (NW < 3 || wv == 1) gather(nc8c, std::integral_constant<int, 1>{});
+      else gather(nc8c, std::integral_constant<int, (NW > 2 ? 2 : 1)>{});
+    };
+    if (nc8 == 2 * KT - 1) gather_w(std::integral_constant<int, 2 * KT - 1>{});
+    else gather_w(std::integral_constant<int, 2 * KT>{});
   }
   bool badrec = false;
   for (int s = tid; s < UMAX; s += NT) {
