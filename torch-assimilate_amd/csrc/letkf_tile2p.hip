@@ -516,6 +516,7 @@ void letkf_tile2p_kernel(Tile2Params P) {
     const unsigned xolast = (unsigned)(k - 1) * ldxb + (unsigned)lrc * 4u;
     const unsigned olane = (unsigned)(4 * h) * ldob + (unsigned)lr * 4u;
     int pf = 0;
+    unsigned amax = 0u;
 #pragma unroll
     for (int jo = 0; jo < J0; ++jo) {
       if (jo < n_out) {
@@ -549,7 +550,10 @@ void letkf_tile2p_kernel(Tile2Params P) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           vq[q] = acc[q] * fo + (mterm + P.f0 * (xre[q] - xm));
-          if (!(fabsf(vq[q]) <= 1e30f) && 16 * tj + 4 * h + q < k) pf = MIA_FLAG_NONFINITE;
+          // (largest |value| as a bit pattern -- NaN > inf > every finite value -- and ONE comparison at the end, letkf_tile2_kernel.h;
+          //  rows beyond the ensemble hold the clamped member k - 1: the same magnitudes)
+          const unsigned ab = __float_as_uint(vq[q]) & 0x7fffffffu;
+          amax = ab > amax ? ab : amax;
           asm volatile("" : "+v"(vq[q]));        // (formed before the store's predicate: tools/check_mfma_hazards.py)
         }
         if (colok && !decl) {
@@ -560,6 +564,7 @@ void letkf_tile2p_kernel(Tile2Params P) {
         }
       }
     }
+    if (amax > 0x7149f2cau) pf = MIA_FLAG_NONFINITE;       // |value| > 1e30, infinite or NaN
     if (colok && !decl) pflag |= pf;
   }
   P_STAMP(6);
