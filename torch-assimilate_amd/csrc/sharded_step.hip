@@ -1439,7 +1439,7 @@ struct LaunchThreads {
 LaunchThreads g_launcher;
 }  // namespace
 
-static thread_local long long t_submit_entry = 0, t_submit_waited = 0;
+static thread_local long long t_submit_entry = 0;      // (diagnostics: when the argument-block submission was entered, mia_debug_step_trace)
 extern "C" int mia_letkf_step_submit(const float* X, int64_t G, int m, int k, const float* Yb, const float* d, int64_t P,
                                      const double* grid_xyz, const double* obs_xyz, int n_coord, const int32_t* coord_group,
                                      const double* gc_c, int n_r, double gc_eps, float inf_factor, float gamma, int method,
@@ -1493,7 +1493,6 @@ extern "C" int mia_letkf_step_submit_args(const mia_step_args_t* a, void** job_o
       if (rc != MIA_OK) return rc;
     }
   }
-  t_submit_waited = LaunchThreads::now_ns();
   return mia_letkf_step_submit(a->X, a->G, a->m, a->k, a->Yb, a->d, a->P, a->grid_xyz, a->obs_xyz, a->n_coord, a->coord_group, a->gc_c,
                                a->n_r, a->gc_eps, a->inf_factor, a->gamma, a->method, a->p_max_assumed, a->comm, a->n_chunks, a->phase,
                                a->Xa, a->flags, a->counters, a->ws, a->ws_bytes, a->stream, a->comm_stream, a->prep_stream, a->step_flags,
