@@ -196,11 +196,18 @@ class TimingEvent:
     """A timing event from the library's pool (mia_timing_event_acquire): what ShardedLetkf.time_next_step hands to the step's
     launch.  ``elapsed_time`` as torch.cuda.Event's; released to the pool, never destroyed, when the object goes away."""
     __slots__ = ("cuda_event",)
+    _free = []          # handles ready for use on this side of the boundary (acquired thirty-two at a time: a library call per event
+                        # was 3 us of every timed step's submission)
 
     def __init__(self):
-        ev = C.c_void_p()
-        check(lib().mia_timing_event_acquire(C.byref(ev)), "mia_timing_event_acquire")
-        self.cuda_event = ev.value
+        free = TimingEvent._free
+        if not free:
+            l = lib()
+            ev = C.c_void_p()
+            for _ in range(32):
+                check(l.mia_timing_event_acquire(C.byref(ev)), "mia_timing_event_acquire")
+                free.append(ev.value)
+        self.cuda_event = free.pop()
 
     def elapsed_time(self, other) -> float:
         ms = C.c_float(0.0)
@@ -210,7 +217,7 @@ class TimingEvent:
     def __del__(self):
         try:
             if self.cuda_event:
-                lib().mia_timing_event_release(self.cuda_event)
+                TimingEvent._free.append(self.cuda_event)      # (reused, never destroyed: a launch thread that still holds it touches a live event)
         except Exception:       # (interpreter shutdown)
             pass
 
