@@ -8,9 +8,12 @@
 //   W_pert = f0 I + cs_phi Yhat M_g Yhat^T,      M_g = Phi(X_g) D_hat^2 = D_hat phi(S_g) D_hat   (symmetric, U x U)
 //   w_mean = cs_psi Yhat Psi(X_g) (D_hat^2 o wdl)                                               (wdl: innovation in the record's scale)
 //
-// A wavefront serves FOUR points of a tile (4 x as many wavefronts as tiles; the four of a tile run on one XCD):
+// A workgroup of FOUR wavefronts serves a tile, each wavefront four of its points.  What belongs to the tile -- record image,
+// Gram matrix and its fragments, interval / degree of the sixteen points, phase A -- is made ONCE, by wave 0, and handed
+// over in LDS (round 4: every quarter made it again, a quarter of the kernel's vector instructions; the kernel is bound by
+// vector issue, so three wavefronts waiting at a barrier cost nothing that counts):
 //   phase A  the vector recurrence of letkf_tile2.hip on the sixteen columns u_0 = D_hat^2 o wdl (one per point) -> w_mean
-//            of all sixteen points from one output product; this wave keeps its four columns (LDS)
+//            of all sixteen points from one output product (LDS)
 //   phase B  per point: V_0 = D_hat^2 (diagonal), V_{j+1} = 2 (alpha D_hat^2 o (Ghat V_j) - V_j) - V_{j-1} on two column
 //            blocks of sixteen -- 12 MFMAs per step at U <= 32 -- accumulating c_j V_j = M_g in the result layout, which by
 //            symmetry IS the A-operand layout of the next product: P = M_g Yhat^T (transposed LDS reads of the records as
@@ -46,53 +49,36 @@ constexpr int kWDegCap = 36;
 #define MIA_W_TRIM 2
 #endif
 
-template <int UT, int KT>
-__global__ __launch_bounds__(64, KT <= 3 ? 3 : 2)
+// K4: the ensemble size is a multiple of four (rows of W are stored sixteen bytes at a time; the predicates and addresses of the
+// element-wise stores are the other instantiation's)
+template <int UT, int KT, bool K4>
+__global__ __launch_bounds__(64 * (16 / kWPts), KT <= 3 ? 3 : 2)
 void letkf_tile2w_kernel(Tile2wParams P) {
   constexpr int UMAX = 16 * UT, NB = (KT + 1) / 2, NKB = (UT + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x, lr = lane & 15, h = lane >> 4;
+  const int lane = threadIdx.x & 63, lr = lane & 15, h = lane >> 4;
+  const int sub = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // this wave's quarter of the tile
   const int k = P.k, nc8 = P.nc8;
   const unsigned IMG = (unsigned)(UT * nc8) * 512u;
   unsigned char* zline = smem + IMG;
   int* ukey = reinterpret_cast<int*>(smem + IMG + 512);      // [UMAX]
   float* wdl = reinterpret_cast<float*>(ukey + UMAX);        // [UMAX]
   float* El = wdl + UMAX;                                    // [UMAX]
-  float* Dl = El + UMAX;                                     // [kWPts][UMAX] D_hat of this wave's points
-  float* wbl = Dl + kWPts * UMAX;                            // [kWPts][16 KT] w_mean of this wave's points
+  float* Dl = El + UMAX;                                     // [16][UMAX] D_hat of the tile's points
+  float* wbl = Dl + 16 * UMAX;                               // [16][16 KT] w_mean of the tile's points
+  int4* ptl = reinterpret_cast<int4*>(wbl + 16 * 16 * KT);   // [16] per point: degree, table row, alpha, declined
+  f4w* gal = reinterpret_cast<f4w*>(ptl + 16);               // [UT][NKB][2][64] 2^-16 Ghat in the A-fragment order of the lanes (f32)
+  int* stl = reinterpret_cast<int*>(gal + UT * NKB * 2 * 64);   // [4] tile without weights (a record that is not finite)
 
-  // work item = (tile, quarter); items w, w + 1, .. of one XCD are consecutive, so the four quarters of a tile share an L2
-  const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-  const int64_t ntile = (P.ng + 15) >> 4, nwork = ntile * (16 / kWPts);
-  if (bid >= nwork) return;
-  const int64_t q8 = nwork >> 3, r8 = nwork & 7, xcd = bid & 7;
-  const int64_t wi = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int64_t tile = wi >> 2;
-  const int sub = (int)(wi & 3);
+  const int64_t tile = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+  const int64_t ntile = (P.ng + 15) >> 4;
+  if (tile >= ntile) return;
   const int64_t p0 = tile << 4;
   const int npts = P.ng - p0 < 16 ? (int)(P.ng - p0) : 16;
-  if (kWPts * sub >= npts) return;
   const bool colok = lr < npts;
   const int64_t kk = (int64_t)k * k;
 
   const int4 hd = P.thdr[tile];
-  int myidx[(UMAX + 63) / 64];
-#pragma unroll
-  for (int r = 0; r < (UMAX + 63) / 64; ++r) {
-    const int s = lane + 64 * r;
-    myidx[r] = s < UMAX ? t2_ld<int32_t>(P.tidx + tile * UMAX, (unsigned)s * 4u) : -1;
-  }
-  f4w dreg[UT];
-#pragma unroll
-  for (int t = 0; t < UT; ++t) dreg[t] = t2_ld<f4w>(P.tD + (tile * UT + t) * 64, (unsigned)lane * 16u);
-  const int sg = 2 * (h & 1) + (h >> 1);
-#pragma unroll
-  for (int r = 0; r < (UMAX + 63) / 64; ++r) {
-    const int s = lane + 64 * r;
-    if (s < UMAX) ukey[s] = myidx[r];
-  }
-  for (int i = lane; i < 32; i += 64) reinterpret_cast<f4w*>(zline)[i] = f4w{0.f, 0.f, 0.f, 0.f};
-  MIA_T2_SYNC();
   const int U = __builtin_amdgcn_readfirstlane(hd.x);
   if (U < 0) {                     // union overflow (flagged by the analysis launch): no weights either
     const float nanv = __builtin_nanf("");
@@ -103,151 +89,13 @@ void letkf_tile2w_kernel(Tile2wParams P) {
     }
     return;
   }
-  // the union's records -> LDS image (letkf_tile2.hip), tails
-  {
-    const int g = lane >> 4, hl = g & 1;
-    int tc = g >> 1;
-    constexpr int NLmax = (UT * 2 * KT + 1) / 2;
-#pragma unroll
-    for (int u = 0; u < NLmax; ++u) {
-      if (2 * u < UT * nc8) {
-        int t = 0, c = tc;
-#pragma unroll
-        for (int i = 1; i < UT; ++i)
-          if (c >= nc8) { c -= nc8; ++t; }
-        const bool valid = tc < UT * nc8;
-        const int r = 16 * t + ((lr - 8 * (c & 1)) & 15);
-        const int idx = valid ? ukey[r] : -1;
-        const int64_t j = idx < 0 ? P.zero_rec : (int64_t)idx;
-        const unsigned char* src = P.rec + j * P.rb + (32 * c + 16 * hl);
-        if (valid)
-          __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>(src),
-                                           (__attribute__((address_space(3))) void*)(smem + u * 1024), 16, 0, 0);
-      }
-      tc += 2;
-    }
-  }
-  f2w tails[(UMAX + 63) / 64];
-#pragma unroll
-  for (int r = 0; r < (UMAX + 63) / 64; ++r) {
-    const int64_t j = myidx[r] < 0 ? P.zero_rec : (int64_t)myidx[r];
-    tails[r] = *reinterpret_cast<const f2w*>(P.rec + j * P.rb + 32 * nc8);
-  }
+  h8v GAh[UT][NKB], GAl[UT][NKB];
+  const int sg = 2 * (h & 1) + (h >> 1);
   auto frag_off = [&](int t, int b) -> unsigned {
     const int c = 4 * b + sg;
     const unsigned col = (unsigned)((lr + 8 * (c & 1)) & 15) * 16u;
     return c < nc8 ? (unsigned)(t * nc8 + c) * 512u + col : IMG + col;
   };
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-
-  // ---- Gram matrix, D_hat, A fragments of Ghat, interval and degree of every point: as in letkf_tile2.hip
-  h8v GAh[UT][NKB], GAl[UT][NKB];
-  float alpha = 0.0f;
-  int deg = 0, tab_idx = 0, degmax = 0;
-  bool decl = false;
-  {
-    f4w G[UT][UT];
-#pragma unroll
-    for (int t1 = 0; t1 < UT; ++t1)
-#pragma unroll
-      for (int t2 = 0; t2 < UT; ++t2) G[t1][t2] = f4w{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      h8v ah[UT], al[UT];
-#pragma unroll
-      for (int t = 0; t < UT; ++t) {
-        const unsigned o = frag_off(t, b);
-        ah[t] = *reinterpret_cast<const h8v*>(smem + o);
-        al[t] = *reinterpret_cast<const h8v*>(smem + o + 256);
-      }
-#pragma unroll
-      for (int t2 = 0; t2 < UT; ++t2)
-#pragma unroll
-        for (int t1 = 0; t1 < UT; ++t1) G[t1][t2] = t2_mfma3(G[t1][t2], ah[t1], al[t1], ah[t2], al[t2]);
-    }
-    bool badrec = false;
-#pragma unroll
-    for (int r = 0; r < (UMAX + 63) / 64; ++r) {
-      const int s = lane + 64 * r;
-      if (s < UMAX) {
-        wdl[s] = tails[r][0];
-        El[s] = tails[r][1];
-        badrec = badrec || !(tails[r][1] == tails[r][1]);
-      }
-    }
-    if (__any(badrec)) return;            // (every point of the tile was handed to the eigensolver by the analysis launch)
-    MIA_T2_SYNC();
-#pragma unroll
-    for (int t = 0; t < UT; ++t) {
-      const f4w e4 = *reinterpret_cast<const f4w*>(El + 16 * t + 4 * h);
-      dreg[t] *= e4;
-    }
-#pragma unroll
-    for (int t = 0; t < UT; ++t)
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) {
-        float gv[8];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) gv[4 * tt + q] = 2 * kb + tt < UT ? G[2 * kb + tt < UT ? 2 * kb + tt : 0][t][q] * 0x1p-16f : 0.0f;
-        split8(gv, GAh[t][kb], GAl[t][kb]);
-      }
-    f4w R[UT];
-#pragma unroll
-    for (int t = 0; t < UT; ++t) R[t] = f4w{0.f, 0.f, 0.f, 0.f};
-    unsigned dmx = 0u;
-#pragma unroll
-    for (int t = 0; t < UT; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { const unsigned a = __float_as_uint(dreg[t][q]); dmx = a > dmx ? a : dmx; }
-    dmx = t2_wave_max_u32(dmx);
-    int esd;
-    const float sd = pow2_scale(dmx, 0, &esd);
-    const float inv_sd = __uint_as_float((unsigned)(127 - esd) << 23);
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-      if (kb == 0 || 32 * kb < U) {     // (kb = 0 unconditionally: no branch between this product and the use of its result)
-        float dv[8];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) dv[4 * tt + q] = 2 * kb + tt < UT ? dreg[2 * kb + tt < UT ? 2 * kb + tt : 0][q] * sd : 0.0f;
-        const h8v dh = hi8(dv);
-#pragma unroll
-        for (int t = 0; t < UT; ++t) {
-          u4w ag = __builtin_bit_cast(u4w, GAh[t][kb]);
-          ag &= 0x7fff7fffu;
-          R[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, ag), dh, R[t], 0, 0, 0);
-        }
-      }
-    float L = 0.0f;
-#pragma unroll
-    for (int t = 0; t < UT; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float v = dreg[t][q] * R[t][q];
-        L = (v > L || v != v) ? v : L;
-      }
-    L = __uint_as_float(t2_max_h(__float_as_uint(L))) * inv_sd;
-    L = fmaxf(L, 1e-37f) * 1.002f;
-    if (!(L == L) || !(fabsf(L) < 1e30f)) L = 1.0f;
-    tab_idx = (int)ceilf(float(kTabPerOctave) * (__builtin_amdgcn_logf(L * P.inv_reg) + 16.0f)) + kTabIdx0;
-    tab_idx = tab_idx < 0 ? 0 : (tab_idx > kTabN - 1 ? kTabN - 1 : tab_idx);
-    const int2 th = t2_ld<int2>(P.tab_hdr, (unsigned)tab_idx * 8u);
-    deg = th.x;
-    alpha = __builtin_ldexpf(__int_as_float(th.y) * P.inv_reg, 16);
-    decl = colok && (deg > P.dmax || deg > kTabDeg - 1);
-    degmax = (int)wave_max_nonneg_dpp((colok && !decl) ? float(deg) : 0.0f);
-  }
-  // D_hat of this wave's points, by slot (phase B reads them as row factors)
-  {
-    const int li = lr - kWPts * sub;
-    if (li >= 0 && li < kWPts)
-#pragma unroll
-      for (int t = 0; t < UT; ++t) *reinterpret_cast<f4w*>(Dl + li * UMAX + 16 * t + 4 * h) = dreg[t];
-  }
   // (split8_tied outside the per-point recurrence: see mia_tiles.h)
   auto rhs_split = [&](const f4w (&tv)[UT], int kb, const float sc, h8v& bh, h8v& bl) {
     float bv[8];
@@ -311,6 +159,167 @@ void letkf_tile2w_kernel(Tile2wParams P) {
     yl = __builtin_bit_cast(h8v, als);
   };
 
+  // (which wave: rotating with the tile -- wave i of every workgroup sits on SIMD i, and with the same wave taking the tile's part
+  //  everywhere that SIMD sets the pace while the other three idle a quarter of the time)
+  const int leader = (int)(((tile >> 3) + (tile >> 8)) & 3);
+  if (sub == leader) {              // ======== the tile's part: one wave
+  int myidx[(UMAX + 63) / 64];
+#pragma unroll
+  for (int r = 0; r < (UMAX + 63) / 64; ++r) {
+    const int s = lane + 64 * r;
+    myidx[r] = s < UMAX ? t2_ld<int32_t>(P.tidx + tile * UMAX, (unsigned)s * 4u) : -1;
+  }
+  f4w dreg[UT];
+#pragma unroll
+  for (int t = 0; t < UT; ++t) dreg[t] = t2_ld<f4w>(P.tD + (tile * UT + t) * 64, (unsigned)lane * 16u);
+#pragma unroll
+  for (int r = 0; r < (UMAX + 63) / 64; ++r) {
+    const int s = lane + 64 * r;
+    if (s < UMAX) ukey[s] = myidx[r];
+  }
+  for (int i = lane; i < 32; i += 64) reinterpret_cast<f4w*>(zline)[i] = f4w{0.f, 0.f, 0.f, 0.f};
+  MIA_T2_SYNC();
+  // the union's records -> LDS image (letkf_tile2.hip), tails
+  {
+    const int g = lane >> 4, hl = g & 1;
+    int tc = g >> 1;
+    constexpr int NLmax = (UT * 2 * KT + 1) / 2;
+#pragma unroll
+    for (int u = 0; u < NLmax; ++u) {
+      if (2 * u < UT * nc8) {
+        int t = 0, c = tc;
+#pragma unroll
+        for (int i = 1; i < UT; ++i)
+          if (c >= nc8) { c -= nc8; ++t; }
+        const bool valid = tc < UT * nc8;
+        const int r = 16 * t + ((lr - 8 * (c & 1)) & 15);
+        const int idx = valid ? ukey[r] : -1;
+        const int64_t j = idx < 0 ? P.zero_rec : (int64_t)idx;
+        const unsigned char* src = P.rec + j * P.rb + (32 * c + 16 * hl);
+        if (valid)
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>(src),
+                                           (__attribute__((address_space(3))) void*)(smem + u * 1024), 16, 0, 0);
+      }
+      tc += 2;
+    }
+  }
+  f2w tails[(UMAX + 63) / 64];
+#pragma unroll
+  for (int r = 0; r < (UMAX + 63) / 64; ++r) {
+    const int64_t j = myidx[r] < 0 ? P.zero_rec : (int64_t)myidx[r];
+    tails[r] = *reinterpret_cast<const f2w*>(P.rec + j * P.rb + 32 * nc8);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- Gram matrix, D_hat, A fragments of Ghat, interval and degree of every point: as in letkf_tile2.hip
+  float alpha = 0.0f;
+  int deg = 0, tab_idx = 0, degmax = 0;
+  bool decl = false, nowt = false;
+  {
+    f4w G[UT][UT];
+#pragma unroll
+    for (int t1 = 0; t1 < UT; ++t1)
+#pragma unroll
+      for (int t2 = 0; t2 < UT; ++t2) G[t1][t2] = f4w{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      h8v ah[UT], al[UT];
+#pragma unroll
+      for (int t = 0; t < UT; ++t) {
+        const unsigned o = frag_off(t, b);
+        ah[t] = *reinterpret_cast<const h8v*>(smem + o);
+        al[t] = *reinterpret_cast<const h8v*>(smem + o + 256);
+      }
+#pragma unroll
+      for (int t2 = 0; t2 < UT; ++t2)
+#pragma unroll
+        for (int t1 = 0; t1 < UT; ++t1) G[t1][t2] = t2_mfma3(G[t1][t2], ah[t1], al[t1], ah[t2], al[t2]);
+    }
+    bool badrec = false;
+#pragma unroll
+    for (int r = 0; r < (UMAX + 63) / 64; ++r) {
+      const int s = lane + 64 * r;
+      if (s < UMAX) {
+        wdl[s] = tails[r][0];
+        El[s] = tails[r][1];
+        badrec = badrec || !(tails[r][1] == tails[r][1]);
+      }
+    }
+    nowt = __any(badrec);                 // (every point of the tile was handed to the eigensolver by the analysis launch)
+    MIA_T2_SYNC();
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      const f4w e4 = *reinterpret_cast<const f4w*>(El + 16 * t + 4 * h);
+      dreg[t] *= e4;
+    }
+#pragma unroll
+    for (int t = 0; t < UT; ++t)
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        float gv[8];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gv[4 * tt + q] = 2 * kb + tt < UT ? G[2 * kb + tt < UT ? 2 * kb + tt : 0][t][q] * 0x1p-16f : 0.0f;
+        split8(gv, GAh[t][kb], GAl[t][kb]);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) gal[((t * NKB + kb) * 2 + tt) * 64 + lane] = f4w{gv[4 * tt], gv[4 * tt + 1], gv[4 * tt + 2], gv[4 * tt + 3]};
+      }
+    f4w R[UT];
+#pragma unroll
+    for (int t = 0; t < UT; ++t) R[t] = f4w{0.f, 0.f, 0.f, 0.f};
+    unsigned dmx = 0u;
+#pragma unroll
+    for (int t = 0; t < UT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const unsigned a = __float_as_uint(dreg[t][q]); dmx = a > dmx ? a : dmx; }
+    dmx = t2_wave_max_u32(dmx);
+    int esd;
+    const float sd = pow2_scale(dmx, 0, &esd);
+    const float inv_sd = __uint_as_float((unsigned)(127 - esd) << 23);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+      if (kb == 0 || 32 * kb < U) {     // (kb = 0 unconditionally: no branch between this product and the use of its result)
+        float dv[8];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dv[4 * tt + q] = 2 * kb + tt < UT ? dreg[2 * kb + tt < UT ? 2 * kb + tt : 0][q] * sd : 0.0f;
+        const h8v dh = hi8(dv);
+#pragma unroll
+        for (int t = 0; t < UT; ++t) {
+          u4w ag = __builtin_bit_cast(u4w, GAh[t][kb]);
+          ag &= 0x7fff7fffu;
+          R[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, ag), dh, R[t], 0, 0, 0);
+        }
+      }
+    float L = 0.0f;
+#pragma unroll
+    for (int t = 0; t < UT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float v = dreg[t][q] * R[t][q];
+        L = (v > L || v != v) ? v : L;
+      }
+    L = __uint_as_float(t2_max_h(__float_as_uint(L))) * inv_sd;
+    L = fmaxf(L, 1e-37f) * 1.002f;
+    if (!(L == L) || !(fabsf(L) < 1e30f)) L = 1.0f;
+    tab_idx = (int)ceilf(float(kTabPerOctave) * (__builtin_amdgcn_logf(L * P.inv_reg) + 16.0f)) + kTabIdx0;
+    tab_idx = tab_idx < 0 ? 0 : (tab_idx > kTabN - 1 ? kTabN - 1 : tab_idx);
+    const int2 th = t2_ld<int2>(P.tab_hdr, (unsigned)tab_idx * 8u);
+    deg = th.x;
+    alpha = __builtin_ldexpf(__int_as_float(th.y) * P.inv_reg, 16);
+    decl = colok && (deg > P.dmax || deg > kTabDeg - 1);
+    degmax = (int)wave_max_nonneg_dpp((colok && !decl) ? float(deg) : 0.0f);
+  }
+  if (lane == 0) stl[0] = nowt ? 1 : 0;
+  if (!nowt) {
+  // D_hat of the tile's points, by slot (phase B reads them as row factors); the fragments of Ghat and what the table said
+#pragma unroll
+  for (int t = 0; t < UT; ++t) *reinterpret_cast<f4w*>(Dl + lr * UMAX + 16 * t + 4 * h) = dreg[t];
+  if (h == 0) ptl[lr] = int4{deg, tab_idx, __float_as_int(alpha), decl ? 1 : 0};
+
   // ---- phase A: w_mean of the sixteen points (columns), Psi(X) (D_hat^2 o wdl)
   {
     const unsigned cbase = (unsigned)tab_idx * (unsigned)(kTabDeg * 8);
@@ -373,7 +382,6 @@ void letkf_tile2w_kernel(Tile2wParams P) {
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) rhs_split1(apsi, kb, ph_[kb], pl_[kb], tied_t{});
     const float fo = P.cs_psi * inv_s2;
-    const int li = lr - kWPts * sub;
 #pragma unroll
     for (int tj = 0; tj < KT; ++tj) {
       f4w acc = f4w{0.f, 0.f, 0.f, 0.f};
@@ -385,18 +393,25 @@ void letkf_tile2w_kernel(Tile2wParams P) {
           acc = t2_mfma3(acc, yh, yl, ph_[kb], pl_[kb]);
         }
       acc *= fo;
-      asm volatile("" : "+v"(acc));        // (formed outside the branch, see the stores of phase B)
-      if (li >= 0 && li < kWPts) *reinterpret_cast<f4w*>(wbl + li * (16 * KT) + 16 * tj + 4 * h) = acc;
+      *reinterpret_cast<f4w*>(wbl + lr * (16 * KT) + 16 * tj + 4 * h) = acc;
     }
   }
-  MIA_T2_SYNC();
+  }   // (a tile with weights)
+  }   // ======== the tile's part
+  __syncthreads();                   // (the only one: nobody leaves before it)
+  if (stl[0] != 0 || kWPts * sub >= npts) return;
+  // (store addresses: row 16 tj + lr, columns 16 ti + 4 h .. -- one lane offset, the blocks' strides are the wave's or immediates;
+  //  only the LAST row / column block can reach beyond k, by the definition of KT)
+  const unsigned offb = (unsigned)(lr * k + 4 * h) * 4u;
+  const bool rowok_last = 16 * (KT - 1) + lr < k, colok_last = 16 * (KT - 1) + 4 * h < k;
 
   // ---- phase B: the points of this wave, one after the other
   for (int i = 0; i < kWPts; ++i) {
     const int g = kWPts * sub + i;                 // (wave-uniform)
     if (g >= npts) break;
-    if (__builtin_amdgcn_readlane((int)decl, g)) continue;
-    const int deg_t = __builtin_amdgcn_readlane(deg, g);
+    const int4 pg = ptl[g];                        // (one address for the wave)
+    if (__builtin_amdgcn_readfirstlane(pg.w)) continue;
+    const int deg_t = __builtin_amdgcn_readfirstlane(pg.x);
     if (deg_t > kWDegCap) {
       if (lane == 0) { atomicOr(P.flags + p0 + g, MIA_FLAG_RETRY); atomicAdd(P.retry_count, 1); }
       continue;
@@ -404,8 +419,8 @@ void letkf_tile2w_kernel(Tile2wParams P) {
     // the table's degree carries two steps of margin over the a-priori count (cheb_table_kernel): the MATRIX recurrence, a
     // thirteenth of this kernel's instructions per step, runs without them (tools/stress_tile.py --weights: unchanged worst case)
     const int deg_g = deg_t - MIA_W_TRIM > 3 ? deg_t - MIA_W_TRIM : (deg_t < 3 ? deg_t : 3);
-    const float alpha_g = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha), g));
-    const unsigned cbase = (unsigned)__builtin_amdgcn_readlane(tab_idx, g) * (unsigned)(kTabDeg * 8);
+    const float alpha_g = __int_as_float(__builtin_amdgcn_readfirstlane(pg.z));
+    const unsigned cbase = (unsigned)__builtin_amdgcn_readfirstlane(pg.y) * (unsigned)(kTabDeg * 8);
     auto coef = [&](int j) -> float {      // (uniform address: scalar loads); 2^-10 keeps M inside the half range for P
       return t2_ld<float2>(P.tab_c, cbase + (unsigned)(j < kTabDeg ? j : kTabDeg - 1) * 8u).x * 0x1p-10f;
     };
@@ -419,7 +434,7 @@ void letkf_tile2w_kernel(Tile2wParams P) {
     unsigned dmx = 0u;
 #pragma unroll
     for (int t = 0; t < UT; ++t) {
-      const f4w d4 = *reinterpret_cast<const f4w*>(Dl + i * UMAX + 16 * t + 4 * h);
+      const f4w d4 = *reinterpret_cast<const f4w*>(Dl + g * UMAX + 16 * t + 4 * h);
       d2[t] = d4 * d4;
 #pragma unroll
       for (int q = 0; q < 4; ++q) { const unsigned a = __float_as_uint(d2[t][q]); dmx = a > dmx ? a : dmx; }
@@ -431,19 +446,20 @@ void letkf_tile2w_kernel(Tile2wParams P) {
     h8v APh[UT][NKB], APl[UT][NKB];
 #pragma unroll
     for (int t = 0; t < UT; ++t) {
-      const float dr = Dl[i * UMAX + 16 * t + lr];                 // D_hat of row 16 t + lr (A layout: lane = row)
+      const float dr = Dl[g * UMAX + 16 * t + lr];                 // D_hat of row 16 t + lr (A layout: lane = row)
       const float r2 = 2.0f * alpha_g * dr * dr;
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
         float av[8];
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+        for (int tt = 0; tt < 2; ++tt) {
+          const f4w g4 = gal[((t * NKB + kb) * 2 + tt) * 64 + lane];      // 2^-16 Ghat (alpha carries 2^16)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float gq = (float)GAh[t][kb][4 * tt + q] + (float)GAl[t][kb][4 * tt + q];      // 2^-16 Ghat (alpha carries 2^16)
             const bool dg = 2 * kb + tt == t && 4 * h + q == lr;
-            av[4 * tt + q] = __builtin_fmaf(r2, gq, dg ? -2.0f : 0.0f);
+            av[4 * tt + q] = __builtin_fmaf(r2, g4[q], dg ? -2.0f : 0.0f);
           }
+        }
         split8_tied(av, APh[t][kb], APl[t][kb]);
       }
     }
@@ -472,7 +488,7 @@ void letkf_tile2w_kernel(Tile2wParams P) {
             }
           h8v bh, bl;
           if constexpr (decltype(neg)::value) {
-            if constexpr (decltype(tied)::value) split8n_tied(bv, bh, bl); else split8n(bv, bh, bl);
+            split8n(bv, bh, bl);
           } else {
             if constexpr (decltype(tied)::value) split8_tied(bv, bh, bl); else split8(bv, bh, bl);
           }
@@ -555,7 +571,7 @@ void letkf_tile2w_kernel(Tile2wParams P) {
         // W_pert is symmetric: this lane's four values W_pert[16 ti + 4 h + q][16 tj + lr] are stored as W[16 tj + lr][16 ti + 4 h + q],
         // q = 0..3 -- FOUR CONSECUTIVE floats of one row, one 16-byte store per lane (round 4: four 4-byte stores per lane, 36 store
         // instructions per point instead of 9); w_mean is the ROW's: one value per lane
-        const float wm = wbl[i * (16 * KT) + 16 * tj + lr];
+        const float wm = wbl[g * (16 * KT) + 16 * tj + lr];
         // (the values are formed outside the store's branch: the compiler pads the wait states between a matrix instruction
         //  and the first vector read of its result on the fall-through side of a branch only -- tools/check_mfma_hazards.py)
         f4w vq;
@@ -567,8 +583,9 @@ void letkf_tile2w_kernel(Tile2wParams P) {
         }
         asm volatile("" : "+v"(vq));
         const int row = col, c0_ = 16 * ti + 4 * h;                    // (col = 16 tj + lr: the stored ROW)
-        if ((k & 3) == 0) {
-          if (row < k && c0_ < k) *reinterpret_cast<f4w*>(Wg + (unsigned)(row * k + c0_)) = vq;
+        if constexpr (K4) {
+          if ((tj < KT - 1 || rowok_last) && (ti < KT - 1 || colok_last))
+            *reinterpret_cast<f4w*>(reinterpret_cast<char*>(Wg) + (offb + (unsigned)(tj * 64 * k)) + 64 * ti) = vq;
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
@@ -581,20 +598,21 @@ void letkf_tile2w_kernel(Tile2wParams P) {
 }
 
 static size_t tile2w_lds_bytes(int ut, int kt, int k) {
-  return (size_t)ut * split_nc8(k) * 512 + 512 + (size_t)16 * ut * 12 + (size_t)kWPts * 16 * ut * 4 + (size_t)kWPts * 16 * kt * 4;
+  return (size_t)ut * split_nc8(k) * 512 + 512 + (size_t)16 * ut * 12 + (size_t)16 * 16 * ut * 4 + (size_t)16 * 16 * kt * 4 + 256 +
+         (size_t)ut * ((ut + 1) / 2) * 2 * 64 * 16 + 16;
 }
 
 template <int UT, int KT>
 static int tile2w_launch(const Tile2wParams& tp, hipStream_t stream) {
   const size_t lds = tile2w_lds_bytes(UT, KT, tp.k);
   if (lds > kMaxDynamicLds) return MIA_ERR_UNSUPPORTED;
-  auto kern = letkf_tile2w_kernel<UT, KT>;
+  auto kern = (tp.k & 3) == 0 ? letkf_tile2w_kernel<UT, KT, true> : letkf_tile2w_kernel<UT, KT, false>;
   if (lds > 48 * 1024) MIA_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int64_t nwork = ((tp.ng + 15) >> 4) * (16 / kWPts);
+  const int64_t nwork = (tp.ng + 15) >> 4;
   const int64_t gx = nwork < 65536 ? nwork : 65536;
   const int64_t gy = (nwork + gx - 1) / gx;
   if (gy > 65535) return MIA_ERR_UNSUPPORTED;
-  kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64), lds, stream>>>(tp);
+  kern<<<dim3((unsigned)gx, (unsigned)gy), dim3(64 * (16 / kWPts)), lds, stream>>>(tp);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

@@ -130,51 +130,29 @@ __device__ __forceinline__ void split8_tied(const float (&x)[8], h8v& hi, h8v& l
   hi = __builtin_bit_cast(h8v, hu);
   lo = __builtin_bit_cast(h8v, lu);
 }
-// ... and of -x (the weights kernel's recurrence alternates the sign of its right-hand sides, letkf_tile2w.hip): the negation rides
-// in the source modifiers of the conversions and of the mixed multiply-adds, hi = f16(-x), lo = f16(-x - hi): no instruction more.
+// The split of -x: the negation rides on source modifiers of the conversions and of the mixed multiply-adds alike (no instruction
+// of its own: the compiler's conversion of a negated pair was a v_xor per value in front of it), all inside one statement.
+// Its outputs are fresh registers of the allocator's choice and the compiler pads nothing around inline assembly: the leading
+// s_nop 2 keeps the first write three wait states behind a matrix instruction that may still read that register as its
+// accumulator input (tools/check_mfma_hazards.py: write-after-read on SrcC); a matrix instruction's RESULT register is never
+// handed out while the result is awaited.  12 vector instructions (round 4: 20, the tied form 24).
 __device__ __forceinline__ void split8n(const float (&x)[8], h8v& hi, h8v& lo) {
   u4w hu, lu;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const f2w v = {-x[2 * i], -x[2 * i + 1]};
-    const h2v a = __builtin_convertvector(v, h2v);
-    hu[i] = __builtin_bit_cast(unsigned, a);
-  }
   asm("s_nop 2\n\t"
-      "v_fma_mixlo_f16 %0, %4, -1.0, -%8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %0, %4, -1.0, -%9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixlo_f16 %1, %5, -1.0, -%10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %1, %5, -1.0, -%11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixlo_f16 %2, %6, -1.0, -%12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %2, %6, -1.0, -%13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixlo_f16 %3, %7, -1.0, -%14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %3, %7, -1.0, -%15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_cvt_pk_f16_f32 %0, -%8, -%9\n\t"
+      "v_cvt_pk_f16_f32 %1, -%10, -%11\n\t"
+      "v_cvt_pk_f16_f32 %2, -%12, -%13\n\t"
+      "v_cvt_pk_f16_f32 %3, -%14, -%15\n\t"
+      "v_fma_mixlo_f16 %4, %0, -1.0, -%8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %4, %0, -1.0, -%9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %5, %1, -1.0, -%10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %5, %1, -1.0, -%11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %6, %2, -1.0, -%12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %6, %2, -1.0, -%13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %7, %3, -1.0, -%14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %7, %3, -1.0, -%15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
       "s_nop 1"
-      : "=&v"(lu[0]), "=&v"(lu[1]), "=&v"(lu[2]), "=&v"(lu[3])
-      : "v"(hu[0]), "v"(hu[1]), "v"(hu[2]), "v"(hu[3]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]),
-        "v"(x[6]), "v"(x[7]));
-  hi = __builtin_bit_cast(h8v, hu);
-  lo = __builtin_bit_cast(h8v, lu);
-}
-__device__ __forceinline__ void split8n_tied(const float (&x)[8], h8v& hi, h8v& lo) {
-  u4w hu, lu;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const f2w v = {-x[2 * i], -x[2 * i + 1]};
-    const h2v a = __builtin_convertvector(v, h2v);
-    hu[i] = __builtin_bit_cast(unsigned, a);
-    lu[i] = hu[i];
-  }
-  asm("v_fma_mixlo_f16 %0, %0, -1.0, -%4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %0, %0, -1.0, -%5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixlo_f16 %1, %1, -1.0, -%6 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %1, %1, -1.0, -%7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixlo_f16 %2, %2, -1.0, -%8 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %2, %2, -1.0, -%9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixlo_f16 %3, %3, -1.0, -%10 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %3, %3, -1.0, -%11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "s_nop 1"
-      : "+v"(lu[0]), "+v"(lu[1]), "+v"(lu[2]), "+v"(lu[3])
+      : "=&v"(hu[0]), "=&v"(hu[1]), "=&v"(hu[2]), "=&v"(hu[3]), "=&v"(lu[0]), "=&v"(lu[1]), "=&v"(lu[2]), "=&v"(lu[3])
       : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
   hi = __builtin_bit_cast(h8v, hu);
   lo = __builtin_bit_cast(h8v, lu);
