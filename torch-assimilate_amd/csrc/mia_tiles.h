@@ -133,12 +133,14 @@ __device__ __forceinline__ void split8_tied(const float (&x)[8], h8v& hi, h8v& l
 // The split of -x: the negation rides on source modifiers of the conversions and of the mixed multiply-adds alike (no instruction
 // of its own: the compiler's conversion of a negated pair was a v_xor per value in front of it), all inside one statement.
 // Its outputs are fresh registers of the allocator's choice and the compiler pads nothing around inline assembly: the leading
-// s_nop 2 keeps the first write three wait states behind a matrix instruction that may still read that register as its
-// accumulator input (tools/check_mfma_hazards.py: write-after-read on SrcC); a matrix instruction's RESULT register is never
-// handed out while the result is awaited.  12 vector instructions (round 4: 20, the tied form 24).
+// s_nop 3 keeps the first write four wait states behind the instruction in front of it.  That covers a matrix instruction
+// that still reads the register as its accumulator input (3), and a matrix instruction's RESULT register: the allocator hands
+// it out once its last reader has issued -- a vector reader sits 8 wait states behind the result already, a matrix reader
+// stands for 4 more itself (the compiler chains accumulators through different registers, so such registers do come free
+// in the middle of a product).  tools/check_mfma_hazards.py checks every build.  12 vector instructions (round 4: 20; tied 24).
 __device__ __forceinline__ void split8n(const float (&x)[8], h8v& hi, h8v& lo) {
   u4w hu, lu;
-  asm("s_nop 2\n\t"
+  asm("s_nop 3\n\t"
       "v_cvt_pk_f16_f32 %0, -%8, -%9\n\t"
       "v_cvt_pk_f16_f32 %1, -%10, -%11\n\t"
       "v_cvt_pk_f16_f32 %2, -%12, -%13\n\t"
