@@ -89,7 +89,8 @@ void letkf_tile2p_kernel(Tile2Params P) {
   constexpr int J0 = (KT + NW - 1) / NW;            // member blocks of the output per wave
   constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lr = lane & 15, h = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, h = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // (a scalar: what depends on it is scalar branches and selects)
   const int k = P.k, nc8 = P.nc8;
   const unsigned IMG = (unsigned)(UT * nc8) * 512u;
   unsigned char* zline = smem + IMG;                         // 512 zero bytes
@@ -281,15 +282,15 @@ void letkf_tile2p_kernel(Tile2Params P) {
       }
   }
   P_STAMP(3);
-  // this wave's own D_hat rows (wave-uniform select out of the register array)
+  // this wave's own D_hat rows: loaded once more by address (cache-hot) -- picking them out of the register array by the wave's
+  // number was a select per value and candidate row block (forty-eight at config 4, each the issue time of three multiply-adds)
   f4w down[OWN];
 #pragma unroll
   for (int o = 0; o < OWN; ++o) {
-    down[o] = dreg[0];
-#pragma unroll
-    for (int t = 1; t < UT; ++t)
-      if (t == t_lo + o) down[o] = dreg[t];
-    if (o >= n_own) down[o] = f4w{0.f, 0.f, 0.f, 0.f};
+    const int t = o < n_own ? t_lo + o : 0;
+    const f4w d4 = t2_ld<f4w>(P.tD + (tile * UT + t) * 64, (unsigned)lane * 16u);
+    const f4w e4 = *reinterpret_cast<const f4w*>(El + 16 * t + 4 * h);
+    down[o] = o < n_own ? d4 * e4 : f4w{0.f, 0.f, 0.f, 0.f};
   }
   // ---- Gershgorin bound over this wave's rows, largest |u_0| of its rows; the other wave's through LDS
   float alpha = 0.0f;
@@ -328,8 +329,8 @@ void letkf_tile2p_kernel(Tile2Params P) {
     for (int o = 0; o < OWN; ++o)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float v = down[o][q] * R[o][q];
-        L = (v > L || v != v) ? v : L;
+        // (a plain maximum: a record that is not finite sent the tile to the eigensolver kernel above, nothing here is NaN)
+        L = __builtin_fmaxf(L, down[o][q] * R[o][q]);
       }
     L = __uint_as_float(t2_max_h(__float_as_uint(L))) * inv_sd;
     if (h == 0) xch[(wv * 3 + 0) * 16 + lr] = L;
