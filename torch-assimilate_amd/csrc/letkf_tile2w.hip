@@ -421,8 +421,10 @@ void letkf_tile2w_kernel(Tile2wParams P) {
     const int deg_g = deg_t - MIA_W_TRIM > 3 ? deg_t - MIA_W_TRIM : (deg_t < 3 ? deg_t : 3);
     const float alpha_g = __int_as_float(__builtin_amdgcn_readfirstlane(pg.z));
     const unsigned cbase = (unsigned)__builtin_amdgcn_readfirstlane(pg.y) * (unsigned)(kTabDeg * 8);
-    auto coef = [&](int j) -> float {      // (uniform address: scalar loads); 2^-10 keeps M inside the half range for P
-      return t2_ld<float2>(P.tab_c, cbase + (unsigned)(j < kTabDeg ? j : kTabDeg - 1) * 8u).x * 0x1p-10f;
+    // (one address for the wave; the value is used RAW -- the factor 2^-10 that keeps M inside the half range for P rides on the
+    //  sign below -- so that the loads issued two steps ahead are waited for where they are used, not where they are issued)
+    auto coef = [&](int j) -> float {
+      return t2_ld<float2>(P.tab_c, cbase + (unsigned)(j < kTabDeg ? j : kTabDeg - 1) * 8u).x;
     };
     // The recurrence as ONE matrix per point: V_{j+1} = A' V_j - V_{j-1} with A' = 2 alpha_g D_hat^2 Ghat - 2 I, whose A fragments are
     // formed once per point (rows scaled by this lane's row factor, the diagonal in place) -- then the matrix instruction does the
@@ -465,7 +467,7 @@ void letkf_tile2w_kernel(Tile2wParams P) {
     }
     // V[cb][t][q] = V[slot 16 t + 4 h + q][slot 16 cb + lr]
     f4w va[UT][UT], vb[UT][UT], am[UT][UT];
-    const float c0 = coef(0), c1 = coef(1);
+    const float c0 = coef(0) * 0x1p-10f, c1 = coef(1) * 0x1p-10f;
     float cn0 = coef(2), cn1 = coef(3);
 #pragma unroll
     for (int cb = 0; cb < UT; ++cb)
@@ -525,13 +527,13 @@ void letkf_tile2w_kernel(Tile2wParams P) {
     };
     int j = 2;
     for (; j + 1 <= deg_g; j += 2) {
-      const float sg_ = (j & 2) ? -1.0f : 1.0f;            // sigma_j = sigma_{j+1} (j even)
+      const float sg_ = (j & 2) ? -0x1p-10f : 0x1p-10f;    // sigma_j = sigma_{j+1} (j even), times 2^-10
       const float cj = cn0 * sg_, cj1 = cn1 * sg_;
       cn0 = coef(j + 2); cn1 = coef(j + 3);
       advance(va, vb, cj, tied_t{});        // W_j     = -A' W_{j-1} + W_{j-2}   (tied_t = "true": negated right-hand side)
       advance(vb, va, cj1, fresh_t{});      // W_{j+1} =  A' W_j     + W_{j-1}
     }
-    if (j <= deg_g) advance(va, vb, cn0 * ((j & 2) ? -1.0f : 1.0f), tied_t{});
+    if (j <= deg_g) advance(va, vb, cn0 * ((j & 2) ? -0x1p-10f : 0x1p-10f), tied_t{});
     // ---- P = M Yhat^T: A fragments of M (row block rb) = the registers of its column block rb (M is symmetric)
     h8v mh[UT][NKB], ml[UT][NKB];
 #pragma unroll
